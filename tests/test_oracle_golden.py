@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (oracle/frcnn_oracle.c) to golden vectors produced by importing the
+reference (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_anchor_base_bit_exact(golden):
+    g = golden("anchors")
+    got = orc.anchor_base()
+    assert got.dtype == np.float32 and got.shape == (9, 4)
+    assert np.array_equal(got, g["anchor_base"])          # anchor.py:15-32
+
+
+@pytest.mark.parametrize("hw", [(600, 1000), (800, 800), (800, 1344), (880, 960), (160, 240), (37, 50)])
+def test_anchor_grid_bit_exact(golden, hw):
+    g = golden("anchors")
+    key = "%dx%d" % hw
+    a = orc.anchor_grid(*hw)                                # anchor.py:34-55
+    assert tuple(g[key + "_shape"]) == a.shape
+    assert sha(a) == str(g[key + "_sha256"])
+    assert np.array_equal(a[:128], g[key + "_head"]) and np.array_equal(a[-128:], g[key + "_tail"])
+    assert np.array_equal(a[::97], g[key + "_stride97"])
+    inside = int(((a[:, 0] >= 0) & (a[:, 1] >= 0) & (a[:, 2] <= 1) & (a[:, 3] <= 1)).sum())
+    assert inside == int(g[key + "_inside"])
+
+
+def test_known_answers_from_reference_comments(golden):
+    # anchor.py:102 "At (600, 1000) image has 20646 all anchors"; SURVEY 8c: 8044 inside
+    a = orc.anchor_grid(600, 1000)
+    assert a.shape == (20646, 4)
+    assert int(golden("anchors")["600x1000_inside"]) == 8044
+
+
+def test_codec_bit_exact(golden):
+    g = golden("codec")
+    assert np.array_equal(orc.xy_to_cxcy(g["xy"]), g["xy_to_cxcy"])       # utils/util.py:22-26
+    assert np.array_equal(orc.cxcy_to_xy(g["xy_to_cxcy"]), g["cxcy_to_xy"])  # utils/util.py:15-19
+
+
+def test_decode(golden):
+    g = golden("codec")
+    ref = g["decode"]                                                        # utils/util.py:46-50 (torch.exp)
+    det = orc.decode(g["t"], g["anc_cxcy"])
+    libm = orc.decode(g["t"], g["anc_cxcy"], use_libm=True)
+    assert np.array_equal(det[:, :2], ref[:, :2])                            # mul+add: bit exact
+    for got in (det, libm):
+        fin = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), fin)
+        rel = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
+        assert rel.max() < 4e-7                                              # <= ~3 ulp, far inside 1e-4
+
+
+def test_encode(golden):
+    g = golden("codec")
+    got = orc.encode(g["gt_cxcy"], g["anc_cxcy"])                            # utils/util.py:39-43
+    assert np.array_equal(got[:, :2], g["encode"][:, :2])                    # sub+div: bit exact
+    assert np.allclose(got[:, 2:], g["encode"][:, 2:], rtol=0, atol=1e-6)   # logf vs torch.log
+
+
+def test_jaccard_bit_exact(golden):
+    g = golden("codec")
+    iou = orc.pairwise_iou(g["s1"], g["s2"], eps=1e-5)                       # utils/util.py:66-102
+    assert np.array_equal(iou, g["jaccard"])
+    assert np.array_equal(iou.max(1), g["row_max"]) and np.array_equal(iou.argmax(1), g["row_arg"])
+    assert np.array_equal(iou.max(0), g["col_max"]) and np.array_equal(iou.argmax(0), g["col_arg"])
+
+
+def test_fg_softmax(golden):
+    g = golden("codec")
+    got = orc.fg_softmax(g["logits"])                                        # models/model_.py:20
+    assert np.abs(got - g["fg_softmax"]).max() < 2e-7
+
+
+def test_det_exp_log2_vs_libm():
+    x = np.concatenate([np.linspace(-104, 89, 20001), np.linspace(-1, 1, 4001), [0.0, -0.0, 1e-8]]).astype(np.float32)
+    got = orc.expf(x).astype(np.float64)
+    want = np.exp(x.astype(np.float64))
+    ok = (want > 1.2e-38) & (want < 3.0e38)                                 # normal, finite range
+    rel = np.abs(got[ok] - want[ok]) / want[ok]
+    assert rel.max() < 2.5e-7, rel.max()
+    assert orc.expf(np.float32(0.0)) == np.float32(1.0)
+    assert np.isinf(orc.expf(np.float32(89.0))) and orc.expf(np.float32(-200.0)) == 0.0
+    a = np.concatenate([np.exp(np.linspace(-80, 80, 20001)), [0.25, 0.5, 1.0, 2.0, 4.0, 8.0]]).astype(np.float32)
+    got = orc.log2f(a).astype(np.float64)
+    want = np.log2(a.astype(np.float64))
+    assert np.abs(got - want).max() < 4e-7 * np.maximum(1.0, np.abs(want)).max()
+    assert list(orc.log2f(np.array([0.25, 0.5, 1.0, 2.0, 4.0], np.float32))) == [-2.0, -1.0, 0.0, 1.0, 2.0]
+
+
+def test_proposal_pre_nms_matches_reference(golden):
+    g = golden("proposal_pre_nms")                                           # models/model_.py:19-49
+    boxes, scores, nv = orc.proposal_prologue(g["reg"], g["cls"], g["anchor"], 1 / 1000)
+    keep = g["keep"]
+    assert nv == int(keep.sum())
+    assert np.array_equal(scores >= 0, keep)
+    assert np.abs(boxes - g["roi_all"]).max() < 1e-6
+    assert np.abs(scores[keep] - g["score_all"][keep]).max() < 2e-7
+    idx, sc = orc.topk_sorted(scores, int(g["K"]))
+    # ordering: identical unless two reference scores are within the exp tolerance of each other
+    same = idx == g["top_orig_idx"]
+    assert same.mean() > 0.995
+    bad = np.nonzero(~same)[0]
+    for j in bad:                                                            # only near-tie swaps allowed
+        assert abs(g["score_all"][idx[j]] - g["score_all"][g["top_orig_idx"][j]]) < 4e-7
+    assert np.abs(sc - g["top_score"]).max() < 2e-7
+
+
+def test_rpn_targets_on_reference_smoke_boxes(golden):
+    g = golden("smoke_targets")                                              # models/model_.py:186-266
+    anchor = orc.anchor_grid(800, 800)
+    cls, reg, (n_pos, n_neg) = orc.rpn_targets(anchor, g["boxes"])
+    assert (n_pos, n_neg) == (int(g["n_pos"]), int(g["n_neg"]))
+    ins = g["inside_idx"]
+    assert np.array_equal(cls[ins].astype(np.float32), g["label_pre_sample"])
+    out = np.ones(len(cls), bool)
+    out[ins] = False
+    assert (cls[out] == -1).all() and (reg[out] == 0).all()
+    assert np.array_equal(reg[ins][:, :2], g["tg"][:, :2])
+    assert np.allclose(reg[ins][:, 2:], g["tg"][:, 2:], rtol=0, atol=1e-6)
+
+
+def test_rpn_target_sampling_semantics(golden):
+    g = golden("smoke_targets")
+    anchor = orc.anchor_grid(800, 800)
+    _, _, (n_pos, n_neg) = orc.rpn_targets(anchor, g["boxes"])
+    rng = np.random.RandomState(0)
+    pp = rng.permutation(n_pos) if n_pos > 128 else None
+    n_pos_eff = min(n_pos, 128)
+    pn = rng.permutation(n_neg)
+    cls, _, _ = orc.rpn_targets(anchor, g["boxes"], pp, pn)
+    assert (cls == 1).sum() == n_pos_eff and (cls == 0).sum() == 256 - n_pos_eff
+    # restate models/model_.py:231-236 in numpy
+    pre = np.full(len(cls), -1.0, np.float32)
+    pre[g["inside_idx"]] = g["label_pre_sample"]
+    neg_idx = np.nonzero(pre == 0)[0]
+    exp = pre.copy()
+    exp[neg_idx[pn[256 - n_pos_eff:]]] = -1
+    assert np.array_equal(cls.astype(np.float32), exp)
+
+
+def test_loss_matches_reference(golden):
+    g = golden("loss")                                                       # losses/loss.py:5-85
+    out = orc.frcnn_loss((g["p_rpn_cls"], g["p_rpn_reg"], g["p_head_cls"], g["p_head_reg"]),
+                         (g["t_rpn_cls"], g["t_rpn_reg"], g["t_head_cls"], g["t_head_reg"]))
+    assert np.allclose(out, g["losses"], rtol=2e-6, atol=1e-6)
