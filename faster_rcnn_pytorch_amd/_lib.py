@@ -1,0 +1,99 @@
+"""ctypes binding of libfrcnn_hip.so (include/frcnn_hip.h).
+
+There is NO fallback: if the shared library is missing the import fails loudly, and every op
+in ops.py refuses non-GPU tensors.  Build with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C faster_rcnn_pytorch_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfrcnn_hip.so")
+
+OK = 0
+OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS = 1, 2, 3, 4, 5
+
+_vp, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); must list EVERY symbol include/frcnn_hip.h declares (tests check this)
+SIGNATURES = {
+    "frcnn_abi_version": (_i, []),
+    "frcnn_last_error": (C.c_char_p, []),
+    "frcnn_workspace_bytes": (_sz, [_i, _i64, _i64]),
+    "frcnn_anchor_base_host": (_i, [_i, _vp, _i, _vp, _i, _vp]),
+    "frcnn_tv_base_anchors_host": (_i, [_f, _vp, _i, _vp]),
+    "frcnn_anchor_grid": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _i64, _vp]),
+    "frcnn_box_codec": (_i, [_i, _vp, _vp, _i64, _vp, _vp]),
+    "frcnn_pairwise_iou": (_i, [_vp, _i64, _vp, _i64, _f, _vp, _vp]),
+    "frcnn_proposal_prologue": (_i, [_vp, _vp, _vp, _i64, _f, _vp, _vp, _vp]),
+    "frcnn_topk_sorted": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_argsort_desc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_nms": (_i, [_vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_region_proposal": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _f, _f, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_roi_pool_fwd": (_i, [_vp, _i, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
+    "frcnn_roi_pool_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "frcnn_roi_level_map": (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp]),
+    "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "frcnn_ms_roi_align_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "frcnn_prof_enable": (_i, [_i]),
+    "frcnn_prof_collect": (_i, []),
+    "frcnn_prof_reset": (_i, []),
+    "frcnn_prof_num_kernels": (_i, []),
+    "frcnn_prof_kernel_name": (C.c_char_p, [_i]),
+    "frcnn_prof_get": (_i, [_i, _vp, _vp]),
+}
+
+
+class FrcnnError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libfrcnn_hip.so not found at %s -- the HIP extension is mandatory (no CPU fallback). "
+            "Build it: make -C faster_rcnn_pytorch_amd/csrc   (or __graft_entry__.build())" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.frcnn_abi_version() != 1:
+        raise ImportError("libfrcnn_hip.so ABI version %d, expected 1" % lib.frcnn_abi_version())
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != OK:
+        msg = lib.frcnn_last_error()
+        raise FrcnnError("%s failed with status %d: %s" % (what or "libfrcnn_hip", rc, msg.decode() if msg else ""))
+
+
+def workspace_bytes(op, n1, n2=0):
+    return int(lib.frcnn_workspace_bytes(op, n1, n2))
+
+
+def prof_enable(on=True):
+    check(lib.frcnn_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    check(lib.frcnn_prof_reset())
+
+
+def prof_report():
+    """{kernel_name: (total_ms, launches)} for kernels launched since the last reset (syncs the events)."""
+    check(lib.frcnn_prof_collect())
+    out = {}
+    for k in range(lib.frcnn_prof_num_kernels()):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(lib.frcnn_prof_get(k, C.byref(ms), C.byref(n)))
+        if n.value:
+            out[lib.frcnn_prof_kernel_name(k).decode()] = (ms.value, n.value)
+    return out

@@ -1,0 +1,492 @@
+"""Host-side operator layer: the reference's box/anchor functions and the five torchvision entry
+points it calls, re-implemented on libfrcnn_hip.so (hand-written gfx950 kernels behind a C ABI).
+
+Mirrors (file:line under the reference):
+  utils/util.py:15-102   cxcy_to_xy, xy_to_cxcy, encode, decode, find_jaccard_overlap
+  util/box_ops.py:24-37  box_iou
+  torchvision.ops.nms            as called at models/model.py:53,394
+  torchvision.ops.RoIPool        as called at models/model.py:97,113
+  torchvision.ops.MultiScaleRoIAlign   as called at models/new_model.py:127,143
+  torchvision AnchorGenerator    as called at models/new_model.py:23-25,46
+
+PyTorch is plumbing here (device memory, streams, autograd glue).  Every op requires contiguous
+fp32 tensors on a HIP device and raises otherwise: there is no CPU path in the product.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+# --------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t, dtype=torch.float32, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s is on %s: the frcnn ops run only on a HIP device (no CPU fallback)" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_WS = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only per-(device, stream) scratch buffer owned by the caller side (torch allocator)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _host_i32(v):
+    return np.ascontiguousarray(v, dtype=np.int32)
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------------------------------------
+# anchors
+# --------------------------------------------------------------------------------------------
+def anchor_base(base_size=16, ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32)):
+    """FRCNNAnchorMaker.generate_anchor_base (anchor.py:15-32) -> np.float32 [len(r)*len(s), 4]."""
+    r = np.ascontiguousarray(ratios, dtype=np.float64)
+    s = np.ascontiguousarray(anchor_scales, dtype=np.float64)
+    out = np.empty((len(r) * len(s), 4), np.float32)
+    check(lib.frcnn_anchor_base_host(base_size, _np_ptr(r), len(r), _np_ptr(s), len(s), _np_ptr(out)), "anchor_base")
+    return out
+
+
+def tv_base_anchors(size, ratios=(0.5, 1.0, 2.0)):
+    r = np.ascontiguousarray(ratios, dtype=np.float32)
+    out = np.empty((len(r), 4), np.float32)
+    check(lib.frcnn_tv_base_anchors_host(float(size), _np_ptr(r), len(r), _np_ptr(out)), "tv_base_anchors")
+    return out
+
+
+def anchor_grid(feat_shapes, strides, base, div_w, div_h, device):
+    """Device anchor grid over levels.  feat_shapes [(fh,fw)], strides [(sh,sw)], base [L,A,4] (host)."""
+    fh = _host_i32([s[0] for s in feat_shapes])
+    fw = _host_i32([s[1] for s in feat_shapes])
+    sh = _host_i32([s[0] for s in strides])
+    sw = _host_i32([s[1] for s in strides])
+    base = np.ascontiguousarray(base, dtype=np.float32).reshape(len(fh), -1, 4)
+    A = base.shape[1]
+    N = int((fh.astype(np.int64) * fw).sum() * A)
+    out = torch.empty((N, 4), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        check(lib.frcnn_anchor_grid(len(fh), _np_ptr(fh), _np_ptr(fw), _np_ptr(sh), _np_ptr(sw), _np_ptr(base), A,
+                                    float(div_w), float(div_h), _ptr(out), N, _stream()), "anchor_grid")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# box codec + IoU (utils/util.py)
+# --------------------------------------------------------------------------------------------
+def _codec(op, a, b=None):
+    a = _req(a, name="boxes")
+    shape = a.shape
+    a2 = a.reshape(-1, 4)
+    b2 = None
+    if b is not None:
+        b2 = _req(b, name="anchors").reshape(-1, 4)
+        if b2.shape != a2.shape:
+            raise ValueError("box codec: operand shapes differ: %s vs %s" % (tuple(a2.shape), tuple(b2.shape)))
+    out = torch.empty_like(a2)
+    with torch.cuda.device(a.device):
+        check(lib.frcnn_box_codec(op, _ptr(a2), _ptr(b2), a2.shape[0], _ptr(out), _stream()), "box_codec")
+    return out.reshape(shape)
+
+
+def xy_to_cxcy(xy):
+    return _codec(0, xy)
+
+
+def cxcy_to_xy(cxcy):
+    return _codec(1, cxcy)
+
+
+def decode(tcxcy, center_anchor):
+    return _codec(2, tcxcy, center_anchor)
+
+
+def encode(gt_cxywh, anc_cxywh):
+    return _codec(3, gt_cxywh, anc_cxywh)
+
+
+def _pairwise(s1, s2, eps):
+    s1 = _req(s1, name="set_1")
+    s2 = _req(s2, name="set_2")
+    out = torch.empty((s1.shape[0], s2.shape[0]), dtype=torch.float32, device=s1.device)
+    with torch.cuda.device(s1.device):
+        check(lib.frcnn_pairwise_iou(_ptr(s1), s1.shape[0], _ptr(s2), s2.shape[0], float(eps), _ptr(out), _stream()), "pairwise_iou")
+    return out
+
+
+def find_jaccard_overlap(set_1, set_2, eps=1e-5):
+    return _pairwise(set_1, set_2, eps)
+
+
+def box_iou(boxes1, boxes2):
+    """util/box_ops.py:24-37 -- returns (iou, union) like the reference; union is recomputed in torch."""
+    iou = _pairwise(boxes1, boxes2, 0.0)
+    a1 = (boxes1[:, 2] - boxes1[:, 0]) * (boxes1[:, 3] - boxes1[:, 1])
+    a2 = (boxes2[:, 2] - boxes2[:, 0]) * (boxes2[:, 3] - boxes2[:, 1])
+    lt = torch.max(boxes1[:, None, :2], boxes2[:, :2])
+    rb = torch.min(boxes1[:, None, 2:], boxes2[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    union = a1[:, None] + a2 - wh[..., 0] * wh[..., 1]
+    return iou, union
+
+
+# --------------------------------------------------------------------------------------------
+# proposal stage (models/model.py:12-58)
+# --------------------------------------------------------------------------------------------
+def proposal_prologue(reg, cls, anchors, min_size_norm):
+    reg = _req(reg, name="reg").reshape(-1, 4)
+    cls = _req(cls, name="cls").reshape(-1, 2)
+    anchors = _req(anchors, name="anchors").reshape(-1, 4)
+    N = reg.shape[0]
+    if cls.shape[0] != N or anchors.shape[0] != N:
+        raise ValueError("prologue: N mismatch")
+    boxes = torch.empty((N, 4), dtype=torch.float32, device=reg.device)
+    scores = torch.empty((N,), dtype=torch.float32, device=reg.device)
+    with torch.cuda.device(reg.device):
+        check(lib.frcnn_proposal_prologue(_ptr(reg), _ptr(cls), _ptr(anchors), N, float(min_size_norm), _ptr(boxes), _ptr(scores),
+                                          _stream()), "proposal_prologue")
+    return boxes, scores
+
+
+def topk_sorted(scores, K, boxes=None, all_live=False):
+    """Returns (idx[K] i64, sorted_scores[K], sorted_boxes[K,4] | None, count (device int32 tensor))."""
+    scores = _req(scores, name="scores").reshape(-1)
+    N = scores.shape[0]
+    K = int(min(K, N))
+    dev = scores.device
+    boxes = None if boxes is None else _req(boxes, name="boxes").reshape(-1, 4)
+    idx = torch.empty((K,), dtype=torch.int64, device=dev)
+    ssc = torch.empty((K,), dtype=torch.float32, device=dev)
+    sbx = None if boxes is None else torch.empty((K, 4), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    nb = _lib.workspace_bytes(_lib.OP_TOPK, N)
+    ws = _workspace(dev, nb)
+    with torch.cuda.device(dev):
+        if all_live:
+            if K != N:
+                raise ValueError("all_live sort returns all N entries")
+            check(lib.frcnn_argsort_desc(_ptr(scores), _ptr(boxes), N, _ptr(idx), _ptr(ssc), _ptr(sbx), _ptr(cnt), _ptr(ws), nb, _stream()),
+                  "argsort_desc")
+        else:
+            check(lib.frcnn_topk_sorted(_ptr(scores), _ptr(boxes), N, K, _ptr(idx), _ptr(ssc), _ptr(sbx), _ptr(cnt), _ptr(ws), nb, _stream()),
+                  "topk_sorted")
+    return idx, ssc, sbx, cnt
+
+
+def nms_sorted(boxes, iou_threshold, post_k=None, n_boxes=None, want_rois=False):
+    """NMS over boxes already in visiting order.  No host sync: returns (keep[post_k] i64, rois|None, count int32[1])."""
+    boxes = _req(boxes, name="boxes").reshape(-1, 4)
+    K = boxes.shape[0]
+    post_k = K if post_k is None else int(min(post_k, K))
+    dev = boxes.device
+    keep = torch.empty((max(post_k, 1),), dtype=torch.int64, device=dev)
+    rois = torch.empty((max(post_k, 1), 4), dtype=torch.float32, device=dev) if want_rois else None
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    nb = _lib.workspace_bytes(_lib.OP_NMS, K)
+    ws = _workspace(dev, nb)
+    if n_boxes is not None:
+        n_boxes = _req(n_boxes, torch.int32, "n_boxes")
+    with torch.cuda.device(dev):
+        check(lib.frcnn_nms(_ptr(boxes), _ptr(n_boxes), K, float(iou_threshold), post_k, _ptr(keep), _ptr(rois), _ptr(cnt), _ptr(ws), nb,
+                            _stream()), "nms")
+    return keep, rois, cnt
+
+
+def nms(boxes, scores, iou_threshold):
+    """Drop-in for torchvision.ops.nms(boxes, scores, iou_threshold) -> int64 indices of kept boxes,
+    sorted by decreasing score (models/model.py:53,394).  Like torchvision it returns a
+    variable-length tensor, which costs one host sync (the count)."""
+    boxes = _req(boxes, name="boxes").reshape(-1, 4)
+    scores = _req(scores, name="scores").reshape(-1)
+    if boxes.shape[0] != scores.shape[0]:
+        raise ValueError("nms: boxes and scores differ in length")
+    if boxes.shape[0] == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    idx, _, sboxes, _ = topk_sorted(scores, boxes.shape[0], boxes, all_live=True)
+    keep, _, cnt = nms_sorted(sboxes, iou_threshold)
+    n = int(cnt.item())
+    return idx[keep[:n]]
+
+
+def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_threshold, post_nms_top_k, grid=None, want_src=False):
+    """RegionProposal.forward in one enqueue (no host sync).
+    anchors: [N,4] device tensor, or None with grid=(fh, fw, stride, base[A,4] host, div_w, div_h).
+    Returns (rois [P,4] fixed capacity, count int32[1] device, src_idx [P] | None)."""
+    reg = _req(reg, name="reg").reshape(-1, 4)
+    cls = _req(cls, name="cls").reshape(-1, 2)
+    N = reg.shape[0]
+    dev = reg.device
+    P = int(post_nms_top_k)
+    K = int(min(pre_nms_top_k, N))
+    rois = torch.zeros((P, 4), dtype=torch.float32, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    src = torch.empty((P,), dtype=torch.int64, device=dev) if want_src else None
+    nb = _lib.workspace_bytes(_lib.OP_REGION_PROPOSAL, N, K)
+    ws = _workspace(dev, nb)
+    if anchors is not None:
+        anchors = _req(anchors, name="anchors").reshape(-1, 4)
+        if anchors.shape[0] != N:
+            raise ValueError("region_proposal: anchors/reg length mismatch")
+        fh = fw = stride = A = 0
+        base_p, dw, dh = None, 1.0, 1.0
+    else:
+        fh, fw, stride, base, dw, dh = grid
+        base = np.ascontiguousarray(base, dtype=np.float32)
+        A = base.shape[0]
+        base_p = _np_ptr(base)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_region_proposal(_ptr(reg), _ptr(cls), _ptr(anchors), N, int(fh), int(fw), int(stride), base_p, int(A),
+                                        float(dw), float(dh), float(min_size_norm), K, float(iou_threshold), P,
+                                        _ptr(rois), _ptr(cnt), _ptr(src), _ptr(ws), nb, _stream()), "region_proposal")
+    return rois, cnt, src
+
+
+# --------------------------------------------------------------------------------------------
+# target makers
+# --------------------------------------------------------------------------------------------
+def _perm(p, dev):
+    if p is None:
+        return None, 0
+    p = torch.as_tensor(p, dtype=torch.int64).to(dev).contiguous()
+    return p, p.numel()
+
+
+def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, offset=0):
+    """RPNTargetMaker.forward.  Returns (cls[N] i64, reg[N,4], counts int32[4] device = n_pos, n_neg, err, -)."""
+    anchors = _req(anchors, name="anchors").reshape(-1, 4)
+    gt = _req(gt, name="gt").reshape(-1, 4)
+    N, G = anchors.shape[0], gt.shape[0]
+    dev = anchors.device
+    cls = torch.empty((N,), dtype=torch.int64, device=dev)
+    reg = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    counts = torch.empty((4,), dtype=torch.int32, device=dev)
+    pp, npp = _perm(perm_pos, dev)
+    pn, npn = _perm(perm_neg, dev)
+    nb = _lib.workspace_bytes(_lib.OP_RPN_TARGETS, N, G)
+    ws = _workspace(dev, nb)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_rpn_targets(int(variant), _ptr(anchors), N, _ptr(gt), G, _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
+                                    _ptr(cls), _ptr(reg), _ptr(counts), _ptr(ws), nb, _stream()), "rpn_targets")
+    return cls, reg, counts
+
+
+def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max_pos=32, total=128,
+                 perm_pos=None, perm_neg=None, seed=0, offset=0, want_keep=False):
+    """FastRcnnTargetMaker.forward.  Returns (cls[total] i64, reg[total,4], sample_rois[total,4], keep|None, counts int32[4])."""
+    rois = _req(rois, name="rois").reshape(-1, 4)
+    gt = _req(gt, name="gt").reshape(-1, 4)
+    gt_label = _req(gt_label, torch.int64, "gt_label").reshape(-1)
+    dev = rois.device
+    if n_rois is not None:
+        n_rois = _req(n_rois, torch.int32, "n_rois")
+    cls = torch.empty((total,), dtype=torch.int64, device=dev)
+    reg = torch.empty((total, 4), dtype=torch.float32, device=dev)
+    srois = torch.empty((total, 4), dtype=torch.float32, device=dev)
+    keep = torch.empty((total,), dtype=torch.int64, device=dev) if want_keep else None
+    counts = torch.empty((4,), dtype=torch.int32, device=dev)
+    pp, npp = _perm(perm_pos, dev)
+    pn, npn = _perm(perm_neg, dev)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_head_targets(int(variant), _ptr(rois), _ptr(n_rois), rois.shape[0], _ptr(gt), _ptr(gt_label), gt.shape[0],
+                                     int(label_offset), int(max_pos), int(total), _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
+                                     _ptr(cls), _ptr(reg), _ptr(srois), _ptr(keep), _ptr(counts), None, 0, _stream()), "head_targets")
+    return cls, reg, srois, keep, counts
+
+
+# --------------------------------------------------------------------------------------------
+# RoIPool (models/model.py:97,113)
+# --------------------------------------------------------------------------------------------
+class _RoIPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, PH, PW, scale):
+        feat = _req(feat, name="features")
+        rois = _req(rois, name="rois").reshape(-1, 4)
+        if feat.dim() != 4 or feat.shape[0] != 1:
+            raise ValueError("RoIPool: features must be [1,C,H,W] (the reference trains with batch 1 per GPU)")
+        _, Cc, H, W = feat.shape
+        R = rois.shape[0]
+        out = torch.empty((R, Cc, PH, PW), dtype=torch.float32, device=feat.device)
+        arg = torch.empty((R, Cc, PH, PW), dtype=torch.int32, device=feat.device)
+        with torch.cuda.device(feat.device):
+            check(lib.frcnn_roi_pool_fwd(_ptr(feat), Cc, H, W, _ptr(rois), R, PH, PW, float(scale), _ptr(out), _ptr(arg), _stream()),
+                  "roi_pool_fwd")
+        ctx.save_for_backward(arg)
+        ctx.shape = (Cc, H, W, PH, PW, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        Cc, H, W, PH, PW, R = ctx.shape
+        grad_out = _req(grad_out, name="grad_out")
+        gf = torch.empty((1, Cc, H, W), dtype=torch.float32, device=grad_out.device)
+        with torch.cuda.device(grad_out.device):
+            check(lib.frcnn_roi_pool_bwd(_ptr(grad_out), _ptr(arg), R, Cc, H, W, PH, PW, _ptr(gf), _stream()), "roi_pool_bwd")
+        return gf, None, None, None, None      # no gradient through box coordinates
+
+
+def roi_pool(features, rois, output_size=(7, 7), spatial_scale=1.0):
+    if isinstance(rois, (list, tuple)):
+        if len(rois) != 1:
+            raise ValueError("roi_pool: one image per call (batch 1 per GPU)")
+        rois = rois[0]
+    if isinstance(output_size, int):
+        output_size = (output_size, output_size)
+    return _RoIPoolFn.apply(features, rois, int(output_size[0]), int(output_size[1]), float(spatial_scale))
+
+
+class RoIPool(torch.nn.Module):
+    """torchvision.ops.RoIPool(output_size, spatial_scale) with the call convention of models/model.py:113."""
+
+    def __init__(self, output_size, spatial_scale):
+        super().__init__()
+        self.output_size = output_size
+        self.spatial_scale = spatial_scale
+
+    def forward(self, input, rois):
+        return roi_pool(input, rois, self.output_size, self.spatial_scale)
+
+
+# --------------------------------------------------------------------------------------------
+# MultiScaleRoIAlign (models/new_model.py:127,143)
+# --------------------------------------------------------------------------------------------
+def roi_level_map(rois, k_min=2, k_max=5, s0=224.0, k0=4, eps=1e-6):
+    rois = _req(rois, name="rois").reshape(-1, 4)
+    out = torch.empty((rois.shape[0],), dtype=torch.int32, device=rois.device)
+    with torch.cuda.device(rois.device):
+        check(lib.frcnn_roi_level_map(_ptr(rois), rois.shape[0], k_min, k_max, float(s0), k0, float(eps), _ptr(out), _stream()), "roi_level_map")
+    return out
+
+
+def _level_tables(feats, scales):
+    n = len(feats)
+    ptrs = (C.c_void_p * n)(*[f.data_ptr() for f in feats])
+    H = _host_i32([f.shape[-2] for f in feats])
+    W = _host_i32([f.shape[-1] for f in feats])
+    sc = np.ascontiguousarray(scales, dtype=np.float32)
+    return ptrs, H, W, sc
+
+
+class _MsRoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, PH, PW, sampling_ratio, aligned, scales, k_min, s0, k0, *feats):
+        feats = [_req(f, name="feature map") for f in feats]
+        rois = _req(rois, name="rois").reshape(-1, 4)
+        Cc = feats[0].shape[1]
+        for f in feats:
+            if f.dim() != 4 or f.shape[0] != 1 or f.shape[1] != Cc:
+                raise ValueError("MultiScaleRoIAlign: feature maps must be [1,C,H,W] with a common C")
+        R = rois.shape[0]
+        out = torch.empty((R, Cc, PH, PW), dtype=torch.float32, device=rois.device)
+        ptrs, H, W, sc = _level_tables(feats, scales)
+        with torch.cuda.device(rois.device):
+            check(lib.frcnn_ms_roi_align_fwd(ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(feats), Cc, _ptr(rois), R, PH, PW,
+                                             sampling_ratio, int(aligned), k_min, float(s0), k0, _ptr(out), None, _stream()), "ms_roi_align_fwd")
+        ctx.save_for_backward(rois)
+        ctx.meta = (PH, PW, sampling_ratio, aligned, tuple(scales), k_min, s0, k0, [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        PH, PW, sampling_ratio, aligned, scales, k_min, s0, k0, shapes = ctx.meta
+        grad_out = _req(grad_out, name="grad_out")
+        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+        ptrs, H, W, sc = _level_tables(grads, scales)
+        with torch.cuda.device(grad_out.device):
+            check(lib.frcnn_ms_roi_align_bwd(_ptr(grad_out), ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(grads), shapes[0][1], _ptr(rois),
+                                             rois.shape[0], PH, PW, sampling_ratio, int(aligned), k_min, float(s0), k0, _stream()),
+                  "ms_roi_align_bwd")
+        return (None,) * 9 + tuple(grads)
+
+
+def ms_roi_align(feats, rois, output_size=7, sampling_ratio=2, scales=(0.25, 0.125, 0.0625, 0.03125), aligned=False,
+                 canonical_scale=224.0, canonical_level=4):
+    k_min = int(round(-np.log2(scales[0])))
+    PH, PW = (output_size, output_size) if isinstance(output_size, int) else output_size
+    return _MsRoIAlignFn.apply(rois, int(PH), int(PW), int(sampling_ratio), bool(aligned), tuple(float(s) for s in scales), k_min,
+                               float(canonical_scale), int(canonical_level), *feats)
+
+
+class MultiScaleRoIAlign(torch.nn.Module):
+    """torchvision.ops.MultiScaleRoIAlign(featmap_names, output_size, sampling_ratio) with the call convention of
+    models/new_model.py:143: forward(features: dict, [rois in image pixels], image_shapes).
+    The per-level scales are explicit (default 1/4 .. 1/32): the reference passes (w, h) where torchvision
+    expects (h, w), so scale inference from image_shapes is deliberately not reproduced."""
+
+    def __init__(self, featmap_names, output_size, sampling_ratio, scales=None):
+        super().__init__()
+        self.featmap_names = list(featmap_names)
+        self.output_size = output_size
+        self.sampling_ratio = sampling_ratio
+        self.scales = tuple(scales) if scales is not None else tuple(2.0 ** -(2 + i) for i in range(len(self.featmap_names)))
+
+    def forward(self, x, boxes, image_shapes=None):
+        if isinstance(boxes, (list, tuple)):
+            if len(boxes) != 1:
+                raise ValueError("MultiScaleRoIAlign: one image per call (batch 1 per GPU)")
+            boxes = boxes[0]
+        feats = [x[k] for k in self.featmap_names]
+        return ms_roi_align(feats, boxes, self.output_size, self.sampling_ratio, self.scales)
+
+
+# --------------------------------------------------------------------------------------------
+# AnchorGenerator (models/new_model.py:23-25,46)
+# --------------------------------------------------------------------------------------------
+class AnchorGenerator(torch.nn.Module):
+    """torchvision.models.detection.rpn.AnchorGenerator(sizes, aspect_ratios) restricted to what the reference
+    uses: one size per level, a shared ratio tuple.  __call__(image_hw, feature_maps) -> [anchors[N,4] in pixels].
+    Anchors depend only on shapes, so they are cached per (image, feature) shape and stay resident in HBM."""
+
+    def __init__(self, sizes=((32,), (64,), (128,), (256,), (512,)), aspect_ratios=((0.5, 1.0, 2.0),) * 5):
+        super().__init__()
+        for s in sizes:
+            if len(s) != 1:
+                raise ValueError("AnchorGenerator: one size per level (as the reference configures it)")
+        self.sizes = tuple(float(s[0]) for s in sizes)
+        self.aspect_ratios = tuple(tuple(float(r) for r in ar) for ar in aspect_ratios)
+        if len(set(self.aspect_ratios)) != 1:
+            raise ValueError("AnchorGenerator: all levels must share the aspect ratios")
+        self._cache = {}
+
+    def grid(self, image_hw, feat_shapes, device, normalise=False):
+        H, W = int(image_hw[0]), int(image_hw[1])
+        key = (H, W, tuple(feat_shapes), str(device), normalise)
+        a = self._cache.get(key)
+        if a is None:
+            base = np.stack([tv_base_anchors(s, self.aspect_ratios[0]) for s in self.sizes[:len(feat_shapes)]])
+            strides = [(H // fh, W // fw) for fh, fw in feat_shapes]
+            a = anchor_grid(feat_shapes, strides, base, W if normalise else 1.0, H if normalise else 1.0, device)
+            self._cache[key] = a
+        return a
+
+    def forward(self, image_hw, feature_maps):
+        shapes = [tuple(f.shape[-2:]) for f in feature_maps]
+        return [self.grid(image_hw, shapes, feature_maps[0].device)]

@@ -1,0 +1,191 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) Faster R-CNN
+ * proposal / RoI-head hot path.
+ *
+ * The reference (csm-kr/faster_rcnn_pytorch) is pure Python and has no FFI; its
+ * boundary for this path is the Python call surface of models/model.py + anchor.py
+ * and, beneath it, five torchvision entry points.  Every function below names the
+ * reference interface (file:line under /root/reference) it replaces; the ctypes
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - extern "C"; plain pointers and sizes; no torch types.  Returns 0 on success,
+ *    a negative frcnn_status otherwise; never throws, never allocates device
+ *    memory, never synchronises the stream (unless stated).
+ *  - Every pointer is a DEVICE pointer unless the name ends in _host.  The caller
+ *    owns every buffer, workspaces included.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *  - Variable-length results use a fixed-capacity buffer + a device-side int32
+ *    count, so a whole training step can be enqueued without a host round trip.
+ *  - Boxes are fp32 xyxy, normalised to [0,1] by image (w,h) unless stated;
+ *    indices are int64 (torch.long in the reference), argmax is int32.
+ *  - Arithmetic is IEEE binary32 with no FMA contraction (the reference's eager
+ *    op chains round after every op); exp / log2 are the fixed +-*-/ sequences
+ *    restated in oracle/frcnn_oracle.c, so integer results (sort order, NMS keep
+ *    lists, level ids, labels) are bit-exact against the oracle.
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_ABI_VERSION 1
+
+typedef enum {
+    FRCNN_OK = 0,
+    FRCNN_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, K > capacity ... */
+    FRCNN_ERR_UNSUPPORTED = -2,   /* size outside what the kernels are built for */
+    FRCNN_ERR_WORKSPACE = -3,     /* workspace too small (see frcnn_workspace_bytes) */
+    FRCNN_ERR_LAUNCH = -4         /* hipGetLastError() after a launch was not hipSuccess */
+} frcnn_status;
+
+/* operation ids for frcnn_workspace_bytes() */
+typedef enum {
+    FRCNN_OP_TOPK = 1,            /* n1 = N candidates */
+    FRCNN_OP_NMS = 2,             /* n1 = K boxes */
+    FRCNN_OP_REGION_PROPOSAL = 3, /* n1 = N anchors, n2 = K */
+    FRCNN_OP_RPN_TARGETS = 4,     /* n1 = N anchors, n2 = G */
+    FRCNN_OP_HEAD_TARGETS = 5     /* n1 = P + G candidates */
+} frcnn_op;
+
+int frcnn_abi_version(void);
+/* thread-local description of the last non-zero status returned on this thread */
+const char *frcnn_last_error(void);
+size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2);
+
+/* ---- anchors -------------------------------------------------------------------------------- */
+/* FRCNNAnchorMaker.generate_anchor_base (anchor.py:15-32).  Host computation (done once).       */
+int frcnn_anchor_base_host(int base_size, const double *ratios_host, int n_ratios,
+                           const double *scales_host, int n_scales, float *out_host /*[nr*ns,4]*/);
+/* torchvision AnchorGenerator.generate_anchors for ONE size (models/new_model.py:23-25). Host.  */
+int frcnn_tv_base_anchors_host(float size, const float *ratios_host, int n_ratios, float *out_host /*[nr,4]*/);
+
+/* Anchor grid over n_levels feature maps, level-major, position-major (y, x), base-minor:
+ *   out[off_l + (y*fw_l + x)*A + a] = (base_l[a] + (x*sw_l, y*sh_l, x*sw_l, y*sh_l)) / (div_w, div_h, div_w, div_h)
+ * One level, A = 9, stride 16, div = (W,H)  == FRCNNAnchorMaker._enumerate_shifted_anchor (anchor.py:34-55);
+ * five levels, A = 3, strides (H//fh, W//fw) == AnchorGenerator(...)(ImageList, feats) followed by the
+ * in-place division at models/new_model.py:46-47.  base_host: [n_levels, A, 4].  div = 1 -> pixels. */
+int frcnn_anchor_grid(int n_levels, const int *fh_host, const int *fw_host,
+                      const int *stride_h_host, const int *stride_w_host,
+                      const float *base_host, int A, float div_w, float div_h,
+                      float *out /*[N,4]*/, int64_t N, void *stream);
+
+/* ---- box codec (utils/util.py:15-50) ---------------------------------------------------------- */
+/* op: 0 xy_to_cxcy(a) | 1 cxcy_to_xy(a) | 2 decode(a = tcxcy, b = center_anchor) | 3 encode(a = gt_cxcy, b = anc_cxcy) */
+int frcnn_box_codec(int op, const float *a, const float *b, int64_t n, float *out, void *stream);
+
+/* find_jaccard_overlap (utils/util.py:66-102; eps = 1e-5) / box_iou (util/box_ops.py:24-37; eps = 0). */
+int frcnn_pairwise_iou(const float *set1, int64_t n1, const float *set2, int64_t n2, float eps,
+                       float *out /*[n1,n2]*/, void *stream);
+
+/* ---- RegionProposal.forward (models/model.py:12-58, models/new_model.py:49-86) ------------------ */
+/* Stage 1: fg softmax + decode + clamp + min-size filter (model.py:20-41).
+ * anchors == NULL is not allowed here; see frcnn_region_proposal for the fused anchor-free form.
+ * out_scores[i] = softmax(cls[i])[1], or -1 where (w < min_size_norm or h < min_size_norm).       */
+int frcnn_proposal_prologue(const float *reg /*[N,4]*/, const float *cls /*[N,2]*/, const float *anchors /*[N,4]*/,
+                            int64_t N, float min_size_norm, float *out_boxes /*[N,4]*/, float *out_scores /*[N]*/,
+                            void *stream);
+
+/* Stage 2: scores.sort(descending=True)[:K] (model.py:44-49).  Ties are ordered by ascending index
+ * (torch's sort is unstable).  Entries with score < 0 never appear.
+ * out_count = min(K, #valid).  boxes_in/out_boxes may both be NULL (no gather).                    */
+int frcnn_topk_sorted(const float *scores /*[N]*/, const float *boxes_in /*[N,4] or NULL*/, int64_t N, int64_t K,
+                      int64_t *out_idx /*[K]*/, float *out_scores /*[K]*/, float *out_boxes /*[K,4] or NULL*/,
+                      int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Full descending argsort (every score live, negatives included): the sort inside torchvision.ops.nms
+ * when the caller's boxes are not pre-sorted (per-class NMS, models/model.py:394).  Ties: ascending index. */
+int frcnn_argsort_desc(const float *scores /*[N]*/, const float *boxes_in /*[N,4] or NULL*/, int64_t N,
+                       int64_t *out_idx /*[N]*/, float *out_scores /*[N]*/, float *out_boxes /*[N,4] or NULL*/,
+                       int32_t *out_count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Stage 3: torchvision.ops.nms (model.py:53,394) on boxes already in visiting (score-descending) order.
+ * Greedy, suppress when inter/(area_i+area_j-inter) > thr (strict).  Writes the first post_k kept
+ * positions (ascending) to out_keep, their boxes to out_rois (optional) and the number to out_count.
+ * n_boxes_dev (optional) is a device int32 with the live box count (<= K), e.g. frcnn_topk_sorted's count. */
+int frcnn_nms(const float *boxes /*[K,4]*/, const int32_t *n_boxes_dev, int64_t K, float iou_threshold, int64_t post_k,
+              int64_t *out_keep /*[post_k]*/, float *out_rois /*[post_k,4] or NULL*/, int32_t *out_count,
+              void *workspace, size_t workspace_bytes, void *stream);
+
+/* All of RegionProposal.forward in one call (prologue -> top-K -> NMS -> first P), no host sync.
+ * anchors may be NULL when the single-level grid description is given (fh,fw,stride,base9x4 on host):
+ * the anchors are then regenerated in registers and never read from HBM (anchor.py:34-55 fused away). */
+int frcnn_region_proposal(const float *reg, const float *cls, const float *anchors /*[N,4] or NULL*/, int64_t N,
+                          int fh, int fw, int stride, const float *base_host /*[A,4] or NULL*/, int A,
+                          float div_w, float div_h,
+                          float min_size_norm, int64_t pre_nms_top_k, float iou_threshold, int64_t post_nms_top_k,
+                          float *out_rois /*[P,4]*/, int32_t *out_count,
+                          int64_t *out_src_idx /*[P] anchor index of each roi, or NULL*/,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- target makers ------------------------------------------------------------------------------ */
+/* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).
+ * Sampling (torch.randperm on the host in the reference, model_.py:228,235):
+ *   perm_pos / perm_neg != NULL : consume the reference's permutations (parity mode); their lengths must
+ *        equal the positive / negative counts (learn them with a first call and out_counts);
+ *   else                        : device Philox4x32-10 keyed by (seed, offset): keep the candidates with the
+ *        smallest (key, index).
+ * out_counts (int32[4], device): {n_pos, n_neg before sampling, error flag, reserved}.               */
+int frcnn_rpn_targets(int variant, const float *anchors /*[N,4]*/, int64_t N, const float *gt /*[G,4]*/, int64_t G,
+                      const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
+                      uint64_t seed, uint64_t offset,
+                      int64_t *out_cls /*[N]*/, float *out_reg /*[N,4]*/, int32_t *out_counts /*[4]*/,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* FastRcnnTargetMaker.forward (models/model_.py:127-179; FPN: models/new_model.py:157-206).
+ * rois [P_cap,4] with a device count n_rois_dev (NULL = P_cap rows are live); candidates = cat(rois, gt).
+ * variant 0: find_jaccard_overlap(roi, gt) eps 1e-5; 1: box_iou(gt, roi).  label_offset 1 (VGG) / 0 (FPN);
+ * max_pos 32 / 128; total 128 / 512.  Rows beyond the number actually sampled (the reference throws in
+ * that case) are filled with class 0, zero boxes; out_counts = {#pos cand, #neg cand, rows written, error}. */
+int frcnn_head_targets(int variant, const float *rois, const int32_t *n_rois_dev, int64_t P_cap,
+                       const float *gt, const int64_t *gt_label, int64_t G,
+                       int64_t label_offset, int64_t max_pos, int64_t total,
+                       const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
+                       uint64_t seed, uint64_t offset,
+                       int64_t *out_cls /*[total]*/, float *out_reg /*[total,4]*/, float *out_rois /*[total,4]*/,
+                       int64_t *out_keep_index /*[total] or NULL*/, int32_t *out_counts /*[4]*/,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- RoI pooling ---------------------------------------------------------------------------------- */
+/* torchvision.ops.RoIPool((PH,PW), spatial_scale) forward/backward (models/model.py:97,113); one image,
+ * feat [C,H,W] fp32 NCHW, rois [R,4] = x1,y1,x2,y2 (the reference pre-multiplies by (fw,fh)). */
+int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, const float *rois, int64_t R, int PH, int PW,
+                       float spatial_scale, float *out /*[R,C,PH,PW]*/, int32_t *argmax /*[R,C,PH,PW]*/, void *stream);
+/* grad_feat [C,H,W] is fully overwritten (no pre-zeroing needed). */
+int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax, int64_t R, int C, int H, int W, int PH, int PW,
+                       float *grad_feat, void *stream);
+
+/* torchvision.ops.MultiScaleRoIAlign(names, PH, sampling_ratio) (models/new_model.py:127,143): level mapper
+ * k = floor(k0 + log2(sqrt(area)/s0) + 1e-6) clamped to [k_min, k_min+n_levels-1]; per level roi_align
+ * (aligned = False).  rois in image pixels.  The per-level scales are explicit.            */
+int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, int k_max, float s0, int k0, float eps,
+                        int32_t *out_level, void *stream);
+int frcnn_ms_roi_align_fwd(const float *const *feats_host /*[n_levels] device ptrs*/, const int *H_host, const int *W_host,
+                           const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
+                           int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0,
+                           float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/, void *stream);
+/* grad_feats[l] [C,H_l,W_l] are ACCUMULATED into with fp32 atomics; the caller zeroes them. */
+int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host, const int *H_host, const int *W_host,
+                           const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
+                           int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0, void *stream);
+
+/* ---- in-library kernel timing (HIP events on the launch stream) -------------------------------------- */
+/* When enabled, every kernel launch made by this library is bracketed by two hipEventRecord on the
+ * caller's stream.  frcnn_prof_collect() synchronises those events (call it after the stream is idle)
+ * and folds them into per-kernel totals readable with frcnn_prof_get().                                 */
+int frcnn_prof_enable(int on);
+int frcnn_prof_collect(void);
+int frcnn_prof_reset(void);
+int frcnn_prof_num_kernels(void);
+const char *frcnn_prof_kernel_name(int kernel_id);
+int frcnn_prof_get(int kernel_id, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

@@ -1,0 +1,435 @@
+"""Parity tests proper: HIP kernels (through the C ABI, via faster_rcnn_pytorch_amd.ops) vs the CPU oracle
+on identical seeded inputs.  Integer results must be bit-exact; floating point as stated per test.
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from faster_rcnn_pytorch_amd import ops as o
+    return o
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def rand_boxes(rng, n, lo=0.02, hi=0.6):
+    c = rng.rand(n, 2) * 0.8 + 0.1
+    wh = rng.rand(n, 2) * (hi - lo) + lo
+    return np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)
+
+
+def rpn_outputs(rng, N, regime):
+    """SURVEY 8d synthetic RPN outputs: init-like / trained-like."""
+    if regime == "init":
+        reg = (rng.randn(N, 4) * 0.02).astype(np.float32)
+        cls = (rng.randn(N, 2) * 0.02).astype(np.float32)
+    else:
+        reg = (rng.randn(N, 4) * np.array([0.1, 0.1, 0.2, 0.2])).astype(np.float32)
+        d = (rng.randn(N) * 2 - 2).astype(np.float32)
+        cls = np.stack([np.zeros(N, np.float32), d], 1)
+    return reg, cls
+
+
+# ------------------------------------------------------------------------------------------ anchors
+@pytest.mark.parametrize("hw", [(600, 1000), (800, 800), (37, 50), (880, 960)])
+def test_anchor_grid_vgg_bit_exact(ops, hw):
+    H, W = hw
+    base = ops.anchor_base()
+    assert np.array_equal(base, orc.anchor_base())
+    got = ops.anchor_grid([(H // 16, W // 16)], [(16, 16)], base[None], W, H, DEV).cpu().numpy()
+    assert np.array_equal(got, orc.anchor_grid(H, W))
+
+
+def test_anchor_grid_fpn_bit_exact(ops, golden):
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    ag = ops.AnchorGenerator()
+    px = ag.grid((800, 1344), shapes, DEV).cpu().numpy()
+    assert np.array_equal(px, orc.tv_anchor_grid(800, 1344, shapes, normalise=False))
+    nm = ag.grid((800, 1344), shapes, DEV, normalise=True).cpu().numpy()
+    assert np.array_equal(nm, orc.tv_anchor_grid(800, 1344, shapes, normalise=True))
+    assert nm.shape == (268569, 4)
+
+
+# ------------------------------------------------------------------------------------------ codec / IoU
+def test_codec_vs_oracle_and_golden(ops, golden):
+    g = golden("codec")
+    assert np.array_equal(ops.xy_to_cxcy(T(g["xy"])).cpu().numpy(), g["xy_to_cxcy"])
+    assert np.array_equal(ops.cxcy_to_xy(T(g["xy_to_cxcy"])).cpu().numpy(), g["cxcy_to_xy"])
+    dec = ops.decode(T(g["t"]), T(g["anc_cxcy"])).cpu().numpy()
+    assert np.array_equal(dec, orc.decode(g["t"], g["anc_cxcy"]), equal_nan=True)          # bit-exact vs oracle (deterministic exp)
+    fin = np.isfinite(g["decode"])
+    assert (np.abs(dec[fin] - g["decode"][fin]) <= 4e-7 * np.abs(g["decode"][fin])).all()   # vs reference torch.exp
+    enc = ops.encode(T(g["gt_cxcy"]), T(g["anc_cxcy"])).cpu().numpy()
+    assert np.array_equal(enc[:, :2], g["encode"][:, :2])
+    assert np.abs(enc[:, 2:] - g["encode"][:, 2:]).max() < 1e-6                             # logf: tolerance 1e-6 (north star: 1e-4)
+
+
+def test_pairwise_iou_bit_exact(ops, golden):
+    g = golden("codec")
+    got = ops.find_jaccard_overlap(T(g["s1"]), T(g["s2"])).cpu().numpy()
+    assert np.array_equal(got, g["jaccard"])                                               # reference vector
+    rng = np.random.RandomState(0)
+    a, b = rand_boxes(rng, 3000), rand_boxes(rng, 11)
+    assert np.array_equal(ops.find_jaccard_overlap(T(a), T(b)).cpu().numpy(), orc.pairwise_iou(a, b, 1e-5))
+    iou, union = ops.box_iou(T(b), T(a))
+    assert np.array_equal(iou.cpu().numpy(), orc.pairwise_iou(b, a, 0.0))
+    assert union.shape == (11, 3000)
+
+
+# ------------------------------------------------------------------------------------------ prologue
+@pytest.mark.parametrize("regime", ["init", "trained"])
+def test_prologue_bit_exact(ops, regime):
+    rng = np.random.RandomState(1)
+    anchor = orc.anchor_grid(600, 1000)
+    N = anchor.shape[0]
+    reg, cls = rpn_outputs(rng, N, regime)
+    reg[::97, 2:] = -12.0                                   # collapse some boxes below min_size
+    reg[5, 2] = 120.0                                       # exp overflow -> inf -> clamp
+    b_o, s_o, nv = orc.proposal_prologue(reg, cls, anchor, 1 / 1000)
+    b_g, s_g = ops.proposal_prologue(T(reg), T(cls), T(anchor), 1 / 1000)
+    assert np.array_equal(b_g.cpu().numpy(), b_o, equal_nan=True)
+    assert np.array_equal(s_g.cpu().numpy(), s_o)
+    assert int((s_g >= 0).sum()) == nv and nv < N
+
+
+def test_prologue_matches_reference_golden(ops, golden):
+    g = golden("proposal_pre_nms")
+    b, s = ops.proposal_prologue(T(g["reg"]), T(g["cls"]), T(g["anchor"]), 1 / 1000)
+    b, s = b.cpu().numpy(), s.cpu().numpy()
+    assert np.array_equal(s >= 0, g["keep"])
+    assert np.abs(b - g["roi_all"]).max() < 1e-6                                             # tolerance 1e-6 << 1e-4
+    assert np.abs(s[g["keep"]] - g["score_all"][g["keep"]]).max() < 2e-7
+
+
+# ------------------------------------------------------------------------------------------ top-k
+@pytest.mark.parametrize("N,K", [(20646, 12000), (20646, 6000), (1000, 1000), (777, 2000), (65, 64), (1, 1)])
+def test_topk_bit_exact(ops, N, K):
+    rng = np.random.RandomState(N + K)
+    s = rng.rand(N).astype(np.float32)
+    s[rng.rand(N) < 0.1] = -1.0                             # filtered
+    boxes = rand_boxes(rng, N)
+    idx_o, sc_o = orc.topk_sorted(s, K)
+    idx, sc, bx, cnt = ops.topk_sorted(T(s), K, T(boxes))
+    n = int(cnt.item())
+    assert n == len(idx_o)
+    assert np.array_equal(idx[:n].cpu().numpy(), idx_o)
+    assert np.array_equal(sc[:n].cpu().numpy(), sc_o)
+    assert np.array_equal(bx[:n].cpu().numpy(), boxes[idx_o])
+
+
+def test_topk_ties_resolve_by_index(ops):
+    rng = np.random.RandomState(7)
+    N = 5000
+    s = (rng.randint(0, 40, N) / 64.0).astype(np.float32)   # heavy ties
+    s[::11] = -1.0
+    idx_o, _ = orc.topk_sorted(s, 3000)
+    idx, _, _, cnt = ops.topk_sorted(T(s), 3000)
+    assert int(cnt.item()) == 3000 and np.array_equal(idx.cpu().numpy(), idx_o)
+    same = np.full(300, 0.5, np.float32)                    # all equal (zero-init RPN): identity order
+    idx, _, _, cnt = ops.topk_sorted(T(same), 200)
+    assert np.array_equal(idx.cpu().numpy(), np.arange(200))
+    allbad = np.full(300, -1.0, np.float32)
+    _, _, _, cnt = ops.topk_sorted(T(allbad), 200)
+    assert int(cnt.item()) == 0
+
+
+# ------------------------------------------------------------------------------------------ NMS
+def test_nms_known_answers(ops):
+    def run(b, thr):
+        b = np.asarray(b, np.float32)
+        sc = np.linspace(1.0, 0.5, len(b)).astype(np.float32)
+        return ops.nms(T(b), T(sc), thr).cpu().tolist()
+    b = [[0, 0, 1, 1], [0.5, 0, 1.5, 1], [2, 2, 3, 3]]
+    assert run(b, 0.3) == [0, 2] and run(b, 0.34) == [0, 1, 2]
+    b2 = [[0, 0, 2, 1], [0, 0, 1, 1]]                       # IoU exactly 0.5: strict > keeps both
+    assert run(b2, 0.5) == [0, 1]
+    assert run(b2, float(np.nextafter(np.float32(0.5), np.float32(0)))) == [0]
+    c = [[0, 0, 1, 1], [0.2, 0, 1.2, 1], [0.4, 0, 1.4, 1]]  # 0 kills 1, so 1 cannot kill 2
+    assert run(c, 0.5) == [0, 2]
+    z = [[0.5, 0.5, 0.5, 0.5], [0.5, 0.5, 0.5, 0.5]]        # 0/0 = NaN is not > thr
+    assert run(z, 0.1) == [0, 1]
+
+
+def test_nms_sorts_by_score_like_torchvision(ops):
+    b = np.array([[0, 0, 1, 1], [0.1, 0, 1.1, 1], [2, 2, 3, 3]], np.float32)
+    sc = np.array([0.2, 0.9, 0.5], np.float32)
+    assert ops.nms(T(b), T(sc), 0.5).cpu().tolist() == [1, 2]
+    order = np.argsort(-sc, kind="stable")
+    assert orc.nms(b, 0.5, order=order).tolist() == [1, 2]
+
+
+@pytest.mark.parametrize("K,thr", [(12000, 0.7), (6000, 0.7), (4000, 0.7), (1000, 0.3), (777, 0.5), (64, 0.5), (65, 0.5), (3, 0.5)])
+def test_nms_bit_exact_vs_oracle(ops, K, thr):
+    rng = np.random.RandomState(K)
+    c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15
+    wh = (rng.rand(K, 2).astype(np.float32) * 0.25 + 0.03)
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    keep_o = orc.nms(b, thr)
+    keep, rois, cnt = ops.nms_sorted(T(b), thr, want_rois=True)
+    n = int(cnt.item())
+    assert n == len(keep_o)
+    assert np.array_equal(keep[:n].cpu().numpy(), keep_o)
+    assert np.array_equal(rois[:n].cpu().numpy(), b[keep_o])
+    # post_k early exit + live count on the device
+    post = max(1, len(keep_o) // 3)
+    keep, _, cnt = ops.nms_sorted(T(b), thr, post_k=post)
+    assert int(cnt.item()) == post and np.array_equal(keep[:post].cpu().numpy(), keep_o[:post])
+    live = max(1, K - 37)
+    keep, _, cnt = ops.nms_sorted(T(b), thr, n_boxes=T(np.array([live], np.int32)))
+    ko = orc.nms(b[:live], thr)
+    assert int(cnt.item()) == len(ko) and np.array_equal(keep[:len(ko)].cpu().numpy(), ko)
+
+
+def test_nms_dense_clusters_near_threshold(ops):
+    # many boxes piled on few objects with IoUs straddling the threshold: stresses the exact-division band
+    rng = np.random.RandomState(3)
+    K = 3000
+    centers = rng.rand(12, 2).astype(np.float32) * 0.6 + 0.2
+    cid = rng.randint(0, 12, K)
+    c = centers[cid] + rng.randn(K, 2).astype(np.float32) * 0.01
+    wh = np.float32(0.2) + rng.randn(K, 2).astype(np.float32) * 0.02
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    for thr in (0.7, 0.5, 0.3):
+        keep_o = orc.nms(b, thr)
+        keep, _, cnt = ops.nms_sorted(T(b), thr)
+        assert int(cnt.item()) == len(keep_o) and np.array_equal(keep[:len(keep_o)].cpu().numpy(), keep_o)
+
+
+# ------------------------------------------------------------------------------------------ whole proposal stage
+@pytest.mark.parametrize("regime,mode", [("init", "train"), ("trained", "train"), ("trained", "test")])
+def test_region_proposal_full_size_bit_exact(ops, regime, mode):
+    rng = np.random.RandomState(11)
+    H, W = 600, 1000
+    anchor = orc.anchor_grid(H, W)
+    N = anchor.shape[0]
+    reg, cls = rpn_outputs(rng, N, regime)
+    K, P = (12000, 2000) if mode == "train" else (6000, 300)
+    rois_o, src_o = orc.region_proposal(reg, cls, anchor, 1 / 1000, K, 0.7, P)
+    # (a) anchors from HBM
+    rois, cnt, src = ops.region_proposal(T(reg), T(cls), T(anchor), 1 / 1000, K, 0.7, P, want_src=True)
+    n = int(cnt.item())
+    assert n == len(rois_o)
+    assert np.array_equal(src[:n].cpu().numpy(), src_o)          # integer indices: bit-exact
+    assert np.array_equal(rois[:n].cpu().numpy(), rois_o)        # boxes: bit-exact (tolerance would be 1e-4)
+    # (b) anchors regenerated in registers (never read from HBM)
+    grid = (H // 16, W // 16, 16, ops.anchor_base(), W, H)
+    rois2, cnt2, src2 = ops.region_proposal(T(reg), T(cls), None, 1 / 1000, K, 0.7, P, grid=grid, want_src=True)
+    assert int(cnt2.item()) == n and torch.equal(src2[:n], src[:n]) and torch.equal(rois2[:n], rois[:n])
+
+
+def test_region_proposal_properties_fpn_size(ops):
+    # N = 268 569 is too slow for the O(N^2) oracle sort in CI; check size-independent properties instead
+    rng = np.random.RandomState(5)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    anchor = orc.tv_anchor_grid(800, 1344, shapes, normalise=True)
+    N = anchor.shape[0]
+    reg, cls = rpn_outputs(rng, N, "trained")
+    rois, cnt, src = ops.region_proposal(T(reg), T(cls), T(anchor), 10 / 1000, 4000, 0.7, 1000, want_src=True)
+    n = int(cnt.item())
+    assert 0 < n <= 1000
+    r = rois[:n].cpu().numpy()
+    s = src[:n].cpu().numpy()
+    assert len(np.unique(s)) == n
+    b_o, s_o, _ = orc.proposal_prologue(reg, cls, anchor, 10 / 1000)
+    assert np.array_equal(r, b_o[s])                              # rois are the decoded boxes of their anchors
+    sc = s_o[s]
+    assert (np.diff(sc) <= 0).all() and (sc >= 0).all()           # score-descending
+    kth = np.sort(s_o)[::-1][3999]
+    assert (sc >= kth).all()                                      # all from the top 4000
+    iou = orc.pairwise_iou(r, r, 0.0)
+    np.fill_diagonal(iou, 0)
+    assert iou.max() <= 0.7                                       # survivors do not suppress each other
+    assert list(orc.nms(r, 0.7)) == list(range(n))                # idempotence
+
+
+# ------------------------------------------------------------------------------------------ target makers
+def _gt(rng, G):
+    c = rng.rand(G, 2) * 0.7 + 0.15
+    wh = rng.rand(G, 2) * 0.52 + 0.08
+    return np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("variant,G,seed", [(0, 1, 0), (0, 3, 1), (0, 8, 2), (1, 5, 3), (0, 40, 4)])
+def test_rpn_targets_host_perm_parity(ops, variant, G, seed):
+    rng = np.random.RandomState(seed)
+    if variant == 0:
+        anchor = orc.anchor_grid(600, 1000)
+    else:
+        anchor = orc.tv_anchor_grid(320, 480, [(80, 120), (40, 60), (20, 30), (10, 15), (5, 8)], normalise=True)
+    gt = _gt(rng, G)
+    _, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt, variant=variant)
+    cls, reg, counts = ops.rpn_targets(T(anchor), T(gt), variant=variant)        # first call: learn the counts
+    assert counts[:2].cpu().tolist() == [n_pos, n_neg]
+    # the reference draws randperm(n_pos) only if n_pos > 128, randperm(n_neg) only if n_neg > 256 - n_pos
+    g = torch.Generator().manual_seed(seed)
+    pp = torch.randperm(n_pos, generator=g).numpy() if n_pos > 128 else None
+    pn = torch.randperm(n_neg, generator=g).numpy() if n_neg > 256 - n_pos else None
+    cls_o, reg_o, _ = orc.rpn_targets(anchor, gt, pp, pn, variant=variant)
+    cls, reg, counts = ops.rpn_targets(T(anchor), T(gt), variant=variant, perm_pos=pp, perm_neg=pn)
+    assert counts.cpu().tolist()[2] == 0
+    assert np.array_equal(cls.cpu().numpy(), cls_o)                               # labels: bit-exact
+    r = reg.cpu().numpy()
+    assert np.array_equal(r[:, :2], reg_o[:, :2])
+    assert np.abs(r[:, 2:] - reg_o[:, 2:]).max() < 1e-6                           # logf tolerance 1e-6
+    npe = min(n_pos, 128)
+    assert (cls_o == 1).sum() == npe and (cls_o == 0).sum() == min(n_neg, 256 - npe)
+
+
+def test_rpn_targets_many_positives_forces_pos_sampling(ops):
+    # a gt equal to a large anchor region -> hundreds of IoU >= 0.7 anchors? use many gts to exceed 128 positives
+    rng = np.random.RandomState(9)
+    anchor = orc.anchor_grid(600, 1000)
+    ins = (anchor[:, 0] >= 0) & (anchor[:, 1] >= 0) & (anchor[:, 2] <= 1) & (anchor[:, 3] <= 1)
+    gt = anchor[ins][rng.choice(ins.sum(), 200, replace=False)]                    # 200 gts == anchors -> >= 200 positives
+    _, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt)
+    assert n_pos > 128
+    g = torch.Generator().manual_seed(0)
+    pp = torch.randperm(n_pos, generator=g).numpy()
+    pn = torch.randperm(n_neg, generator=g).numpy()
+    cls_o, _, _ = orc.rpn_targets(anchor, gt, pp, pn)
+    cls, _, counts = ops.rpn_targets(T(anchor), T(gt), perm_pos=pp, perm_neg=pn)
+    assert counts.cpu().tolist()[:3] == [n_pos, n_neg, 0]
+    assert np.array_equal(cls.cpu().numpy(), cls_o)
+    assert (cls_o == 1).sum() == 128 and (cls_o == 0).sum() == 128
+
+
+def test_rpn_targets_device_sampling_properties(ops):
+    rng = np.random.RandomState(4)
+    anchor = orc.anchor_grid(600, 1000)
+    gt = _gt(rng, 6)
+    pre, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt)
+    a = ops.rpn_targets(T(anchor), T(gt), seed=123, offset=0)[0].cpu().numpy()
+    b = ops.rpn_targets(T(anchor), T(gt), seed=123, offset=0)[0].cpu().numpy()
+    c = ops.rpn_targets(T(anchor), T(gt), seed=124, offset=0)[0].cpu().numpy()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)      # deterministic in (seed, offset)
+    npe = min(n_pos, 128)
+    assert (a == 1).sum() == npe and (a == 0).sum() == min(n_neg, 256 - npe)
+    assert ((a == 1) <= (pre == 1)).all() and ((a == 0) <= (pre == 0)).all()   # sampling only demotes to -1
+    # uniformity smoke check: kept negatives spread over the whole candidate list
+    kept = np.nonzero(a == 0)[0]
+    cand = np.nonzero(pre == 0)[0]
+    q = np.searchsorted(cand, kept) / len(cand)
+    assert 0.35 < q.mean() < 0.65
+
+
+@pytest.mark.parametrize("variant,label_offset,max_pos,total,P", [(0, 1, 32, 128, 2000), (0, 1, 32, 128, 300), (1, 0, 128, 512, 1000)])
+def test_head_targets_host_perm_parity(ops, variant, label_offset, max_pos, total, P):
+    rng = np.random.RandomState(P + variant)
+    G = 5
+    gt = _gt(rng, G)
+    lab = rng.randint(0, 20, G).astype(np.int64) + (1 - label_offset)
+    rois = rand_boxes(rng, P, 0.05, 0.5)
+    rois[:40] = np.clip(gt[rng.randint(0, G, 40)] + rng.randn(40, 4).astype(np.float32) * 0.01, 0, 1)
+    n_live = P - 13
+    npc, nnc = orc.head_target_counts(rois[:n_live], gt, lab, variant)
+    g = torch.Generator().manual_seed(1)
+    pp = torch.randperm(npc, generator=g).numpy()                 # the reference always draws both (model_.py:149,155)
+    pn = torch.randperm(nnc, generator=g).numpy()
+    cls_o, reg_o, rois_o, keep_o = orc.head_targets(rois[:n_live], gt, lab, pp, pn, variant, label_offset, max_pos, total)
+    cls, reg, srois, keep, counts = ops.head_targets(T(rois), T(gt), T(lab), n_rois=T(np.array([n_live], np.int32)), variant=variant,
+                                                     label_offset=label_offset, max_pos=max_pos, total=total, perm_pos=pp, perm_neg=pn,
+                                                     want_keep=True)
+    assert counts.cpu().tolist() == [npc, nnc, len(cls_o), 0]
+    assert len(cls_o) == total
+    assert np.array_equal(keep.cpu().numpy(), keep_o) and np.array_equal(cls.cpu().numpy(), cls_o)
+    assert np.array_equal(srois.cpu().numpy(), rois_o)
+    assert np.allclose(reg.cpu().numpy(), reg_o, rtol=0, atol=1e-5)               # logf then /0.2: tolerance 1e-5
+
+
+def test_head_targets_device_sampling_properties(ops):
+    rng = np.random.RandomState(2)
+    G, P = 4, 2000
+    gt = _gt(rng, G)
+    lab = rng.randint(0, 20, G).astype(np.int64)
+    rois = rand_boxes(rng, P, 0.05, 0.5)
+    rois[:100] = np.clip(gt[rng.randint(0, G, 100)] + rng.randn(100, 4).astype(np.float32) * 0.01, 0, 1)
+    npc, nnc = orc.head_target_counts(rois, gt, lab)
+    out1 = ops.head_targets(T(rois), T(gt), T(lab), seed=5, want_keep=True)
+    out2 = ops.head_targets(T(rois), T(gt), T(lab), seed=5, want_keep=True)
+    out3 = ops.head_targets(T(rois), T(gt), T(lab), seed=6, want_keep=True)
+    keep = out1[3].cpu().numpy()
+    assert np.array_equal(keep, out2[3].cpu().numpy()) and not np.array_equal(keep, out3[3].cpu().numpy())
+    assert out1[4].cpu().tolist() == [npc, nnc, 128, 0]
+    n_pos = min(npc, 32)
+    allr = np.concatenate([rois, gt])
+    iou = orc.pairwise_iou(allr, gt, 1e-5)
+    mx, am = iou.max(1), iou.argmax(1)
+    assert len(np.unique(keep)) == 128
+    assert (mx[keep[:n_pos]] >= 0.5).all() and (mx[keep[n_pos:]] < 0.5).all()
+    cls = out1[0].cpu().numpy()
+    assert np.array_equal(cls[:n_pos], lab[am[keep[:n_pos]]] + 1) and (cls[n_pos:] == 0).all()
+    assert np.array_equal(out1[2].cpu().numpy(), allr[keep])
+    e = orc.encode(orc.xy_to_cxcy(gt[am[keep]]), orc.xy_to_cxcy(allr[keep])) / np.array([0.1, 0.1, 0.2, 0.2], np.float32)
+    assert np.allclose(out1[1].cpu().numpy(), e, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ RoIPool
+def test_roi_pool_known_answers(ops):
+    f = np.arange(16, dtype=np.float32).reshape(1, 1, 4, 4)
+    out = ops.roi_pool(T(f), T(np.array([[0, 0, 3, 3]], np.float32)), (2, 2), 1.0)
+    assert out.reshape(-1).cpu().tolist() == [5, 7, 13, 15]
+    out = ops.roi_pool(T(f), T(np.array([[0.5, 0.5, 2.5, 2.5]], np.float32)), (1, 1), 1.0)   # round half away from zero
+    assert out.item() == 15
+    out = ops.roi_pool(T(f), T(np.array([[10, 10, 12, 12]], np.float32)), (2, 2), 1.0)       # outside -> empty bins -> 0
+    assert (out == 0).all()
+
+
+@pytest.mark.parametrize("C,H,W,R", [(512, 37, 62, 128), (512, 37, 62, 300), (3, 9, 11, 5), (64, 50, 50, 17)])
+def test_roi_pool_fwd_bwd_vs_oracle(ops, C, H, W, R):
+    rng = np.random.RandomState(C + R)
+    f = rng.randn(C, H, W).astype(np.float32)
+    rois = rand_boxes(rng, R, 0.02, 0.9) * np.array([W, H, W, H], np.float32)     # reference pre-scales by (fw,fh)
+    rois[0] = [0, 0, W, H]
+    rois[1] = [W * 0.5, H * 0.5, W * 0.5, H * 0.5]
+    out_o, arg_o = orc.roi_pool_fwd(f, rois, 7, 7, 1.0)
+    ft = T(f[None]).requires_grad_(True)
+    out = ops.RoIPool((7, 7), 1.0)(ft, [T(rois)])
+    assert np.array_equal(out.detach().cpu().numpy(), out_o)                      # max-pool values: bit-exact
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    out.backward(T(go))
+    gf_o = orc.roi_pool_bwd(go, arg_o, C, H, W)
+    assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-5, atol=1e-5)      # fp32 sum order differs: 1e-5
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign
+def test_level_map_bit_exact(ops):
+    rng = np.random.RandomState(0)
+    rois = rand_boxes(rng, 5000, 0.005, 0.95) * np.array([1344, 800, 1344, 800], np.float32)
+    sq = np.array([[0, 0, s, s] for s in (50, 111.9, 112, 223.9, 224, 447.9, 448, 895, 896, 2000, 0)], np.float32)
+    rois = np.concatenate([sq, rois])
+    assert np.array_equal(ops.roi_level_map(T(rois)).cpu().numpy(), orc.roi_level_map(rois))
+
+
+def test_ms_roi_align_fwd_bwd_vs_oracle(ops):
+    rng = np.random.RandomState(1)
+    C = 16
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    feats = [rng.randn(C, h, w).astype(np.float32) for h, w in shapes]
+    rois = rand_boxes(rng, 60, 0.02, 0.9) * np.array([672, 400, 672, 400], np.float32)
+    rois[0] = [-20, -10, 100, 90]
+    rois[1] = [600, 350, 700, 420]
+    out_o, lv = orc.ms_roi_align(feats, rois)
+    assert len(set(lv.tolist())) >= 3
+    fts = [T(f[None]).requires_grad_(True) for f in feats]
+    m = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = m({str(i): f for i, f in enumerate(fts)}, [T(rois)], [(672, 400)])
+    assert np.abs(out.detach().cpu().numpy() - out_o).max() < 1e-5               # tolerance 1e-5 (north star 1e-4)
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    out.backward(T(go))
+    for l, f in enumerate(fts):
+        gf_o = orc.roi_align_bwd(go, feats[l].shape, rois, 0.25 / (1 << l), 2, False, lv, l)
+        assert np.allclose(f.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=1e-4)  # atomics: order-nondeterministic
