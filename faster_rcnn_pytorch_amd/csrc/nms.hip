@@ -87,8 +87,9 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict
             const int live = n - b * 64;
             const unsigned long long valid = live >= 64 ? ~0ull : ((1ull << live) - 1ull);
             const unsigned long long rem = removed[b];
-            unsigned long long alive = ~(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
-                                         (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)rem)) & valid;
+            // NB: the readfirstlane/readlane builtins return int: go through unsigned or the low word sign-extends
+            unsigned long long alive = ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
+                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem)) & valid;
             unsigned long long kept = 0ull;
             int cnt = 0;
             const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict
                 const int i = __builtin_ctzll(alive);
                 kept |= 1ull << i;
                 ++cnt;
-                const unsigned long long di = (unsigned long long)__builtin_amdgcn_readlane(dlo, i) |
-                                              ((unsigned long long)__builtin_amdgcn_readlane(dhi, i) << 32);
+                const unsigned long long di = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, i) |
+                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, i) << 32);
                 alive &= ~(di | (1ull << i));
             }
             if ((kept >> lane) & 1ull) {
