@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on its config[1]/[2]: training images/sec of VGG16 Faster R-CNN on
+synthetic 600x1000 frames, batch 1 per GPU, the proposal / RoI-head path on the hand-written HIP kernels.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward (backbone -> RPN -> proposals -> targets -> RoIPool -> head) + loss + backward + SGD on one
+frame per GPU.  Frames and boxes are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+`roofline` describes the dominant hand-written kernel of the hot path, timed live with HIP events on the launch
+stream (libfrcnn_hip's frcnn_prof_* facility) inside the timed region; `cpu_baseline` is the oracle's CPU
+restatement of the same training step (oracle/model_ref.py) on a bounded number of steps.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H, W = 600, 1000                      # BASELINE.json configs[1]
+NUM_CLASSES = 21                      # VOC: 20 + background (models/model.py:141)
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def synth_frame(rank, step):
+    """x ~ randn(1,3,600,1000); G ~ U{1..8}; centres U(.15,.85)^2, sides U(.08,.6); labels U{0..19}."""
+    g = torch.Generator().manual_seed(1000 + rank * 10 ** 6 + step)
+    x = torch.randn(1, 3, H, W, generator=g)
+    G = int(torch.randint(1, 9, (1,), generator=g))
+    c = torch.rand(G, 2, generator=g) * 0.7 + 0.15
+    wh = torch.rand(G, 2, generator=g) * 0.52 + 0.08
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1)
+    labels = torch.randint(0, 20, (G,), generator=g)
+    return x, boxes, labels
+
+
+def algorithmic_bytes(kernel, N, K, P, R, C, fh, fw, G):
+    """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels')."""
+    nblk = (K + 63) // 64
+    return {
+        "proposal_prologue_kernel": 44 * N,                               # reg 16N + cls 8N in, boxes 16N + scores 4N out
+        "topk_rank_kernel": 4 * N,                                        # scores in (partials are workspace traffic)
+        "topk_scatter_kernel": 4 * N + 16 * N + 28 * K,                   # scores + boxes in, idx/score/box out
+        "nms_mask_kernel": 16 * K + 8 * K * nblk // 2,                    # boxes in + upper-triangle mask out
+        "nms_scan_kernel": 16 * K + 8 * P + 16 * P,                       # compulsory: boxes in, keep + rois out
+        "rpn_colmax_kernel": 16 * (N + G),
+        "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
+        "rpn_sample_kernel": 9 * N,
+        "head_targets_kernel": 16 * (P + G) + 44 * R,
+        "roi_pool_fwd_kernel": 4 * C * fh * fw + 16 * R + 8 * R * C * 49,  # features + rois in, out + argmax out
+        "roi_pool_bwd_kernel": 8 * R * C * 49 + 4 * C * fh * fw,           # grad_out + argmax in, grad_feat out
+    }.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
+    ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
+    args = ap.parse_args()
+
+    from faster_rcnn_pytorch_amd import _lib, parallel
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    from faster_rcnn_pytorch_amd.model import FRCNN
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    rank, local_rank, world, device = parallel.init_for_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    torch.backends.cudnn.benchmark = True          # MIOpen: search the convolution algorithms once during warm-up
+
+    torch.manual_seed(0)
+    model = FRCNN(num_classes=NUM_CLASSES, sampling="device", seed=1234 + rank).to(device)
+    net = parallel.wrap_ddp(model, device)
+    crit = FRCNNLoss(None)
+    opt = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)       # main.py:55-60
+
+    frames = []
+    for i in range(args.frames):
+        x, b, l = synth_frame(rank, i)
+        frames.append((x.to(device), b.to(device), l.to(device)))
+    torch.cuda.synchronize()
+
+    def step(i):
+        x, b, l = frames[i % len(frames)]
+        pred, target = net(x, [b], [l])
+        loss = crit(pred, target)[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    dt = parallel.max_over_ranks(dt, device)
+    final_loss = float(loss)
+    kernels = {} if args.no_kernel_events else _lib.prof_report()
+
+    if rank != 0:
+        return
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+    N = (H // 16) * (W // 16) * 9
+    fh, fw = H // 16, W // 16
+    shape = dict(N=N, K=12000, P=2000, R=128, C=512, fh=fh, fw=fw, G=8)
+    per_kernel = {}
+    for name, (ms, n) in kernels.items():
+        us = ms / n * 1e3
+        ab = algorithmic_bytes(name, **shape)
+        per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
+                            "GB_s": round(ab / us * 1e-3, 2) if ab else None}
+    roofline = None
+    if per_kernel:
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
+        d = per_kernel[dom]
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(d["GB_s"] / HBM_PEAK_GBS, 5) if d["GB_s"] else None, "traffic": None,
+                    "avg_launch_us": d["avg_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
+    hot_us = sum(v["avg_us"] for v in per_kernel.values())
+
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(args.cpu_steps, args.lr)
+
+    out = {
+        "metric": "train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)", "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
+                               "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)",
+                   "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * 2000, 1), "kernels": per_kernel},
+        "final_loss": round(final_loss, 4),
+    }
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(steps, lr):
+    """The oracle's CPU restatement of the same training step (kind 'port'), bounded sample."""
+    from oracle import oracle as orc
+    from oracle.model_ref import RefFRCNN, ref_loss
+    orc.build()
+    torch.manual_seed(0)
+    ref = RefFRCNN(NUM_CLASSES)
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            torch.nn.init.zeros_(m.bias)
+    for m in (ref.rpn.inter_layer, ref.rpn.cls_layer, ref.rpn.reg_layer):
+        m.weight.data.normal_(0, 0.01)
+        m.bias.data.zero_()
+    opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    cores = torch.get_num_threads()
+
+    def one(i):
+        x, b, l = synth_frame(0, i)
+        pred, target = ref(x, [b], [l])
+        loss = ref_loss(pred, target)[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    one(0)                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(1 + i)
+    dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d full training steps (fwd+loss+bwd+SGD) of oracle/model_ref.RefFRCNN on the same synthetic 600x1000 "
+                      "frames, torch CPU %d threads + oracle C path, %.1f s" % (steps, cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,70 @@
+"""Detection losses -- mirror of the reference's losses/loss.py:5-85.
+
+Same classes and values (SmoothL1Loss, RPNLoss, FastRCNNLoss, FRCNNLoss), but the reference's
+boolean-mask indexing `pred_reg[target_cls > 0]` (loss.py:33,56), which forces a nonzero() host
+sync on every step, is replaced by the algebraically identical masked sum, so the whole training
+step stays asynchronous.  Plain torch ops: these are a handful of tiny launches next to the path.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class SmoothL1Loss(nn.Module):
+    def __init__(self, beta=1.):
+        super().__init__()
+        self.beta = beta
+
+    def forward(self, pred, target):
+        x = (pred - target).abs()
+        l1 = x - 0.5 * self.beta
+        l2 = 0.5 * x ** 2 / self.beta
+        return torch.where(x >= self.beta, l1, l2)
+
+
+class RPNLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.smooth_l1_loss = SmoothL1Loss(beta=1 / 9)
+        self.rpn_lambda = 10          # defined but unused in the reference too
+
+    def forward(self, pred_cls, pred_reg, target_cls, target_reg):
+        rpn_cls_loss = F.cross_entropy(pred_cls.squeeze(0), target_cls, ignore_index=-1)
+        pos = (target_cls > 0).to(pred_reg.dtype).unsqueeze(-1)
+        reg = self.smooth_l1_loss(pred_reg.squeeze(0), target_reg) * pos
+        rpn_reg_loss = reg.sum() / (target_cls >= 0).sum()
+        return rpn_cls_loss, rpn_reg_loss
+
+
+class FastRCNNLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.smooth_l1_loss = SmoothL1Loss(1)
+
+    def forward(self, pred_cls, pred_reg, target_cls, target_reg):
+        cls_loss = F.cross_entropy(pred_cls.squeeze(0), target_cls)
+        pos = (target_cls > 0).to(pred_reg.dtype).unsqueeze(-1)
+        reg = self.smooth_l1_loss(pred_reg.squeeze(0), target_reg) * pos
+        reg_loss = reg.sum() / (target_cls >= 0).sum()
+        return cls_loss, reg_loss
+
+
+class FRCNNLoss(nn.Module):
+    def __init__(self, opts=None):
+        super().__init__()
+        self.opts = opts
+        self.rpn_loss = RPNLoss()
+        self.fast_rcnn_loss = FastRCNNLoss()
+
+    def forward(self, pred, target):
+        pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg = pred
+        target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg = target
+        rpn_cls_loss, rpn_reg_loss = self.rpn_loss(pred_rpn_cls, pred_rpn_reg, target_rpn_cls, target_rpn_reg)
+        fast_rcnn_cls_loss, fast_rcnn_reg_loss = self.fast_rcnn_loss(pred_fast_rcnn_cls, pred_fast_rcnn_reg,
+                                                                     target_fast_rcnn_cls, target_fast_rcnn_reg)
+        total_loss = rpn_cls_loss + rpn_reg_loss + fast_rcnn_cls_loss + fast_rcnn_reg_loss
+        return total_loss, rpn_cls_loss, rpn_reg_loss, fast_rcnn_cls_loss, fast_rcnn_reg_loss
+
+
+def build_loss(opts=None):
+    return FRCNNLoss(opts)

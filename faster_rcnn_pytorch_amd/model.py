@@ -1,0 +1,281 @@
+"""VGG16 Faster R-CNN -- host-side mirror of the reference's models/model.py (authoritative variant:
+models/model_.py) on top of the HIP hot path.
+
+Same classes, constructor arguments, sub-module names and forward()/predict() signatures as the
+reference (models/model.py:12-402), so train.py:31 / test.py:60 work unchanged:
+    FRCNN(num_classes).forward(x, bbox, label)
+        -> (rpn_cls[1,N,2], rpn_reg[1,N,4], head_cls[R,C], head_reg[R,4]),
+           (tgt_rpn_cls[N] i64, tgt_rpn_reg[N,4], tgt_cls[R] i64, tgt_reg[R,4])
+    FRCNN.predict(x, opts | threshold) -> (bbox[M,4] f32, label[M] i32, score[M] f32)
+
+What changed underneath (each step cites the reference lines it replaces):
+  * anchors: cached in HBM per image shape / regenerated in registers (model.py:310-312 numpy + H2D)
+  * RegionProposal: one enqueue of 5 HIP kernels, fixed-capacity output + device count
+    (model.py:17-58: ~20 launches, 3 host syncs, torchvision nms with a host scan)
+  * target makers: 3 + 1 HIP kernels, sampling by device Philox keys (model.py:127-266: ~45 launches,
+    7-9 host syncs, CPU randperm).  sampling='host' reproduces the reference's RNG stream exactly
+    (torch.randperm on the CPU generator, RPN maker first: SURVEY Q4) at the price of the same syncs.
+  * RoIPool: HIP forward/backward (torchvision.ops.RoIPool, model.py:97,113)
+The backbone, the RPN convolutions and the FC head stay on PyTorch-ROCm (MIOpen / hipBLASLt).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .anchor import FRCNNAnchorMaker
+
+
+def _unwrap(t):
+    """bbox/label calling convention: a list with one tensor (model_.py:130-131,188) or a bare tensor (train.py:18-19)."""
+    return t[0] if isinstance(t, (list, tuple)) else t
+
+
+def normal_init(m, mean, stddev):
+    m.weight.data.normal_(mean, stddev)
+    m.bias.data.zero_()
+
+
+def vgg16_features():
+    """torchvision.models.vgg16().features with identical layer indices (state_dict keys extractor.N.*);
+    random init here: pretrained weights need the network."""
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+    layers, c_in = [], 3
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(c_in, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            c_in = v
+    for m in layers:
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            nn.init.constant_(m.bias, 0)
+    return layers
+
+
+class RegionProposal(nn.Module):
+    """models/model.py:12-58."""
+
+    def __init__(self):
+        super().__init__()
+        self.min_size = 1
+        self.nms_threshold = 0.7
+
+    @staticmethod
+    def top_k(mode):
+        return (6000, 300) if mode == "test" else (12000, 2000)              # model.py:24-28
+
+    def propose(self, cls, reg, anchor, mode, grid=None, want_src=False):
+        """Asynchronous form: (rois [P,4] fixed capacity, count int32[1] on device, src | None)."""
+        pre, post = self.top_k(mode)
+        return ops.region_proposal(reg.detach(), cls.detach(), anchor, self.min_size / 1000, pre, self.nms_threshold, post,
+                                   grid=grid, want_src=want_src)
+
+    def forward(self, cls, reg, anchor, mode):
+        """Reference signature: returns roi_tensor [n,4] (variable length -> one host sync for n)."""
+        rois, cnt, _ = self.propose(cls, reg, anchor, mode)
+        return rois[:int(cnt.item())]
+
+
+class RegionProposalNetwork(nn.Module):
+    """models/model.py:61-84."""
+
+    def __init__(self, in_channels=512, out_channels=512):
+        super().__init__()
+        num_anchors = 9
+        self.inter_layer = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.cls_layer = nn.Conv2d(in_channels, num_anchors * 2, kernel_size=1)
+        self.reg_layer = nn.Conv2d(in_channels, num_anchors * 4, kernel_size=1)
+        normal_init(self.inter_layer, 0, 0.01)
+        normal_init(self.cls_layer, 0, 0.01)
+        normal_init(self.reg_layer, 0, 0.01)
+
+    def forward(self, features):
+        batch_size = features.size(0)
+        x = torch.relu(self.inter_layer(features))
+        pred_cls = self.cls_layer(x)
+        pred_reg = self.reg_layer(x)
+        pred_reg = pred_reg.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, 4)
+        pred_cls = pred_cls.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, 2)
+        return pred_cls, pred_reg
+
+
+class FastRCNNHead(nn.Module):
+    """models/model.py:87-120."""
+
+    def __init__(self, num_classes, roi_size, classifier):
+        super().__init__()
+        self.num_classes = num_classes
+        self.cls_head = nn.Linear(4096, num_classes)
+        self.reg_head = nn.Linear(4096, num_classes * 4)
+        self.roi_pool = ops.RoIPool(output_size=(roi_size, roi_size), spatial_scale=1.)
+        self.classifier = classifier
+        normal_init(self.cls_head, 0, 0.01)
+        normal_init(self.reg_head, 0, 0.001)
+
+    def forward(self, features, roi):
+        f_height, f_width = features.size()[2:]
+        scale = torch.tensor([f_width, f_height, f_width, f_height], dtype=torch.float32, device=roi.device)
+        scaled_roi = roi * scale                                               # model.py:107-109
+        pool = self.roi_pool(features, [scaled_roi])
+        x = pool.view(pool.size(0), -1)
+        x = self.classifier(x)
+        return self.cls_head(x), self.reg_head(x)
+
+
+class _Sampler(object):
+    """Sampling policy shared by the two target makers."""
+
+    def __init__(self, sampling="device", seed=0):
+        if sampling not in ("device", "host"):
+            raise ValueError("sampling must be 'device' (Philox on the GPU, no sync) or 'host' (reference RNG stream)")
+        self.sampling = sampling
+        self.seed = int(seed)
+        self.offset = 0
+
+    def next_offset(self):
+        self.offset += 1
+        return self.offset
+
+
+class FastRcnnTargetMaker(nn.Module):
+    """models/model_.py:123-179."""
+
+    def __init__(self, sampler=None):
+        super().__init__()
+        self.sampler = sampler or _Sampler()
+
+    def forward(self, bbox, label, rois, n_rois=None):
+        bbox = _unwrap(bbox)
+        label = _unwrap(label).to(torch.int64)
+        s = self.sampler
+        if s.sampling == "host":
+            c = ops.head_targets(rois, bbox, label, n_rois=n_rois)[4].cpu().tolist()     # learn the candidate counts
+            perm_pos = torch.randperm(c[0])                                                # model_.py:149
+            perm_neg = torch.randperm(c[1])                                                # model_.py:155
+            cls, reg, srois, _, counts = ops.head_targets(rois, bbox, label, n_rois=n_rois, perm_pos=perm_pos, perm_neg=perm_neg)
+            if counts.cpu().tolist()[2] != 128:
+                raise RuntimeError("FastRcnnTargetMaker: fewer than 128 samples (the reference fails here too, model_.py:340)")
+        else:
+            cls, reg, srois, _, _ = ops.head_targets(rois, bbox, label, n_rois=n_rois, seed=s.seed, offset=s.next_offset())
+        return cls, reg, srois
+
+
+class RPNTargetMaker(nn.Module):
+    """models/model_.py:182-266."""
+
+    def __init__(self, sampler=None):
+        super().__init__()
+        self.sampler = sampler or _Sampler()
+
+    def forward(self, bbox, anchor):
+        bbox = _unwrap(bbox)
+        s = self.sampler
+        if s.sampling == "host":
+            n_pos, n_neg = ops.rpn_targets(anchor, bbox)[2].cpu().tolist()[:2]
+            perm_pos = torch.randperm(n_pos) if n_pos > 128 else None                      # model_.py:225-229
+            perm_neg = torch.randperm(n_neg) if n_neg > 256 - n_pos else None              # model_.py:231-236
+            cls, reg, counts = ops.rpn_targets(anchor, bbox, perm_pos=perm_pos, perm_neg=perm_neg)
+            if counts.cpu().tolist()[2] != 0:
+                raise RuntimeError("RPNTargetMaker: permutation length mismatch")
+        else:
+            cls, reg, _ = ops.rpn_targets(anchor, bbox, seed=s.seed, offset=s.next_offset())
+        return cls, reg
+
+
+class FRCNN(nn.Module):
+    """models/model.py:269-402 (VGG16 Faster R-CNN)."""
+
+    def __init__(self, num_classes=81, pretrained=False, sampling="device", seed=0):
+        super().__init__()
+        if pretrained:
+            raise RuntimeError("pretrained weights need the network (gdown / torchvision hub); load a state_dict instead")
+        self.num_classes = num_classes
+        self.extractor = nn.Sequential(*vgg16_features()[:-1])                 # model.py:279-281: drop the last max-pool
+        self.classifier = nn.Sequential(nn.Linear(in_features=25088, out_features=4096), nn.ReLU(inplace=True),
+                                        nn.Linear(in_features=4096, out_features=4096), nn.ReLU(inplace=True))
+        self.sampler = _Sampler(sampling, seed)
+        self.rpn = RegionProposalNetwork()
+        self.rp = RegionProposal()
+        self.anchor_maker = FRCNNAnchorMaker()
+        self.rpn_target_maker = RPNTargetMaker(self.sampler)
+        self.fast_rcnn_target_maker = FastRcnnTargetMaker(self.sampler)
+        self.fast_rcnn_head = FastRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
+
+    def count_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def forward(self, x, bbox, label):
+        # 1. extract features                                                  model.py:307
+        features = self.extractor(x)
+        # 2. anchors: resident in HBM (targets) / regenerated in registers (proposals)   model.py:310-312
+        hw = x.size()[2:]
+        anchor = self.anchor_maker.device_anchors(hw, x.device)
+        # 3. forward rpn                                                       model.py:315
+        pred_rpn_cls, pred_rpn_reg = self.rpn(features)
+        # 4. propose regions -> fixed-capacity rois + device count             model.py:318
+        rois, n_rois, _ = self.rp.propose(pred_rpn_cls.squeeze(0), pred_rpn_reg.squeeze(0), None, "train",
+                                          grid=self.anchor_maker.grid_desc(hw))
+        # 5. rpn targets                                                       model.py:324
+        target_rpn_cls, target_rpn_reg = self.rpn_target_maker(bbox=bbox, anchor=anchor)
+        # 6. fast rcnn targets                                                 model.py:328
+        target_fast_rcnn_cls, target_fast_rcnn_reg, sample_rois = self.fast_rcnn_target_maker(bbox=bbox, label=label, rois=rois,
+                                                                                              n_rois=n_rois)
+        # 7. fast rcnn head                                                    model.py:335
+        pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.fast_rcnn_head(features, sample_rois)
+        # 8. regression row of the target class                                model.py:340-341
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(128, -1, 4)
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg[torch.arange(0, 128, device=x.device), target_fast_rcnn_cls]
+        return (pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg), \
+               (target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg)
+
+    @torch.no_grad()
+    def predict(self, x, opts):
+        """opts: an object with .thres (model.py:346) or a bare float threshold (model_.py:346)."""
+        threshold = float(getattr(opts, "thres", opts))
+        features = self.extractor(x)
+        hw = x.size()[2:]
+        pred_rpn_cls, pred_rpn_reg = self.rpn(features)
+        rois, n_rois, _ = self.rp.propose(pred_rpn_cls.squeeze(0), pred_rpn_reg.squeeze(0), None, "test",
+                                          grid=self.anchor_maker.grid_desc(hw))
+        rois = rois[:int(n_rois.item())]
+        pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.fast_rcnn_head(features, rois)
+        pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)                    # model.py:369
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4)
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg * torch.tensor([0.1, 0.1, 0.2, 0.2], device=x.device)   # model.py:372
+        rois = rois.reshape(-1, 1, 4).expand_as(pred_fast_rcnn_reg)
+        pred_bbox = ops.decode(pred_fast_rcnn_reg.reshape(-1, 4).contiguous(), ops.xy_to_cxcy(rois.reshape(-1, 4).contiguous()))
+        pred_bbox = ops.cxcy_to_xy(pred_bbox)
+        pred_bbox = pred_bbox.reshape(-1, self.num_classes * 4).clamp(min=0, max=1)
+        return self._suppress(pred_bbox, pred_cls, threshold)
+
+    def _suppress(self, raw_cls_bbox, raw_prob, threshold):
+        """models/model.py:382-402: per-class score mask + nms(0.3), class 0 = background skipped."""
+        bbox, label, score = [], [], []
+        boxes = raw_cls_bbox.reshape((-1, self.num_classes, 4))
+        for l in range(1, self.num_classes):
+            cls_bbox_l = boxes[:, l, :]
+            prob_l = raw_prob[:, l]
+            mask = prob_l > threshold
+            cls_bbox_l = cls_bbox_l[mask].contiguous()
+            prob_l = prob_l[mask].contiguous()
+            keep = ops.nms(cls_bbox_l, prob_l, 0.3)
+            bbox.append(cls_bbox_l[keep].cpu().numpy())
+            label.append((l - 1) * np.ones((len(keep),)))
+            score.append(prob_l[keep].cpu().numpy())
+        bbox = torch.from_numpy(np.concatenate(bbox, axis=0).astype(np.float32))
+        label = torch.from_numpy(np.concatenate(label, axis=0).astype(np.int32))
+        score = torch.from_numpy(np.concatenate(score, axis=0).astype(np.float32))
+        return bbox, label, score
+
+
+def build_model(opts=None, num_classes=21, device=None, **kw):
+    """models/build.py:7-19: construct, move to the device, wrap in DDP when torch.distributed is initialised."""
+    from .parallel import wrap_ddp
+    num_classes = getattr(opts, "num_classes", num_classes) if opts is not None else num_classes
+    model = FRCNN(num_classes=num_classes, **kw)
+    if device is not None:
+        model = model.to(device)
+        model = wrap_ddp(model, torch.device(device))
+    return model

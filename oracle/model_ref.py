@@ -1,0 +1,122 @@
+"""CPU ORACLE of the model-level path (test infrastructure; see oracle/frcnn_oracle.c header).
+
+A torch-CPU + oracle-C restatement of models/model_.py:304-344 (FRCNN.forward, VGG16), used
+  * by tests/ and __graft_entry__.smoke() to check the HIP-backed model stage by stage on identical
+    inputs (the conv/FC layers are plain torch on both sides; the path stages go through oracle.py);
+  * by bench.py's cpu_baseline leg (kind "port"): the whole training step on the host cores.
+It draws torch.randperm from the CPU default generator in the reference's order (RPN maker first,
+model_.py:324 then :328).  Never imported by faster_rcnn_pytorch_amd/.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import oracle as orc
+
+
+def path_forward(features, rpn_cls, rpn_reg, bbox, label, hw, mode="train"):
+    """Steps 2,4,5,6 + the RoIPool of step 7 of models/model_.py:304-344 on numpy inputs.
+    features [C,fh,fw]; rpn_cls [N,2]; rpn_reg [N,4]; bbox [G,4]; label [G]; hw = (H, W)."""
+    H, W = int(hw[0]), int(hw[1])
+    anchor = orc.anchor_grid(H, W)                                             # model_.py:310
+    K, P = (12000, 2000) if mode == "train" else (6000, 300)
+    rois, src = orc.region_proposal(rpn_reg, rpn_cls, anchor, 1 / 1000, K, 0.7, P)   # model_.py:318
+    out = {"anchor": anchor, "rois": rois, "src": src}
+    if mode != "train":
+        return out
+    _, _, (n_pos, n_neg) = orc.rpn_targets(anchor, bbox)                       # model_.py:324
+    pp = torch.randperm(n_pos).numpy() if n_pos > 128 else None
+    pn = torch.randperm(n_neg).numpy() if n_neg > 256 - n_pos else None
+    t_rpn_cls, t_rpn_reg, _ = orc.rpn_targets(anchor, bbox, pp, pn)
+    npc, nnc = orc.head_target_counts(rois, bbox, label)                       # model_.py:328
+    hp = torch.randperm(npc).numpy()
+    hn = torch.randperm(nnc).numpy()
+    t_cls, t_reg, srois, keep = orc.head_targets(rois, bbox, label, hp, hn)
+    fh, fw = features.shape[1:]
+    scaled = srois * np.array([fw, fh, fw, fh], np.float32)                     # model_.py:107-109
+    pool, argmax = orc.roi_pool_fwd(features, scaled, 7, 7, 1.0)               # model_.py:113
+    out.update(t_rpn_cls=t_rpn_cls, t_rpn_reg=t_rpn_reg, t_cls=t_cls, t_reg=t_reg, sample_rois=srois, keep=keep,
+               pool=pool, argmax=argmax, counts=(n_pos, n_neg, npc, nnc))
+    return out
+
+
+class _RefRoIPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois):
+        f = feat.detach().numpy()[0]
+        out, arg = orc.roi_pool_fwd(f, rois.numpy(), 7, 7, 1.0)
+        ctx.arg = arg
+        ctx.shape = f.shape
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, go):
+        C, H, W = ctx.shape
+        return torch.from_numpy(orc.roi_pool_bwd(go.contiguous().numpy(), ctx.arg, C, H, W))[None], None
+
+
+def _vgg16_features():
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+    layers, c = [], 3
+    for v in cfg:
+        if v == "M":
+            layers.append(nn.MaxPool2d(2, 2))
+        else:
+            layers += [nn.Conv2d(c, v, 3, padding=1), nn.ReLU(inplace=True)]
+            c = v
+    return layers
+
+
+class RefFRCNN(nn.Module):
+    """CPU restatement of models/model_.py:269-344 with the same sub-module names, so a state_dict from the
+    HIP-backed model loads directly."""
+
+    def __init__(self, num_classes=21):
+        super().__init__()
+        self.num_classes = num_classes
+        self.extractor = nn.Sequential(*_vgg16_features()[:-1])
+        self.classifier = nn.Sequential(nn.Linear(25088, 4096), nn.ReLU(inplace=True), nn.Linear(4096, 4096), nn.ReLU(inplace=True))
+        self.rpn = nn.Module()
+        self.rpn.inter_layer = nn.Conv2d(512, 512, 3, padding=1)
+        self.rpn.cls_layer = nn.Conv2d(512, 18, 1)
+        self.rpn.reg_layer = nn.Conv2d(512, 36, 1)
+        self.fast_rcnn_head = nn.Module()
+        self.fast_rcnn_head.cls_head = nn.Linear(4096, num_classes)
+        self.fast_rcnn_head.reg_head = nn.Linear(4096, num_classes * 4)
+        self.fast_rcnn_head.classifier = self.classifier
+
+    def forward(self, x, bbox, label):
+        features = self.extractor(x)
+        h = torch.relu(self.rpn.inter_layer(features))
+        pred_cls = self.rpn.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2)
+        pred_reg = self.rpn.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4)
+        bbox = bbox[0] if isinstance(bbox, (list, tuple)) else bbox
+        label = label[0] if isinstance(label, (list, tuple)) else label
+        p = path_forward(features.detach().numpy()[0], pred_cls.detach().numpy()[0], pred_reg.detach().numpy()[0],
+                         bbox.numpy(), label.numpy().astype(np.int64), x.shape[2:])
+        fh, fw = features.shape[2:]
+        scaled = torch.from_numpy(p["sample_rois"] * np.array([fw, fh, fw, fh], np.float32))
+        pool = _RefRoIPool.apply(features, scaled)
+        z = self.classifier(pool.view(pool.size(0), -1))
+        head_cls = self.fast_rcnn_head.cls_head(z)
+        head_reg = self.fast_rcnn_head.reg_head(z).reshape(128, -1, 4)
+        t_cls = torch.from_numpy(p["t_cls"])
+        head_reg = head_reg[torch.arange(128), t_cls]
+        return (pred_cls, pred_reg, head_cls, head_reg), \
+               (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
+
+
+def ref_loss(pred, target):
+    """losses/loss.py:5-85 in torch (CPU), written as the reference writes it (boolean-mask indexing)."""
+    import torch.nn.functional as F
+    rc, rr, hc, hr = pred
+    trc, trr, thc, thr = target
+
+    def sl1(p, t, beta):
+        x = (p - t).abs()
+        return torch.where(x >= beta, x - 0.5 * beta, 0.5 * x ** 2 / beta)
+    l1 = F.cross_entropy(rc.squeeze(0), trc, ignore_index=-1)
+    l2 = sl1(rr.squeeze(0)[trc > 0], trr[trc > 0], 1 / 9).sum() / (trc >= 0).sum()
+    l3 = F.cross_entropy(hc, thc)
+    l4 = sl1(hr[thc > 0], thr[thc > 0], 1.0).sum() / (thc >= 0).sum()
+    return l1 + l2 + l3 + l4, l1, l2, l3, l4

@@ -1,0 +1,110 @@
+"""Model-level parity: the HIP-backed FRCNN (faster_rcnn_pytorch_amd.model) vs the CPU oracle of the same
+path (oracle/model_ref.py) on IDENTICAL stage inputs: the GPU model's own features / RPN outputs are
+copied to the host and pushed through the oracle stages."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def synth(seed, H, W, G):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, 3, H, W, generator=g)
+    c = torch.rand(G, 2, generator=g) * 0.7 + 0.15
+    wh = torch.rand(G, 2, generator=g) * 0.52 + 0.08
+    boxes = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1)
+    labels = torch.randint(0, 20, (G,), generator=g)
+    return x, boxes, labels
+
+
+@pytest.fixture(scope="module")
+def model():
+    from faster_rcnn_pytorch_amd.model import FRCNN
+    torch.manual_seed(0)
+    m = FRCNN(num_classes=21, sampling="host").to(DEV)
+    # make the RPN outputs non-trivial (init is N(0, 0.01): all scores ~0.5)
+    with torch.no_grad():
+        m.rpn.cls_layer.weight.mul_(30)
+        m.rpn.reg_layer.weight.mul_(10)
+    return m
+
+
+@pytest.mark.parametrize("H,W,G,seed", [(600, 1000, 4, 1), (320, 480, 2, 2)])
+def test_forward_matches_oracle_stage_by_stage(model, H, W, G, seed):
+    x, boxes, labels = synth(seed, H, W, G)
+    cap = {}
+    h1 = model.extractor.register_forward_hook(lambda m, i, o: cap.__setitem__("feat", o.detach()))
+    h2 = model.fast_rcnn_head.roi_pool.register_forward_hook(lambda m, i, o: cap.__setitem__("pool", o.detach()))
+    model.train()
+    torch.manual_seed(100 + seed)                         # the CPU generator both sides draw randperm from
+    pred, target = model(x.to(DEV), [boxes.to(DEV)], [labels.to(DEV)])
+    h1.remove()
+    h2.remove()
+    torch.manual_seed(100 + seed)
+    ref = model_ref.path_forward(cap["feat"][0].cpu().numpy(), pred[0][0].detach().cpu().numpy(), pred[1][0].detach().cpu().numpy(),
+                                 boxes.numpy(), labels.numpy().astype(np.int64), (H, W))
+    N = (H // 16) * (W // 16) * 9
+    assert pred[0].shape == (1, N, 2) and pred[1].shape == (1, N, 4) and pred[2].shape == (128, 21) and pred[3].shape == (128, 4)
+    assert target[0].dtype == torch.int64 and target[2].dtype == torch.int64
+    # RPN targets: labels bit-exact, deltas within 1e-6 (logf)
+    assert np.array_equal(target[0].cpu().numpy(), ref["t_rpn_cls"])
+    assert np.abs(target[1].cpu().numpy() - ref["t_rpn_reg"]).max() < 1e-6
+    # head targets (these depend on the proposals, the sort, the NMS and the sampling all being identical)
+    assert np.array_equal(target[2].cpu().numpy(), ref["t_cls"])
+    assert np.abs(target[3].cpu().numpy() - ref["t_reg"]).max() < 1e-5
+    # RoIPool output of the sampled rois: bit-exact
+    assert np.array_equal(cap["pool"].cpu().numpy(), ref["pool"])
+    # head regression rows are those of the target class (model.py:340-341)
+    assert pred[3].shape == (128, 4)
+
+
+def test_loss_and_backward(model):
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    x, boxes, labels = synth(7, 320, 480, 3)
+    model.train()
+    model.zero_grad()
+    pred, target = model(x.to(DEV), boxes.to(DEV), labels.to(DEV))            # bare tensors are accepted too (train.py:18-19)
+    out = FRCNNLoss(None)(pred, target)
+    ref = model_ref.ref_loss([p.detach().cpu() for p in pred], [t.cpu() for t in target])
+    for a, b in zip(out, ref):
+        assert abs(float(a) - float(b)) < 2e-5 * max(1.0, abs(float(b)))
+    out[0].backward()
+    for n, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert model.extractor[0].weight.grad.abs().sum() > 0                     # gradient reaches the first conv through RoIPool bwd
+
+
+def test_device_sampling_forward_is_async_and_valid():
+    from faster_rcnn_pytorch_amd.model import FRCNN
+    torch.manual_seed(1)
+    m = FRCNN(num_classes=21, sampling="device", seed=3).to(DEV)
+    x, boxes, labels = synth(3, 320, 480, 3)
+    pred, target = m(x.to(DEV), [boxes.to(DEV)], [labels.to(DEV)])
+    t_rpn = target[0].cpu().numpy()
+    assert set(np.unique(t_rpn)) <= {-1, 0, 1}
+    assert (t_rpn == 1).sum() <= 128 and (t_rpn >= 0).sum() <= 256 and (t_rpn == 1).sum() >= 1
+    t_cls = target[2].cpu().numpy()
+    assert t_cls.shape == (128,) and (t_cls >= 0).all() and (t_cls <= 20).all() and (t_cls > 0).sum() <= 32
+
+
+def test_predict_api(model):
+    x, _, _ = synth(9, 320, 480, 1)
+    model.eval()
+
+    class O:
+        thres = 0.05
+    bbox, label, score = model.predict(x.to(DEV), O())
+    assert bbox.dtype == torch.float32 and label.dtype == torch.int32 and score.dtype == torch.float32
+    assert bbox.shape[0] == label.shape[0] == score.shape[0] and bbox.shape[1:] == (4,)
+    assert (score > 0.05).all() and (bbox >= 0).all() and (bbox <= 1).all()
+    b, l = bbox.numpy(), label.numpy()
+    for c in np.unique(l):                                                    # per-class NMS(0.3) output is NMS-stable
+        bc = b[l == c]
+        assert list(orc.nms(bc, 0.3)) == list(range(len(bc)))
+    b2, l2, s2 = model.predict(x.to(DEV), 0.05)                               # model_.py signature: bare threshold
+    assert torch.equal(b2, bbox) and torch.equal(l2, label)

@@ -1,0 +1,91 @@
+"""CPU-only tests of the host logic: losses vs the reference's golden values, data-parallel plumbing
+with gloo (world_size 2), sharding."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_loss_matches_reference_golden(golden):
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    g = golden("loss")                                                      # produced by the reference's losses/loss.py
+    t = lambda k: torch.from_numpy(g[k])                                    # noqa: E731
+    out = FRCNNLoss(None)((t("p_rpn_cls"), t("p_rpn_reg"), t("p_head_cls"), t("p_head_reg")),
+                          (t("t_rpn_cls"), t("t_rpn_reg"), t("t_head_cls"), t("t_head_reg")))
+    got = np.array([float(o) for o in out], np.float32)
+    assert np.allclose(got, g["losses"], rtol=2e-6, atol=1e-6)
+
+
+def test_loss_gradient_equals_boolean_mask_form(golden):
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    from oracle.model_ref import ref_loss
+    g = golden("loss")
+    ps = [torch.from_numpy(g[k]).clone().requires_grad_(True) for k in ("p_rpn_cls", "p_rpn_reg", "p_head_cls", "p_head_reg")]
+    ts = [torch.from_numpy(g[k]) for k in ("t_rpn_cls", "t_rpn_reg", "t_head_cls", "t_head_reg")]
+    FRCNNLoss(None)(ps, ts)[0].backward()
+    g1 = [p.grad.clone() for p in ps]
+    for p in ps:
+        p.grad = None
+    ref_loss(ps, ts)[0].backward()
+    for a, p in zip(g1, ps):
+        assert torch.allclose(a, p.grad, atol=1e-7)
+
+
+def test_shard_indices_partition():
+    from faster_rcnn_pytorch_amd.parallel import shard_indices
+    for world in (1, 2, 3, 8):
+        parts = [shard_indices(29, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(29))
+        assert all(p == list(range(r, 29, world)) for r, p in enumerate(parts))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from faster_rcnn_pytorch_amd import parallel
+    r, lr, w, dev = parallel.init_for_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    ddp = parallel.wrap_ddp(model, dev)
+    # each rank sees a different "image" (its shard); after backward the gradients must be the rank-average
+    xs = torch.arange(4 * 8, dtype=torch.float32).reshape(4, 8) / 10
+    mine = parallel.shard_indices(4, r, w)
+    loss = ddp(xs[mine]).pow(2).mean()
+    loss.backward()
+    grad = model[0].weight.grad.clone()
+    t = parallel.max_over_ranks(1.0 + r, dev)
+    s = parallel.sum_over_ranks(1.0 + r, dev)
+    parallel.barrier()
+    q.put((r, grad.numpy(), t, s))
+    dist.destroy_process_group()
+
+
+def test_ddp_gloo_world2_gradient_average_and_timing_rule():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.allclose(res[0][1], res[1][1])                               # all-reduced gradients agree
+    assert res[0][2] == res[1][2] == 2.0 and res[0][3] == res[1][3] == 3.0  # MAX / SUM over ranks
+    # and equal the average of the per-shard gradients computed in one process
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 2))
+    xs = torch.arange(4 * 8, dtype=torch.float32).reshape(4, 8) / 10
+    gs = []
+    for r in range(2):
+        model.zero_grad()
+        model(xs[list(range(r, 4, 2))]).pow(2).mean().backward()
+        gs.append(model[0].weight.grad.clone())
+    assert np.allclose(res[0][1], ((gs[0] + gs[1]) / 2).numpy(), atol=1e-6)
