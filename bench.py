@@ -58,6 +58,9 @@ def algorithmic_bytes(kernel, N, K, P, R, C, fh, fw, G):
     }.get(kernel)
 
 
+T0 = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,9 +68,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
+    ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
     args = ap.parse_args()
 
     from faster_rcnn_pytorch_amd import _lib, parallel
@@ -79,7 +83,11 @@ def main():
     rank, local_rank, world, device = parallel.init_for_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
-    torch.backends.cudnn.benchmark = True          # MIOpen: search the convolution algorithms once during warm-up
+    torch.backends.cudnn.benchmark = bool(args.miopen_search)
+
+    def log(msg):
+        if rank == 0:
+            print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
     torch.manual_seed(0)
     model = FRCNN(num_classes=NUM_CLASSES, sampling="device", seed=1234 + rank).to(device)
@@ -102,9 +110,11 @@ def main():
         opt.step()
         return loss
 
+    log("model + %d frames resident; warm-up" % len(frames))
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
     if not args.no_kernel_events:
         _lib.prof_reset()
         _lib.prof_enable(True)
@@ -119,7 +129,8 @@ def main():
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     dt = parallel.max_over_ranks(dt, device)
-    final_loss = float(loss)
+    log("timed region: %d steps in %.3f s" % (args.steps, dt))
+    final_loss = float(loss.detach())
     kernels = {} if args.no_kernel_events else _lib.prof_report()
 
     if rank != 0:
@@ -178,7 +189,14 @@ def cpu_baseline(steps, lr):
         m.weight.data.normal_(0, 0.01)
         m.bias.data.zero_()
     opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
-    cores = torch.get_num_threads()
+    # the GPU box gives one GPU's share of the host: 16 cores; more threads than that oversubscribes the cgroup
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))
+    torch.set_num_threads(cores)
+    print("[bench] cpu baseline on %d threads (affinity %d, cpu_count %s)" % (cores, avail, os.cpu_count()), file=sys.stderr, flush=True)
 
     def one(i):
         x, b, l = synth_frame(0, i)
@@ -188,9 +206,11 @@ def cpu_baseline(steps, lr):
         loss.backward()
         opt.step()
     one(0)                                   # warm-up (allocator, thread pool)
+    print("[bench] cpu baseline warm-up step done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for i in range(steps):
         one(1 + i)
+        print("[bench] cpu baseline step %d done (%.1f s)" % (i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     return {"value": round(steps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d full training steps (fwd+loss+bwd+SGD) of oracle/model_ref.RefFRCNN on the same synthetic 600x1000 "
