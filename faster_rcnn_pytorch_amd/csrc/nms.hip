@@ -1,42 +1,87 @@
 // nms.hip -- torchvision.ops.nms as the reference calls it (models/model.py:53,394), gfx950.
 //
 // Two kernels, no host round trip (torchvision copies the 18 MB mask to the host and scans there):
+//
 //  nms_mask_kernel : chip-wide.  Upper-triangular 64x64 tiles of the suppression matrix; one wave per
-//      tile, lane = row box, the 64 column boxes arrive through the scalar path (wave-uniform
-//      addresses), each lane builds one uint64 word with 64 IoU tests.  The decision
-//      inter/(a_i+a_j-inter) > thr is taken WITHOUT the IEEE division on the fast path: if inter is
-//      outside a 2^-20 relative band around thr*union the comparison is already decided; only inside
-//      the band is the exact division evaluated, so results are bit-identical to the oracle.
-//  nms_scan_kernel : one 1024-thread workgroup.  Wave 0 resolves each 64-box block with scalar bit
-//      tricks (s_ff1 + v_readlane on the diagonal words), then all 16 waves OR the mask rows of the
-//      boxes just kept into an LDS-resident `removed` bit vector (ds_or_b64).  Emits the first post_k
-//      kept positions, their boxes and the count; stops as soon as post_k boxes are kept.
+//      tile, lane = row box.  The wave stages its 64 column boxes (+ areas) in LDS with one coalesced
+//      load and reads them back as wave-uniform (broadcast) ds_read_b128; each lane builds one uint64
+//      word with 64 IoU tests.  inter/(a_i+a_j-inter) > thr is decided WITHOUT the IEEE division on the
+//      fast path: if inter is outside a 2^-20 relative band around thr*union the comparison is already
+//      decided; only inside the band is the exact division evaluated, so results are bit-identical to
+//      the oracle.  Boxes must be NaN-free (v_max/v_min drop NaNs where std::max would keep one).
+//
+//  nms_scan_fast_kernel (K <= 12288) : one 1024-thread workgroup, software-pipelined so that the
+//      sequential resolver never waits for global memory:
+//        wave 0  resolver: per 64-box block, scalar loop (s_ff1 + v_readlane) over the surviving rows;
+//                the same loop ORs the rows' words for the NEXT THREE blocks (near words), so the
+//                dependency block b -> b+1..b+3 never leaves registers / LDS.
+//        wave 1  prefetcher: streams each block's diagonal word + 3 near words (32 contiguous bytes
+//                per row) into an LDS ring four blocks ahead of the resolver; loads stay in flight
+//                across two barriers.
+//        waves 2-15 helpers: for the rows kept in block c they fetch the FAR words (>= c+4) from the
+//                row-major mask and ds_or them into the LDS-resident `removed` vector; the loads are
+//                issued one iteration after the block resolves and applied two iterations later, so
+//                their latency is hidden behind the resolver.
+//      One s_barrier per block.  Emits the first post_k kept positions, their boxes, their source
+//      indices and the count; stops as soon as post_k boxes are kept.
+//  nms_scan_kernel : the simple unpipelined form, used for K > 12288.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 
 #define NMS_MAX_BLOCKS 4096            // K <= 262144
+#define NMS_FAST_MAX_BLOCKS 192        // pipelined scan: 3 far words per lane
+#define NMS_WS_PAD 256                 // the prefetcher reads 3 words past a row's last word
 
-__device__ __forceinline__ bool nms_suppress(float4 a, float area_a, float4 b, float area_b, float thr)
+typedef unsigned long long u64;
+
+// v_max_f32 / v_min_f32 without LLVM's sNaN-canonicalising v_max(x,x) in front of every operand
+__device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// exact form: torchvision's expression, IEEE division
+__device__ __forceinline__ bool nms_suppress_exact(float4 a, float area_a, float4 b, float area_b, float thr)
 {
-    const float xx1 = a.x > b.x ? a.x : b.x;
-    const float yy1 = a.y > b.y ? a.y : b.y;
-    const float xx2 = a.z < b.z ? a.z : b.z;
-    const float yy2 = a.w < b.w ? a.w : b.w;
-    float w = xx2 - xx1; if (!(w > 0.0f)) w = 0.0f;
-    float h = yy2 - yy1; if (!(h > 0.0f)) h = 0.0f;
+    const float w = vmaxf(vminf(a.z, b.z) - vmaxf(a.x, b.x), 0.0f);
+    const float h = vmaxf(vminf(a.w, b.w) - vmaxf(a.y, b.y), 0.0f);
     const float inter = w * h;
-    const float uni = area_a + area_b - inter;
-    // fast path: inter vs thr*uni with a guard band (relative 2^-20 >> the 2^-23 of two roundings)
-    const float p = thr * uni;
-    const float d = inter - p;
-    const float band = __builtin_fabsf(p) * 9.5367431640625e-07f;
-    if (uni > 0.0f && __builtin_fabsf(d) > band) return d > 0.0f;
-    return inter / uni > thr;          // exact IEEE division (also the NaN / inf / zero-area cases)
+    return inter / (area_a + area_b - inter) > thr;
+}
+
+// 32 columns [j0, j0+32) of one tile.  Returns the per-lane result word; *unsure gets the lanes (as a wave
+// mask) for which at least one column fell inside the guard band (or had a non-positive union) and must be
+// re-evaluated with the exact division.  CHECK = diagonal or tail tile (col > row, col < n tests needed).
+template <bool CHECK>
+__device__ __forceinline__ unsigned mask_half(float4 a, float area_a, const float4 *__restrict__ sb, const float *__restrict__ sa,
+                                              float thr, int c0, int row, int n, u64 *unsure)
+{
+    unsigned word = 0u;
+    u64 uns = 0ull;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const float4 b = sb[j];                                  // wave-uniform address: LDS broadcast
+        const float w = vmaxf(vminf(a.z, b.z) - vmaxf(a.x, b.x), 0.0f);
+        const float h = vmaxf(vminf(a.w, b.w) - vmaxf(a.y, b.y), 0.0f);
+        const float inter = w * h;
+        const float uni = area_a + sa[j] - inter;
+        // inter/uni > thr  <=>  inter > thr*uni, decided safely when |inter - thr*uni| exceeds a 2^-20
+        // relative band (>> the 2^-23 of the two roundings); everything else goes to the exact path
+        const float p = thr * uni;
+        const float d = inter - p;
+        const bool sure = (__builtin_fabsf(d) > __builtin_fabsf(p) * 9.5367431640625e-07f) && (uni > 0.0f);
+        uns |= __ballot(!sure);
+        bool s = d > 0.0f;
+        if (CHECK) s = s && (c0 + j > row) && (c0 + j < n);
+        word |= s ? (1u << j) : 0u;
+    }
+    *unsure |= uns;
+    return word;
 }
 
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
-                                                       float thr, int nblk, unsigned long long *__restrict__ mask)
+                                                       float thr, int nblk, u64 *__restrict__ mask, u64 *__restrict__ rowmask)
 {
+    __shared__ float4 s_box[4][64];
+    __shared__ float s_area[4][64];
     const int n = n_dev ? min(*n_dev, K) : K;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -47,58 +92,257 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
     const int row = rb * 64 + lane;
     const float4 a = boxes[min(row, K - 1)];
     const float area_a = (a.z - a.x) * (a.w - a.y);
-    unsigned long long bits = 0ull;
+    u64 bits = 0ull;
     const int c0 = cb * 64;
     if (c0 < n) {
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) {
-            const int col = c0 + j;                             // wave-uniform
-            const float4 b = boxes[min(col, K - 1)];            // scalar load
-            const float area_b = (b.z - b.x) * (b.w - b.y);
-            const bool s = nms_suppress(a, area_a, b, area_b, thr) && col > row && col < n;
-            bits |= s ? (1ull << j) : 0ull;
+        const float4 cbx = boxes[min(c0 + lane, K - 1)];        // coalesced 1 KB
+        s_box[wave][lane] = cbx;
+        s_area[wave][lane] = (cbx.z - cbx.x) * (cbx.w - cbx.y);
+        __builtin_amdgcn_wave_barrier();                        // same-wave LDS RAW: ds ops of one wave complete in order
+        u64 unsure = 0ull;
+        unsigned lo, hi;
+        if (cb == rb || c0 + 64 > n) {                          // diagonal / tail tile
+            lo = mask_half<true>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure);
+            hi = mask_half<true>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure);
+        } else {
+            lo = mask_half<false>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure);
+            hi = mask_half<false>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure);
+        }
+        bits = ((u64)hi << 32) | lo;
+        if (unsure != 0ull) {                                   // rare: redo the affected rows with the IEEE division
+            if ((unsure >> lane) & 1ull) {
+                bits = 0ull;
+                for (int j = 0; j < 64; ++j) {
+                    const bool s = nms_suppress_exact(a, area_a, s_box[wave][j], s_area[wave][j], thr) && (c0 + j > row) && (c0 + j < n);
+                    bits |= s ? (1ull << j) : 0ull;
+                }
+            }
         }
     }
     if (row < K) mask[(size_t)row * nblk + cb] = bits;
+    // which rows of this tile have any bit: lets the scan skip the (typically all-zero) far words of kept rows
+    const u64 any = __ballot(bits != 0ull && row < K);
+    if (lane == 0) rowmask[(size_t)rb * nblk + cb] = any;
 }
 
+// ------------------------------------------------------------------------------------------------
+// pipelined scan (K <= 12288)
+// ------------------------------------------------------------------------------------------------
+#define RL(v, i) ((unsigned)__builtin_amdgcn_readlane((v), (i)))          // builtin returns int: cast before widening
+#define RFL(v) ((unsigned)__builtin_amdgcn_readfirstlane((v)))
+
+#define SCAN_RING 8
+#define SCAN_PF 4
+#define SCAN_HELPERS 14
+#define SCAN_Q 4                       // far-word loads kept in flight per lane and 64-word chunk
+
+struct NearWords { u64 w[4]; u64 rm[3]; };   // diag, +1, +2, +3 words of my row; row-mask words lane, lane+64, lane+128
+
+__device__ __forceinline__ NearWords load_near(const u64 *__restrict__ mask, const u64 *__restrict__ rowmask, int nblk, int K, int blk, int lane)
+{
+    // 32 contiguous bytes of row (64*blk + lane): words blk .. blk+3 (may run past the row end: padded workspace)
+    const int row = min(blk * 64 + lane, K - 1);
+    const u64 *p = mask + (size_t)row * nblk + blk;
+    NearWords r;
+    r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; r.w[3] = p[3];
+    const u64 *q = rowmask + (size_t)blk * nblk;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) r.rm[m] = (lane + 64 * m < nblk) ? q[lane + 64 * m] : 0ull;
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
+                                                             int nblk, const u64 *__restrict__ mask, const u64 *__restrict__ rowmask,
+                                                             int post_k, int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
+                                                             const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
+                                                             int32_t *__restrict__ out_count)
+{
+    __shared__ u64 removed[NMS_FAST_MAX_BLOCKS + 4];
+    __shared__ u64 ring[SCAN_RING][4][64];
+    __shared__ u64 rm_ring[SCAN_RING][NMS_FAST_MAX_BLOCKS];
+    __shared__ u64 s_kept[4];
+    __shared__ int s_total[2];       // by block parity: a fast wave may already be one iteration ahead
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = n_dev ? min(*n_dev, K) : K;
+    const int nb = (n + 63) >> 6;
+
+    for (int w = tid; w < NMS_FAST_MAX_BLOCKS + 4; w += 1024) removed[w] = 0ull;
+    if (tid < 4) s_kept[tid] = 0ull;
+    if (tid < 2) s_total[tid] = 0;
+    // prefetcher state: two generations of in-flight near words + row masks
+    NearWords pf0 = {}, pf1 = {};
+    if (wave == 1) {
+        for (int blk = 0; blk < SCAN_PF && blk < nb; ++blk) {
+            const NearWords t = load_near(mask, rowmask, nblk, K, blk, lane);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) ring[blk % SCAN_RING][d][lane] = t.w[d];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rm_ring[blk % SCAN_RING][lane + 64 * m] = t.rm[m];
+        }
+        if (SCAN_PF + 0 < nb) pf0 = load_near(mask, rowmask, nblk, K, SCAN_PF + 0, lane);
+        if (SCAN_PF + 1 < nb) pf1 = load_near(mask, rowmask, nblk, K, SCAN_PF + 1, lane);
+    }
+    // helper state: the far words of ONE block (c = pend_c) in flight; a helper owns every 14th block
+    u64 pend[3][SCAN_Q];
+    int pend_c = -1;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q = 0; q < SCAN_Q; ++q) pend[m][q] = 0ull;
+    __syncthreads();
+
+    int total = 0;
+
+#define SCAN_ITER(B, PFSET)                                                                                          \
+    {                                                                                                                \
+        const int b = (B);                                                                                           \
+        if (wave == 0) {                                                                                             \
+            const int slot = b % SCAN_RING;                                                                          \
+            const u64 d0 = ring[slot][0][lane], u1 = ring[slot][1][lane], u2 = ring[slot][2][lane], u3 = ring[slot][3][lane]; \
+            const unsigned d0l = (unsigned)d0, d0h = (unsigned)(d0 >> 32);                                           \
+            const unsigned u1l = (unsigned)u1, u1h = (unsigned)(u1 >> 32);                                           \
+            const unsigned u2l = (unsigned)u2, u2h = (unsigned)(u2 >> 32);                                           \
+            const unsigned u3l = (unsigned)u3, u3h = (unsigned)(u3 >> 32);                                           \
+            const int live = n - b * 64;                                                                             \
+            const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);                                   \
+            const u64 rem = removed[b];                                                                              \
+            u64 alive = ~(((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem)) & valid;               \
+            /* in-block resolution: only rows that can suppress a live row are visited */                              \
+            u64 act = __ballot((d0 & alive) != 0ull) & alive;                                                        \
+            while (act != 0ull) {                                                                                    \
+                const int i = __builtin_ctzll(act);                                                                  \
+                act &= act - 1ull;                                                                                   \
+                if ((alive >> i) & 1ull) alive &= ~((u64)RL(d0l, i) | ((u64)RL(d0h, i) << 32));                      \
+            }                                                                                                        \
+            u64 kept = alive;                                                                                        \
+            int cnt = __builtin_popcountll(kept);                                                                    \
+            if (total + cnt > post_k) {                     /* keep only the first post_k - total survivors */       \
+                cnt = post_k - total;                                                                                \
+                u64 t = kept;                                                                                        \
+                for (int q = 0; q < cnt; ++q) t &= t - 1ull;                                                         \
+                kept &= ~t;                                                                                          \
+            }                                                                                                        \
+            /* near words: OR over the kept rows that have any bit set there */                                      \
+            const bool mine = (kept >> lane) & 1ull;                                                                 \
+            u64 r1 = 0ull, r2 = 0ull, r3 = 0ull;                                                                     \
+            for (u64 any = __ballot(mine && u1 != 0ull); any != 0ull; any &= any - 1ull) {                           \
+                const int i = __builtin_ctzll(any);                                                                  \
+                r1 |= (u64)RL(u1l, i) | ((u64)RL(u1h, i) << 32);                                                     \
+            }                                                                                                        \
+            for (u64 any = __ballot(mine && u2 != 0ull); any != 0ull; any &= any - 1ull) {                           \
+                const int i = __builtin_ctzll(any);                                                                  \
+                r2 |= (u64)RL(u2l, i) | ((u64)RL(u2h, i) << 32);                                                     \
+            }                                                                                                        \
+            for (u64 any = __ballot(mine && u3 != 0ull); any != 0ull; any &= any - 1ull) {                           \
+                const int i = __builtin_ctzll(any);                                                                  \
+                r3 |= (u64)RL(u3l, i) | ((u64)RL(u3h, i) << 32);                                                     \
+            }                                                                                                        \
+            const int row = b * 64 + lane;                                                                           \
+            if (mine) {                                                                                              \
+                const int pos = total + __builtin_popcountll(kept & ((1ull << lane) - 1ull));                        \
+                out_keep[pos] = row;                                                                                 \
+                if (out_rois) out_rois[pos] = boxes[row];                                                            \
+                if (out_src) out_src[pos] = src_map ? src_map[row] : (int64_t)row;                                   \
+            }                                                                                                        \
+            if (lane == 0) {                                                                                         \
+                s_kept[b & 3] = kept;                                                                                \
+                s_total[b & 1] = total + cnt;                                                                        \
+                if (r1 && b + 1 < nb) atomicOr(&removed[b + 1], r1);                                                 \
+                if (r2 && b + 2 < nb) atomicOr(&removed[b + 2], r2);                                                 \
+                if (r3 && b + 3 < nb) atomicOr(&removed[b + 3], r3);                                                 \
+            }                                                                                                        \
+        } else if (wave == 1) {                                                                                      \
+            /* rings <- block b+PF (issued two iterations ago); re-issue this generation for block b+PF+2 */         \
+            if (b + SCAN_PF < nb) {                                                                                  \
+                const int slot = (b + SCAN_PF) % SCAN_RING;                                                          \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) ring[slot][d][lane] = PFSET.w[d];                      \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = PFSET.rm[m];            \
+            }                                                                                                        \
+            if (b + SCAN_PF + 2 < nb) PFSET = load_near(mask, rowmask, nblk, K, b + SCAN_PF + 2, lane);              \
+        } else {                                                                                                     \
+            /* far words (>= c+4) of the rows kept in block c: fetched at iteration c+1, applied at c+3 */           \
+            if (pend_c >= 0 && b == pend_c + 3) {                                                                    \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                      \
+                    u64 acc = 0ull;                                                                                  \
+                    _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q) { acc |= pend[m][q]; pend[m][q] = 0ull; }     \
+                    if (acc) atomicOr(&removed[lane + 64 * m], acc);                                                 \
+                }                                                                                                    \
+                pend_c = -1;                                                                                         \
+            }                                                                                                        \
+            const int c = b - 1;                                                                                     \
+            if (c >= 0 && (c % SCAN_HELPERS) == wave - 2 && c + 4 < nb) {                                            \
+                const u64 kc = s_kept[c & 3];                                                                        \
+                const size_t rb0 = (size_t)c * 64;                                                                   \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                      \
+                    const int w = lane + 64 * m;                                                                     \
+                    u64 need = (w >= c + 4 && w < nb) ? (rm_ring[c % SCAN_RING][w] & kc) : 0ull;                     \
+                    _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q)                                               \
+                        if (need != 0ull) {                                                                          \
+                            const int i = __builtin_ctzll(need);                                                     \
+                            need &= need - 1ull;                                                                     \
+                            pend[m][q] = mask[(rb0 + i) * nblk + w];                                                 \
+                        }                                                                                            \
+                    while (need != 0ull) {                  /* rare: more than SCAN_Q suppressing rows for a word */ \
+                        const int i = __builtin_ctzll(need);                                                         \
+                        need &= need - 1ull;                                                                         \
+                        pend[m][0] |= mask[(rb0 + i) * nblk + w];                                                    \
+                    }                                                                                                \
+                }                                                                                                    \
+                pend_c = c;                                                                                          \
+            }                                                                                                        \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        total = s_total[b & 1];                                                                                      \
+    }
+
+    for (int b0 = 0; b0 < nb && total < post_k; b0 += 2) {
+        SCAN_ITER(b0, pf0)
+        if (b0 + 1 >= nb || total >= post_k) break;
+        SCAN_ITER(b0 + 1, pf1)
+    }
+#undef SCAN_ITER
+    if (tid == 0) *out_count = total < post_k ? total : post_k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// simple scan (any K up to 262144): two memory round trips per block
+// ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
-                                                        int nblk, const unsigned long long *__restrict__ mask, int post_k,
+                                                        int nblk, const u64 *__restrict__ mask, int post_k,
                                                         int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
                                                         const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
                                                         int32_t *__restrict__ out_count)
 {
-    extern __shared__ unsigned long long removed[];             // [nblk]
-    __shared__ unsigned long long s_kept;
-    __shared__ int s_total;
-    __shared__ int s_rows[64];
+    extern __shared__ u64 removed_dyn[];             // [nblk]
+    __shared__ u64 s_kept1;
+    __shared__ int s_total1;
+    __shared__ int s_rows1[64];
+    u64 *removed = removed_dyn;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int n = n_dev ? min(*n_dev, K) : K;
     const int nb = (n + 63) >> 6;
     for (int w = tid; w < nb; w += 1024) removed[w] = 0ull;
-    if (tid == 0) { s_total = 0; s_kept = 0ull; }
+    if (tid == 0) { s_total1 = 0; s_kept1 = 0ull; }
     __syncthreads();
     int total = 0;
     for (int b = 0; b < nb; ++b) {
         if (wave == 0) {
             const int row = b * 64 + lane;
-            const unsigned long long d = row < n ? mask[(size_t)row * nblk + b] : 0ull;   // diagonal word of my row
+            const u64 d = row < n ? mask[(size_t)row * nblk + b] : 0ull;   // diagonal word of my row
             const int live = n - b * 64;
-            const unsigned long long valid = live >= 64 ? ~0ull : ((1ull << live) - 1ull);
-            const unsigned long long rem = removed[b];
-            // NB: the readfirstlane/readlane builtins return int: go through unsigned or the low word sign-extends
-            unsigned long long alive = ~(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(rem >> 32)) << 32) |
-                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)rem)) & valid;
-            unsigned long long kept = 0ull;
+            const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);
+            const u64 rem = removed[b];
+            u64 alive = ~(((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem)) & valid;
+            u64 kept = 0ull;
             int cnt = 0;
             const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
-            while (alive != 0ull && total + cnt < post_k) {                                // wave-uniform loop
+            while (alive != 0ull && total + cnt < post_k) {                // wave-uniform loop
                 const int i = __builtin_ctzll(alive);
                 kept |= 1ull << i;
                 ++cnt;
-                const unsigned long long di = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(dlo, i) |
-                                              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(dhi, i) << 32);
+                const u64 di = (u64)RL(dlo, i) | ((u64)RL(dhi, i) << 32);
                 alive &= ~(di | (1ull << i));
             }
             if ((kept >> lane) & 1ull) {
@@ -106,20 +350,20 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict
                 out_keep[pos] = row;
                 if (out_rois) out_rois[pos] = boxes[row];
                 if (out_src) out_src[pos] = src_map ? src_map[row] : (int64_t)row;
-                s_rows[pos - total] = lane;
+                s_rows1[pos - total] = lane;
             }
-            if (lane == 0) { s_kept = kept; s_total = total + cnt; }
+            if (lane == 0) { s_kept1 = kept; s_total1 = total + cnt; }
         }
         __syncthreads();
-        const unsigned long long kept = s_kept;
-        total = s_total;
+        const u64 kept = s_kept1;
+        total = s_total1;
         if (total >= post_k) break;
         const int nrows = __builtin_popcountll(kept);
         if (nrows > 0 && b + 1 < nb) {
             for (int ri = wave; ri < nrows; ri += 16) {
-                const size_t rowbase = (size_t)(b * 64 + s_rows[ri]) * nblk;
+                const size_t rowbase = (size_t)(b * 64 + s_rows1[ri]) * nblk;
                 for (int w = b + 1 + lane; w < nb; w += 64) {
-                    const unsigned long long v = mask[rowbase + w];
+                    const u64 v = mask[rowbase + w];
                     if (v) atomicOr(&removed[w], v);
                 }
             }
@@ -132,7 +376,7 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict
 size_t frcnn_ws_nms(int64_t K)
 {
     const int64_t nblk = (K + 63) / 64;
-    return align_up((size_t)K * (size_t)nblk * 8, 256);
+    return align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256) + align_up((size_t)nblk * (size_t)nblk * 8, 256);
 }
 
 int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
@@ -143,13 +387,20 @@ int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, 
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_nms(K));
     const int nblk = (int)((K + 63) / 64);
     if (nblk > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
-    unsigned long long *mask = (unsigned long long *)ws;
+    u64 *mask = (u64 *)ws;
+    u64 *rowmask = (u64 *)((char *)ws + align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256));
     FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K,
-                 thr, nblk, mask);
+                 thr, nblk, mask, rowmask);
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
-    FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_kernel, dim3(1), dim3(1024), (size_t)nblk * 8, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk,
-                 mask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
-    FRCNN_CHECK_LAUNCH("nms_scan_kernel");
+    if (nblk <= NMS_FAST_MAX_BLOCKS) {
+        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_fast_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
+                     rowmask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
+        FRCNN_CHECK_LAUNCH("nms_scan_fast_kernel");
+    } else {
+        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_kernel, dim3(1), dim3(1024), (size_t)nblk * 8, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk,
+                     mask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
+        FRCNN_CHECK_LAUNCH("nms_scan_kernel");
+    }
     return FRCNN_OK;
 }
 
