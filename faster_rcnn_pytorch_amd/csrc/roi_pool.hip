@@ -12,6 +12,16 @@
 #include "frcnn_internal.h"
 #include <cfloat>
 
+#ifndef ROI_FWD_CB
+#define ROI_FWD_CB 1
+#endif
+#ifndef ROI_FWD_RB
+#define ROI_FWD_RB 32
+#endif
+#ifndef ROI_BWD_CB
+#define ROI_BWD_CB 1
+#endif
+
 struct RoiBins { int sw, sh; float bw, bh; };
 
 __device__ __forceinline__ RoiBins roi_bins(float4 b, float scale, int PH, int PW)
@@ -88,6 +98,130 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_atomic_kernel(const float *_
     atomicAdd(grad_feat + (size_t)c * HW + a, grad_out[e]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-staged forward (the shape the reference runs: PHxPW = 7x7, plane <= 64 KB / CB):
+// grid (ceil(C/CB), ceil(R/RB)); a block stages CB adjacent channel planes in LDS with one coalesced
+// pass, builds the bin-boundary table of its RB RoIs once, then every lane produces outputs
+// (roi, channel, bin) with the window scan served from LDS.  For one RoI the CB*49 outputs of the
+// block are contiguous in memory (784 B at CB = 4): the stores stay coalesced.
+// ------------------------------------------------------------------------------------------------
+template <int CB, int PH, int PW>
+__global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__restrict__ feat, int C, int H, int W,
+                                                               const float4 *__restrict__ rois, int R, int RB, float scale,
+                                                               float *__restrict__ out, int32_t *__restrict__ argmax)
+{
+    extern __shared__ float smem[];
+    const int HW = H * W;
+    float *planes = smem;                                        // [CB][HW]
+    int *tab = (int *)(smem + CB * HW);                          // [RB][2*PH + 2*PW]: hs[PH] he[PH] ws[PW] we[PW]
+    constexpr int BINS = PH * PW;
+    constexpr int TW = 2 * PH + 2 * PW;
+    const int c0 = blockIdx.x * CB;
+    const int r0 = blockIdx.y * RB;
+    const int nr = min(RB, R - r0);
+    const int nch = min(CB, C - c0);
+    const float *src = feat + (size_t)c0 * HW;
+    {   // stage the planes: 8 independent loads in flight per lane (a plain copy loop waits for every load in turn)
+        const int n_stage = nch * HW;
+        for (int base = 0; base < n_stage; base += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                v[u] = src[min(i, n_stage - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < n_stage) planes[i] = v[u];
+            }
+        }
+    }
+    for (int t = threadIdx.x; t < nr * (PH + PW); t += 256) {
+        const int rl = t / (PH + PW), k = t - rl * (PH + PW);
+        const RoiBins g = roi_bins(rois[r0 + rl], scale, PH, PW);
+        int *row = tab + rl * TW;
+        if (k < PH) {
+            const int hs = (int)floorf((float)k * g.bh) + g.sh, he = (int)ceilf((float)(k + 1) * g.bh) + g.sh;
+            row[k] = min(max(hs, 0), H);
+            row[PH + k] = min(max(he, 0), H);
+        } else {
+            const int q = k - PH;
+            const int ws = (int)floorf((float)q * g.bw) + g.sw, we = (int)ceilf((float)(q + 1) * g.bw) + g.sw;
+            row[2 * PH + q] = min(max(ws, 0), W);
+            row[2 * PH + PW + q] = min(max(we, 0), W);
+        }
+    }
+    __syncthreads();
+    const int per_roi = nch * BINS;
+    const int total = nr * per_roi;
+    for (int o = threadIdx.x; o < total; o += 256) {
+        const int rl = o / per_roi, rem = o - rl * per_roi;
+        const int ch = rem / BINS, p = rem - ch * BINS;
+        const int ph = p / PW, pw = p - ph * PW;
+        const int *row = tab + rl * TW;
+        const int hs = row[ph], he = row[PH + ph], ws = row[2 * PH + pw], we = row[2 * PH + PW + pw];
+        const bool empty = (he <= hs) || (we <= ws);
+        float mv = empty ? 0.0f : -FLT_MAX;
+        int mi = -1;
+        const float *pl = planes + ch * HW;
+        for (int h = hs; h < he; ++h) {
+            const float *prow = pl + h * W;
+            for (int w = ws; w < we; w += 4) {                   // 4 independent LDS reads in flight; order of the
+                const int w1 = min(w + 1, we - 1), w2 = min(w + 2, we - 1), w3 = min(w + 3, we - 1);   // compares unchanged
+                const float v0 = prow[w], v1 = prow[w1], v2 = prow[w2], v3 = prow[w3];
+                if (v0 > mv) { mv = v0; mi = h * W + w; }
+                if (v1 > mv) { mv = v1; mi = h * W + w1; }       // clamped duplicates can never be > the running max
+                if (v2 > mv) { mv = v2; mi = h * W + w2; }
+                if (v3 > mv) { mv = v3; mi = h * W + w3; }
+            }
+        }
+        const size_t e = ((size_t)(r0 + rl) * C + c0 + ch) * BINS + p;
+        out[e] = mv;
+        argmax[e] = mi;
+    }
+}
+
+// LDS-accumulating backward, CB adjacent channels per block (contiguous CB*bins runs of grad_out / argmax)
+template <int CB>
+__global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
+                                                               int R, int C, int HW, int bins, float *__restrict__ grad_feat)
+{
+    extern __shared__ float plane[];                 // [CB][HW]
+    const int c0 = blockIdx.x * CB;
+    const int nch = min(CB, C - c0);
+    for (int i = threadIdx.x; i < nch * HW; i += 512) plane[i] = 0.0f;
+    __syncthreads();
+    // thread -> (roi slot, position inside the block's contiguous CB*bins run); U independent RoIs in flight per
+    // thread so that 2*U global loads are outstanding before the first ds_add (the loads must not be sunk into
+    // the `argmax >= 0` branch: that serialises two HBM round trips per element)
+    const int run = nch * bins;
+    const int rpp = 512 / run;                        // RoIs covered per pass of the block
+    const int rsub = threadIdx.x / run, rem = threadIdx.x - rsub * run;
+    if (rsub < rpp) {
+        const int pl_off = (rem / bins) * HW;
+        constexpr int U = 16;
+        for (int r0 = rsub; r0 < R; r0 += rpp * U) {
+            int a[U];
+            float g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rpp;
+                const size_t idx = ((size_t)min(r, R - 1) * C + c0) * bins + rem;
+                a[u] = __builtin_nontemporal_load(argmax + idx);
+                g[u] = __builtin_nontemporal_load(grad_out + idx);
+                if (r >= R) a[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (a[u] >= 0) atomicAdd(&plane[pl_off + a[u]], g[u]);
+        }
+    }
+    __syncthreads();
+    float *dst = grad_feat + (size_t)c0 * HW;
+    for (int i = threadIdx.x; i < nch * HW; i += 512) dst[i] = plane[i];
+}
+
 FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, const float *rois, int64_t R, int PH, int PW,
                                     float spatial_scale, float *out, int32_t *argmax, void *stream)
 {
@@ -98,6 +232,16 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     const int64_t total = R * C * PH * PW;
     FRCNN_REQUIRE(total < ((int64_t)1 << 38), "roi_pool_fwd: output too large");
     hipStream_t s = (hipStream_t)stream;
+    constexpr int CB = ROI_FWD_CB;
+    const size_t plane_bytes = (size_t)CB * H * W * 4;
+    if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24)) {
+        const int RB = ROI_FWD_RB;
+        const size_t shmem = plane_bytes + (size_t)RB * (2 * 7 + 2 * 7) * 4;
+        FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<CB, 7, 7>), dim3((C + CB - 1) / CB, (unsigned)((R + RB - 1) / RB)), dim3(256),
+                     shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
+        FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");
+        return FRCNN_OK;
+    }
     FRCNN_LAUNCH(KID_ROI_POOL_FWD, roi_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, C, H, W,
                  (const float4 *)rois, total, PH, PW, spatial_scale, out, argmax);
     FRCNN_CHECK_LAUNCH("roi_pool_fwd_kernel");
@@ -117,7 +261,11 @@ FRCNN_EXPORT int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax
     }
     FRCNN_REQUIRE(grad_out && argmax, "roi_pool_bwd: NULL pointer");
     FRCNN_REQUIRE(R * PH * PW < ((int64_t)1 << 31), "roi_pool_bwd: R*bins too large");
-    if (HW * 4 <= 64 * 1024) {
+    if (HW * 4 * ROI_BWD_CB <= 64 * 1024) {
+        FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_lds_kernel<ROI_BWD_CB>, dim3((C + ROI_BWD_CB - 1) / ROI_BWD_CB), dim3(512), (size_t)HW * 4 * ROI_BWD_CB, s, grad_out, argmax, (int)R, C,
+                     (int)HW, PH * PW, grad_feat);
+        FRCNN_CHECK_LAUNCH("roi_pool_bwd_lds_kernel");
+    } else if (HW * 4 <= 64 * 1024) {
         FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_kernel, dim3(C), dim3(256), (size_t)HW * 4, s, grad_out, argmax, (int)R, C, (int)HW,
                      PH * PW, grad_feat);
         FRCNN_CHECK_LAUNCH("roi_pool_bwd_kernel");
