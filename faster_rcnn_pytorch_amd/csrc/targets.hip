@@ -15,6 +15,7 @@
 #include "frcnn_internal.h"
 
 #define EPS_JACCARD 1e-5f
+#define RS_LDS_MAX 24576              // rpn_sample keeps the Philox keys of up to this many anchors in LDS (96 KB)
 
 // IoU of candidate box `b` against gt `g` in the operand order of the reference variant
 __device__ __forceinline__ float iou_variant(int variant, float4 b, float4 g)
@@ -24,31 +25,58 @@ __device__ __forceinline__ float iou_variant(int variant, float4 b, float4 g)
 __device__ __forceinline__ bool anchor_inside(float4 a) { return a.x >= 0.0f && a.y >= 0.0f && a.z <= 1.0f && a.w <= 1.0f; }
 
 // ------------------------------------------------------------------------------------------------
+// wave-wide max of a 64-bit key (6 xor-shuffle steps on both halves)
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)k, o);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(k >> 32), o);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        k = other > k ? other : k;
+    }
+    return k;
+}
+
+// colkey[g * CK_STRIDE]: one 64-byte line per GT box, so the per-box atomics of different boxes go to different
+// L2 channels instead of serialising on one line (1944 same-line atomics cost ~23 us; this form ~2 us)
+#define CK_STRIDE 8
+
 __global__ __launch_bounds__(256) void rpn_colmax_kernel(int variant, const float4 *__restrict__ anchors, int N,
                                                          const float4 *__restrict__ gt, int G,
                                                          unsigned long long *__restrict__ colkey, int32_t *__restrict__ counts_zero)
 {
-    extern __shared__ unsigned long long s_key[];      // [G]
+    __shared__ unsigned long long s_k[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (counts_zero && blockIdx.x == 0 && threadIdx.x < 4) counts_zero[threadIdx.x] = 0;
-    for (int g = threadIdx.x; g < G; g += 256) s_key[g] = 0ull;
-    __syncthreads();
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool live = false;
     if (i < N) {
-        const float4 a = anchors[i];
-        if (variant == 1 || anchor_inside(a)) {
-            for (int g = 0; g < G; ++g) {
-                const float v = iou_variant(variant, a, gt[g]);
-                if (v >= 0.0f) {        // NaN never wins
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-                    // cheap pre-test against the block's current best to keep LDS atomics rare
-                    if (key > s_key[g]) atomicMax(&s_key[g], key);
-                }
-            }
-        }
+        a = anchors[i];
+        live = variant == 1 || anchor_inside(a);
     }
-    __syncthreads();
-    for (int g = threadIdx.x; g < G; g += 256)
-        if (s_key[g] != 0ull) atomicMax(&colkey[g], s_key[g]);
+    if (__syncthreads_or(live) == 0) return;            // whole block outside the image: nothing to contribute
+    for (int g = 0; g < G; ++g) {
+        unsigned long long key = 0ull;
+        if (live) {
+            const float v = iou_variant(variant, a, gt[g]);
+            if (v >= 0.0f)                              // NaN never wins
+                key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        }
+        key = wave_max_u64(key);
+        if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long m = s_k[0];
+            m = s_k[1] > m ? s_k[1] : m;
+            m = s_k[2] > m ? s_k[2] : m;
+            m = s_k[3] > m ? s_k[3] : m;
+            // monotone target: a (possibly stale) plain read that already beats m makes the atomic unnecessary
+            if (m != 0ull && m > __hip_atomic_load(&colkey[(size_t)g * CK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&colkey[(size_t)g * CK_STRIDE], m);
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(256) void rpn_label_kernel(int variant, const float4 *__restrict__ anchors, int N,
@@ -70,7 +98,7 @@ __global__ __launch_bounds__(256) void rpn_label_kernel(int variant, const float
             for (int g = 0; g < G; ++g) {
                 const float v = iou_variant(variant, a, gt[g]);
                 if (v > best) { best = v; arg = g; }
-                const unsigned long long ck = colkey[g];
+                const unsigned long long ck = colkey[(size_t)g * CK_STRIDE];
                 if (variant == 1) match |= (v == __uint_as_float((unsigned)(ck >> 32))) && ck != 0ull;
                 else match |= (0xFFFFFFFFu - (unsigned)ck) == (unsigned)i && ck != 0ull;
             }
@@ -120,41 +148,65 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int *total)
     return base + inc - v;
 }
 
-// Radix select over 32-bit keys of the flagged elements: finds T = the `keep`-th smallest key
-// (1-based) and `rem` = how many elements with key == T still belong to the kept set.
-// Elements are owned chunk-wise: thread t owns [t*chunk, min((t+1)*chunk, n)).
+// Radix select over the 32-bit keys of the candidate elements (1024 threads, elements owned interleaved:
+// thread t owns t, t+1024, ... so every pass is a coalesced sweep).  Finds T = the `keep`-th smallest key
+// (1-based), rem = how many elements with key == T still belong to the kept set, n_eq = #(key == T).
+// Histograms are private per wave (16 x 256 bins) to keep LDS atomic contention low; the digit search is a
+// wave-parallel prefix scan.  s_hist: 16*256 unsigned; s_pref: 4 unsigned.
 template <typename KeyFn, typename FlagFn>
-__device__ void block_radix_select(int n, int chunk, int keep, KeyFn key_of, FlagFn is_cand, unsigned *s_hist /*[256]*/,
-                                   unsigned *s_pref /*[2]*/, unsigned *outT, int *outRem)
+__device__ void block_radix_select(int n, int keep, KeyFn key_of, FlagFn is_cand, unsigned *s_hist, unsigned *s_pref,
+                                   unsigned *outT, int *outRem, int *outEq)
 {
     unsigned prefix = 0u;
     int remaining = keep;
-    const int lo = threadIdx.x * chunk, hi = min(lo + chunk, n);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
+        for (int i = threadIdx.x; i < 16 * 256; i += 1024) s_hist[i] = 0u;
         __syncthreads();
         const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = lo; i < hi; ++i)
+        for (int i = threadIdx.x; i < n; i += 1024)
             if (is_cand(i)) {
                 const unsigned k = key_of(i);
-                if ((k & himask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+                if ((k & himask) == prefix) atomicAdd(&s_hist[wave * 256 + ((k >> shift) & 255u)], 1u);
             }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = 0;
-            unsigned d = 0;
-            for (; d < 256u; ++d) {
-                const int c = (int)s_hist[d];
-                if (acc + c >= remaining) break;
-                acc += c;
+        if (wave == 0) {
+            // lane owns bins 4*lane .. 4*lane+3 (summed over the 16 private histograms)
+            unsigned c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned t = 0u;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) t += s_hist[w * 256 + 4 * lane + q];
+                c[q] = t;
             }
-            s_pref[0] = prefix | (d << shift);
-            s_pref[1] = (unsigned)(remaining - acc);
+            const unsigned mine = c[0] + c[1] + c[2] + c[3];
+            unsigned inc = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const unsigned exc = inc - mine;
+            const unsigned long long hit = __ballot(inc >= (unsigned)remaining);       // first lane whose cumulative count reaches it
+            const int L = __builtin_ctzll(hit);
+            if (lane == L) {
+                unsigned acc = exc;
+                int q = 0;
+                for (; q < 3; ++q) {
+                    if (acc + c[q] >= (unsigned)remaining) break;
+                    acc += c[q];
+                }
+                s_pref[0] = prefix | ((unsigned)(4 * lane + q) << shift);
+                s_pref[1] = (unsigned)remaining - acc;
+                s_pref[2] = c[q];
+            }
         }
         __syncthreads();
         prefix = s_pref[0];
         remaining = (int)s_pref[1];
+        *outEq = (int)s_pref[2];
         __syncthreads();
     }
     *outT = prefix;
@@ -174,8 +226,10 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
                                                           int32_t *__restrict__ counts)
 {
     __shared__ int s_w[17];
-    __shared__ unsigned s_hist[256];
-    __shared__ unsigned s_pref[2];
+    __shared__ unsigned s_hist[16 * 256];
+    __shared__ unsigned s_pref[4];
+    __shared__ int s_cnt;
+    __shared__ unsigned s_keys[RS_LDS_MAX];
     const int n_pos = counts[0], n_neg = counts[1];
     const int np_eff = min(n_pos, 128);
     const bool drop_pos = n_pos > 128;
@@ -198,6 +252,7 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
                 if (threadIdx.x == 0) counts[2] = 1;
                 continue;
             }
+            // ordered compaction (ascending index): contiguous ownership + block scan
             int c = 0;
             for (int i = lo; i < hi; ++i) c += label8[i] == want;
             int tot;
@@ -214,23 +269,76 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
             // label8 is stale for the demoted entries from here on; the negative pass only looks at label 0
         } else {
             const unsigned stream_id = (unsigned)cls_id;
-            for (int i = lo; i < hi; ++i)
+            if (N <= RS_LDS_MAX) {
+                // compact the candidates (any order) into LDS keys + a global index list, then select in LDS
+                if (threadIdx.x == 0) s_cnt = 0;
+                __syncthreads();
+                for (int i0 = 0; i0 < N; i0 += 1024 * 8) {
+                    int8_t lab[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * 1024 + threadIdx.x;
+                        lab[u] = i < N ? label8[i] : (int8_t)-2;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + u * 1024 + threadIdx.x;
+                        const bool c = lab[u] == want;
+                        const unsigned long long bm = __ballot(c);
+                        if (bm != 0ull) {
+                            int base = 0;
+                            if ((threadIdx.x & 63) == 0) base = atomicAdd(&s_cnt, __builtin_popcountll(bm));
+                            base = __shfl(base, 0);
+                            if (c) {
+                                const int slot = base + __builtin_popcountll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
+                                s_keys[slot] = philox_first(seed, offset, stream_id, (unsigned)i);
+                                list[slot] = i;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                const int m = s_cnt;                         // == n_c
+                unsigned T; int rem, n_eq;
+                block_radix_select(m, keep, [&](int q) { return s_keys[q]; }, [&](int) { return true; }, s_hist, s_pref, &T, &rem, &n_eq);
+                for (int q = threadIdx.x; q < m; q += 1024) {
+                    const unsigned k = s_keys[q];
+                    bool kept = k < T;
+                    if (k == T) {
+                        if (rem == n_eq) kept = true;
+                        else {                               // rare: ties straddle the threshold -> first `rem` by anchor index stay
+                            const int me = list[q];
+                            int before = 0;
+                            for (int o = 0; o < m; ++o) before += (s_keys[o] == T && list[o] < me);
+                            kept = before < rem;
+                        }
+                    }
+                    if (!kept) out_cls[list[q]] = -1;
+                }
+                __syncthreads();
+                continue;
+            }
+            for (int i = threadIdx.x; i < N; i += 1024)
                 if (label8[i] == want) keys[i] = philox_first(seed, offset, stream_id, (unsigned)i);
             __syncthreads();
-            unsigned T; int rem;
-            block_radix_select(N, chunk, keep, [&](int i) { return keys[i]; }, [&](int i) { return label8[i] == want; }, s_hist, s_pref, &T, &rem);
-            // ties at T: the first `rem` in index order stay
-            int c = 0;
-            for (int i = lo; i < hi; ++i) c += (label8[i] == want && keys[i] == T);
-            int tot;
-            int base = block_excl_scan_1024(c, s_w, &tot);
-            for (int i = lo; i < hi; ++i)
-                if (label8[i] == want) {
-                    const unsigned k = keys[i];
-                    bool kept = k < T;
-                    if (k == T) { kept = base < rem; ++base; }
-                    if (!kept) out_cls[i] = -1;
-                }
+            unsigned T; int rem, n_eq;
+            block_radix_select(N, keep, [&](int i) { return keys[i]; }, [&](int i) { return label8[i] == want; }, s_hist, s_pref, &T, &rem, &n_eq);
+            if (rem == n_eq) {                               // no tie straddles the threshold (the common case)
+                for (int i = threadIdx.x; i < N; i += 1024)
+                    if (label8[i] == want && keys[i] > T) out_cls[i] = -1;
+            } else {                                         // ties at T: the first `rem` in index order stay
+                int c = 0;
+                for (int i = lo; i < hi; ++i) c += (label8[i] == want && keys[i] == T);
+                int tot;
+                int base = block_excl_scan_1024(c, s_w, &tot);
+                for (int i = lo; i < hi; ++i)
+                    if (label8[i] == want) {
+                        const unsigned k = keys[i];
+                        bool kept = k < T;
+                        if (k == T) { kept = base < rem; ++base; }
+                        if (!kept) out_cls[i] = -1;
+                    }
+            }
             __syncthreads();
         }
     }
@@ -259,6 +367,10 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     __shared__ int s_err;
     __shared__ unsigned s_key[HT_MAX];
     __shared__ int s_row[HT_ROWS_MAX];
+    __shared__ unsigned short s_sel[HT_ROWS_MAX];
+    __shared__ unsigned s_hist[16 * 256];
+    __shared__ unsigned s_pref[4];
+    __shared__ int s_nsel;
     const int tid = threadIdx.x;
     const int n_rois = n_rois_dev ? min(max(*n_rois_dev, 0), P_cap) : P_cap;
     const int n = n_rois + G;
@@ -305,24 +417,42 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
             }
         }
     } else {
-        // rank by (philox key, candidate id) inside each list; rank r < quota -> output row
+        // per list: radix-select the `quota` smallest (philox key, position) pairs, compact them, then order
+        // the <= quota survivors by counting rank (quota^2 / 1024 compares per lane instead of m^2 / 1024)
         for (int which = 0; which < 2; ++which) {
             const int m = which == 0 ? npc : nnc;
             const int quota = which == 0 ? n_pos : n_neg;
             const int rowbase = which == 0 ? 0 : n_pos;
             __syncthreads();
+            if (quota <= 0) continue;                               // uniform
             for (int q = tid; q < m; q += 1024) s_key[q] = philox_first(seed, offset, 2u + (unsigned)which, (unsigned)s_list[which][q]);
+            if (tid == 0) s_nsel = 0;
             __syncthreads();
-            if (quota > 0)
-                for (int q = tid; q < m; q += 1024) {
-                    const unsigned kq = s_key[q];
-                    int rank = 0;
-                    for (int o = 0; o < m; ++o) {
-                        const unsigned ko = s_key[o];
-                        rank += (ko < kq) || (ko == kq && o < q);
-                    }
-                    if (rank < quota) s_row[rowbase + rank] = s_list[which][q];
+            unsigned T = 0xFFFFFFFFu; int rem = 0, n_eq = 0;
+            if (quota < m) block_radix_select(m, quota, [&](int q) { return s_key[q]; }, [&](int) { return true; }, s_hist, s_pref, &T, &rem, &n_eq);
+            // selected: key < T, plus the first `rem` (in list order) with key == T
+            for (int q0 = 0; q0 < m; q0 += 1024) {
+                const int q = q0 + tid;
+                const bool eq = q < m && quota < m && s_key[q] == T;
+                int tot;
+                const int tie_rank = block_excl_scan_1024(eq, s_w, &tot);
+                const bool sel = q < m && (quota >= m || s_key[q] < T || (eq && tie_rank < rem));
+                rem -= tot;                                         // ties consumed by earlier rounds (rem may go negative: harmless)
+                if (sel) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)q;
+            }
+            __syncthreads();
+            const int ns = s_nsel;                                  // == quota
+            for (int a = tid; a < ns; a += 1024) {
+                const int qa = s_sel[a];
+                const unsigned ka = s_key[qa];
+                int rank = 0;
+                for (int o = 0; o < ns; ++o) {
+                    const int qo = s_sel[o];
+                    const unsigned ko = s_key[qo];
+                    rank += (ko < ka) || (ko == ka && qo < qa);
                 }
+                s_row[rowbase + rank] = s_list[which][qa];
+            }
         }
     }
     __syncthreads();
@@ -354,7 +484,7 @@ static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
 {
     RpnWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
-    w.colkey = (unsigned long long *)take((size_t)G * 8);
+    w.colkey = (unsigned long long *)take((size_t)G * 8 * 8);
     w.label8 = (int8_t *)take((size_t)N);
     w.list = (int32_t *)take((size_t)N * 4);
     w.keys = (unsigned *)take((size_t)N * 4);
@@ -378,9 +508,9 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     RpnWs w = carve_rpn(workspace, N, G);
     if (workspace_bytes < w.total) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_targets: workspace %zu < %zu bytes", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(w.colkey, 0, (size_t)G * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
+    if (hipMemsetAsync(w.colkey, 0, (size_t)G * 8 * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
-    FRCNN_LAUNCH(KID_RPN_COLMAX, rpn_colmax_kernel, grid, block, (size_t)G * 8, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
+    FRCNN_LAUNCH(KID_RPN_COLMAX, rpn_colmax_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
                  (int)G, w.colkey, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_colmax_kernel");
     FRCNN_LAUNCH(KID_RPN_LABEL, rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
