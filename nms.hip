@@ -167,6 +167,7 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
     __shared__ u64 rm_ring[SCAN_RING][NMS_FAST_MAX_BLOCKS + 4];
     __shared__ u64 s_kept[4];
     __shared__ int s_base[4];
+    __shared__ unsigned char s_rows[4][64];      // lane ids of the kept rows of a block, in order
     __shared__ int s_total[2];                   // by block parity: a fast wave may already be one iteration ahead
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -200,11 +201,8 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
     __syncthreads();
 
     int total = 0;
-    bool hx_any = false, hy_any = false;
-    u64 wmask = 0ull;                                            // rows owned by this helper wave
-    for (int i = wave - 2; i >= 0 && i < 64; i += SCAN_HELPERS) wmask |= 1ull << i;
 
-#define SCAN_ITER(B, HSET, HFLAG)                                                            \
+#define SCAN_ITER(B, HSET)                                                            \
     {                                                                                                                \
         const int b = (B);                                                                                           \
         if (wave == 0) {                                                                                             \
@@ -249,6 +247,7 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
                 const int i = __builtin_ctzll(nd);                                                                   \
                 r3 |= RL64(u3l, u3h, i);                                                                             \
             }                                                                                                        \
+            if ((kept >> lane) & 1ull) s_rows[b & 3][__builtin_popcountll(kept & ((1ull << lane) - 1ull))] = (unsigned char)lane; \
             if (lane == 0) {                                                                                         \
                 s_kept[b & 3] = kept;                                                                                \
                 s_base[b & 3] = total;                                                                               \
@@ -266,44 +265,33 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
             }                                                                                                        \
             if (b + SCAN_PF + 2 < nb) PF_LOAD(HSET, b + SCAN_PF + 2)                                                 \
         } else {                                                                                                     \
-            /* this generation was issued two iterations ago (block b-3): apply its far words (skipped outright      \
-               when nothing was fetched, the common case) */                                                         \
-            if (HFLAG) {                                                                                             \
-                _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k)                                                \
-                    _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                  \
-                        const u64 v = HSET[k * 3 + m];                                                               \
-                        if (v) atomicOr(&removed[lane + 64 * m], v);                                                 \
-                        HSET[k * 3 + m] = 0ull;                                                                      \
-                    }                                                                                                \
-                HFLAG = false;                                                                                       \
-            }                                                                                                        \
-            /* issue for block c = b-1.  This wave owns the rows whose lane index is h, h+14, h+28, h+42, h+56       \
-               (h = wave-2); a far word is fetched only where the row mask says one of those kept rows has a bit */ \
+            /* this generation was issued two iterations ago (block b-3): apply its far words, store its outputs */ \
+            _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k)                                                    \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                      \
+                    const u64 v = HSET[k * 3 + m];                                                                   \
+                    if (v) atomicOr(&removed[lane + 64 * m], v);                                                     \
+                    HSET[k * 3 + m] = 0ull;                                                                          \
+                }                                                                                                    \
+            /* issue for block c = b-1: this wave's rows are the (wave-2 + 14k)-th kept rows; a far word is          \
+               fetched only where the row mask says the row has a bit in it */                                       \
             const int c = b - 1;                                                                                     \
             if (c >= 0) {                                                                                            \
-                const u64 kcv = s_kept[c & 3];                                                                       \
-                const u64 kc = ((u64)RFL((unsigned)(kcv >> 32)) << 32) | (u64)RFL((unsigned)kcv);                    \
-                const u64 mine = kc & wmask;                                                                         \
-                if (mine != 0ull) {                                                                                  \
-                    const int cslot = c % SCAN_RING;                                                                 \
-                    if (c + 4 < nb) {                                                                                \
-                        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                              \
-                            const int w = lane + 64 * m;                                                             \
-                            const u64 need = (w >= c + 4 && w < nb) ? (rm_ring[cslot][w] & mine) : 0ull;             \
-                            if (__ballot(need != 0ull) != 0ull) {                                                    \
-                                HFLAG = true;                                                                        \
-                                _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k) {                              \
-                                    const int i = (wave - 2) + SCAN_HELPERS * k;                                     \
-                                    if (i < 64 && ((need >> i) & 1ull)) HSET[k * 3 + m] = mask[(size_t)(c * 64 + i) * nblk + w]; \
-                                }                                                                                    \
-                            }                                                                                        \
-                        }                                                                                            \
+                const int nrows = __builtin_popcountll(s_kept[c & 3]);                                               \
+                const int cslot = c % SCAN_RING;                                                                     \
+                const u64 rmw0 = rm_ring[cslot][lane], rmw1 = rm_ring[cslot][lane + 64], rmw2 = rm_ring[cslot][lane + 128]; \
+                _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k) {                                              \
+                    const int ri = (wave - 2) + SCAN_HELPERS * k;                                                    \
+                    if (ri < nrows) {                                                                                \
+                        const int i = s_rows[c & 3][ri];                                                             \
+                        const u64 *rowp = mask + (size_t)(c * 64 + i) * nblk;                                        \
+                        if (lane >= c + 4 && lane < nb && ((rmw0 >> i) & 1ull)) HSET[k * 3 + 0] = rowp[lane];             \
+                        if (lane + 64 >= c + 4 && lane + 64 < nb && ((rmw1 >> i) & 1ull)) HSET[k * 3 + 1] = rowp[lane + 64]; \
+                        if (lane + 128 >= c + 4 && lane + 128 < nb && ((rmw2 >> i) & 1ull)) HSET[k * 3 + 2] = rowp[lane + 128]; \
                     }                                                                                                \
-                    if (lane < SCAN_KMAX) {      /* kept positions only; boxes / source ids are gathered after the scan */ \
-                        const int i = (wave - 2) + SCAN_HELPERS * lane;                                              \
-                        if (i < 64 && ((kc >> i) & 1ull))                                                            \
-                            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << i) - 1ull))] = (int64_t)(c * 64 + i); \
-                    }                                                                                                \
+                }                                                                                                    \
+                if (lane < SCAN_KMAX) {          /* kept positions only; boxes / source ids are gathered after the scan */ \
+                    const int ri = (wave - 2) + SCAN_HELPERS * lane;                                                 \
+                    if (ri < nrows) out_keep[s_base[c & 3] + ri] = (int64_t)(c * 64 + s_rows[c & 3][ri]);            \
                 }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
@@ -313,18 +301,17 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 
     int last_b = -1;
     for (int b0 = 0; b0 < nb && total < post_k; b0 += 2) {
-        SCAN_ITER(b0, hx, hx_any)
+        SCAN_ITER(b0, hx)
         last_b = b0;
         if (b0 + 1 >= nb || total >= post_k) break;
-        SCAN_ITER(b0 + 1, hy, hy_any)
+        SCAN_ITER(b0 + 1, hy)
         last_b = b0 + 1;
     }
     if (wave >= 2 && last_b >= 0 && lane < SCAN_KMAX) {         // the last resolved block was never emitted
         const int c = last_b;
-        const u64 kc = s_kept[c & 3];
-        const int i = (wave - 2) + SCAN_HELPERS * lane;
-        if (i < 64 && ((kc >> i) & 1ull))
-            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << i) - 1ull))] = (int64_t)(c * 64 + i);
+        const int nrows = __builtin_popcountll(s_kept[c & 3]);
+        const int ri = (wave - 2) + SCAN_HELPERS * lane;
+        if (ri < nrows) out_keep[s_base[c & 3] + ri] = (int64_t)(c * 64 + s_rows[c & 3][ri]);
     }
     __syncthreads();                                            // out_keep complete and visible to the whole workgroup
     const int n_out = total < post_k ? total : post_k;
