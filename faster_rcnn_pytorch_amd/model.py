@@ -202,23 +202,35 @@ class FRCNN(nn.Module):
         self.rpn_target_maker = RPNTargetMaker(self.sampler)
         self.fast_rcnn_target_maker = FastRcnnTargetMaker(self.sampler)
         self.fast_rcnn_head = FastRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
+        self._streams = {}
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
+    def _side_stream(self, device):
+        st = self._streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            self._streams[device] = st
+        return st
+
     def forward(self, x, bbox, label):
+        hw = x.size()[2:]
+        main = torch.cuda.current_stream(x.device)
+        # 5. rpn targets depend only on the anchors and the ground truth (model.py:324), not on the network:
+        #    they run on a second HIP stream underneath the backbone instead of after the proposals
+        anchor = self.anchor_maker.device_anchors(hw, x.device)           # model.py:310-312: resident in HBM
+        side = self._side_stream(x.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            target_rpn_cls, target_rpn_reg = self.rpn_target_maker(bbox=bbox, anchor=anchor)
         # 1. extract features                                                  model.py:307
         features = self.extractor(x)
-        # 2. anchors: resident in HBM (targets) / regenerated in registers (proposals)   model.py:310-312
-        hw = x.size()[2:]
-        anchor = self.anchor_maker.device_anchors(hw, x.device)
         # 3. forward rpn                                                       model.py:315
         pred_rpn_cls, pred_rpn_reg = self.rpn(features)
-        # 4. propose regions -> fixed-capacity rois + device count             model.py:318
+        # 4. propose regions -> fixed-capacity rois + device count (anchors regenerated in registers)   model.py:318
         rois, n_rois, _ = self.rp.propose(pred_rpn_cls.squeeze(0), pred_rpn_reg.squeeze(0), None, "train",
                                           grid=self.anchor_maker.grid_desc(hw))
-        # 5. rpn targets                                                       model.py:324
-        target_rpn_cls, target_rpn_reg = self.rpn_target_maker(bbox=bbox, anchor=anchor)
         # 6. fast rcnn targets                                                 model.py:328
         target_fast_rcnn_cls, target_fast_rcnn_reg, sample_rois = self.fast_rcnn_target_maker(bbox=bbox, label=label, rois=rois,
                                                                                               n_rois=n_rois)
@@ -227,6 +239,9 @@ class FRCNN(nn.Module):
         # 8. regression row of the target class                                model.py:340-341
         pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(128, -1, 4)
         pred_fast_rcnn_reg = pred_fast_rcnn_reg[torch.arange(0, 128, device=x.device), target_fast_rcnn_cls]
+        main.wait_stream(side)
+        target_rpn_cls.record_stream(main)
+        target_rpn_reg.record_stream(main)
         return (pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg), \
                (target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg)
 
