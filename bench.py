@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
     ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
+    ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
     args = ap.parse_args()
 
     from faster_rcnn_pytorch_amd import _lib, parallel
@@ -91,6 +92,8 @@ def main():
 
     torch.manual_seed(0)
     model = FRCNN(num_classes=NUM_CLASSES, sampling="device", seed=1234 + rank).to(device)
+    if args.channels_last:
+        model.extractor = model.extractor.to(memory_format=torch.channels_last)
     net = parallel.wrap_ddp(model, device)
     crit = FRCNNLoss(None)
     opt = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)       # main.py:55-60
@@ -98,7 +101,10 @@ def main():
     frames = []
     for i in range(args.frames):
         x, b, l = synth_frame(rank, i)
-        frames.append((x.to(device), b.to(device), l.to(device)))
+        x = x.to(device)
+        if args.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        frames.append((x, b.to(device), l.to(device)))
     torch.cuda.synchronize()
 
     def step(i):

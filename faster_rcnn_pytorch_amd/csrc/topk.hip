@@ -108,10 +108,173 @@ __global__ __launch_bounds__(256) void topk_scatter_kernel(const float *__restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large N with K << N (FPN: N = 268 569, K = 4000): the O(N^2) rank sort would be ~72 G compares, so a two-level
+// radix histogram (11 + 11 bits of the order-preserving key) first finds a 22-bit prefix threshold that at least K
+// keys reach; those M >= K candidates (M - K = ties inside one 2^-13-relative score band, typically tens) are
+// compacted and rank-sorted among themselves with the explicit (key desc, index asc) order.
+//   topk_hist_kernel<0>  ->  topk_hist_kernel<1>  ->  topk_compact_kernel  ->  topk_rank_cand_kernel  ->  topk_scatter_cand_kernel
+// Every kernel re-derives what it needs from the previous histogram in its prologue (2048 bins, one block scan), so
+// there is no single-block "pick the digit" launch in between.
+// ------------------------------------------------------------------------------------------------
+#define SEL_BINS 2048
+
+struct SelCtl { unsigned hist1[SEL_BINS]; unsigned hist2[SEL_BINS]; int m; int pad[15]; };
+
+// descending search: returns the bin holding the `want`-th largest key (1-based) and the number of keys in higher bins;
+// if the histogram holds fewer than `want` keys, returns bin 0 (everything qualifies).  256 threads.
+__device__ __forceinline__ void sel_find_bin(const unsigned *__restrict__ hist, int want, int *s_tmp /*[8]*/, int *bin, int *above)
+{
+    const int t = threadIdx.x;                       // thread t owns descending bins d = 8t .. 8t+7  (bin = 2047 - d)
+    unsigned c[8];
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { c[q] = hist[SEL_BINS - 1 - (8 * t + q)]; local += (int)c[q]; }
+    // block-wide exclusive scan of `local` over 256 threads
+    const int lane = t & 63, wave = t >> 6;
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[wave] = inc;
+    if (t == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < wave) base += s_tmp[w];
+    const int excl = base + inc - local;
+    if (excl < want && want <= excl + local) {       // exactly one thread (if the total reaches `want`)
+        int acc = excl, q = 0;
+        for (; q < 7; ++q) {
+            if (acc + (int)c[q] >= want) break;
+            acc += (int)c[q];
+        }
+        s_tmp[4] = SEL_BINS - 1 - (8 * t + q);
+        s_tmp[5] = acc;
+        s_tmp[6] = 1;
+    }
+    __syncthreads();
+    *bin = s_tmp[6] ? s_tmp[4] : 0;
+    *above = s_tmp[6] ? s_tmp[5] : 0;
+    __syncthreads();
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ scores, int N, int K, int proposal_mode, SelCtl *__restrict__ ctl)
+{
+    __shared__ unsigned s_hist[SEL_BINS];
+    __shared__ int s_tmp[8];
+    int bin1 = 0, above1 = 0;
+    if (LEVEL == 1) sel_find_bin(ctl->hist1, K, s_tmp, &bin1, &above1);
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256) s_hist[i] = 0u;
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const float sc = scores[i];
+        if (proposal_mode && !(sc >= 0.0f)) continue;
+        const uint32_t k = f2key(sc);
+        if (LEVEL == 0) atomicAdd(&s_hist[k >> 21], 1u);
+        else if ((int)(k >> 21) == bin1) atomicAdd(&s_hist[(k >> 10) & (SEL_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned *dst = LEVEL == 0 ? ctl->hist1 : ctl->hist2;
+    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
+        if (s_hist[i]) atomicAdd(&dst[i], s_hist[i]);
+}
+
+__global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restrict__ scores, int N, int K, int proposal_mode,
+                                                           SelCtl *__restrict__ ctl, uint32_t *__restrict__ cand_key,
+                                                           int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_rank)
+{
+    __shared__ int s_tmp[8];
+    int bin1, above1, bin2, above2;
+    sel_find_bin(ctl->hist1, K, s_tmp, &bin1, &above1);
+    sel_find_bin(ctl->hist2, K - above1, s_tmp, &bin2, &above2);
+    const uint32_t thr22 = ((uint32_t)bin1 << 11) | (uint32_t)bin2;      // keep keys whose top 22 bits reach this
+    for (int i0 = blockIdx.x * 256; i0 < N; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
+        bool c = false;
+        uint32_t k = 0u;
+        if (i < N) {
+            const float sc = scores[i];
+            k = f2key(sc);
+            c = (!proposal_mode || sc >= 0.0f) && (k >> 10) >= thr22;
+        }
+        const unsigned long long bm = __ballot(c);
+        if (bm != 0ull) {
+            int base = 0;
+            if ((threadIdx.x & 63) == 0) base = atomicAdd(&ctl->m, __builtin_popcountll(bm));
+            base = __shfl(base, 0);
+            if (c) {
+                const int slot = base + __builtin_popcountll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
+                cand_key[slot] = k;
+                cand_idx[slot] = i;
+                cand_rank[slot] = 0;
+            }
+        }
+    }
+}
+
+// rank among the M candidates (M on the device); persistent grid over (256-row block) x (1024-column segment) tiles
+__global__ __launch_bounds__(256) void topk_rank_cand_kernel(const SelCtl *__restrict__ ctl, const uint32_t *__restrict__ cand_key,
+                                                             const int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_rank)
+{
+    __shared__ uint32_t s_k[TOPK_SEG];
+    __shared__ int32_t s_i[TOPK_SEG];
+    const int M = ctl->m;
+    const int nrow = (M + TOPK_ROWS - 1) / TOPK_ROWS, nseg = (M + TOPK_SEG - 1) / TOPK_SEG;
+    for (int tile = blockIdx.x; tile < nrow * nseg; tile += gridDim.x) {
+        const int rb = tile / nseg, sg = tile - rb * nseg;
+        const int c0 = sg * TOPK_SEG;
+        const int cn = min(TOPK_SEG, M - c0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cn; t += 256) { s_k[t] = cand_key[c0 + t]; s_i[t] = cand_idx[c0 + t]; }
+        __syncthreads();
+        const int r = rb * TOPK_ROWS + threadIdx.x;
+        if (r < M) {
+            const uint32_t kr = cand_key[r];
+            const int32_t ir = cand_idx[r];
+            int rank = 0;
+            for (int t = 0; t < cn; ++t) {
+                const uint32_t k = s_k[t];
+                rank += (k > kr) || (k == kr && s_i[t] < ir);
+            }
+            if (rank) atomicAdd(&cand_rank[r], rank);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_scatter_cand_kernel(const SelCtl *__restrict__ ctl, const float *__restrict__ scores,
+                                                                const float4 *__restrict__ boxes_in, const int32_t *__restrict__ cand_idx,
+                                                                const int32_t *__restrict__ cand_rank, int K, int64_t *__restrict__ out_idx,
+                                                                float *__restrict__ out_scores, float4 *__restrict__ out_boxes,
+                                                                int32_t *__restrict__ out_count)
+{
+    const int M = ctl->m;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = M < K ? M : K;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
+        const int rank = cand_rank[r];
+        if (rank < K) {
+            const int i = cand_idx[r];
+            out_idx[rank] = i;
+            out_scores[rank] = scores[i];
+            if (out_boxes) out_boxes[rank] = boxes_in[i];
+        }
+    }
+}
+
+static inline bool topk_use_select(int64_t N, int64_t K) { return N > 32768 && K * 4 <= N; }
+
 size_t frcnn_ws_topk(int64_t N)
 {
     const int64_t nseg = (N + TOPK_SEG - 1) / TOPK_SEG;
-    return align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
+    const size_t direct = N > 32768 ? 0 : align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
+    const size_t direct_big = align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
+    const size_t select = align_up(sizeof(SelCtl), 256) + 3 * align_up((size_t)N * 4, 256);
+    // N > 32768: the select path needs `select`; the direct path (K close to N) needs `direct_big`
+    return N > 32768 ? (direct_big > select ? direct_big : select) : direct;
 }
 
 int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int64_t K, int proposal_mode,
@@ -120,6 +283,28 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
 {
     if (ws_bytes < frcnn_ws_topk(N))
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "topk: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_topk(N));
+    if (topk_use_select(N, K)) {
+        char *p = (char *)ws;
+        SelCtl *ctl = (SelCtl *)p; p += align_up(sizeof(SelCtl), 256);
+        uint32_t *cand_key = (uint32_t *)p; p += align_up((size_t)N * 4, 256);
+        int32_t *cand_idx = (int32_t *)p; p += align_up((size_t)N * 4, 256);
+        int32_t *cand_rank = (int32_t *)p;
+        if (hipMemsetAsync(ctl, 0, sizeof(SelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "topk: memset failed");
+        const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_hist_kernel<0>, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl);
+        FRCNN_CHECK_LAUNCH("topk_hist_kernel<0>");
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_hist_kernel<1>, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl);
+        FRCNN_CHECK_LAUNCH("topk_hist_kernel<1>");
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_compact_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl, cand_key,
+                     cand_idx, cand_rank);
+        FRCNN_CHECK_LAUNCH("topk_compact_kernel");
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_rank_cand_kernel, dim3(1024), dim3(256), 0, s, ctl, cand_key, cand_idx, cand_rank);
+        FRCNN_CHECK_LAUNCH("topk_rank_cand_kernel");
+        FRCNN_LAUNCH(KID_TOPK_SCATTER, topk_scatter_cand_kernel, dim3(256), dim3(256), 0, s, ctl, scores, (const float4 *)boxes_in, cand_idx,
+                     cand_rank, (int)K, out_idx, out_scores, (float4 *)out_boxes, out_count);
+        FRCNN_CHECK_LAUNCH("topk_scatter_cand_kernel");
+        return FRCNN_OK;
+    }
     const int nseg = (int)((N + TOPK_SEG - 1) / TOPK_SEG);
     const int nrow = (int)((N + TOPK_ROWS - 1) / TOPK_ROWS);
     int32_t *partial = (int32_t *)ws;

@@ -116,7 +116,8 @@ def test_prologue_matches_reference_golden(ops, golden):
 
 
 # ------------------------------------------------------------------------------------------ top-k
-@pytest.mark.parametrize("N,K", [(20646, 12000), (20646, 6000), (1000, 1000), (777, 2000), (65, 64), (1, 1)])
+@pytest.mark.parametrize("N,K", [(20646, 12000), (20646, 6000), (1000, 1000), (777, 2000), (65, 64), (1, 1),
+                                 (268569, 4000), (268569, 2000), (100000, 2000), (40000, 10000)])   # last four: radix-select pre-filter path
 def test_topk_bit_exact(ops, N, K):
     rng = np.random.RandomState(N + K)
     s = rng.rand(N).astype(np.float32)
@@ -129,6 +130,22 @@ def test_topk_bit_exact(ops, N, K):
     assert np.array_equal(idx[:n].cpu().numpy(), idx_o)
     assert np.array_equal(sc[:n].cpu().numpy(), sc_o)
     assert np.array_equal(bx[:n].cpu().numpy(), boxes[idx_o])
+
+
+def test_topk_large_n_with_heavy_ties_and_few_valid(ops):
+    rng = np.random.RandomState(3)
+    N = 150000
+    s = (rng.randint(0, 2000, N) / 4096.0).astype(np.float32)      # ~75 equal scores per value: the candidate band is wide
+    s[::7] = -1.0
+    idx_o, sc_o = orc.topk_sorted(s, 3000)
+    idx, sc, _, cnt = ops.topk_sorted(T(s), 3000)
+    assert int(cnt.item()) == 3000 and np.array_equal(idx.cpu().numpy(), idx_o) and np.array_equal(sc.cpu().numpy(), sc_o)
+    few = np.full(N, -1.0, np.float32)                              # fewer valid entries than K
+    pos = rng.choice(N, 500, replace=False)
+    few[pos] = rng.rand(500).astype(np.float32)
+    idx_o, _ = orc.topk_sorted(few, 3000)
+    idx, _, _, cnt = ops.topk_sorted(T(few), 3000)
+    assert int(cnt.item()) == 500 and np.array_equal(idx[:500].cpu().numpy(), idx_o)
 
 
 def test_topk_ties_resolve_by_index(ops):
