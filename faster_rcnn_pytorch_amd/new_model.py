@@ -1,0 +1,327 @@
+"""ResNet-50-FPN Faster R-CNN -- host-side mirror of the reference's models/new_model.py on the HIP hot path.
+
+Same classes / signatures as the reference (models/new_model.py:17-470):
+    FRCNN(num_classes).forward(x, boxes, labels) -> ((rpn_cls[1,N,2], rpn_reg[1,N,4], head_cls[512,C], head_reg[512,4]),
+                                                      (tgt_rpn_cls[N], tgt_rpn_reg[N,4], tgt_cls[512], tgt_reg[512,4]))
+    FRCNN.predict(x, opts) -> (bbox, label, score)
+Hot-path stages go through libfrcnn_hip (FPN variants): multi-level anchor grid (torchvision AnchorGenerator,
+new_model.py:23-25,46-47), ONE global proposal stage over all levels (new_model.py:49-86), tie-inclusive RPN
+matching (new_model.py:299-349), 512-sample head targets with raw labels (new_model.py:157-206), MultiScaleRoIAlign
+(new_model.py:127,143).  The backbone is a from-scratch torch definition of torchvision's resnet_fpn_backbone('resnet50',
+trainable_layers=3) -- FrozenBatchNorm2d, 5 output maps '0','1','2','3','pool' -- with random init (weights need the network).
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .model import _Sampler, _unwrap, normal_init
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """torchvision.ops.misc.FrozenBatchNorm2d: fixed statistics and affine parameters (buffers)."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def forward(self, x):
+        scale = (self.weight * (self.running_var + self.eps).rsqrt()).reshape(1, -1, 1, 1)
+        bias = self.bias.reshape(1, -1, 1, 1) - self.running_mean.reshape(1, -1, 1, 1) * scale
+        return x * scale + bias
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        idt = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            idt = self.downsample(x)
+        return self.relu(out + idt)
+
+
+class ResNet50Body(nn.Module):
+    """IntermediateLayerGetter(resnet50, {'layer1':'0', ..., 'layer4':'3'})."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.inplanes = 64
+        self.layer1 = self._make_layer(64, 3, 1)
+        self.layer2 = self._make_layer(128, 4, 2)
+        self.layer3 = self._make_layer(256, 6, 2)
+        self.layer4 = self._make_layer(512, 3, 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def _make_layer(self, planes, blocks, stride):
+        down = None
+        if stride != 1 or self.inplanes != planes * 4:
+            down = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False), FrozenBatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, down)]
+        self.inplanes = planes * 4
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        out = OrderedDict()
+        for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
+            x = layer(x)
+            out[str(i)] = x
+        return out
+
+
+class FeaturePyramidNetwork(nn.Module):
+    """torchvision.ops.FeaturePyramidNetwork([256,512,1024,2048], 256, extra_blocks=LastLevelMaxPool())."""
+
+    def __init__(self, in_channels_list=(256, 512, 1024, 2048), out_channels=256):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(c, out_channels, 1)) for c in in_channels_list])
+        self.layer_blocks = nn.ModuleList([nn.Sequential(nn.Conv2d(out_channels, out_channels, 3, padding=1)) for _ in in_channels_list])
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        names, xs = list(x.keys()), list(x.values())
+        last = self.inner_blocks[-1](xs[-1])
+        results = [self.layer_blocks[-1](last)]
+        for idx in range(len(xs) - 2, -1, -1):
+            lat = self.inner_blocks[idx](xs[idx])
+            last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            results.insert(0, self.layer_blocks[idx](last))
+        names.append("pool")
+        results.append(F.max_pool2d(results[-1], 1, 2, 0))           # LastLevelMaxPool
+        return OrderedDict(zip(names, results))
+
+
+class BackboneWithFPN(nn.Module):
+    def __init__(self, trainable_layers=3):
+        super().__init__()
+        self.body = ResNet50Body()
+        self.fpn = FeaturePyramidNetwork()
+        self.out_channels = 256
+        train = ["layer4", "layer3", "layer2", "layer1", "conv1"][:trainable_layers]
+        for name, p in self.body.named_parameters():
+            if all(not name.startswith(t) for t in train):
+                p.requires_grad_(False)
+
+    def forward(self, x):
+        return self.fpn(self.body(x))
+
+
+class RPNHead(nn.Module):
+    """models/new_model.py:89-114."""
+
+    def __init__(self, in_channels=256, out_channels=256):
+        super().__init__()
+        num_anchors = 3
+        self.inter_layer = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.cls_layer = nn.Conv2d(in_channels, num_anchors * 2, kernel_size=1)
+        self.reg_layer = nn.Conv2d(in_channels, num_anchors * 4, kernel_size=1)
+        normal_init(self.inter_layer, 0, 0.01)
+        normal_init(self.cls_layer, 0, 0.01)
+        normal_init(self.reg_layer, 0, 0.01)
+
+    def forward(self, features):
+        batch_size = features.size(0)
+        x = torch.relu(self.inter_layer(features))
+        pred_cls = self.cls_layer(x)
+        pred_reg = self.reg_layer(x)
+        pred_reg = pred_reg.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, 4)
+        pred_cls = pred_cls.permute(0, 2, 3, 1).contiguous().view(batch_size, -1, 2)
+        return pred_cls, pred_reg
+
+
+class RegionProposalNetwork(nn.Module):
+    """models/new_model.py:17-86."""
+
+    def __init__(self):
+        super().__init__()
+        self.min_size = 10
+        self.rpn_head = RPNHead()
+        self.anchor_generator = ops.AnchorGenerator(sizes=((32,), (64,), (128,), (256,), (512,)),
+                                                    aspect_ratios=((0.5, 1.0, 2.0),) * 5)
+
+    @staticmethod
+    def top_k(mode):
+        return (2000, 1000) if mode == "test" else (4000, 1000)                   # new_model.py:54-58
+
+    def propose(self, x, features, mode):
+        """Asynchronous form: (pred_rpn_cls [N,2], pred_rpn_reg [N,4], rois [P,4] fixed, count int32[1], anchors [N,4])."""
+        feats = list(features.values())
+        cls, reg = [], []
+        for f in feats:
+            c, r = self.rpn_head(f)
+            cls.append(c)
+            reg.append(r)
+        pred_rpn_cls = torch.cat(cls, dim=1).flatten(0, -2)
+        pred_rpn_reg = torch.cat(reg, dim=1).reshape(-1, 4)
+        h, w = x.shape[2:]
+        shapes = [tuple(f.shape[-2:]) for f in feats]
+        anchor = self.anchor_generator.grid((h, w), shapes, x.device, normalise=True)   # new_model.py:46-47, cached in HBM
+        pre, post = self.top_k(mode)
+        rois, cnt, _ = ops.region_proposal(pred_rpn_reg.detach(), pred_rpn_cls.detach(), anchor, self.min_size / 1000, pre, 0.7, post)
+        return pred_rpn_cls, pred_rpn_reg, rois, cnt, anchor
+
+    def forward(self, x, features, mode):
+        pred_rpn_cls, pred_rpn_reg, rois, cnt, anchor = self.propose(x, features, mode)
+        return pred_rpn_cls, pred_rpn_reg, rois[:int(cnt.item())], anchor
+
+
+class FRCNNHead(nn.Module):
+    """models/new_model.py:117-150."""
+
+    def __init__(self, num_classes, roi_size, classifier):
+        super().__init__()
+        self.num_classes = num_classes
+        self.cls_head = nn.Linear(1024, num_classes)
+        self.reg_head = nn.Linear(1024, num_classes * 4)
+        self.roi_pool = ops.MultiScaleRoIAlign(featmap_names=["0", "1", "2", "3"], output_size=roi_size, sampling_ratio=2)
+        self.classifier = classifier
+        normal_init(self.cls_head, 0, 0.01)
+        normal_init(self.reg_head, 0, 0.001)
+
+    def forward(self, features, roi, img_shape):
+        h, w = img_shape
+        scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=roi.device)
+        scaled_roi = roi * scale                                                   # new_model.py:136-140: image pixels
+        pool = self.roi_pool(features, [scaled_roi], [(w, h)])
+        x = self.classifier(pool.view(pool.size(0), -1))
+        return self.cls_head(x), self.reg_head(x)
+
+
+class FRCNNTargetMaker(nn.Module):
+    """models/new_model.py:153-206: box_iou (no eps), labels used raw, <= 128 positives of 512 samples."""
+
+    def __init__(self, sampler=None):
+        super().__init__()
+        self.sampler = sampler or _Sampler()
+
+    def forward(self, boxes, labels, rois, n_rois=None):
+        boxes = _unwrap(boxes)
+        labels = _unwrap(labels).to(torch.int64)
+        s = self.sampler
+        kw = dict(n_rois=n_rois, variant=1, label_offset=0, max_pos=128, total=512)
+        if s.sampling == "host":
+            c = ops.head_targets(rois, boxes, labels, **kw)[4].cpu().tolist()
+            perm_pos, perm_neg = torch.randperm(c[0]), torch.randperm(c[1])        # new_model.py:175,180
+            cls, reg, srois, _, counts = ops.head_targets(rois, boxes, labels, perm_pos=perm_pos, perm_neg=perm_neg, **kw)
+            if counts.cpu().tolist()[2] != 512:
+                raise RuntimeError("FRCNNTargetMaker: fewer than 512 samples (assert at new_model.py:183)")
+        else:
+            cls, reg, srois, _, _ = ops.head_targets(rois, boxes, labels, seed=s.seed, offset=s.next_offset(), **kw)
+        return cls, reg, srois
+
+
+class RPNTargetMaker(nn.Module):
+    """models/new_model.py:299-349: no inside filter, tie-inclusive low-quality matches."""
+
+    def __init__(self, sampler=None):
+        super().__init__()
+        self.sampler = sampler or _Sampler()
+
+    def forward(self, boxes, anchors):
+        boxes = _unwrap(boxes)
+        s = self.sampler
+        if s.sampling == "host":
+            n_pos, n_neg = ops.rpn_targets(anchors, boxes, variant=1)[2].cpu().tolist()[:2]
+            perm_pos = torch.randperm(n_pos) if n_pos > 128 else None
+            perm_neg = torch.randperm(n_neg) if n_neg > 256 - n_pos else None
+            cls, reg, counts = ops.rpn_targets(anchors, boxes, variant=1, perm_pos=perm_pos, perm_neg=perm_neg)
+            if counts.cpu().tolist()[2] != 0:
+                raise RuntimeError("RPNTargetMaker: permutation length mismatch")
+        else:
+            cls, reg, _ = ops.rpn_targets(anchors, boxes, variant=1, seed=s.seed, offset=s.next_offset())
+        return cls, reg
+
+
+class FRCNN(nn.Module):
+    """models/new_model.py:366-470."""
+
+    def __init__(self, num_classes, sampling="device", seed=0):
+        super().__init__()
+        self.num_classes = num_classes
+        self.backbone = BackboneWithFPN(trainable_layers=3)
+        self.classifier = nn.Sequential(nn.Linear(in_features=12544, out_features=1024), nn.ReLU(inplace=True),
+                                        nn.Linear(in_features=1024, out_features=1024), nn.ReLU(inplace=True))
+        self.sampler = _Sampler(sampling, seed)
+        self.rpn = RegionProposalNetwork()
+        self.rpn_target_maker = RPNTargetMaker(self.sampler)
+        self.frcnn_target_maker = FRCNNTargetMaker(self.sampler)
+        self.frcnn_head = FRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
+
+    def count_parameters(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def forward(self, x, boxes, labels):
+        features = self.backbone(x)                                                # new_model.py:394
+        pred_rpn_cls, pred_rpn_reg, rois, n_rois, anchors = self.rpn.propose(x, features, "train")
+        target_rpn_cls, target_rpn_reg = self.rpn_target_maker(boxes=boxes, anchors=anchors)
+        target_fast_rcnn_cls, target_fast_rcnn_reg, sample_rois = self.frcnn_target_maker(boxes=boxes, labels=labels, rois=rois,
+                                                                                          n_rois=n_rois)
+        pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.frcnn_head(features, sample_rois, x.shape[2:])
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(512, -1, 4)
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg[torch.arange(0, 512, device=x.device), target_fast_rcnn_cls]
+        return (pred_rpn_cls.unsqueeze(0), pred_rpn_reg.unsqueeze(0), pred_fast_rcnn_cls, pred_fast_rcnn_reg), \
+               (target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg)
+
+    @torch.no_grad()
+    def predict(self, x, opts):
+        threshold = float(getattr(opts, "thres", opts))
+        features = self.backbone(x)
+        _, _, rois, n_rois, _ = self.rpn.propose(x, features, "test")
+        rois = rois[:int(n_rois.item())]
+        pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.frcnn_head(features, rois, x.shape[2:])
+        pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4) * torch.tensor([0.1, 0.1, 0.2, 0.2], device=x.device)
+        rois = rois.reshape(-1, 1, 4).expand_as(pred_fast_rcnn_reg)
+        pred_bbox = ops.cxcy_to_xy(ops.decode(pred_fast_rcnn_reg.reshape(-1, 4).contiguous(), ops.xy_to_cxcy(rois.reshape(-1, 4).contiguous())))
+        pred_bbox = pred_bbox.reshape(-1, self.num_classes * 4).clamp(min=0, max=1)
+        return self._suppress(pred_bbox, pred_cls, threshold)
+
+    def _suppress(self, raw_cls_bbox, raw_prob, threshold):
+        bbox, label, score = [], [], []
+        boxes = raw_cls_bbox.reshape((-1, self.num_classes, 4))
+        for l in range(1, self.num_classes):                                       # new_model.py:450-460
+            prob_l = raw_prob[:, l]
+            mask = prob_l > threshold
+            cls_bbox_l = boxes[:, l, :][mask].contiguous()
+            prob_l = prob_l[mask].contiguous()
+            keep = ops.nms(cls_bbox_l, prob_l, 0.3)
+            bbox.append(cls_bbox_l[keep].cpu().numpy())
+            label.append((l - 1) * np.ones((len(keep),)))
+            score.append(prob_l[keep].cpu().numpy())
+        bbox = torch.from_numpy(np.concatenate(bbox, axis=0).astype(np.float32))
+        label = torch.from_numpy(np.concatenate(label, axis=0).astype(np.int32))
+        score = torch.from_numpy(np.concatenate(score, axis=0).astype(np.float32))
+        return bbox, label, score

@@ -40,6 +40,28 @@ def path_forward(features, rpn_cls, rpn_reg, bbox, label, hw, mode="train"):
     return out
 
 
+def fpn_path(feats4, shapes5, rpn_cls, rpn_reg, bbox, label, hw, mode="train"):
+    """models/new_model.py:391-418 hot-path stages on numpy inputs: feats4 = levels '0'..'3' as [C,h,w]; shapes5 = (h,w) of all 5 maps."""
+    H, W = int(hw[0]), int(hw[1])
+    anchor = orc.tv_anchor_grid(H, W, shapes5, normalise=True)                 # new_model.py:46-47
+    K, P = (4000, 1000) if mode == "train" else (2000, 1000)
+    rois, src = orc.region_proposal(rpn_reg, rpn_cls, anchor, 10 / 1000, K, 0.7, P)   # new_model.py:49-84
+    out = {"anchor": anchor, "rois": rois, "src": src}
+    if mode != "train":
+        return out
+    _, _, (n_pos, n_neg) = orc.rpn_targets(anchor, bbox, variant=1)            # new_model.py:400
+    pp = torch.randperm(n_pos).numpy() if n_pos > 128 else None
+    pn = torch.randperm(n_neg).numpy() if n_neg > 256 - n_pos else None
+    t_rpn_cls, t_rpn_reg, _ = orc.rpn_targets(anchor, bbox, pp, pn, variant=1)
+    npc, nnc = orc.head_target_counts(rois, bbox, label, variant=1)            # new_model.py:404
+    hp, hn = torch.randperm(npc).numpy(), torch.randperm(nnc).numpy()
+    t_cls, t_reg, srois, keep = orc.head_targets(rois, bbox, label, hp, hn, variant=1, label_offset=0, max_pos=128, total=512)
+    scaled = srois * np.array([W, H, W, H], np.float32)                        # new_model.py:136-140
+    pool, lv = orc.ms_roi_align(feats4, scaled)                                # new_model.py:143
+    out.update(t_rpn_cls=t_rpn_cls, t_rpn_reg=t_rpn_reg, t_cls=t_cls, t_reg=t_reg, sample_rois=srois, keep=keep, pool=pool, level=lv)
+    return out
+
+
 class _RefRoIPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois):

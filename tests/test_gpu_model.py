@@ -108,3 +108,53 @@ def test_predict_api(model):
         assert list(orc.nms(bc, 0.3)) == list(range(len(bc)))
     b2, l2, s2 = model.predict(x.to(DEV), 0.05)                               # model_.py signature: bare threshold
     assert torch.equal(b2, bbox) and torch.equal(l2, label)
+
+
+# ------------------------------------------------------------------------------------------------ ResNet-50-FPN (models/new_model.py)
+@pytest.fixture(scope="module")
+def fpn_model():
+    from faster_rcnn_pytorch_amd.new_model import FRCNN
+    torch.manual_seed(0)
+    m = FRCNN(num_classes=91, sampling="host").to(DEV)
+    with torch.no_grad():
+        m.rpn.rpn_head.cls_layer.weight.mul_(30)
+        m.rpn.rpn_head.reg_layer.weight.mul_(2)
+    return m
+
+
+def test_fpn_forward_matches_oracle_stage_by_stage(fpn_model):
+    H, W, G, seed = 384, 512, 3, 5
+    x, boxes, labels = synth(seed, H, W, G)
+    labels = labels + 1                                    # raw COCO-style ids, 0 = background
+    cap = {}
+    h1 = fpn_model.backbone.register_forward_hook(lambda m, i, o: cap.__setitem__("feats", [v.detach() for v in o.values()]))
+    h2 = fpn_model.frcnn_head.roi_pool.register_forward_hook(lambda m, i, o: cap.__setitem__("pool", o.detach()))
+    fpn_model.train()
+    torch.manual_seed(200 + seed)
+    pred, target = fpn_model(x.to(DEV), boxes.to(DEV), labels.to(DEV))
+    h1.remove()
+    h2.remove()
+    feats = [f[0].cpu().numpy() for f in cap["feats"]]
+    shapes5 = [f.shape[1:] for f in feats]
+    assert len(feats) == 5 and shapes5[0] == (H // 4, W // 4) and shapes5[4] == ((H // 32 + 1) // 2, (W // 32 + 1) // 2)
+    torch.manual_seed(200 + seed)
+    ref = model_ref.fpn_path(feats[:4], shapes5, pred[0][0].detach().cpu().numpy(), pred[1][0].detach().cpu().numpy(),
+                             boxes.numpy(), labels.numpy().astype(np.int64), (H, W))
+    N = sum(h * w for h, w in shapes5) * 3
+    assert pred[0].shape == (1, N, 2) and pred[2].shape == (512, 91) and pred[3].shape == (512, 4)
+    assert np.array_equal(target[0].cpu().numpy(), ref["t_rpn_cls"])                       # tie-inclusive labels: bit-exact
+    assert np.abs(target[1].cpu().numpy() - ref["t_rpn_reg"]).max() < 1e-5
+    assert np.array_equal(target[2].cpu().numpy(), ref["t_cls"])                           # depends on proposals + sort + NMS + sampling
+    assert np.abs(target[3].cpu().numpy() - ref["t_reg"]).max() < 1e-5
+    assert np.abs(cap["pool"].cpu().numpy() - ref["pool"]).max() < 1e-5                    # MultiScaleRoIAlign, tolerance 1e-5
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    FRCNNLoss(None)(pred, target)[0].backward()
+    assert fpn_model.backbone.fpn.inner_blocks[0][0].weight.grad.abs().sum() > 0           # RoIAlign backward reaches the FPN
+    assert fpn_model.backbone.body.conv1.weight.grad is None                               # frozen stem (trainable_layers=3)
+
+
+def test_fpn_predict_api(fpn_model):
+    x, _, _ = synth(11, 320, 448, 1)
+    fpn_model.eval()
+    bbox, label, score = fpn_model.predict(x.to(DEV), 0.02)
+    assert bbox.dtype == torch.float32 and label.dtype == torch.int32 and bbox.shape[0] == score.shape[0]
