@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
     ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
     ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
+    ap.add_argument("--amp", default="none", choices=["none", "bf16"],
+                    help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
     args = ap.parse_args()
 
     from faster_rcnn_pytorch_amd import _lib, parallel
@@ -109,7 +111,12 @@ def main():
 
     def step(i):
         x, b, l = frames[i % len(frames)]
-        pred, target = net(x, [b], [l])
+        if args.amp == "bf16":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred, target = net(x, [b], [l])
+            pred = tuple(p.float() for p in pred)
+        else:
+            pred, target = net(x, [b], [l])
         loss = crit(pred, target)[0]
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -168,7 +175,7 @@ def main():
     out = {
         "metric": "train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)", "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "none" else "bf16(torch layers)+f32(hot path)", "data": "synthetic",
         "config": {"workload": "VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
                                "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)",
                    "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},

@@ -113,15 +113,17 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
     extern __shared__ float smem[];
     const int HW = H * W;
     float *planes = smem;                                        // [CB][HW]
-    int *tab = (int *)(smem + CB * HW);                          // [RB][2*PH + 2*PW]: hs[PH] he[PH] ws[PW] we[PW]
+    int *tab = (int *)(smem + CB * HW);                          // [RB][PH + PW]: (hs | he << 16) x PH, (ws | we << 16) x PW
     constexpr int BINS = PH * PW;
-    constexpr int TW = 2 * PH + 2 * PW;
+    constexpr int TW = PH + PW;
+    constexpr int GROUPS = 256 / (CB * BINS);                    // RoIs processed concurrently by the block
+    static_assert(GROUPS >= 1, "CB * PH * PW must fit one 256-thread block");
     const int c0 = blockIdx.x * CB;
     const int r0 = blockIdx.y * RB;
     const int nr = min(RB, R - r0);
     const int nch = min(CB, C - c0);
     const float *src = feat + (size_t)c0 * HW;
-    {   // stage the planes: 8 independent loads in flight per lane (a plain copy loop waits for every load in turn)
+    {   // stage the planes: 8 independent loads in flight per lane
         const int n_stage = nch * HW;
         for (int base = 0; base < n_stage; base += 256 * 8) {
             float v[8];
@@ -137,34 +139,34 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
             }
         }
     }
-    for (int t = threadIdx.x; t < nr * (PH + PW); t += 256) {
-        const int rl = t / (PH + PW), k = t - rl * (PH + PW);
+    for (int t = threadIdx.x; t < nr * TW; t += 256) {
+        const int rl = t / TW, k = t - rl * TW;
         const RoiBins g = roi_bins(rois[r0 + rl], scale, PH, PW);
-        int *row = tab + rl * TW;
         if (k < PH) {
             const int hs = (int)floorf((float)k * g.bh) + g.sh, he = (int)ceilf((float)(k + 1) * g.bh) + g.sh;
-            row[k] = min(max(hs, 0), H);
-            row[PH + k] = min(max(he, 0), H);
+            tab[t] = min(max(hs, 0), H) | (min(max(he, 0), H) << 16);
         } else {
             const int q = k - PH;
             const int ws = (int)floorf((float)q * g.bw) + g.sw, we = (int)ceilf((float)(q + 1) * g.bw) + g.sw;
-            row[2 * PH + q] = min(max(ws, 0), W);
-            row[2 * PH + PW + q] = min(max(we, 0), W);
+            tab[t] = min(max(ws, 0), W) | (min(max(we, 0), W) << 16);
         }
     }
     __syncthreads();
-    const int per_roi = nch * BINS;
-    const int total = nr * per_roi;
-    for (int o = threadIdx.x; o < total; o += 256) {
-        const int rl = o / per_roi, rem = o - rl * per_roi;
-        const int ch = rem / BINS, p = rem - ch * BINS;
-        const int ph = p / PW, pw = p - ph * PW;
-        const int *row = tab + rl * TW;
-        const int hs = row[ph], he = row[PH + ph], ws = row[2 * PH + pw], we = row[2 * PH + PW + pw];
+    // lane -> fixed (RoI group, channel, bin): all index arithmetic happens once; the loop only walks RoIs
+    const int grp = threadIdx.x / (CB * BINS);
+    const int rem = threadIdx.x - grp * (CB * BINS);
+    const int ch = rem / BINS, p = rem - ch * BINS;
+    const int ph = p / PW, pw = p - ph * PW;
+    if (grp >= GROUPS || ch >= nch) return;
+    const float *pl = planes + ch * HW;
+    size_t e = ((size_t)(r0 + grp) * C + c0 + ch) * BINS + p;
+    const size_t estep = (size_t)GROUPS * C * BINS;
+    for (int rl = grp; rl < nr; rl += GROUPS, e += estep) {
+        const int th = tab[rl * TW + ph], tw = tab[rl * TW + PH + pw];
+        const int hs = th & 0xFFFF, he = th >> 16, ws = tw & 0xFFFF, we = tw >> 16;
         const bool empty = (he <= hs) || (we <= ws);
         float mv = empty ? 0.0f : -FLT_MAX;
         int mi = -1;
-        const float *pl = planes + ch * HW;
         for (int h = hs; h < he; ++h) {
             const float *prow = pl + h * W;
             for (int w = ws; w < we; w += 4) {                   // 4 independent LDS reads in flight; order of the
@@ -176,7 +178,6 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
                 if (v3 > mv) { mv = v3; mi = h * W + w3; }
             }
         }
-        const size_t e = ((size_t)(r0 + rl) * C + c0 + ch) * BINS + p;
         out[e] = mv;
         argmax[e] = mi;
     }
@@ -236,7 +237,7 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     const size_t plane_bytes = (size_t)CB * H * W * 4;
     if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24)) {
         const int RB = ROI_FWD_RB;
-        const size_t shmem = plane_bytes + (size_t)RB * (2 * 7 + 2 * 7) * 4;
+        const size_t shmem = plane_bytes + (size_t)RB * (7 + 7) * 4;
         FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<CB, 7, 7>), dim3((C + CB - 1) / CB, (unsigned)((R + RB - 1) / RB)), dim3(256),
                      shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
         FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");

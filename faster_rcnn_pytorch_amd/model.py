@@ -69,7 +69,7 @@ class RegionProposal(nn.Module):
     def propose(self, cls, reg, anchor, mode, grid=None, want_src=False):
         """Asynchronous form: (rois [P,4] fixed capacity, count int32[1] on device, src | None)."""
         pre, post = self.top_k(mode)
-        return ops.region_proposal(reg.detach(), cls.detach(), anchor, self.min_size / 1000, pre, self.nms_threshold, post,
+        return ops.region_proposal(reg.detach().float(), cls.detach().float(), anchor, self.min_size / 1000, pre, self.nms_threshold, post,
                                    grid=grid, want_src=want_src)
 
     def forward(self, cls, reg, anchor, mode):
@@ -118,7 +118,7 @@ class FastRCNNHead(nn.Module):
         f_height, f_width = features.size()[2:]
         scale = torch.tensor([f_width, f_height, f_width, f_height], dtype=torch.float32, device=roi.device)
         scaled_roi = roi * scale                                               # model.py:107-109
-        pool = self.roi_pool(features, [scaled_roi])
+        pool = self.roi_pool(features.float(), [scaled_roi])           # the hot path computes in fp32 (also under autocast)
         x = pool.view(pool.size(0), -1)
         x = self.classifier(x)
         return self.cls_head(x), self.reg_head(x)
