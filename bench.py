@@ -158,13 +158,29 @@ def main():
         us = ms / n * 1e3
         ab = algorithmic_bytes(name, **shape)
         per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
-                            "GB_s": round(ab / us * 1e-3, 2) if ab else None}
+                            "GB_s": round(ab / us * 1e-3, 2) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+    # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh; separate FETCH_SIZE / WRITE_SIZE runs,
+    # gfx950 fetch correction): measured once per round on the same shapes and committed under profiles/
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hotpath_pmc_traffic.json")) as f:
+            pmc = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        pmc = {}
+
+    def pmc_traffic(name):
+        stem = name[:-len("_kernel")] if name.endswith("_kernel") else name
+        for k, v in pmc.items():
+            if k.startswith(stem):
+                return v["traffic_bytes"]
+        return None
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
         d = per_kernel[dom]
         roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(d["GB_s"] / HBM_PEAK_GBS, 5) if d["GB_s"] else None, "traffic": None,
+                    "frac": round(d["GB_s"] / HBM_PEAK_GBS, 5) if d["GB_s"] else None, "traffic": pmc_traffic(dom),
+                    "traffic_source": "profiles/r01_hotpath_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                     "avg_launch_us": d["avg_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
     hot_us = sum(v["avg_us"] for v in per_kernel.values())
 
