@@ -55,6 +55,7 @@ def algorithmic_bytes(kernel, N, K, P, R, C, fh, fw, G):
         "head_targets_kernel": 16 * (P + G) + 44 * R,
         "roi_pool_fwd_kernel": 4 * C * fh * fw + 16 * R + 8 * R * C * 49,  # features + rois in, out + argmax out
         "roi_pool_bwd_kernel": 8 * R * C * 49 + 4 * C * fh * fw,           # grad_out + argmax in, grad_feat out
+        "rpn_head_tail_kernel": 4 * C * fh * fw + 4 * 54 * C + 4 * 54 * fh * fw,   # conv output + weights in, cls + reg out
     }.get(kernel)
 
 
@@ -153,12 +154,6 @@ def main():
     N = (H // 16) * (W // 16) * 9
     fh, fw = H // 16, W // 16
     shape = dict(N=N, K=12000, P=2000, R=128, C=512, fh=fh, fw=fw, G=8)
-    per_kernel = {}
-    for name, (ms, n) in kernels.items():
-        us = ms / n * 1e3
-        ab = algorithmic_bytes(name, **shape)
-        per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
-                            "GB_s": round(ab / us * 1e-3, 2) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
     # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh; separate FETCH_SIZE / WRITE_SIZE runs,
     # gfx950 fetch correction): measured once per round on the same shapes and committed under profiles/
     pmc = {}
@@ -174,6 +169,12 @@ def main():
             if k.startswith(stem):
                 return v["traffic_bytes"]
         return None
+    per_kernel = {}
+    for name, (ms, n) in kernels.items():
+        us = ms / n * 1e3
+        ab = algorithmic_bytes(name, **shape)
+        per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
+                            "GB_s": round(ab / us * 1e-3, 2) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])

@@ -28,6 +28,7 @@ enum FrcnnKernelId {
     KID_ROI_LEVEL_MAP,
     KID_ROI_ALIGN_FWD,
     KID_ROI_ALIGN_BWD,
+    KID_RPN_HEAD_TAIL,
     KID_COUNT
 };
 

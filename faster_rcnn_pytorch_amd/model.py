@@ -92,7 +92,12 @@ class RegionProposalNetwork(nn.Module):
         normal_init(self.reg_layer, 0, 0.01)
 
     def forward(self, features):
-        batch_size = features.size(0)
+        if features.is_cuda and features.dtype == torch.float32 and features.size(0) == 1:
+            # 3x3 on MIOpen without its bias; bias + ReLU + both 1x1 heads + the NHWC layout in one MFMA kernel
+            raw = torch.nn.functional.conv2d(features, self.inter_layer.weight, None, padding=1)
+            return ops.rpn_head_tail(raw, self.inter_layer.bias, self.cls_layer.weight, self.cls_layer.bias,
+                                     self.reg_layer.weight, self.reg_layer.bias)
+        batch_size = features.size(0)                                              # reference form (autocast / batch > 1)
         x = torch.relu(self.inter_layer(features))
         pred_cls = self.cls_layer(x)
         pred_reg = self.reg_layer(x)

@@ -269,6 +269,54 @@ def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_thresho
 
 
 # --------------------------------------------------------------------------------------------
+# RPN head tail (models/model.py:79-83): bias + ReLU + both 1x1 heads + NHWC store on the fp32 matrix cores
+# --------------------------------------------------------------------------------------------
+class _RPNHeadTailFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, b3, w_cls, b_cls, w_reg, b_reg):
+        raw = _req(raw, name="conv_raw")
+        if raw.dim() != 4 or raw.shape[0] != 1:
+            raise ValueError("rpn_head_tail: conv_raw must be [1,C,fh,fw] (batch 1 per GPU)")
+        _, Cc, fh, fw = raw.shape
+        P = fh * fw
+        b3, b_cls, b_reg = _req(b3, name="b3"), _req(b_cls, name="b_cls"), _req(b_reg, name="b_reg")
+        wc = _req(w_cls, name="w_cls").reshape(w_cls.shape[0], -1)
+        wr = _req(w_reg, name="w_reg").reshape(w_reg.shape[0], -1)
+        n_cls, n_reg = wc.shape[0], wr.shape[0]
+        if wc.shape[1] != Cc or wr.shape[1] != Cc or b3.numel() != Cc:
+            raise ValueError("rpn_head_tail: channel mismatch")
+        out_cls = torch.empty((1, P * n_cls // 2, 2), dtype=torch.float32, device=raw.device)
+        out_reg = torch.empty((1, P * n_reg // 4, 4), dtype=torch.float32, device=raw.device)
+        with torch.cuda.device(raw.device):
+            check(lib.frcnn_rpn_head_tail_fwd(_ptr(raw), Cc, P, _ptr(b3), _ptr(wc), _ptr(b_cls), n_cls, _ptr(wr), _ptr(b_reg), n_reg,
+                                              _ptr(out_cls), _ptr(out_reg), _stream()), "rpn_head_tail_fwd")
+        ctx.save_for_backward(raw, b3, wc, wr)
+        ctx.w_shapes = (w_cls.shape, w_reg.shape)
+        return out_cls, out_reg
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        raw, b3, wc, wr = ctx.saved_tensors
+        _, Cc, fh, fw = raw.shape
+        P = fh * fw
+        n_cls, n_reg = wc.shape[0], wr.shape[0]
+        g = torch.cat([g_cls.reshape(P, n_cls), g_reg.reshape(P, n_reg)], dim=1)          # [P, n_cls + n_reg]
+        z = raw.reshape(Cc, P) + b3[:, None]
+        h = torch.relu(z)                                                                   # recomputed, never stored in forward
+        dW = g.t() @ h.t()                                                                  # [n_out, C]
+        db = g.sum(0)
+        dh = torch.cat([wc, wr], dim=0).t() @ g.t()                                         # [C, P]
+        dz = dh * (z > 0).to(dh.dtype)
+        return (dz.reshape(raw.shape), dz.sum(1), dW[:n_cls].reshape(ctx.w_shapes[0]), db[:n_cls],
+                dW[n_cls:].reshape(ctx.w_shapes[1]), db[n_cls:])
+
+
+def rpn_head_tail(conv_raw, b3, w_cls, b_cls, w_reg, b_reg):
+    """(pred_cls [1, P*A, 2], pred_reg [1, P*A, 4]) from the bias-free 3x3 output; see include/frcnn_hip.h."""
+    return _RPNHeadTailFn.apply(conv_raw, b3, w_cls, b_cls, w_reg, b_reg)
+
+
+# --------------------------------------------------------------------------------------------
 # target makers
 # --------------------------------------------------------------------------------------------
 def _perm(p, dev):

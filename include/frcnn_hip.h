@@ -123,6 +123,16 @@ int frcnn_region_proposal(const float *reg, const float *cls, const float *ancho
                           int64_t *out_src_idx /*[P] anchor index of each roi, or NULL*/,
                           void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- RPN head tail (models/model.py:79-83; models/new_model.py:109-113) ---------------------------------------- */
+/* conv_raw [C,P] = the 3x3 inter_layer convolution WITHOUT its bias (NCHW, P = fh*fw).  Computes
+ *   h = relu(conv_raw + b3);  cls = w_cls[n_cls,C] h + b_cls;  reg = w_reg[n_reg,C] h + b_reg
+ * on the fp32 matrix cores and stores them as [P, n_cls] / [P, n_reg] row-major, i.e. exactly
+ * pred.permute(0,2,3,1).contiguous().view(1,-1,2|4).  C % 64 == 0, n_cls + n_reg <= 64.                          */
+int frcnn_rpn_head_tail_fwd(const float *conv_raw, int C, int64_t P, const float *b3,
+                            const float *w_cls, const float *b_cls, int n_cls,
+                            const float *w_reg, const float *b_reg, int n_reg,
+                            float *out_cls, float *out_reg, void *stream);
+
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).
  * Sampling (torch.randperm on the host in the reference, model_.py:228,235):

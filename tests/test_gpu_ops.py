@@ -450,3 +450,36 @@ def test_ms_roi_align_fwd_bwd_vs_oracle(ops):
     for l, f in enumerate(fts):
         gf_o = orc.roi_align_bwd(go, feats[l].shape, rois, 0.25 / (1 << l), 2, False, lv, l)
         assert np.allclose(f.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=1e-4)  # atomics: order-nondeterministic
+
+
+# ------------------------------------------------------------------------------------------ RPN head tail (MFMA)
+@pytest.mark.parametrize("C,fh,fw,A", [(512, 37, 62, 9), (256, 50, 84, 3), (64, 5, 7, 9)])
+def test_rpn_head_tail_vs_torch_fp32(ops, C, fh, fw, A):
+    """Floating-point kernel: compared with the plain fp32 op chain of models/model.py:79-83 (torch CPU, float64 check),
+    tolerance 1e-5 absolute on outputs of magnitude ~0.1 (north star: 1e-4)."""
+    g = torch.Generator().manual_seed(C + A)
+    raw = torch.randn(1, C, fh, fw, generator=g)
+    b3 = torch.randn(C, generator=g) * 0.1
+    wc = torch.randn(2 * A, C, 1, 1, generator=g) * 0.02
+    bc = torch.randn(2 * A, generator=g) * 0.1
+    wr = torch.randn(4 * A, C, 1, 1, generator=g) * 0.02
+    br = torch.randn(4 * A, generator=g) * 0.1
+    h = torch.relu(raw.double() + b3.double()[None, :, None, None])
+    ref_cls = torch.nn.functional.conv2d(h, wc.double(), bc.double()).permute(0, 2, 3, 1).contiguous().view(1, -1, 2)
+    ref_reg = torch.nn.functional.conv2d(h, wr.double(), br.double()).permute(0, 2, 3, 1).contiguous().view(1, -1, 4)
+    args = [t.to(DEV).requires_grad_(True) for t in (raw, b3, wc, bc, wr, br)]
+    cls, reg = ops.rpn_head_tail(*args)
+    assert cls.shape == ref_cls.shape and reg.shape == ref_reg.shape
+    assert (cls.detach().cpu().double() - ref_cls).abs().max() < 1e-5
+    assert (reg.detach().cpu().double() - ref_reg).abs().max() < 1e-5
+    # backward against autograd of the reference op chain
+    gc, gr = torch.randn(cls.shape, generator=g), torch.randn(reg.shape, generator=g)
+    (cls * gc.to(DEV)).sum().backward(retain_graph=True)
+    (reg * gr.to(DEV)).sum().backward()
+    ref_in = [t.clone().double().requires_grad_(True) for t in (raw, b3, wc, bc, wr, br)]
+    h2 = torch.relu(ref_in[0] + ref_in[1][None, :, None, None])
+    c2 = torch.nn.functional.conv2d(h2, ref_in[2], ref_in[3]).permute(0, 2, 3, 1).contiguous().view(1, -1, 2)
+    r2 = torch.nn.functional.conv2d(h2, ref_in[4], ref_in[5]).permute(0, 2, 3, 1).contiguous().view(1, -1, 4)
+    ((c2 * gc.double()).sum() + (r2 * gr.double()).sum()).backward()
+    for a, b in zip(args, ref_in):
+        assert (a.grad.cpu().double() - b.grad).abs().max() < 2e-4 * max(1.0, float(b.grad.abs().max()))
