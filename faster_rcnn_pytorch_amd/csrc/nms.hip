@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
 #define SCAN_RING 8
 #define SCAN_PF 4
 #define SCAN_HELPERS 14
-#define SCAN_KMAX 5                    // ceil(64 / SCAN_HELPERS) rows per helper wave
+#define SCAN_Q 8                       // far-word loads kept in flight per lane and 64-word chunk
 
 struct NearWords { u64 w[4]; u64 rm[3]; };   // diag, +1, +2, +3 words of my row; row-mask words lane, lane+64, lane+128
 
@@ -178,12 +178,14 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
     if (tid < 4) s_kept[tid] = 0ull;
     if (tid < 2) s_total[tid] = 0;
     __syncthreads();
-    // two generations (by block parity) of in-flight state.  Roles are per wave but registers are per kernel, so the
-    // prefetcher (near words w[4] + row masks rm[3] -> slots 0..6) and the helpers (far words [row slot][chunk]) share them
-    u64 hx[SCAN_KMAX * 3], hy[SCAN_KMAX * 3];
+    // In-flight state.  Roles are per wave but registers are per kernel, so the prefetcher's two generations (7 words
+    // each) and the block-owning helper's 3 x SCAN_Q far words share one array.
+    u64 st[3 * SCAN_Q];
 #pragma unroll
-    for (int k = 0; k < SCAN_KMAX * 3; ++k) { hx[k] = 0ull; hy[k] = 0ull; }
-#define PF_LOAD(H, BLK) { const NearWords t_ = load_near(mask, rowmask, nblk, K, (BLK), lane); H[0] = t_.w[0]; H[1] = t_.w[1]; H[2] = t_.w[2]; H[3] = t_.w[3]; H[4] = t_.rm[0]; H[5] = t_.rm[1]; H[6] = t_.rm[2]; }
+    for (int k = 0; k < 3 * SCAN_Q; ++k) st[k] = 0ull;
+#define PF_LOAD(G, BLK) { const NearWords t_ = load_near(mask, rowmask, nblk, K, (BLK), lane);                       \
+        st[(G) * 8 + 0] = t_.w[0]; st[(G) * 8 + 1] = t_.w[1]; st[(G) * 8 + 2] = t_.w[2]; st[(G) * 8 + 3] = t_.w[3]; \
+        st[(G) * 8 + 4] = t_.rm[0]; st[(G) * 8 + 5] = t_.rm[1]; st[(G) * 8 + 6] = t_.rm[2]; }
     if (wave == 1) {
         for (int blk = 0; blk < SCAN_PF && blk < nb; ++blk) {
             const NearWords t = load_near(mask, rowmask, nblk, K, blk, lane);
@@ -192,22 +194,19 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 #pragma unroll
             for (int m = 0; m < 3; ++m) rm_ring[blk % SCAN_RING][lane + 64 * m] = t.rm[m];
         }
-        if (SCAN_PF + 0 < nb) PF_LOAD(hx, SCAN_PF + 0)
-        if (SCAN_PF + 1 < nb) PF_LOAD(hy, SCAN_PF + 1)
+        if (SCAN_PF + 0 < nb) PF_LOAD(0, SCAN_PF + 0)
+        if (SCAN_PF + 1 < nb) PF_LOAD(1, SCAN_PF + 1)
     }
-    // helper state: two generations (by block parity) of in-flight far words [row slot][64-word chunk] and of
-    // output records (lane k < SCAN_KMAX emits this wave's k-th row)
     __syncthreads();
 
     int total = 0;
-    bool hx_any = false, hy_any = false;
-    u64 wmask = 0ull;                                            // rows owned by this helper wave
-    for (int i = wave - 2; i >= 0 && i < 64; i += SCAN_HELPERS) wmask |= 1ull << i;
+    int pend_c = -1;                             // helper: block whose far words are in flight
 
-#define SCAN_ITER(B, HSET, HFLAG)                                                            \
+#define SCAN_ITER(B, G)                                                                                              \
     {                                                                                                                \
         const int b = (B);                                                                                           \
         if (wave == 0) {                                                                                             \
+            /* ---- resolver ---- */                                                                                 \
             const int slot = b % SCAN_RING;                                                                          \
             const u64 d0 = ring[slot][0][lane], u1 = ring[slot][1][lane], u2 = ring[slot][2][lane], u3 = ring[slot][3][lane]; \
             const u64 rmv = rm_ring[slot][b + (lane & 3)];      /* lanes 0..3: which rows have bits in words b..b+3 */ \
@@ -258,52 +257,51 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
                 if (r3) atomicOr(&removed[b + 3], r3);                                                               \
             }                                                                                                        \
         } else if (wave == 1) {                                                                                      \
-            /* rings <- block b+PF (issued two iterations ago); re-issue this generation for block b+PF+2 */         \
+            /* ---- prefetcher: rings <- block b+PF (issued two iterations ago); re-issue for block b+PF+2 ---- */   \
             if (b + SCAN_PF < nb) {                                                                                  \
                 const int slot = (b + SCAN_PF) % SCAN_RING;                                                          \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d) ring[slot][d][lane] = HSET[d];                          \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = HSET[4 + m];             \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) ring[slot][d][lane] = st[(G) * 8 + d];                 \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = st[(G) * 8 + 4 + m];    \
             }                                                                                                        \
-            if (b + SCAN_PF + 2 < nb) PF_LOAD(HSET, b + SCAN_PF + 2)                                                 \
+            if (b + SCAN_PF + 2 < nb) PF_LOAD(G, b + SCAN_PF + 2)                                                    \
         } else {                                                                                                     \
-            /* this generation was issued two iterations ago (block b-3): apply its far words (skipped outright      \
-               when nothing was fetched, the common case) */                                                         \
-            if (HFLAG) {                                                                                             \
-                _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k)                                                \
-                    _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                  \
-                        const u64 v = HSET[k * 3 + m];                                                               \
-                        if (v) atomicOr(&removed[lane + 64 * m], v);                                                 \
-                        HSET[k * 3 + m] = 0ull;                                                                      \
-                    }                                                                                                \
-                HFLAG = false;                                                                                       \
+            /* ---- helpers: ONE wave owns a whole block (c % 14 == wave-2); lane = far word (3 chunks of 64).       \
+               Up to SCAN_Q suppressing kept rows per word are fetched at iteration c+1 and OR-ed into `removed`     \
+               at iteration c+3; the other 13 helpers only pass the barrier, so they never compete for the SIMDs. */ \
+            if (pend_c >= 0 && b == pend_c + 3) {                                                                    \
+                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                      \
+                    u64 acc = 0ull;                                                                                  \
+                    _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q) { acc |= st[m * SCAN_Q + q]; st[m * SCAN_Q + q] = 0ull; } \
+                    if (acc) atomicOr(&removed[lane + 64 * m], acc);                                                 \
+                }                                                                                                    \
+                pend_c = -1;                                                                                         \
             }                                                                                                        \
-            /* issue for block c = b-1.  This wave owns the rows whose lane index is h, h+14, h+28, h+42, h+56       \
-               (h = wave-2); a far word is fetched only where the row mask says one of those kept rows has a bit */ \
             const int c = b - 1;                                                                                     \
-            if (c >= 0) {                                                                                            \
+            if (c >= 0 && (c % SCAN_HELPERS) == wave - 2) {                                                          \
                 const u64 kcv = s_kept[c & 3];                                                                       \
                 const u64 kc = ((u64)RFL((unsigned)(kcv >> 32)) << 32) | (u64)RFL((unsigned)kcv);                    \
-                const u64 mine = kc & wmask;                                                                         \
-                if (mine != 0ull) {                                                                                  \
+                /* kept positions of block c (boxes / source ids are gathered after the scan) */                     \
+                if ((kc >> lane) & 1ull)                                                                             \
+                    out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane); \
+                if (c + 4 < nb && kc != 0ull) {                                                                      \
+                    const size_t rb0 = (size_t)c * 64;                                                               \
                     const int cslot = c % SCAN_RING;                                                                 \
-                    if (c + 4 < nb) {                                                                                \
-                        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                              \
-                            const int w = lane + 64 * m;                                                             \
-                            const u64 need = (w >= c + 4 && w < nb) ? (rm_ring[cslot][w] & mine) : 0ull;             \
-                            if (__ballot(need != 0ull) != 0ull) {                                                    \
-                                HFLAG = true;                                                                        \
-                                _Pragma("unroll") for (int k = 0; k < SCAN_KMAX; ++k) {                              \
-                                    const int i = (wave - 2) + SCAN_HELPERS * k;                                     \
-                                    if (i < 64 && ((need >> i) & 1ull)) HSET[k * 3 + m] = mask[(size_t)(c * 64 + i) * nblk + w]; \
-                                }                                                                                    \
+                    _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                  \
+                        const int w = lane + 64 * m;                                                                 \
+                        u64 need = (w >= c + 4 && w < nb) ? (rm_ring[cslot][w] & kc) : 0ull;                         \
+                        _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q)                                           \
+                            if (need != 0ull) {                                                                      \
+                                const int i = __builtin_ctzll(need);                                                 \
+                                need &= need - 1ull;                                                                 \
+                                st[m * SCAN_Q + q] = mask[(rb0 + i) * nblk + w];                                     \
                             }                                                                                        \
+                        while (need != 0ull) {              /* rare: more than SCAN_Q suppressing rows for a word */ \
+                            const int i = __builtin_ctzll(need);                                                     \
+                            need &= need - 1ull;                                                                     \
+                            st[m * SCAN_Q] |= mask[(rb0 + i) * nblk + w];                                            \
                         }                                                                                            \
                     }                                                                                                \
-                    if (lane < SCAN_KMAX) {      /* kept positions only; boxes / source ids are gathered after the scan */ \
-                        const int i = (wave - 2) + SCAN_HELPERS * lane;                                              \
-                        if (i < 64 && ((kc >> i) & 1ull))                                                            \
-                            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << i) - 1ull))] = (int64_t)(c * 64 + i); \
-                    }                                                                                                \
+                    pend_c = c;                                                                                      \
                 }                                                                                                    \
             }                                                                                                        \
         }                                                                                                            \
@@ -313,18 +311,19 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 
     int last_b = -1;
     for (int b0 = 0; b0 < nb && total < post_k; b0 += 2) {
-        SCAN_ITER(b0, hx, hx_any)
+        SCAN_ITER(b0, 0)
         last_b = b0;
         if (b0 + 1 >= nb || total >= post_k) break;
-        SCAN_ITER(b0 + 1, hy, hy_any)
+        SCAN_ITER(b0 + 1, 1)
         last_b = b0 + 1;
     }
-    if (wave >= 2 && last_b >= 0 && lane < SCAN_KMAX) {         // the last resolved block was never emitted
+#undef SCAN_ITER
+#undef PF_LOAD
+    if (wave == 2 && last_b >= 0) {                             // the last resolved block was never emitted
         const int c = last_b;
         const u64 kc = s_kept[c & 3];
-        const int i = (wave - 2) + SCAN_HELPERS * lane;
-        if (i < 64 && ((kc >> i) & 1ull))
-            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << i) - 1ull))] = (int64_t)(c * 64 + i);
+        if ((kc >> lane) & 1ull)
+            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane);
     }
     __syncthreads();                                            // out_keep complete and visible to the whole workgroup
     const int n_out = total < post_k ? total : post_k;
@@ -334,9 +333,7 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
             if (out_rois) out_rois[p] = boxes[row];
             if (out_src) out_src[p] = src_map ? src_map[row] : row;
         }
-#undef SCAN_ITER
-#undef PF_LOAD
-    if (tid == 0) *out_count = total < post_k ? total : post_k;
+    if (tid == 0) *out_count = n_out;
 }
 
 // ------------------------------------------------------------------------------------------------
