@@ -27,10 +27,12 @@
 //  nms_scan_kernel : the simple unpipelined form, used for K > 12288.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 #define NMS_MAX_BLOCKS 4096            // K <= 262144
 #define NMS_FAST_MAX_BLOCKS 192        // pipelined scan: 3 far words per lane
-#define NMS_WS_PAD 256                 // the prefetcher reads 3 words past a row's last word
+#define NMS_WS_PAD 256                 // the prefetchers read up to 7 words past a row's last word
 
 typedef unsigned long long u64;
 
@@ -337,6 +339,204 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// dataflow scan (K <= 12288): same roles as above but NO workgroup barrier inside the loop.  The resolver (wave 0),
+// two prefetchers (waves 1-2, even / odd blocks) and 13 block-owning helpers (waves 3-15) run free and hand data to
+// each other through LDS words (progress counter, per-block ready / done flags), polled with s_sleep.  The resolver's
+// per-block time is then its own scalar work only; every other latency (near-word prefetch, far-word fetch of the
+// kept rows) is overlapped by waves that are several blocks ahead of / behind it.
+//   resolver  b : needs ring_ready[b] (prefetcher) and fdone[b - FLOW_LAG] (far words of all blocks <= b - FLOW_LAG)
+//   prefetcher j: fills ring slot j % FLOW_RING once progress >= j - FLOW_AHEAD
+//   helper    c : waits progress > c, emits the kept positions of block c, fetches its far words (>= c + FLOW_LAG + 1... see code),
+//                 ORs them into `removed`, sets fdone[c]
+// Every spin is bounded (FLOW_SPIN_MAX polls): on overflow the kernel aborts with out_count = -1 instead of hanging.
+// ------------------------------------------------------------------------------------------------
+#define FLOW_NEAR 3                     // near words handled by the resolver itself: blocks b+1 .. b+FLOW_NEAR
+#define FLOW_RING 16
+#define FLOW_AHEAD 7                    // <= FLOW_RING - FLOW_NEAR - 2: a ring slot is recycled only after its helper has set fdone
+#define FLOW_Q 8
+#define FLOW_HELPERS 13
+#define FLOW_SPIN_MAX (1 << 22)
+
+__device__ __forceinline__ int lds_ld(const volatile int *p) { return *p; }
+
+// OR-reduction over the 64 lanes; the result is valid in lane 63 (LLVM's DPP scan sequence: row_shr 1,2,4,8 inside
+// the four 16-lane rows, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3)
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v)
+{
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1 and 3
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+#define FLOW_WAIT(COND)                                                                                              \
+    {                                                                                                                \
+        int spins_ = 0;                                                                                              \
+        while (!(COND)) {                                                                                            \
+            __builtin_amdgcn_s_sleep(1);                                                                             \
+            if (++spins_ > FLOW_SPIN_MAX || lds_ld(&s_abort)) { s_abort = 1; break; }                                \
+        }                                                                                                            \
+        asm volatile("" ::: "memory");                                                                               \
+    }
+
+__global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
+                                                             int nblk, const u64 *__restrict__ mask, const u64 *__restrict__ rowmask,
+                                                             int post_k, int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
+                                                             const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
+                                                             int32_t *__restrict__ out_count)
+{
+    __shared__ u64 removed[NMS_FAST_MAX_BLOCKS + 8];
+    __shared__ u64 ring[FLOW_RING][1 + FLOW_NEAR][64];                  // 64 KB
+    __shared__ u64 rm_ring[FLOW_RING][NMS_FAST_MAX_BLOCKS + 8];         // 25 KB
+    __shared__ u64 s_kept[NMS_FAST_MAX_BLOCKS];
+    __shared__ int s_base[NMS_FAST_MAX_BLOCKS];
+    __shared__ volatile int ring_ready[NMS_FAST_MAX_BLOCKS];            // 1 once block j's ring slot is filled
+    __shared__ volatile int fdone[NMS_FAST_MAX_BLOCKS];                 // 1 once block c's far words are in `removed`
+    __shared__ volatile int s_progress;                                 // blocks resolved so far
+    __shared__ volatile int s_finished;                                 // resolver done (end of boxes or post_k reached)
+    __shared__ volatile int s_abort;
+    __shared__ int s_total_out;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = n_dev ? min(*n_dev, K) : K;
+    const int nb = (n + 63) >> 6;
+
+    for (int w = tid; w < NMS_FAST_MAX_BLOCKS + 8; w += 1024) removed[w] = 0ull;
+    for (int w = tid; w < FLOW_RING * (NMS_FAST_MAX_BLOCKS + 8); w += 1024) (&rm_ring[0][0])[w] = 0ull;
+    for (int w = tid; w < NMS_FAST_MAX_BLOCKS; w += 1024) { ring_ready[w] = 0; fdone[w] = 0; }
+    if (tid == 0) { s_progress = 0; s_finished = 0; s_abort = 0; s_total_out = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        // ------------------------------------------------ resolver
+        // The LDS of a CU executes one wave's operations in issue order, so "data then flag" needs no s_waitcnt between
+        // them, and the only LDS round trip a block has to wait for is the batch {removed[b], near words, row masks};
+        // the flags of block b+1 are sampled while block b resolves and re-polled only if they were not set yet.
+        int total = 0;
+        FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)
+        for (int b = 0; b < nb && !lds_ld(&s_abort); ++b) {
+            const int slot = b % FLOW_RING;
+            const int nxt_far = b + 1 - FLOW_NEAR - 1;                  // far words of blocks <= nxt_far must be in before block b+1
+            const int f_ring = b + 1 < nb ? lds_ld(&ring_ready[b + 1]) : 1;
+            const int f_far = nxt_far >= 0 ? lds_ld(&fdone[nxt_far]) : 1;
+            u64 nw[1 + FLOW_NEAR];
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = ring[slot][d][lane];
+            const u64 rmv = rm_ring[slot][b];                           // which rows have any bit in the diagonal tile
+            const u64 rem = removed[b];
+            const int live = n - b * 64;
+            const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);
+            u64 alive = ~(((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem)) & valid;
+            {
+                const unsigned dl = (unsigned)nw[0], dh = (unsigned)(nw[0] >> 32);
+                u64 act = alive & (((u64)RFL((unsigned)(rmv >> 32)) << 32) | (u64)RFL((unsigned)rmv));
+                while (act != 0ull) {                                   // only live rows with a bit in the diagonal tile
+                    const int i = __builtin_ctzll(act);
+                    act &= act - 1ull;
+                    if ((alive >> i) & 1ull) alive &= ~RL64(dl, dh, i);
+                }
+            }
+            u64 kept = alive;
+            int cnt = __builtin_popcountll(kept);
+            if (total + cnt > post_k) {                                 // keep only the first post_k - total survivors
+                cnt = post_k - total;
+                u64 t = kept;
+                for (int q = 0; q < cnt; ++q) t &= t - 1ull;
+                kept &= ~t;
+            }
+            if (lane == 0) { s_kept[b] = kept; s_base[b] = total; s_progress = b + 1; }   // in-order: data lands before the counter
+            total += cnt;
+            if (total >= post_k) break;
+            // near words: every kept lane whose word is non-zero ORs it straight into `removed` (ds_or_b64); this wave's
+            // next read of removed[b+1] is queued behind them, and no helper touches words < c + FLOW_NEAR + 1
+            const bool mine = (kept >> lane) & 1ull;
+#pragma unroll
+            for (int d = 1; d <= FLOW_NEAR; ++d)
+                if (b + d < nb && mine && nw[d] != 0ull) atomicOr(&removed[b + d], nw[d]);
+            if (!f_ring) FLOW_WAIT(lds_ld(&ring_ready[b + 1]) != 0)
+            if (!f_far) FLOW_WAIT(lds_ld(&fdone[nxt_far]) != 0)
+        }
+        if (lane == 0) { s_total_out = total; s_finished = 1; }
+    } else if (wave <= 2) {
+        // ------------------------------------------------ prefetchers: wave 1 even blocks, wave 2 odd blocks
+        for (int j = wave - 1; j < nb; j += 2) {
+            FLOW_WAIT(lds_ld(&s_progress) >= j - FLOW_AHEAD || lds_ld(&s_finished))
+            if (lds_ld(&s_finished) || lds_ld(&s_abort)) break;
+            const int row = min(j * 64 + lane, K - 1);
+            const u64 *p = mask + (size_t)row * nblk + j;
+            u64 v[1 + FLOW_NEAR];
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) v[d] = p[d];          // 64 contiguous bytes of my row (padded workspace)
+            const u64 *q = rowmask + (size_t)j * nblk;
+            u64 rmw[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rmw[m] = (lane + 64 * m < nblk) ? q[lane + 64 * m] : 0ull;
+            const int slot = j % FLOW_RING;
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) ring[slot][d][lane] = v[d];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = rmw[m];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) ring_ready[j] = 1;
+        }
+    } else {
+        // ------------------------------------------------ helpers: block c, c + 13, ...
+        for (int c = wave - 3; c < nb; c += FLOW_HELPERS) {
+            FLOW_WAIT(lds_ld(&s_progress) > c || lds_ld(&s_finished))
+            if (lds_ld(&s_abort) || lds_ld(&s_progress) <= c) break;    // finished before block c was resolved
+            const u64 kcv = s_kept[c];
+            const u64 kc = ((u64)RFL((unsigned)(kcv >> 32)) << 32) | (u64)RFL((unsigned)kcv);
+            if ((kc >> lane) & 1ull)
+                out_keep[s_base[c] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane);
+            const int w0 = c + FLOW_NEAR + 1;                           // first far word
+            if (w0 < nb && kc != 0ull) {
+                const size_t rb0 = (size_t)c * 64;
+                const int cslot = c % FLOW_RING;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int w = lane + 64 * m;
+                    u64 need = (w >= w0 && w < nb) ? (rm_ring[cslot][w] & kc) : 0ull;
+                    u64 v[FLOW_Q];
+#pragma unroll
+                    for (int q = 0; q < FLOW_Q; ++q) {
+                        v[q] = 0ull;
+                        if (need != 0ull) {
+                            const int i = __builtin_ctzll(need);
+                            need &= need - 1ull;
+                            v[q] = mask[(rb0 + i) * nblk + w];
+                        }
+                    }
+                    u64 acc = 0ull;
+                    while (need != 0ull) {                              // rare: more than FLOW_Q suppressing rows for one word
+                        const int i = __builtin_ctzll(need);
+                        need &= need - 1ull;
+                        acc |= mask[(rb0 + i) * nblk + w];
+                    }
+#pragma unroll
+                    for (int q = 0; q < FLOW_Q; ++q) acc |= v[q];
+                    if (acc) atomicOr(&removed[w], acc);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my ORs are in LDS before the flag
+            if (lane == 0) fdone[c] = 1;
+        }
+    }
+    __syncthreads();                                                  // everybody out of the dataflow; out_keep complete
+    const int total = s_abort ? 0 : s_total_out;
+    const int n_out = total < post_k ? total : post_k;
+    if (out_rois || out_src)
+        for (int p = tid; p < n_out; p += 1024) {
+            const int64_t row = out_keep[p];
+            if (out_rois) out_rois[p] = boxes[row];
+            if (out_src) out_src[p] = src_map ? src_map[row] : row;
+        }
+    if (tid == 0) *out_count = s_abort ? -1 : n_out;
+}
+
+// ------------------------------------------------------------------------------------------------
 // simple scan (any K up to 262144): two memory round trips per block
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
@@ -423,7 +623,12 @@ int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, 
     FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K,
                  thr, nblk, mask, rowmask);
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
-    if (nblk <= NMS_FAST_MAX_BLOCKS) {
+    static const bool use_pipe = getenv("FRCNN_NMS_SCAN") && !strcmp(getenv("FRCNN_NMS_SCAN"), "pipe");
+    if (nblk <= NMS_FAST_MAX_BLOCKS && !use_pipe) {
+        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_flow_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
+                     rowmask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
+        FRCNN_CHECK_LAUNCH("nms_scan_flow_kernel");
+    } else if (nblk <= NMS_FAST_MAX_BLOCKS) {
         FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_fast_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
                      rowmask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
         FRCNN_CHECK_LAUNCH("nms_scan_fast_kernel");
