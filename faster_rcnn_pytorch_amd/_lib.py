@@ -29,6 +29,7 @@ SIGNATURES = {
     "frcnn_topk_sorted": (_i, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_argsort_desc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_nms": (_i, [_vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_nms_classed": (_i, [_vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_region_proposal": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _f, _f, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_head_tail_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),

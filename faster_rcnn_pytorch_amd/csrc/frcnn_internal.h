@@ -27,6 +27,6 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
                       void *ws, size_t ws_bytes, hipStream_t s);
 
 size_t frcnn_ws_nms(int64_t K);
-int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
+int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
                      int64_t *out_keep, float *out_rois, const int64_t *src_map, int64_t *out_src, int32_t *out_count,
                      void *ws, size_t ws_bytes, hipStream_t s);

@@ -52,9 +52,9 @@ __device__ __forceinline__ bool nms_suppress_exact(float4 a, float area_a, float
 // 32 columns [j0, j0+32) of one tile.  Returns the per-lane result word; *unsure gets the lanes (as a wave
 // mask) for which at least one column fell inside the guard band (or had a non-positive union) and must be
 // re-evaluated with the exact division.  CHECK = diagonal or tail tile (col > row, col < n tests needed).
-template <bool CHECK>
+template <bool CHECK, bool CLS>
 __device__ __forceinline__ unsigned mask_half(float4 a, float area_a, const float4 *__restrict__ sb, const float *__restrict__ sa,
-                                              float thr, int c0, int row, int n, u64 *unsure)
+                                              float thr, int c0, int row, int n, u64 *unsure, int my_cls, const int *__restrict__ sc)
 {
     unsigned word = 0u;
     u64 uns = 0ull;
@@ -73,17 +73,20 @@ __device__ __forceinline__ unsigned mask_half(float4 a, float area_a, const floa
         uns |= __ballot(!sure);
         bool s = d > 0.0f;
         if (CHECK) s = s && (c0 + j > row) && (c0 + j < n);
+        if (CLS) s = s && (sc[j] == my_cls);                     // batched (per-class) NMS: only same-class boxes suppress
         word |= s ? (1u << j) : 0u;
     }
     *unsure |= uns;
     return word;
 }
 
-__global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
+template <bool CLS>
+__global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev, int K,
                                                        float thr, int nblk, u64 *__restrict__ mask, u64 *__restrict__ rowmask)
 {
     __shared__ float4 s_box[4][64];
     __shared__ float s_area[4][64];
+    __shared__ int s_cls[4][64];
     const int n = n_dev ? min(*n_dev, K) : K;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -94,28 +97,31 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
     const int row = rb * 64 + lane;
     const float4 a = boxes[min(row, K - 1)];
     const float area_a = (a.z - a.x) * (a.w - a.y);
+    const int my_cls = CLS ? cls[min(row, K - 1)] : 0;
     u64 bits = 0ull;
     const int c0 = cb * 64;
     if (c0 < n) {
         const float4 cbx = boxes[min(c0 + lane, K - 1)];        // coalesced 1 KB
+        if (CLS) s_cls[wave][lane] = cls[min(c0 + lane, K - 1)];
         s_box[wave][lane] = cbx;
         s_area[wave][lane] = (cbx.z - cbx.x) * (cbx.w - cbx.y);
         __builtin_amdgcn_wave_barrier();                        // same-wave LDS RAW: ds ops of one wave complete in order
         u64 unsure = 0ull;
         unsigned lo, hi;
         if (cb == rb || c0 + 64 > n) {                          // diagonal / tail tile
-            lo = mask_half<true>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure);
-            hi = mask_half<true>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure);
+            lo = mask_half<true, CLS>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure, my_cls, s_cls[wave]);
+            hi = mask_half<true, CLS>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure, my_cls, s_cls[wave] + 32);
         } else {
-            lo = mask_half<false>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure);
-            hi = mask_half<false>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure);
+            lo = mask_half<false, CLS>(a, area_a, s_box[wave], s_area[wave], thr, c0, row, n, &unsure, my_cls, s_cls[wave]);
+            hi = mask_half<false, CLS>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, c0 + 32, row, n, &unsure, my_cls, s_cls[wave] + 32);
         }
         bits = ((u64)hi << 32) | lo;
         if (unsure != 0ull) {                                   // rare: redo the affected rows with the IEEE division
             if ((unsure >> lane) & 1ull) {
                 bits = 0ull;
                 for (int j = 0; j < 64; ++j) {
-                    const bool s = nms_suppress_exact(a, area_a, s_box[wave][j], s_area[wave][j], thr) && (c0 + j > row) && (c0 + j < n);
+                    const bool s = nms_suppress_exact(a, area_a, s_box[wave][j], s_area[wave][j], thr) && (c0 + j > row) && (c0 + j < n) &&
+                                   (!CLS || s_cls[wave][j] == my_cls);
                     bits |= s ? (1ull << j) : 0ull;
                 }
             }
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
         // them, and the only LDS round trip a block has to wait for is the batch {removed[b], near words, row masks};
         // the flags of block b+1 are sampled while block b resolves and re-polled only if they were not set yet.
         int total = 0;
-        FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)
+        if (nb > 0) FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)           // nb == 0: no live box, nothing will ever be prefetched
         for (int b = 0; b < nb && !lds_ld(&s_abort); ++b) {
             const int slot = b % FLOW_RING;
             const int nxt_far = b + 1 - FLOW_NEAR - 1;                  // far words of blocks <= nxt_far must be in before block b+1
@@ -610,7 +616,7 @@ size_t frcnn_ws_nms(int64_t K)
     return align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256) + align_up((size_t)nblk * (size_t)nblk * 8, 256);
 }
 
-int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
+int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
                      int64_t *out_keep, float *out_rois, const int64_t *src_map, int64_t *out_src, int32_t *out_count,
                      void *ws, size_t ws_bytes, hipStream_t s)
 {
@@ -620,8 +626,12 @@ int frcnn_launch_nms(const float *boxes, const int32_t *n_boxes_dev, int64_t K, 
     if (nblk > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
     u64 *mask = (u64 *)ws;
     u64 *rowmask = (u64 *)((char *)ws + align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256));
-    FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K,
-                 thr, nblk, mask, rowmask);
+    if (cls)
+        FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel<true>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
+                     (int)K, thr, nblk, mask, rowmask);
+    else
+        FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel<false>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
+                     (int)K, thr, nblk, mask, rowmask);
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
     static const bool use_pipe = getenv("FRCNN_NMS_SCAN") && !strcmp(getenv("FRCNN_NMS_SCAN"), "pipe");
     if (nblk <= NMS_FAST_MAX_BLOCKS && !use_pipe) {
@@ -652,6 +662,24 @@ FRCNN_EXPORT int frcnn_nms(const float *boxes, const int32_t *n_boxes_dev, int64
         return FRCNN_OK;
     }
     FRCNN_REQUIRE(boxes && out_keep && workspace, "nms: NULL pointer");
-    return frcnn_launch_nms(boxes, n_boxes_dev, K, iou_threshold, post_k, out_keep, out_rois, nullptr, nullptr, out_count, workspace,
+    return frcnn_launch_nms(boxes, nullptr, n_boxes_dev, K, iou_threshold, post_k, out_keep, out_rois, nullptr, nullptr, out_count, workspace,
+                            workspace_bytes, s);
+}
+
+// torchvision.ops.batched_nms semantics for FRCNN._suppress (models/model.py:382-402): greedy in score order, a box is
+// suppressed only by a kept box of the SAME class.  boxes / cls are already in visiting (score-descending) order.
+FRCNN_EXPORT int frcnn_nms_classed(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float iou_threshold,
+                                   int64_t post_k, int64_t *out_keep, float *out_rois, int32_t *out_count, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    FRCNN_REQUIRE(K >= 0 && post_k >= 0, "nms_classed: negative size");
+    FRCNN_REQUIRE(out_count, "nms_classed: NULL out_count");
+    hipStream_t s = (hipStream_t)stream;
+    if (K == 0 || post_k == 0) {
+        if (hipMemsetAsync(out_count, 0, sizeof(int32_t), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms_classed: memset failed");
+        return FRCNN_OK;
+    }
+    FRCNN_REQUIRE(boxes && cls && out_keep && workspace, "nms_classed: NULL pointer");
+    return frcnn_launch_nms(boxes, cls, n_boxes_dev, K, iou_threshold, post_k, out_keep, out_rois, nullptr, nullptr, out_count, workspace,
                             workspace_bytes, s);
 }

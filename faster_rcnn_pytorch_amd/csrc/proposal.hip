@@ -64,6 +64,6 @@ FRCNN_EXPORT int frcnn_region_proposal(const float *reg, const float *cls, const
     if (rc) return rc;
     rc = frcnn_launch_topk(w.scores, w.boxes, N, K, 1, w.sidx, w.sscores, w.sboxes, w.ctrl, w.topk_ws, w.topk_bytes, s);
     if (rc) return rc;
-    return frcnn_launch_nms(w.sboxes, w.ctrl, K, iou_threshold, P < K ? P : K, w.keep, out_rois, w.sidx, out_src_idx, out_count, w.nms_ws,
+    return frcnn_launch_nms(w.sboxes, nullptr, w.ctrl, K, iou_threshold, P < K ? P : K, w.keep, out_rois, w.sidx, out_src_idx, out_count, w.nms_ws,
                             w.nms_bytes, s);
 }

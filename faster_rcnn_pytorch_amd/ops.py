@@ -235,6 +235,31 @@ def nms(boxes, scores, iou_threshold):
     return idx[keep[:n]]
 
 
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms semantics: NMS is performed independently per class id in `idxs`, in ONE launch pair
+    (class-aware suppression mask + scan).  Returns int64 indices of the kept boxes sorted by decreasing score.
+    Replaces the per-class python loop of FRCNN._suppress (models/model.py:382-402): one host sync instead of C-1."""
+    boxes = _req(boxes, name="boxes").reshape(-1, 4)
+    scores = _req(scores, name="scores").reshape(-1)
+    idxs = _req(idxs.to(torch.int32), torch.int32, "idxs").reshape(-1)
+    n = boxes.shape[0]
+    if scores.shape[0] != n or idxs.shape[0] != n:
+        raise ValueError("batched_nms: boxes, scores and idxs differ in length")
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order, _, sboxes, _ = topk_sorted(scores, n, boxes, all_live=True)
+    scls = idxs[order].contiguous()
+    dev = boxes.device
+    keep = torch.empty((n,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+    nb = _lib.workspace_bytes(_lib.OP_NMS, n)
+    ws = _workspace(dev, nb)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_nms_classed(_ptr(sboxes), _ptr(scls), None, n, float(iou_threshold), n, _ptr(keep), None, _ptr(cnt), _ptr(ws), nb,
+                                    _stream()), "nms_classed")
+    return order[keep[:int(cnt.item())]]
+
+
 def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_threshold, post_nms_top_k, grid=None, want_src=False):
     """RegionProposal.forward in one enqueue (no host sync).
     anchors: [N,4] device tensor, or None with grid=(fh, fw, stride, base[A,4] host, div_w, div_h).

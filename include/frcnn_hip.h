@@ -112,6 +112,13 @@ int frcnn_nms(const float *boxes /*[K,4]*/, const int32_t *n_boxes_dev, int64_t 
               int64_t *out_keep /*[post_k]*/, float *out_rois /*[post_k,4] or NULL*/, int32_t *out_count,
               void *workspace, size_t workspace_bytes, void *stream);
 
+/* Per-class NMS of FRCNN._suppress (models/model.py:382-402; torchvision batched_nms semantics) in ONE launch pair
+ * instead of C-1 nms calls + C-1 device-to-host copies: like frcnn_nms, but box j is suppressed only by a kept box i
+ * with cls[i] == cls[j].  boxes / cls are in visiting (score-descending) order.                                      */
+int frcnn_nms_classed(const float *boxes /*[K,4]*/, const int32_t *cls /*[K]*/, const int32_t *n_boxes_dev, int64_t K,
+                      float iou_threshold, int64_t post_k, int64_t *out_keep, float *out_rois /*or NULL*/, int32_t *out_count,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
 /* All of RegionProposal.forward in one call (prologue -> top-K -> NMS -> first P), no host sync.
  * anchors may be NULL when the single-level grid description is given (fh,fw,stride,base9x4 on host):
  * the anchors are then regenerated in registers and never read from HBM (anchor.py:34-55 fused away). */

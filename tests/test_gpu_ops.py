@@ -483,3 +483,94 @@ def test_rpn_head_tail_vs_torch_fp32(ops, C, fh, fw, A):
     ((c2 * gc.double()).sum() + (r2 * gr.double()).sum()).backward()
     for a, b in zip(args, ref_in):
         assert (a.grad.cpu().double() - b.grad).abs().max() < 2e-4 * max(1.0, float(b.grad.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ edge cases (empty / ragged / extreme sizes)
+def test_empty_and_degenerate_inputs(ops):
+    e4 = torch.zeros((0, 4), device=DEV)
+    e1 = torch.zeros((0,), device=DEV)
+    assert ops.nms(e4, e1, 0.5).shape == (0,)
+    assert ops.xy_to_cxcy(e4).shape == (0, 4)
+    assert ops.find_jaccard_overlap(e4, T(np.array([[0, 0, 1, 1]], np.float32))).shape == (0, 1)
+    one = T(np.array([[0.1, 0.1, 0.4, 0.5]], np.float32))
+    assert ops.nms(one, T(np.array([0.3], np.float32)), 0.5).cpu().tolist() == [0]
+    # RoIPool with zero RoIs: empty output, zero gradient
+    f = torch.randn(1, 8, 5, 6, device=DEV, requires_grad=True)
+    out = ops.roi_pool(f, e4, (7, 7), 1.0)
+    assert out.shape == (0, 8, 7, 7)
+    # every box filtered by min_size: zero proposals, count 0, no crash downstream
+    anchor = orc.anchor_grid(160, 240)
+    N = anchor.shape[0]
+    reg = np.zeros((N, 4), np.float32)
+    reg[:, 2:] = -30.0                                          # all boxes collapse
+    cls = np.zeros((N, 2), np.float32)
+    rois, cnt, _ = ops.region_proposal(T(reg), T(cls), T(anchor), 1 / 1000, 12000, 0.7, 2000)
+    assert int(cnt.item()) == 0 and orc.region_proposal(reg, cls, anchor, 1 / 1000, 12000, 0.7, 2000)[0].shape[0] == 0
+    # head targets with zero live proposals: candidates are the GT boxes alone (model_.py:135), rows padded to 128
+    gt = _gt(np.random.RandomState(0), 3)
+    lab = np.array([1, 2, 3], np.int64)
+    cls_t, reg_t, srois, keep, counts = ops.head_targets(rois, T(gt), T(lab), n_rois=cnt, seed=1, want_keep=True)
+    c = counts.cpu().tolist()
+    assert c[0] == 3 and c[1] == 0 and c[2] == 3 and c[3] == 0
+    k = keep.cpu().numpy()
+    assert sorted(k[:3].tolist()) == [0, 1, 2] and (k[3:] == -1).all() and (cls_t.cpu().numpy()[3:] == 0).all()
+
+
+def test_nms_all_identical_boxes_and_single_survivor(ops):
+    K = 5000
+    b = np.tile(np.array([[0.2, 0.2, 0.6, 0.7]], np.float32), (K, 1))
+    keep, _, cnt = ops.nms_sorted(T(b), 0.7)
+    assert int(cnt.item()) == 1 and int(keep[0]) == 0             # IoU = 1 > thr: only the first survives
+    disjoint = np.zeros((K, 4), np.float32)                       # nobody overlaps: everyone survives, in order
+    g = np.arange(K)
+    disjoint[:, 0] = (g % 100) * 0.01
+    disjoint[:, 1] = (g // 100) * 0.01
+    disjoint[:, 2] = disjoint[:, 0] + 0.005
+    disjoint[:, 3] = disjoint[:, 1] + 0.005
+    keep, _, cnt = ops.nms_sorted(T(disjoint), 0.3)
+    assert int(cnt.item()) == K and np.array_equal(keep.cpu().numpy(), np.arange(K))
+
+
+def test_nms_above_fast_path_limit_uses_generic_scan(ops):
+    rng = np.random.RandomState(1)
+    K = 13000                                                     # > 12288: the unpipelined scan
+    c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15
+    wh = rng.rand(K, 2).astype(np.float32) * 0.2 + 0.03
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    keep_o = orc.nms(b, 0.6)
+    keep, _, cnt = ops.nms_sorted(T(b), 0.6)
+    assert int(cnt.item()) == len(keep_o) and np.array_equal(keep[:len(keep_o)].cpu().numpy(), keep_o)
+
+
+def test_rpn_targets_single_gt_and_gt_outside_all_anchors(ops):
+    anchor = orc.anchor_grid(600, 1000)
+    gt = np.array([[0.0, 0.0, 0.004, 0.004]], np.float32)         # tiny box: max IoU far below 0.3 -> only the forced match is positive
+    cls_o, reg_o, (n_pos, n_neg) = orc.rpn_targets(anchor, gt)
+    assert n_pos == 1
+    pn = np.random.RandomState(0).permutation(n_neg)
+    cls_o, _, _ = orc.rpn_targets(anchor, gt, None, pn)
+    cls, _, counts = ops.rpn_targets(T(anchor), T(gt), perm_neg=pn)
+    assert counts.cpu().tolist()[:3] == [1, n_neg, 0] and np.array_equal(cls.cpu().numpy(), cls_o)
+
+
+def test_batched_nms_equals_per_class_loop(ops):
+    """FRCNN._suppress (models/model.py:382-402): one class-aware NMS must reproduce the per-class nms(0.3) loop."""
+    rng = np.random.RandomState(4)
+    n, C = 4000, 20
+    centers = rng.rand(30, 2).astype(np.float32) * 0.6 + 0.2
+    c = centers[rng.randint(0, 30, n)] + rng.randn(n, 2).astype(np.float32) * 0.02
+    wh = np.float32(0.2) + rng.randn(n, 2).astype(np.float32) * 0.03
+    b = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)
+    sc = rng.rand(n).astype(np.float32)
+    cl = rng.randint(0, C, n).astype(np.int64)
+    keep = ops.batched_nms(T(b), T(sc), T(cl), 0.3).cpu().numpy()
+    exp = []
+    for l in range(C):
+        m = np.nonzero(cl == l)[0]
+        order = m[np.argsort(-sc[m], kind="stable")]
+        exp.append(order[orc.nms(b[order], 0.3)])
+    exp = np.concatenate(exp)
+    assert sorted(keep.tolist()) == sorted(exp.tolist())                      # same survivors
+    assert (np.diff(sc[keep]) <= 0).all()                                     # returned in global score order
+    for l in range(C):                                                        # and per class in the per-class order
+        assert np.array_equal(keep[cl[keep] == l], exp[cl[exp] == l])
