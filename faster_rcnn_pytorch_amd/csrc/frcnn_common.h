@@ -29,6 +29,7 @@ enum FrcnnKernelId {
     KID_ROI_ALIGN_FWD,
     KID_ROI_ALIGN_BWD,
     KID_RPN_HEAD_TAIL,
+    KID_DET_LOSS,
     KID_COUNT
 };
 

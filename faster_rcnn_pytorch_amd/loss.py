@@ -57,6 +57,9 @@ class FRCNNLoss(nn.Module):
         self.fast_rcnn_loss = FastRCNNLoss()
 
     def forward(self, pred, target):
+        if all(t.is_cuda and t.dtype == torch.float32 for t in pred):
+            from . import ops                                   # fused HIP kernel: 3 launches instead of ~15
+            return ops.detection_loss(pred, target)
         pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg = pred
         target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg = target
         rpn_cls_loss, rpn_reg_loss = self.rpn_loss(pred_rpn_cls, pred_rpn_reg, target_rpn_cls, target_rpn_reg)

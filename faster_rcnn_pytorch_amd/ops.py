@@ -394,6 +394,49 @@ def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max
 
 
 # --------------------------------------------------------------------------------------------
+# detection losses (losses/loss.py:5-85)
+# --------------------------------------------------------------------------------------------
+class _DetLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rpn_cls, rpn_reg, head_cls, head_reg, t_rpn_cls, t_rpn_reg, t_cls, t_reg):
+        shapes = (rpn_cls.shape, rpn_reg.shape, head_cls.shape, head_reg.shape)
+        rc = _req(rpn_cls, name="pred_rpn_cls").reshape(-1, 2)
+        rr = _req(rpn_reg, name="pred_rpn_reg").reshape(-1, 4)
+        hc = _req(head_cls, name="pred_fast_rcnn_cls")
+        hr = _req(head_reg, name="pred_fast_rcnn_reg").reshape(-1, 4)
+        trc = _req(t_rpn_cls, torch.int64, "target_rpn_cls").reshape(-1)
+        trr = _req(t_rpn_reg, name="target_rpn_reg").reshape(-1, 4)
+        tc = _req(t_cls, torch.int64, "target_fast_rcnn_cls").reshape(-1)
+        tr = _req(t_reg, name="target_fast_rcnn_reg").reshape(-1, 4)
+        N, R, NC = rc.shape[0], hc.shape[0], hc.shape[1]
+        if rr.shape[0] != N or trc.shape[0] != N or trr.shape[0] != N or hr.shape[0] != R or tc.shape[0] != R or tr.shape[0] != R:
+            raise ValueError("detection_loss: shape mismatch")
+        dev = rc.device
+        out = torch.empty((7,), dtype=torch.float32, device=dev)
+        g = [torch.empty_like(t) for t in (rc, rr, hc, hr)]
+        ws = _workspace(dev, 256)
+        with torch.cuda.device(dev):
+            check(lib.frcnn_detection_loss(_ptr(rc), _ptr(rr), _ptr(trc), _ptr(trr), N, _ptr(hc), _ptr(hr), _ptr(tc), _ptr(tr), R, NC,
+                                           _ptr(out), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(ws), 256, _stream()), "detection_loss")
+        ctx.save_for_backward(out, *g)
+        ctx.shapes = shapes
+        return out[0], out[1], out[2], out[3], out[4]
+
+    @staticmethod
+    def backward(ctx, g_total, g1, g2, g3, g4):
+        out, g_rc, g_rr, g_hc, g_hr = ctx.saved_tensors
+        s_rpn, s_head = out[5], out[6]
+        sh = ctx.shapes
+        return ((g_rc * ((g_total + g1) * s_rpn)).reshape(sh[0]), (g_rr * ((g_total + g2) * s_rpn)).reshape(sh[1]),
+                (g_hc * ((g_total + g3) * s_head)).reshape(sh[2]), (g_hr * ((g_total + g4) * s_head)).reshape(sh[3]), None, None, None, None)
+
+
+def detection_loss(pred, target):
+    """FRCNNLoss.forward (losses/loss.py:71-85): (total, rpn_cls, rpn_reg, fast_rcnn_cls, fast_rcnn_reg)."""
+    return _DetLossFn.apply(pred[0], pred[1], pred[2], pred[3], target[0], target[1], target[2], target[3])
+
+
+# --------------------------------------------------------------------------------------------
 # RoIPool (models/model.py:97,113)
 # --------------------------------------------------------------------------------------------
 class _RoIPoolFn(torch.autograd.Function):

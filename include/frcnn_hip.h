@@ -191,6 +191,17 @@ int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host,
                            const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
                            int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0, void *stream);
 
+/* ---- detection losses (losses/loss.py:5-85) ------------------------------------------------- */
+/* FRCNNLoss forward AND the un-normalised input gradients in one pass.  out7 (device): total, rpn_cls, rpn_reg,
+ * head_cls, head_reg losses, then 1/#(rpn label >= 0) and 1/R (the scales backward multiplies the gradients by).
+ * g_* have the shapes of the predictions.  workspace >= 32 bytes.                                                  */
+int frcnn_detection_loss(const float *rpn_cls /*[N,2]*/, const float *rpn_reg /*[N,4]*/, const int64_t *t_rpn_cls /*[N]*/,
+                         const float *t_rpn_reg /*[N,4]*/, int64_t N,
+                         const float *head_cls /*[R,NC]*/, const float *head_reg /*[R,4]*/, const int64_t *t_cls /*[R]*/,
+                         const float *t_reg /*[R,4]*/, int64_t R, int NC,
+                         float *out7, float *g_rpn_cls, float *g_rpn_reg, float *g_head_cls, float *g_head_reg,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream) -------------------------------------- */
 /* When enabled, every kernel launch made by this library is bracketed by two hipEventRecord on the
  * caller's stream.  frcnn_prof_collect() synchronises those events (call it after the stream is idle)

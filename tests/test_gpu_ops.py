@@ -574,3 +574,26 @@ def test_batched_nms_equals_per_class_loop(ops):
     assert (np.diff(sc[keep]) <= 0).all()                                     # returned in global score order
     for l in range(C):                                                        # and per class in the per-class order
         assert np.array_equal(keep[cl[keep] == l], exp[cl[exp] == l])
+
+
+# ------------------------------------------------------------------------------------------ fused detection loss (losses/loss.py:5-85)
+def test_detection_loss_matches_reference_golden_and_autograd(ops, golden):
+    """Floating-point kernel: values vs the reference's own FRCNNLoss (golden), gradients vs autograd of the torch fp32
+    op chain of losses/loss.py; tolerance 2e-6 relative on the losses, 1e-6 absolute on the gradients."""
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    from oracle.model_ref import ref_loss
+    g = golden("loss")
+    names_p = ("p_rpn_cls", "p_rpn_reg", "p_head_cls", "p_head_reg")
+    names_t = ("t_rpn_cls", "t_rpn_reg", "t_head_cls", "t_head_reg")
+    pred = [T(g[k]).requires_grad_(True) for k in names_p]
+    target = [T(g[k]) for k in names_t]
+    out = FRCNNLoss(None)(pred, target)                                       # dispatches to the HIP kernel on GPU tensors
+    got = np.array([float(o) for o in out], np.float32)
+    assert np.allclose(got, g["losses"], rtol=2e-6, atol=1e-6)
+    (out[0] + 0.5 * out[2]).backward()
+    ref_in = [torch.from_numpy(g[k]).clone().requires_grad_(True) for k in names_p]
+    r = ref_loss(ref_in, [torch.from_numpy(g[k]) for k in names_t])
+    (r[0] + 0.5 * r[2]).backward()
+    for a, b in zip(pred, ref_in):
+        assert (a.grad.cpu() - b.grad).abs().max() < 1e-6
+    assert np.allclose(orc.frcnn_loss([g[k] for k in names_p], [g[k] for k in names_t]), g["losses"], rtol=2e-6, atol=1e-6)
