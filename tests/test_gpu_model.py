@@ -1,6 +1,8 @@
 """Model-level parity: the HIP-backed FRCNN (faster_rcnn_pytorch_amd.model) vs the CPU oracle of the same
 path (oracle/model_ref.py) on IDENTICAL stage inputs: the GPU model's own features / RPN outputs are
 copied to the host and pushed through the oracle stages."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -158,3 +160,57 @@ def test_fpn_predict_api(fpn_model):
     fpn_model.eval()
     bbox, label, score = fpn_model.predict(x.to(DEV), 0.02)
     assert bbox.dtype == torch.float32 and label.dtype == torch.int32 and bbox.shape[0] == score.shape[0]
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel step (2 ranks, one GPU, gloo)
+def _ddp_worker(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from faster_rcnn_pytorch_amd import parallel
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    from faster_rcnn_pytorch_amd.model import FRCNN
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device = torch.device("cuda", 0)
+    torch.manual_seed(0)                                                      # identical weights on both ranks
+    model = FRCNN(num_classes=21, sampling="device", seed=10 + rank).to(device)
+    net = parallel.wrap_ddp(model, device)
+    crit = FRCNNLoss(None)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
+    losses = []
+    for step in range(2):
+        x, b, l = synth(50 + rank * 100 + step, 320, 480, 3)                  # a different image per rank (the shard)
+        pred, target = net(x.to(device), [b.to(device)], [l.to(device)])
+        loss = crit(pred, target)[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    w = model.rpn.inter_layer.weight.detach().float().cpu()
+    g = model.extractor[0].weight.grad.detach().cpu()
+    q.put((rank, losses, float(w.double().sum()), float(g.double().abs().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_one_gpu_gloo():
+    """The N > 1 path end to end (DDP hooks, shared classifier parameters, side stream, custom autograd functions):
+    two ranks on the one GPU with gloo standing in for RCCL; after all-reduced steps the replicas must stay identical."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 1000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(np.isfinite(res[r][1]).all() for r in range(2))
+    assert res[0][1] != res[1][1]                                             # different images -> different local losses
+    assert abs(res[0][2] - res[1][2]) < 1e-6 * max(1.0, abs(res[0][2]))       # but identical weights after the averaged updates
+    assert abs(res[0][3] - res[1][3]) < 1e-5 * max(1.0, abs(res[0][3]))       # and identical (all-reduced) gradients
