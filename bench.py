@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
     ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
     ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
+    ap.add_argument("--no-fused-sgd", action="store_true")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"],
                     help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
     args = ap.parse_args()
@@ -99,7 +100,8 @@ def main():
         model.extractor = model.extractor.to(memory_format=torch.channels_last)
     net = parallel.wrap_ddp(model, device)
     crit = FRCNNLoss(None)
-    opt = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)       # main.py:55-60
+    opt = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4,        # main.py:55-60
+                          fused=not args.no_fused_sgd)   # same update rule, one multi-tensor kernel
 
     frames = []
     for i in range(args.frames):

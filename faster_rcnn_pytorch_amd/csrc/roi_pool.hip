@@ -13,10 +13,10 @@
 #include <cfloat>
 
 #ifndef ROI_FWD_CB
-#define ROI_FWD_CB 1
+#define ROI_FWD_CB 4
 #endif
 #ifndef ROI_FWD_RB
-#define ROI_FWD_RB 32
+#define ROI_FWD_RB 16
 #endif
 #ifndef ROI_BWD_CB
 #define ROI_BWD_CB 1
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
     int *tab = (int *)(smem + CB * HW);                          // [RB][PH + PW]: (hs | he << 16) x PH, (ws | we << 16) x PW
     constexpr int BINS = PH * PW;
     constexpr int TW = PH + PW;
-    constexpr int GROUPS = 256 / (CB * BINS);                    // RoIs processed concurrently by the block
-    static_assert(GROUPS >= 1, "CB * PH * PW must fit one 256-thread block");
+    constexpr int GROUPS = 256 / BINS;                           // RoIs processed concurrently by the block
+    static_assert(GROUPS >= 1, "PH * PW must fit one 256-thread block");
     const int c0 = blockIdx.x * CB;
     const int r0 = blockIdx.y * RB;
     const int nr = min(RB, R - r0);
@@ -152,34 +152,39 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
         }
     }
     __syncthreads();
-    // lane -> fixed (RoI group, channel, bin): all index arithmetic happens once; the loop only walks RoIs
-    const int grp = threadIdx.x / (CB * BINS);
-    const int rem = threadIdx.x - grp * (CB * BINS);
-    const int ch = rem / BINS, p = rem - ch * BINS;
+    // lane -> fixed (RoI group, bin); the CB channels of the block are an INNER loop, so the window geometry, the loop
+    // control and the clamps are paid once per CB outputs and the CB LDS reads of a pixel are independent
+    const int grp = threadIdx.x / BINS;
+    const int p = threadIdx.x - grp * BINS;
     const int ph = p / PW, pw = p - ph * PW;
-    if (grp >= GROUPS || ch >= nch) return;
-    const float *pl = planes + ch * HW;
-    size_t e = ((size_t)(r0 + grp) * C + c0 + ch) * BINS + p;
+    if (grp >= GROUPS) return;
+    size_t e = ((size_t)(r0 + grp) * C + c0) * BINS + p;
     const size_t estep = (size_t)GROUPS * C * BINS;
     for (int rl = grp; rl < nr; rl += GROUPS, e += estep) {
         const int th = tab[rl * TW + ph], tw = tab[rl * TW + PH + pw];
         const int hs = th & 0xFFFF, he = th >> 16, ws = tw & 0xFFFF, we = tw >> 16;
         const bool empty = (he <= hs) || (we <= ws);
-        float mv = empty ? 0.0f : -FLT_MAX;
-        int mi = -1;
+        float mv[CB];
+        int mi[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) { mv[c] = empty ? 0.0f : -FLT_MAX; mi[c] = -1; }
         for (int h = hs; h < he; ++h) {
-            const float *prow = pl + h * W;
-            for (int w = ws; w < we; w += 4) {                   // 4 independent LDS reads in flight; order of the
-                const int w1 = min(w + 1, we - 1), w2 = min(w + 2, we - 1), w3 = min(w + 3, we - 1);   // compares unchanged
-                const float v0 = prow[w], v1 = prow[w1], v2 = prow[w2], v3 = prow[w3];
-                if (v0 > mv) { mv = v0; mi = h * W + w; }
-                if (v1 > mv) { mv = v1; mi = h * W + w1; }       // clamped duplicates can never be > the running max
-                if (v2 > mv) { mv = v2; mi = h * W + w2; }
-                if (v3 > mv) { mv = v3; mi = h * W + w3; }
+            const int rowoff = h * W;
+            for (int w = ws; w < we; w += 2) {                   // 2 pixels x CB planes = 2*CB independent LDS reads in flight
+                const int w1 = min(w + 1, we - 1);               // a clamped duplicate can never be > the running max
+                float v0[CB], v1[CB];
+#pragma unroll
+                for (int c = 0; c < CB; ++c) { v0[c] = planes[c * HW + rowoff + w]; v1[c] = planes[c * HW + rowoff + w1]; }
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    if (v0[c] > mv[c]) { mv[c] = v0[c]; mi[c] = rowoff + w; }
+                    if (v1[c] > mv[c]) { mv[c] = v1[c]; mi[c] = rowoff + w1; }
+                }
             }
         }
-        out[e] = mv;
-        argmax[e] = mi;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+            if (c < nch) { out[e + (size_t)c * BINS] = mv[c]; argmax[e + (size_t)c * BINS] = mi[c]; }
     }
 }
 
