@@ -12,6 +12,8 @@
 //   head_targets_kernel: one workgroup does IoU + ordered compaction + sampling + encode for <= 4096
 //                       candidates and writes the fixed [total] rows.
 #include "frcnn_common.h"
+#include <cstdlib>
+#include <cstring>
 #include "frcnn_internal.h"
 
 #define EPS_JACCARD 1e-5f
@@ -345,6 +347,127 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large N (FPN: 268 569 anchors): the single-workgroup sampler above would sweep the anchors ~6 times from one CU
+// (~0.5 ms).  Device-RNG mode therefore runs as four chip-wide launches: three radix-histogram levels (11 + 11 + 10
+// bits of the Philox key, both classes in the same pass) and an apply pass that demotes every candidate whose key is
+// above the exact threshold.  Each launch re-derives the digit chosen so far from the previous level's histogram.
+// ------------------------------------------------------------------------------------------------
+#define RSB 2048
+struct RpnSelCtl { unsigned hist[2][3][RSB]; };          // [class 0 = neg, 1 = pos][level][bin]
+
+// ascending search over a 2048-bin histogram: bin of the `want`-th smallest key (1-based) and the count below it
+__device__ __forceinline__ void find_bin_asc(const unsigned *__restrict__ hist, int nbins, int want, int *s_tmp /*[8]*/, int *bin, int *below, int *inbin)
+{
+    const int t = threadIdx.x;                           // 256 threads x 8 bins
+    unsigned c[8];
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int b = 8 * t + q; c[q] = b < nbins ? hist[b] : 0u; local += (int)c[q]; }
+    const int lane = t & 63, wave = t >> 6;
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[wave] = inc;
+    if (t == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; s_tmp[7] = 0; }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < wave) base += s_tmp[w];
+    const int excl = base + inc - local;
+    if (excl < want && want <= excl + local) {
+        int acc = excl, q = 0;
+        for (; q < 7; ++q) {
+            if (acc + (int)c[q] >= want) break;
+            acc += (int)c[q];
+        }
+        s_tmp[4] = 8 * t + q; s_tmp[5] = acc; s_tmp[6] = 1; s_tmp[7] = (int)c[q];
+    }
+    __syncthreads();
+    *bin = s_tmp[4]; *below = s_tmp[5]; *inbin = s_tmp[7];
+    __syncthreads();
+}
+
+struct RpnSelState { bool drop; int keep; unsigned prefix; int want; int inbin; };
+
+// what is known about class `c` after `levels` histogram levels
+__device__ __forceinline__ RpnSelState rpn_sel_state(const RpnSelCtl *ctl, const int32_t *counts, int c, int levels, int *s_tmp)
+{
+    const int n_pos = counts[0], n_neg = counts[1];
+    RpnSelState st;
+    st.drop = c == 1 ? (n_pos > 128) : (n_neg > 256 - n_pos);
+    st.keep = c == 1 ? 128 : 256 - min(n_pos, 128);
+    st.prefix = 0u; st.want = st.keep; st.inbin = 0;
+    for (int l = 0; l < levels; ++l) {                   // uniform
+        int bin, below, inbin;
+        find_bin_asc(ctl->hist[c][l], l < 2 ? 2048 : 1024, st.want, s_tmp, &bin, &below, &inbin);
+        st.prefix |= (unsigned)bin << (l == 0 ? 21 : (l == 1 ? 10 : 0));
+        st.want -= below;
+        st.inbin = inbin;
+    }
+    return st;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(256) void rpn_samp_hist_kernel(const int8_t *__restrict__ label8, int N, unsigned long long seed,
+                                                            unsigned long long offset, RpnSelCtl *__restrict__ ctl,
+                                                            const int32_t *__restrict__ counts)
+{
+    __shared__ unsigned s_hist[2][RSB];
+    __shared__ int s_tmp[8];
+    const RpnSelState sn = rpn_sel_state(ctl, counts, 0, LEVEL, s_tmp);
+    const RpnSelState sp = rpn_sel_state(ctl, counts, 1, LEVEL, s_tmp);
+    if (!sn.drop && !sp.drop) return;
+    for (int i = threadIdx.x; i < 2 * RSB; i += 256) (&s_hist[0][0])[i] = 0u;
+    __syncthreads();
+    const unsigned himask = LEVEL == 0 ? 0u : (LEVEL == 1 ? 0xFFE00000u : 0xFFFFFC00u);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const int lab = label8[i];
+        if (lab < 0 || !(lab == 1 ? sp.drop : sn.drop)) continue;
+        const unsigned k = philox_first(seed, offset, (unsigned)lab, (unsigned)i);
+        if ((k & himask) != (lab == 1 ? sp.prefix : sn.prefix)) continue;
+        const unsigned d = LEVEL == 0 ? (k >> 21) : (LEVEL == 1 ? ((k >> 10) & 2047u) : (k & 1023u));
+        atomicAdd(&s_hist[lab][d], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * RSB; i += 256) {
+        const unsigned v = (&s_hist[0][0])[i];
+        if (v) atomicAdd(&ctl->hist[i / RSB][LEVEL][i % RSB], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void rpn_samp_apply_kernel(const int8_t *__restrict__ label8, int N, unsigned long long seed,
+                                                             unsigned long long offset, const RpnSelCtl *__restrict__ ctl,
+                                                             const int32_t *__restrict__ counts, int64_t *__restrict__ out_cls)
+{
+    __shared__ int s_tmp[8];
+    const RpnSelState sn = rpn_sel_state(ctl, counts, 0, 3, s_tmp);      // prefix = exact threshold key T, want = #(key == T) to keep
+    const RpnSelState sp = rpn_sel_state(ctl, counts, 1, 3, s_tmp);
+    if (!sn.drop && !sp.drop) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const int lab = label8[i];
+        if (lab < 0) continue;
+        const RpnSelState &st = lab == 1 ? sp : sn;
+        if (!st.drop) continue;
+        const unsigned k = philox_first(seed, offset, (unsigned)lab, (unsigned)i);
+        bool kept = k < st.prefix;
+        if (k == st.prefix) {
+            kept = true;
+            if (st.want != st.inbin) {                   // a 32-bit key tie straddles the threshold (p ~ N / 2^32): lowest indices stay
+                int before = 0;
+                for (int j = 0; j < i; ++j)
+                    before += (label8[j] == lab && philox_first(seed, offset, (unsigned)lab, (unsigned)j) == k);
+                kept = before < st.want;
+            }
+        }
+        if (!kept) out_cls[i] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // head_targets_kernel (one workgroup of 1024 threads, n = n_rois + G <= HT_MAX candidates)
 // ------------------------------------------------------------------------------------------------
 #define HT_MAX 4096
@@ -479,7 +602,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-struct RpnWs { unsigned long long *colkey; int8_t *label8; int32_t *list; unsigned *keys; size_t total; };
+struct RpnWs { unsigned long long *colkey; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
 static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
 {
     RpnWs w; char *p = (char *)ws; size_t o = 0;
@@ -488,6 +611,7 @@ static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
     w.label8 = (int8_t *)take((size_t)N);
     w.list = (int32_t *)take((size_t)N * 4);
     w.keys = (unsigned *)take((size_t)N * 4);
+    w.sel = (RpnSelCtl *)take(sizeof(RpnSelCtl));
     w.total = o;
     return w;
 }
@@ -516,6 +640,17 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     FRCNN_LAUNCH(KID_RPN_LABEL, rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
                  w.colkey, out_cls, (float4 *)out_reg, w.label8, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_label_kernel");
+    static const bool force_block = [] { const char *e = getenv("FRCNN_RPN_SAMPLE"); return e && !strcmp(e, "block"); }();   // tests: old path
+    if (N > RS_LDS_MAX && !perm_pos && !perm_neg && !force_block) {     // chip-wide device-RNG sampler for FPN-sized N
+        if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
+        const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<0>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<1>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<2>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_apply_kernel, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts, out_cls);
+        FRCNN_CHECK_LAUNCH("rpn_samp kernels");
+        return FRCNN_OK;
+    }
     FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_sample_kernel, dim3(1), dim3(1024), 0, s, (int)N, w.label8, out_cls, perm_pos, (int)n_perm_pos, perm_neg,
                  (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, w.list, w.keys, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_sample_kernel");

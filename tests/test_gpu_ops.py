@@ -343,6 +343,33 @@ def test_rpn_targets_device_sampling_properties(ops):
     assert 0.35 < q.mean() < 0.65
 
 
+def test_rpn_targets_device_sampling_fpn_size_chipwide_equals_single_workgroup(ops):
+    """N = 268 569 (config F) takes the chip-wide radix sampler; it must pick exactly what the single-workgroup sampler picks
+    (same Philox keys, same smallest-keys rule), which a child process with FRCNN_RPN_SAMPLE=block provides."""
+    import os, subprocess, sys, tempfile
+    rng = np.random.RandomState(12)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    anchor = orc.tv_anchor_grid(800, 1344, shapes, normalise=True)
+    ins = np.nonzero((anchor[:, 0] >= 0) & (anchor[:, 1] >= 0) & (anchor[:, 2] <= 1) & (anchor[:, 3] <= 1))[0]
+    for G, tag in ((8, "neg-only"), (300, "pos+neg")):
+        gt = anchor[ins[rng.choice(len(ins), G, replace=False)]] if G > 100 else _gt(rng, G)
+        pre, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt, variant=1)
+        if G > 100:
+            assert n_pos > 128
+        a = ops.rpn_targets(T(anchor), T(gt), variant=1, seed=77, offset=5)[0].cpu().numpy()
+        npe = min(n_pos, 128)
+        assert (a == 1).sum() == npe and (a == 0).sum() == min(n_neg, 256 - npe), tag
+        assert ((a == 1) <= (pre == 1)).all() and ((a == 0) <= (pre == 0)).all()
+        with tempfile.TemporaryDirectory() as d:
+            np.save(os.path.join(d, "anchor.npy"), anchor), np.save(os.path.join(d, "gt.npy"), gt)
+            code = ("import numpy as np, torch, sys; from faster_rcnn_pytorch_amd import ops;"
+                    "d=sys.argv[1]; a=torch.from_numpy(np.load(d+'/anchor.npy')).cuda(); g=torch.from_numpy(np.load(d+'/gt.npy')).cuda();"
+                    "np.save(d+'/out.npy', ops.rpn_targets(a, g, variant=1, seed=77, offset=5)[0].cpu().numpy())")
+            env = dict(os.environ, FRCNN_RPN_SAMPLE="block", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            subprocess.run([sys.executable, "-c", code, d], check=True, env=env, timeout=300)
+            assert np.array_equal(a, np.load(os.path.join(d, "out.npy"))), tag
+
+
 @pytest.mark.parametrize("variant,label_offset,max_pos,total,P", [(0, 1, 32, 128, 2000), (0, 1, 32, 128, 300), (1, 0, 128, 512, 1000)])
 def test_head_targets_host_perm_parity(ops, variant, label_offset, max_pos, total, P):
     rng = np.random.RandomState(P + variant)
