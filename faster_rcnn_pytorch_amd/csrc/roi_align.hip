@@ -5,8 +5,9 @@
 // launch + per-level gathers/scatters as torchvision does.
 //
 // 7x7 bins, sampling_ratio 2 (the only shape the reference uses, new_model.py:127):
-//   forward : a workgroup owns (RoI, 32 channels); a lane owns one bin, sets up its 4 samples x 4 taps ONCE and
-//             walks the channels.  Channel groups are pinned to XCDs (blockIdx & 7) so that each XCD's L2 only ever
+//   forward : a workgroup owns (RoI, 32 channels); it stages the RoI's footprint rows of as many channels as fit in
+//             25 KB of LDS with coalesced row loads, then a lane owns one bin, sets up its 4 samples x 4 taps ONCE
+//             and walks the staged channels (same operation order as the oracle: bit-identical outputs).  Channel groups are pinned to XCDs (blockIdx & 7) so that each XCD's L2 only ever
 //             holds its own eighth of the pyramid instead of all 91 MB streaming through all eight.
 //   backward: bilinear scatter is separable,  dF = Wy^T (7 x fh) . dOut (7x7) . Wx (7 x fw)  over the RoI's footprint,
 //             so a workgroup (RoI, 16 channels) builds the two small weight tables in LDS, forms T = dOut . Wx per
@@ -16,6 +17,7 @@
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include <cstdlib>
 
 struct MsLevels {
     int n_levels;
@@ -163,21 +165,36 @@ __device__ __forceinline__ void tile_of_block(int b, int R, int n_cg, int *cg, i
     else { *cg = b / R; *r = b % R; }
 }
 
+#ifndef RA_FWD_CG
 #define RA_FWD_CG 32
-__global__ __launch_bounds__(256) void roi_align_fwd77_kernel(MsLevels L, int C, const float4 *__restrict__ rois, int R, int aligned, int k_min,
+#endif
+#ifndef RA_FWD_WAVES
+#define RA_FWD_WAVES 3
+#endif
+#ifndef RA_FWD_LDS
+#define RA_FWD_LDS 8128
+#endif
+//                 // floats of footprint staging per workgroup (25 KB -> 6 workgroups / CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVES, 8))) void roi_align_fwd77_kernel(MsLevels L, int C, const float4 *__restrict__ rois, int R, int aligned, int k_min,
                                                               float s0, int k0, float *__restrict__ out, int32_t *__restrict__ out_level, int n_cg)
 {
+    __shared__ float s_f[RA_FWD_LDS];
     int cg, r;
     tile_of_block(blockIdx.x, R, n_cg, &cg, &r);
     const int t = threadIdx.x, grp = t / 49, bin = t - grp * 49;
     const float4 b = rois[r];
     const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
     if (out_level && cg == 0 && t == 0) out_level[r] = l;
-    if (grp >= 5) return;
     const int ph = bin / 7, pw = bin - ph * 7;
     const int H = L.H[l], W = L.W[l];
     const AlignGeom g = align_geom(b, L.scale[l], 7, 7, 2, aligned != 0);
-    int o[4][4]; float w[4][4]; bool ok[4];
+    // footprint of the RoI on its level (sample coordinates are monotonic in the bin index)
+    const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
+    const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
+    const int y0 = ya.lo, x0 = xa.lo, fh = yb.hi - y0 + 1, fw = xb.hi - x0 + 1;
+    const int fwp = fw | 1, fp = fh * fwp;
+    int yl[4], yh[4], xl[4], xh[4]; float w[4][4]; bool ok[4];
+    bool inside = true;                                  // every tap of this lane lies inside the footprint box
 #pragma unroll
     for (int iy = 0; iy < 2; ++iy)
 #pragma unroll
@@ -187,31 +204,89 @@ __global__ __launch_bounds__(256) void roi_align_fwd77_kernel(MsLevels L, int C,
             const Bilin s = bilin_setup(H, W, y, x);
             const int q = iy * 2 + ix;
             ok[q] = s.ok;
-            o[q][0] = s.yl * W + s.xl; o[q][1] = s.yl * W + s.xh; o[q][2] = s.yh * W + s.xl; o[q][3] = s.yh * W + s.xh;
+            yl[q] = s.yl; yh[q] = s.yh; xl[q] = s.xl; xh[q] = s.xh;
             w[q][0] = s.w1; w[q][1] = s.w2; w[q][2] = s.w3; w[q][3] = s.w4;
+            inside = inside && s.yl >= y0 && s.yh < y0 + fh && s.xl >= x0 && s.xh < x0 + fw;
         }
-    const int c_end = min(C, (cg + 1) * RA_FWD_CG);
+    const int c0 = cg * RA_FWD_CG, c_end = min(C, c0 + RA_FWD_CG);
     const size_t plane = (size_t)H * W;
-    for (int c = cg * RA_FWD_CG + grp; c < c_end; c += 5) {
-        const float *pl = L.feat[l] + (size_t)c * plane;
-        float v[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[q][k] = pl[o[q][k]];
-        float acc = 0.0f;
+    int cb = (fh >= 1 && fw >= 1 && fp <= RA_FWD_LDS) ? min(RA_FWD_LDS / fp, RA_FWD_CG) : 0;
+    if (__syncthreads_or(!inside && grp < 5)) cb = 0;     // (cannot happen for finite boxes; keeps the LDS path in-bounds regardless)
+    int o[4][4];
+    {
+        const int stride = cb == 0 ? W : fwp, by = cb == 0 ? 0 : y0, bx = cb == 0 ? 0 : x0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float sv = w[q][0] * v[q][0] + w[q][1] * v[q][1] + w[q][2] * v[q][2] + w[q][3] * v[q][3];
-            if (!ok[q]) sv = 0.0f;
-            acc += sv;
+            o[q][0] = (yl[q] - by) * stride + xl[q] - bx; o[q][1] = (yl[q] - by) * stride + xh[q] - bx;
+            o[q][2] = (yh[q] - by) * stride + xl[q] - bx; o[q][3] = (yh[q] - by) * stride + xh[q] - bx;
         }
-        out[((size_t)r * C + c) * 49 + bin] = acc / g.cnt;
+    }
+    if (cb == 0) {                                       // footprint larger than the staging buffer: gather straight from global
+        if (grp >= 5) return;
+        for (int c = c0 + grp; c < c_end; c += 5) {
+            const float *pl = L.feat[l] + (size_t)c * plane;
+            float acc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float sv = w[q][0] * pl[o[q][0]] + w[q][1] * pl[o[q][1]] + w[q][2] * pl[o[q][2]] + w[q][3] * pl[o[q][3]];
+                if (!ok[q]) sv = 0.0f;
+                acc += sv;
+            }
+            out[((size_t)r * C + c) * 49 + bin] = acc * 0.25f;                  // cnt == 4: exact
+        }
+        return;
+    }
+    // staging: the pass's (channel, row, column) space is flattened so that consecutive lanes read consecutive columns of a
+    // footprint row; 8 independent loads are in flight per lane before the first LDS store.  Divisions by the (uniform)
+    // footprint width / height go through float reciprocals with a one-step correction.
+    const unsigned ufw = (unsigned)fw, ufh = (unsigned)fh;
+    const float rcp_fw = 1.0f / (float)fw, rcp_fh = 1.0f / (float)fh;
+    const float *lvl = L.feat[l];
+    for (int cbase = c0; cbase < c_end; cbase += cb) {
+        const int n = min(cb, c_end - cbase);
+        __syncthreads();
+        const unsigned total = (unsigned)(n * fh * fw);
+        const unsigned gbase = (unsigned)cbase * (unsigned)plane + (unsigned)(y0 * W + x0);
+        for (unsigned e0 = 0; e0 < total; e0 += 256 * 8) {
+            float v[8]; unsigned lo[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned e = e0 + u * 256 + t;
+                unsigned row = (unsigned)((float)e * rcp_fw);             // row = c * fh + y
+                unsigned x = e - row * ufw;
+                if ((int)x < 0) { --row; x += ufw; } else if (x >= ufw) { ++row; x -= ufw; }
+                unsigned c = (unsigned)((float)row * rcp_fh);
+                unsigned y = row - c * ufh;
+                if ((int)y < 0) { --c; y += ufh; } else if (y >= ufh) { ++c; y -= ufh; }
+                lo[u] = e < total ? c * (unsigned)fp + y * (unsigned)fwp + x : 0xFFFFFFFFu;
+                v[u] = e < total ? lvl[gbase + c * (unsigned)plane + y * (unsigned)W + x] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (lo[u] != 0xFFFFFFFFu) s_f[lo[u]] = v[u];
+        }
+        __syncthreads();
+        if (grp < 5)
+            for (int c = grp; c < n; c += 5) {
+                const float *pl = s_f + c * fp;
+                float acc = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float sv = w[q][0] * pl[o[q][0]] + w[q][1] * pl[o[q][1]] + w[q][2] * pl[o[q][2]] + w[q][3] * pl[o[q][3]];
+                    if (!ok[q]) sv = 0.0f;
+                    acc += sv;
+                }
+                out[((size_t)r * C + cbase + c) * 49 + bin] = acc * 0.25f;                  // cnt == 4: exact
+            }
     }
 }
 
+#ifndef RA_BWD_CB
 #define RA_BWD_CB 16
+#endif
+#ifndef RA_BWD_XC
 #define RA_BWD_XC 64
+#endif
 #define RA_BWD_MAXROWS 256
 // generic scatter of one (RoI, channel range) -- used when the RoI's footprint is taller than the LDS row table
 __device__ void roi_align_bwd_scatter(const MsLevels &L, int l, int C, int r, int c0, int c1, const AlignGeom &g,
@@ -356,7 +431,9 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
     const int64_t total = R * C * PH * PW;
     FRCNN_REQUIRE(total < ((int64_t)1 << 38), "ms_roi_align_fwd: output too large");
     hipStream_t s = (hipStream_t)stream;
-    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
+    bool small_planes = true;                          // the staged forward indexes a level with 32-bit element offsets
+    for (int l = 0; l < n_levels; ++l) small_planes = small_planes && (int64_t)C * H[l] * W[l] < ((int64_t)1 << 30);
+    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24) && small_planes) {
         const int n_cg = (C + RA_FWD_CG - 1) / RA_FWD_CG;
         FRCNN_LAUNCH(KID_ROI_ALIGN_FWD, roi_align_fwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,
                      aligned, k_min, s0, k0, out, out_level, n_cg);

@@ -479,6 +479,29 @@ def test_ms_roi_align_fwd_bwd_vs_oracle(ops):
         assert np.allclose(f.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=1e-4)  # atomics: order-nondeterministic
 
 
+@pytest.mark.parametrize("PH,SR", [(7, 2), (5, 3), (7, 0)])
+def test_single_level_roi_align_big_footprints_and_generic_shapes(ops, PH, SR):
+    """One level of 300 x 260 at scale 1: RoIs whose footprint exceeds the forward staging buffer (fh*fw > 8192) and the
+    backward row table (fh > 256) must take the in-kernel gather/scatter fallbacks; other bin/sampling shapes the generic kernels."""
+    rng = np.random.RandomState(PH * 10 + SR)
+    C, H, W = 20, 300, 260
+    f = rng.randn(C, H, W).astype(np.float32)
+    rois = rand_boxes(rng, 40, 0.02, 0.5) * np.array([W, H, W, H], np.float32)
+    rois[0] = [0, 0, W, H]                                   # whole map: fh = 300 > 256, fp = 78 000
+    rois[1] = [-20, -30, W + 25, H + 40]                     # sticks out on all sides (samples beyond [-1, H] contribute 0)
+    rois[2] = [10, 5, 250, 100]                              # fp = 96 x 241 > 8192, fh < 256
+    rois[3] = [100.5, 100.5, 100.7, 100.6]                   # tiny (clamped to 1 x 1)
+    rois[4] = [W - 1.5, H - 1.5, W + 3, H + 3]               # bottom-right corner clamp
+    out_o = orc.roi_align_fwd(f, rois, PH, PH, 1.0, SR, False)
+    ft = T(f[None]).requires_grad_(True)
+    out = ops.ms_roi_align([ft], T(rois), PH, SR, scales=(1.0,))
+    assert np.abs(out.detach().cpu().numpy() - out_o).max() < 1e-5
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    out.backward(T(go))
+    gf_o = orc.roi_align_bwd(go, f.shape, rois, 1.0, SR, False)
+    assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=2e-4)
+
+
 # ------------------------------------------------------------------------------------------ RPN head tail (MFMA)
 @pytest.mark.parametrize("C,fh,fw,A", [(512, 37, 62, 9), (256, 50, 84, 3), (64, 5, 7, 9)])
 def test_rpn_head_tail_vs_torch_fp32(ops, C, fh, fw, A):
