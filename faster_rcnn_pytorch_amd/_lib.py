@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
-OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS = 1, 2, 3, 4, 5
+OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS = 1, 2, 3, 4, 5, 6
 
 _vp, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -41,6 +41,8 @@ SIGNATURES = {
     "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "frcnn_ms_roi_align_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "frcnn_detection_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_preprocess_image": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_preprocess_boxes": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "frcnn_prof_enable": (_i, [_i]),
     "frcnn_prof_collect": (_i, []),
     "frcnn_prof_reset": (_i, []),

@@ -30,6 +30,7 @@ enum FrcnnKernelId {
     KID_ROI_ALIGN_BWD,
     KID_RPN_HEAD_TAIL,
     KID_DET_LOSS,
+    KID_PREPROCESS,
     KID_COUNT
 };
 

@@ -50,7 +50,8 @@ typedef enum {
     FRCNN_OP_NMS = 2,             /* n1 = K boxes */
     FRCNN_OP_REGION_PROPOSAL = 3, /* n1 = N anchors, n2 = K */
     FRCNN_OP_RPN_TARGETS = 4,     /* n1 = N anchors, n2 = G */
-    FRCNN_OP_HEAD_TARGETS = 5     /* n1 = P + G candidates */
+    FRCNN_OP_HEAD_TARGETS = 5,    /* n1 = P + G candidates */
+    FRCNN_OP_PREPROCESS = 6       /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
 } frcnn_op;
 
 int frcnn_abi_version(void);
@@ -201,6 +202,19 @@ int frcnn_detection_loss(const float *rpn_cls /*[N,2]*/, const float *rpn_reg /*
                          const float *t_reg /*[R,4]*/, int64_t R, int NC,
                          float *out7, float *g_rpn_cls, float *g_rpn_reg, float *g_head_cls, float *g_head_reg,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- input stage in front of the path ------------------------------------------------------
+ * One uint8 HWC RGB frame in HBM -> [hflip] -> PIL-bilinear resize to (oh, ow) -> /255 -> (x - mean) / std -> float CHW
+ * [3, pad_h, pad_w], zero outside (oh, ow).  Replaces T.RandomHorizontalFlip / T.Resize(800, max 1333) / T.ToTensor /
+ * T.Normalize (new_datasets/transforms.py:57-132,238-281; new_datasets/build.py:20-33, datasets/build.py:10-24) and the
+ * pad-to-32 collate (new_datasets/coco_dataset.py:49-66).  Bit-identical to Pillow's 8-bit resampler.  mean/std: host,
+ * 3 floats.  out_u8 (optional, [oh, ow, 3]) receives the resized uint8 frame; either output may be NULL, not both.  */
+int frcnn_preprocess_image(const uint8_t *src_hwc, int h, int w, int flip, int oh, int ow, int pad_h, int pad_w,
+                           const float *mean_host, const float *std_host, float *out_chw, uint8_t *out_u8,
+                           void *workspace, size_t workspace_bytes, void *stream);
+/* Boxes xyxy in source pixels -> hflip (transforms.py:64-68) -> x resize ratios (:113-117) -> / resized (w, h) (:276-280),
+ * i.e. the normalised boxes the model takes.  binary32 throughout, like the reference's tensors.                   */
+int frcnn_preprocess_boxes(const float *boxes, int64_t n, int w, int h, int flip, int ow, int oh, float *out, void *stream);
 
 /* ---- in-library kernel timing (HIP events on the launch stream) -------------------------------------- */
 /* When enabled, every kernel launch made by this library is bracketed by two hipEventRecord on the

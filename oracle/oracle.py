@@ -313,3 +313,27 @@ def frcnn_loss(pred, target):
                               _p(head_cls), _p(head_reg), _p(t_cls), _p(t_reg), C.c_int64(head_cls.shape[0]),
                               C.c_int(head_cls.shape[1]), _p(out)), "frcnn_loss")
     return out
+
+
+# -- (f)3 input stage ----------------------------------------------------------------------
+def preprocess_image(img_u8_hwc, out_hw, pad_hw=None, flip=False, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """hflip -> PIL-bilinear resize -> to_tensor -> normalize -> zero pad.  Returns (resized uint8 HWC, float32 CHW padded)."""
+    img = np.ascontiguousarray(img_u8_hwc, dtype=np.uint8)
+    h, w, c = img.shape
+    assert c == 3
+    oh, ow = out_hw
+    ph, pw = pad_hw if pad_hw is not None else out_hw
+    u8 = np.empty((oh, ow, 3), np.uint8)
+    out = np.empty((3, ph, pw), np.float32)
+    m, s = _f32(mean), _f32(std)
+    _chk(lib().orc_preprocess_image(_p(img), C.c_int(h), C.c_int(w), C.c_int(int(flip)), C.c_int(oh), C.c_int(ow), C.c_int(ph), C.c_int(pw),
+                                    _p(m), _p(s), _p(u8), _p(out)), "preprocess_image")
+    return u8, out
+
+
+def preprocess_boxes(boxes, src_wh, out_wh, flip=False):
+    b = _f32(boxes).reshape(-1, 4)
+    out = np.empty_like(b)
+    _chk(lib().orc_preprocess_boxes(_p(b), C.c_int64(b.shape[0]), C.c_int(src_wh[0]), C.c_int(src_wh[1]), C.c_int(int(flip)),
+                                    C.c_int(out_wh[0]), C.c_int(out_wh[1]), _p(out)), "preprocess_boxes")
+    return out
