@@ -32,6 +32,7 @@ SIGNATURES = {
     "frcnn_nms_classed": (_i, [_vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_region_proposal": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _f, _f, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_head_tail_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "frcnn_rpn_head_tail_ml_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -152,6 +152,21 @@ class RPNHead(nn.Module):
         normal_init(self.cls_layer, 0, 0.01)
         normal_init(self.reg_layer, 0, 0.01)
 
+    def forward_levels(self, feats):
+        """All levels at once: 3x3 per level on MIOpen without its bias, then ONE MFMA kernel for bias + ReLU + both 1x1 heads
+        + the NHWC layout + the concatenation (new_model.py:37-44).  Under bf16 autocast the 3x3 outputs are bf16 and the
+        heads contract on the bf16 matrix cores with fp32 accumulate; predictions (hence box regression) stay fp32."""
+        f0 = feats[0]
+        if f0.is_cuda and f0.size(0) == 1 and f0.dtype in (torch.float32, torch.bfloat16):
+            raws = [torch.nn.functional.conv2d(f, self.inter_layer.weight, None, padding=1) for f in feats]
+            if raws[0].dtype in (torch.float32, torch.bfloat16) and all(r.dtype == raws[0].dtype for r in raws):
+                with torch.autocast("cuda", enabled=False):
+                    return ops.rpn_head_tail_levels(raws, self.inter_layer.bias, self.cls_layer.weight, self.cls_layer.bias,
+                                                    self.reg_layer.weight, self.reg_layer.bias,
+                                                    mfma="bf16" if raws[0].dtype == torch.bfloat16 else "f32")
+        cls, reg = zip(*[self.forward(f) for f in feats])                          # reference form (batch > 1)
+        return torch.cat(cls, dim=1), torch.cat(reg, dim=1)
+
     def forward(self, features):
         batch_size = features.size(0)
         x = torch.relu(self.inter_layer(features))
@@ -179,13 +194,9 @@ class RegionProposalNetwork(nn.Module):
     def propose(self, x, features, mode):
         """Asynchronous form: (pred_rpn_cls [N,2], pred_rpn_reg [N,4], rois [P,4] fixed, count int32[1], anchors [N,4])."""
         feats = list(features.values())
-        cls, reg = [], []
-        for f in feats:
-            c, r = self.rpn_head(f)
-            cls.append(c)
-            reg.append(r)
-        pred_rpn_cls = torch.cat(cls, dim=1).flatten(0, -2)
-        pred_rpn_reg = torch.cat(reg, dim=1).reshape(-1, 4)
+        cls, reg = self.rpn_head.forward_levels(feats)
+        pred_rpn_cls = cls.float().flatten(0, -2)
+        pred_rpn_reg = reg.float().reshape(-1, 4)
         h, w = x.shape[2:]
         shapes = [tuple(f.shape[-2:]) for f in feats]
         anchor = self.anchor_generator.grid((h, w), shapes, x.device, normalise=True)   # new_model.py:46-47, cached in HBM

@@ -297,48 +297,80 @@ def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_thresho
 # RPN head tail (models/model.py:79-83): bias + ReLU + both 1x1 heads + NHWC store on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------
 class _RPNHeadTailFn(torch.autograd.Function):
+    """All levels in one launch.  args: (mfma_bf16, b3, w_cls, b_cls, w_reg, b_reg, *raws); raws are the bias-free 3x3 outputs
+    [1, C, fh_l, fw_l], all fp32 or all bf16."""
+
     @staticmethod
-    def forward(ctx, raw, b3, w_cls, b_cls, w_reg, b_reg):
-        raw = _req(raw, name="conv_raw")
-        if raw.dim() != 4 or raw.shape[0] != 1:
-            raise ValueError("rpn_head_tail: conv_raw must be [1,C,fh,fw] (batch 1 per GPU)")
-        _, Cc, fh, fw = raw.shape
-        P = fh * fw
+    def forward(ctx, mfma_bf16, b3, w_cls, b_cls, w_reg, b_reg, *raws):
+        if not raws:
+            raise ValueError("rpn_head_tail: no feature level")
+        dt = raws[0].dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise TypeError("rpn_head_tail: conv output must be float32 or bfloat16, got %s" % dt)
+        raws = [_req(r, dt, "conv_raw") for r in raws]
+        for r in raws:
+            if r.dim() != 4 or r.shape[0] != 1 or r.shape[1] != raws[0].shape[1]:
+                raise ValueError("rpn_head_tail: every level must be [1,C,fh,fw] (batch 1 per GPU) with the same C")
+        Cc = raws[0].shape[1]
+        Ps = [r.shape[2] * r.shape[3] for r in raws]
         b3, b_cls, b_reg = _req(b3, name="b3"), _req(b_cls, name="b_cls"), _req(b_reg, name="b_reg")
         wc = _req(w_cls, name="w_cls").reshape(w_cls.shape[0], -1)
         wr = _req(w_reg, name="w_reg").reshape(w_reg.shape[0], -1)
         n_cls, n_reg = wc.shape[0], wr.shape[0]
         if wc.shape[1] != Cc or wr.shape[1] != Cc or b3.numel() != Cc:
             raise ValueError("rpn_head_tail: channel mismatch")
-        out_cls = torch.empty((1, P * n_cls // 2, 2), dtype=torch.float32, device=raw.device)
-        out_reg = torch.empty((1, P * n_reg // 4, 4), dtype=torch.float32, device=raw.device)
-        with torch.cuda.device(raw.device):
-            check(lib.frcnn_rpn_head_tail_fwd(_ptr(raw), Cc, P, _ptr(b3), _ptr(wc), _ptr(b_cls), n_cls, _ptr(wr), _ptr(b_reg), n_reg,
-                                              _ptr(out_cls), _ptr(out_reg), _stream()), "rpn_head_tail_fwd")
-        ctx.save_for_backward(raw, b3, wc, wr)
+        dev = raws[0].device
+        Pt = sum(Ps)
+        out_cls = torch.empty((1, Pt * n_cls // 2, 2), dtype=torch.float32, device=dev)
+        out_reg = torch.empty((1, Pt * n_reg // 4, 4), dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * len(raws))(*[r.data_ptr() for r in raws])
+        pl = (C.c_int64 * len(raws))(*Ps)
+        with torch.cuda.device(dev):
+            check(lib.frcnn_rpn_head_tail_ml_fwd(ptrs, 1 if dt == torch.bfloat16 else 0, 1 if mfma_bf16 else 0, Cc, pl, len(raws), _ptr(b3),
+                                                 _ptr(wc), _ptr(b_cls), n_cls, _ptr(wr), _ptr(b_reg), n_reg, _ptr(out_cls), _ptr(out_reg),
+                                                 _stream()), "rpn_head_tail_ml_fwd")
+        ctx.save_for_backward(b3, wc, wr, *raws)
         ctx.w_shapes = (w_cls.shape, w_reg.shape)
         return out_cls, out_reg
 
     @staticmethod
     def backward(ctx, g_cls, g_reg):
-        raw, b3, wc, wr = ctx.saved_tensors
-        _, Cc, fh, fw = raw.shape
-        P = fh * fw
+        b3, wc, wr = ctx.saved_tensors[:3]
+        raws = ctx.saved_tensors[3:]
         n_cls, n_reg = wc.shape[0], wr.shape[0]
-        g = torch.cat([g_cls.reshape(P, n_cls), g_reg.reshape(P, n_reg)], dim=1)          # [P, n_cls + n_reg]
-        z = raw.reshape(Cc, P) + b3[:, None]
-        h = torch.relu(z)                                                                   # recomputed, never stored in forward
-        dW = g.t() @ h.t()                                                                  # [n_out, C]
-        db = g.sum(0)
-        dh = torch.cat([wc, wr], dim=0).t() @ g.t()                                         # [C, P]
-        dz = dh * (z > 0).to(dh.dtype)
-        return (dz.reshape(raw.shape), dz.sum(1), dW[:n_cls].reshape(ctx.w_shapes[0]), db[:n_cls],
-                dW[n_cls:].reshape(ctx.w_shapes[1]), db[n_cls:])
+        Cc = wc.shape[1]
+        w_all = torch.cat([wc, wr], dim=0)
+        dW = torch.zeros((n_cls + n_reg, Cc), dtype=torch.float32, device=wc.device)
+        db = torch.zeros((n_cls + n_reg,), dtype=torch.float32, device=wc.device)
+        db3 = torch.zeros((Cc,), dtype=torch.float32, device=wc.device)
+        g_cls, g_reg = g_cls.reshape(-1, n_cls), g_reg.reshape(-1, n_reg)
+        d_raws, p0 = [], 0
+        for raw in raws:
+            P = raw.shape[2] * raw.shape[3]
+            g = torch.cat([g_cls[p0:p0 + P], g_reg[p0:p0 + P]], dim=1)                       # [P, n_cls + n_reg]
+            z = raw.reshape(Cc, P).float() + b3[:, None]
+            h = torch.relu(z)                                                               # recomputed, never stored in forward
+            dW += g.t() @ h.t()
+            db += g.sum(0)
+            dz = (w_all.t() @ g.t()) * (z > 0).to(torch.float32)                            # [C, P]
+            db3 += dz.sum(1)
+            d_raws.append(dz.reshape(raw.shape).to(raw.dtype))
+            p0 += P
+        return (None, db3, dW[:n_cls].reshape(ctx.w_shapes[0]), db[:n_cls], dW[n_cls:].reshape(ctx.w_shapes[1]), db[n_cls:], *d_raws)
 
 
 def rpn_head_tail(conv_raw, b3, w_cls, b_cls, w_reg, b_reg):
     """(pred_cls [1, P*A, 2], pred_reg [1, P*A, 4]) from the bias-free 3x3 output; see include/frcnn_hip.h."""
-    return _RPNHeadTailFn.apply(conv_raw, b3, w_cls, b_cls, w_reg, b_reg)
+    return _RPNHeadTailFn.apply(False, b3, w_cls, b_cls, w_reg, b_reg, conv_raw)
+
+
+def rpn_head_tail_levels(conv_raws, b3, w_cls, b_cls, w_reg, b_reg, mfma="f32"):
+    """The shared RPN head tail over all FPN levels (models/new_model.py:37-44,109-113) in one launch: outputs are the
+    torch.cat(dim=1) of the per-level results.  mfma='bf16' contracts bf16-rounded operands with fp32 accumulation
+    (mixed-precision configuration); biases and outputs are fp32 either way."""
+    if mfma not in ("f32", "bf16"):
+        raise ValueError("mfma must be 'f32' or 'bf16'")
+    return _RPNHeadTailFn.apply(mfma == "bf16", b3, w_cls, b_cls, w_reg, b_reg, *conv_raws)
 
 
 # --------------------------------------------------------------------------------------------
@@ -547,6 +579,8 @@ def ms_roi_align(feats, rois, output_size=7, sampling_ratio=2, scales=(0.25, 0.1
                  canonical_scale=224.0, canonical_level=4):
     k_min = int(round(-np.log2(scales[0])))
     PH, PW = (output_size, output_size) if isinstance(output_size, int) else output_size
+    feats = [f if f.dtype == torch.float32 else f.float() for f in feats]      # under autocast: pooling runs in fp32 (as torchvision's does)
+    rois = rois.float()
     return _MsRoIAlignFn.apply(rois, int(PH), int(PW), int(sampling_ratio), bool(aligned), tuple(float(s) for s in scales), k_min,
                                float(canonical_scale), int(canonical_level), *feats)
 

@@ -44,6 +44,8 @@ typedef enum {
     FRCNN_ERR_LAUNCH = -4         /* hipGetLastError() after a launch was not hipSuccess */
 } frcnn_status;
 
+typedef enum { FRCNN_DTYPE_F32 = 0, FRCNN_DTYPE_BF16 = 1 } frcnn_dtype;
+
 /* operation ids for frcnn_workspace_bytes() */
 typedef enum {
     FRCNN_OP_TOPK = 1,            /* n1 = N candidates */
@@ -140,6 +142,14 @@ int frcnn_rpn_head_tail_fwd(const float *conv_raw, int C, int64_t P, const float
                             const float *w_cls, const float *b_cls, int n_cls,
                             const float *w_reg, const float *b_reg, int n_reg,
                             float *out_cls, float *out_reg, void *stream);
+/* The same for all FPN levels in one launch (models/new_model.py:37-44: the shared head applied per level, outputs
+ * concatenated along the anchor axis).  conv_raw_levels / P_levels: HOST arrays (n_levels <= 5) of device pointers
+ * [C, P_l] and position counts.  dtype: element type of the conv outputs (FRCNN_DTYPE_F32 | FRCNN_DTYPE_BF16);
+ * mfma: FRCNN_DTYPE_F32 = exact fp32 contraction, FRCNN_DTYPE_BF16 = operands rounded to bf16, fp32 accumulate (the
+ * mixed-precision configuration of BASELINE.json configs[4]; biases, outputs and everything downstream stay fp32). */
+int frcnn_rpn_head_tail_ml_fwd(const void *const *conv_raw_levels, int dtype, int mfma, int C, const int64_t *P_levels, int n_levels,
+                               const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
+                               const float *b_reg, int n_reg, float *out_cls, float *out_reg, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

@@ -162,6 +162,36 @@ def test_fpn_predict_api(fpn_model):
     assert bbox.dtype == torch.float32 and label.dtype == torch.int32 and bbox.shape[0] == score.shape[0]
 
 
+def test_fpn_bf16_mixed_precision_step_keeps_box_path_fp32(fpn_model):
+    """BASELINE.json configs[4]: ResNet-50-FPN under bf16 autocast -- backbone / FPN / 3x3 RPN conv in bf16, the head tail on
+    the bf16 matrix cores with fp32 accumulate, RPN predictions, proposals, targets, RoIAlign input boxes and losses in fp32.
+    Checked against the fp32 run of the same weights and frame: predictions agree to bf16 accuracy, the step trains."""
+    from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+    H, W, G, seed = 384, 512, 3, 5
+    x, boxes, labels = synth(seed, H, W, G)
+    labels = labels + 1
+    fpn_model.train()
+    torch.manual_seed(123)
+    pred32, _ = fpn_model(x.to(DEV), [boxes.to(DEV)], [labels.to(DEV)])
+    fpn_model.zero_grad(set_to_none=True)
+    torch.manual_seed(123)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pred, target = fpn_model(x.to(DEV), [boxes.to(DEV)], [labels.to(DEV)])
+    assert pred[0].dtype == torch.float32 and pred[1].dtype == torch.float32            # RPN cls / reg: fp32 out of the MFMA kernel
+    assert target[1].dtype == torch.float32 and target[3].dtype == torch.float32
+    assert torch.isfinite(pred[0]).all() and torch.isfinite(pred[1]).all()
+    d_cls = (pred[0] - pred32[0]).abs().max().item() / max(1.0, pred32[0].abs().max().item())
+    d_reg = (pred[1] - pred32[1]).abs().max().item() / max(1.0, pred32[1].abs().max().item())
+    assert d_cls < 0.08 and d_reg < 0.08, (d_cls, d_reg)                                 # bf16 backbone: ~2-3 significant digits
+    loss = FRCNNLoss(None)(tuple(p.float() for p in pred), target)[0]
+    assert torch.isfinite(loss)
+    loss.backward()
+    gw = fpn_model.rpn.rpn_head.inter_layer.weight.grad
+    assert gw is not None and gw.dtype == torch.float32 and torch.isfinite(gw).all() and gw.abs().sum() > 0
+    assert fpn_model.rpn.rpn_head.cls_layer.weight.grad.abs().sum() > 0 and fpn_model.rpn.rpn_head.inter_layer.bias.grad.abs().sum() > 0
+    fpn_model.zero_grad(set_to_none=True)
+
+
 # ------------------------------------------------------------------------------------------------ data-parallel step (2 ranks, one GPU, gloo)
 def _ddp_worker(rank, world, port, q):
     import os

@@ -535,6 +535,52 @@ def test_rpn_head_tail_vs_torch_fp32(ops, C, fh, fw, A):
         assert (a.grad.cpu().double() - b.grad).abs().max() < 2e-4 * max(1.0, float(b.grad.abs().max()))
 
 
+@pytest.mark.parametrize("dtype,mfma,tol", [("f32", "f32", 1e-5), ("f32", "bf16", 2e-2), ("bf16", "bf16", 2e-2), ("bf16", "f32", 1e-5)])
+def test_rpn_head_tail_all_fpn_levels_one_launch(ops, dtype, mfma, tol):
+    """The shared FPN head (new_model.py:37-44,109-113: A = 3, C = 256, five levels) in one launch, fp32 and the mixed
+    precision forms.  Reference: the plain op chain in float64 on the SAME (possibly bf16-rounded) conv outputs.  Tolerances:
+    exact-fp32 MFMA 1e-5 absolute; bf16 operands (8 mantissa bits, K = 256, |out| ~ 0.3) 2e-2 absolute."""
+    g = torch.Generator().manual_seed(11)
+    C_, A = 256, 3
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    raws = [torch.randn(1, C_, h, w, generator=g) for h, w in shapes]
+    if dtype == "bf16":
+        raws = [r.bfloat16() for r in raws]
+    b3 = torch.randn(C_, generator=g) * 0.1
+    wc, bc = torch.randn(2 * A, C_, 1, 1, generator=g) * 0.02, torch.randn(2 * A, generator=g) * 0.1
+    wr, br = torch.randn(4 * A, C_, 1, 1, generator=g) * 0.02, torch.randn(4 * A, generator=g) * 0.1
+    ref_c, ref_r = [], []
+    for r in raws:
+        h = torch.relu(r.double() + b3.double()[None, :, None, None])
+        ref_c.append(torch.nn.functional.conv2d(h, wc.double(), bc.double()).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
+        ref_r.append(torch.nn.functional.conv2d(h, wr.double(), br.double()).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
+    ref_c, ref_r = torch.cat(ref_c, 1), torch.cat(ref_r, 1)
+    dr = [r.to(DEV).requires_grad_(True) for r in raws]
+    params = [t.to(DEV).requires_grad_(True) for t in (b3, wc, bc, wr, br)]
+    cls, reg = ops.rpn_head_tail_levels(dr, *params, mfma=mfma)
+    assert cls.dtype == torch.float32 and reg.dtype == torch.float32                  # box regression stays fp32
+    assert cls.shape == ref_c.shape and reg.shape == ref_r.shape
+    assert (cls.detach().cpu().double() - ref_c).abs().max() < tol and (reg.detach().cpu().double() - ref_r).abs().max() < tol
+    if mfma == "f32" and dtype == "f32":                                             # one level through the old entry point: identical bits
+        c1, r1 = ops.rpn_head_tail(dr[1].detach(), *[p.detach() for p in params])
+        n0, n1 = shapes[0][0] * shapes[0][1] * A, shapes[1][0] * shapes[1][1] * A
+        assert torch.equal(c1[0], cls[0, n0:n0 + n1].detach()) and torch.equal(r1[0], reg[0, n0:n0 + n1].detach())
+    # backward (fp32 torch ops on recomputed activations) against float64 autograd of the op chain
+    gc, gr = torch.randn(cls.shape, generator=g), torch.randn(reg.shape, generator=g)
+    ((cls * gc.to(DEV)).sum() + (reg * gr.to(DEV)).sum()).backward()
+    ref_in = [r.double().requires_grad_(True) for r in raws] + [t.clone().double().requires_grad_(True) for t in (b3, wc, bc, wr, br)]
+    cc, rr = [], []
+    for r in ref_in[:5]:
+        h = torch.relu(r + ref_in[5][None, :, None, None])
+        cc.append(torch.nn.functional.conv2d(h, ref_in[6], ref_in[7]).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
+        rr.append(torch.nn.functional.conv2d(h, ref_in[8], ref_in[9]).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
+    ((torch.cat(cc, 1) * gc.double()).sum() + (torch.cat(rr, 1) * gr.double()).sum()).backward()
+    btol = 2e-4 if dtype == "f32" else 1e-2                                           # bf16 leaf: its gradient is rounded to bf16
+    for a, b in zip(dr + params, ref_in):
+        assert a.grad.dtype == a.dtype
+        assert (a.grad.cpu().double() - b.grad).abs().max() < btol * max(1.0, float(b.grad.abs().max()))
+
+
 # ------------------------------------------------------------------------------------------ edge cases (empty / ragged / extreme sizes)
 def test_empty_and_degenerate_inputs(ops):
     e4 = torch.zeros((0, 4), device=DEV)
