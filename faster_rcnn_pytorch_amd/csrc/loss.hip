@@ -3,17 +3,27 @@
 //   head: CE over [R,C]            + SmoothL1(beta 1)   over the positives, both / R                   (loss.py:43-61)
 // The reference spends ~15 eager launches and two boolean-mask host syncs (loss.py:33,56) per forward and about as
 // many per backward.  Here one pass over the predictions produces the four sums AND the un-normalised gradients
-// (softmax - onehot, SmoothL1'), so backward is four scalar multiplies.  One lane per anchor / per RoI row; wave
-// shuffle reductions, then one atomic per block and quantity.
+// (softmax - onehot, SmoothL1'), so backward is four scalar multiplies.  RPN rows: one lane per anchor, grid-stride over at
+// most 256 workgroups; head rows: one WAVE per RoI (lanes over the classes, coalesced row reads, shuffle max / sum).  Every
+// workgroup writes its partial sums to its own slot and the finalize kernel adds the slots in index order: no atomics
+// (1051 same-line atomics x 5 cost 50 us at FPN size) and a loss that is bit-reproducible run to run.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 
-struct LossAcc { float rpn_ce, rpn_sl1, head_ce, head_sl1; int rpn_valid; int pad[3]; };
+struct LossAcc { float rpn_ce, rpn_sl1, head_ce, head_sl1; int rpn_valid; int pad[3]; };      // one 32-byte slot per workgroup
+#define LOSS_MAX_BLOCKS 256                                                                    // per part (RPN rows, head rows)
 
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
 
@@ -31,70 +41,84 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float2 *__restrict_
                                                        const int64_t *__restrict__ t_cls, const float4 *__restrict__ t_reg, int R, int NC,
                                                        float2 *__restrict__ g_rpn_cls, float4 *__restrict__ g_rpn_reg,
                                                        float *__restrict__ g_head_cls, float4 *__restrict__ g_head_reg,
-                                                       LossAcc *__restrict__ acc)
+                                                       LossAcc *__restrict__ slots, int nb_rpn)
 {
     __shared__ float s_part[4][4];
     __shared__ int s_cnt[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     float ce = 0.f, sl = 0.f, hce = 0.f, hsl = 0.f;
     int valid = 0;
-    if (i < N) {                                                       // ---- RPN row i
-        const int64_t t = t_rpn_cls[i];
-        float2 gc = make_float2(0.f, 0.f);
-        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0) {
-            const float2 c = rpn_cls[i];
-            const float m = fmaxf(c.x, c.y);
-            const float e0 = expf(c.x - m), e1 = expf(c.y - m);
-            const float s = e0 + e1;
-            ce = m + logf(s) - (t == 0 ? c.x : c.y);
-            gc = make_float2(e0 / s - (t == 0 ? 1.f : 0.f), e1 / s - (t == 1 ? 1.f : 0.f));
-            valid = 1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if ((int)blockIdx.x < nb_rpn) {                                    // ---- RPN rows, grid-stride
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += nb_rpn * 256) {
+            const int64_t t = t_rpn_cls[i];
+            float2 gc = make_float2(0.f, 0.f);
+            float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0) {
+                const float2 c = rpn_cls[i];
+                const float m = fmaxf(c.x, c.y);
+                const float e0 = expf(c.x - m), e1 = expf(c.y - m);
+                const float s = e0 + e1;
+                ce += m + logf(s) - (t == 0 ? c.x : c.y);
+                gc = make_float2(e0 / s - (t == 0 ? 1.f : 0.f), e1 / s - (t == 1 ? 1.f : 0.f));
+                ++valid;
+            }
+            if (t > 0) {
+                const float4 p = rpn_reg[i], q = t_rpn_reg[i];
+                sl += sl1(p.x, q.x, 1.f / 9.f, &gr.x) + sl1(p.y, q.y, 1.f / 9.f, &gr.y) + sl1(p.z, q.z, 1.f / 9.f, &gr.z) + sl1(p.w, q.w, 1.f / 9.f, &gr.w);
+            }
+            g_rpn_cls[i] = gc;
+            g_rpn_reg[i] = gr;
         }
-        if (t > 0) {
-            const float4 p = rpn_reg[i], q = t_rpn_reg[i];
-            sl = sl1(p.x, q.x, 1.f / 9.f, &gr.x) + sl1(p.y, q.y, 1.f / 9.f, &gr.y) + sl1(p.z, q.z, 1.f / 9.f, &gr.z) + sl1(p.w, q.w, 1.f / 9.f, &gr.w);
+    } else {                                                           // ---- head rows, one wave per RoI
+        const int nb_head = gridDim.x - nb_rpn;
+        for (int r = ((int)blockIdx.x - nb_rpn) * 4 + w; r < R; r += nb_head * 4) {
+            const float *row = head_cls + (size_t)r * NC;
+            const int t = (int)t_cls[r];
+            float m = -__builtin_inff();
+            for (int c = lane; c < NC; c += 64) m = fmaxf(m, row[c]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int c = lane; c < NC; c += 64) s += expf(row[c] - m);
+            s = wave_sum(s);
+            float *g = g_head_cls + (size_t)r * NC;
+            for (int c = lane; c < NC; c += 64) g[c] = expf(row[c] - m) / s - (c == t ? 1.f : 0.f);
+            if (lane == 0) {
+                hce += m + logf(s) - row[t];
+                float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t > 0) {
+                    const float4 p = head_reg[r], q = t_reg[r];
+                    hsl += sl1(p.x, q.x, 1.f, &gr.x) + sl1(p.y, q.y, 1.f, &gr.y) + sl1(p.z, q.z, 1.f, &gr.z) + sl1(p.w, q.w, 1.f, &gr.w);
+                }
+                g_head_reg[r] = gr;
+            }
         }
-        g_rpn_cls[i] = gc;
-        g_rpn_reg[i] = gr;
-    } else if (i - N < R) {                                            // ---- head row r (the grid covers N + R lanes)
-        const int r = i - N;
-        const float *row = head_cls + (size_t)r * NC;
-        const int t = (int)t_cls[r];
-        float m = row[0];
-        for (int c = 1; c < NC; ++c) m = fmaxf(m, row[c]);
-        float s = 0.f;
-        for (int c = 0; c < NC; ++c) s += expf(row[c] - m);
-        hce = m + logf(s) - row[t];
-        float *g = g_head_cls + (size_t)r * NC;
-        for (int c = 0; c < NC; ++c) g[c] = expf(row[c] - m) / s - (c == t ? 1.f : 0.f);
-        float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t > 0) {
-            const float4 p = head_reg[r], q = t_reg[r];
-            hsl = sl1(p.x, q.x, 1.f, &gr.x) + sl1(p.y, q.y, 1.f, &gr.y) + sl1(p.z, q.z, 1.f, &gr.z) + sl1(p.w, q.w, 1.f, &gr.w);
-        }
-        g_head_reg[r] = gr;
     }
     ce = wave_sum(ce); sl = wave_sum(sl); hce = wave_sum(hce); hsl = wave_sum(hsl);
-    const int vc = __builtin_popcountll(__ballot(valid));
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_part[w][0] = ce; s_part[w][1] = sl; s_part[w][2] = hce; s_part[w][3] = hsl; s_cnt[w] = vc; }
+    int vc = valid;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vc += __shfl_xor(vc, o);
+    if (lane == 0) { s_part[w][0] = ce; s_part[w][1] = sl; s_part[w][2] = hce; s_part[w][3] = hsl; s_cnt[w] = vc; }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const float v = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-        if (v != 0.f) atomicAdd(&acc->rpn_ce + threadIdx.x, v);
-    }
-    if (threadIdx.x == 4) {
-        const int c = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        if (c) atomicAdd(&acc->rpn_valid, c);
-    }
+    if (threadIdx.x < 4) (&slots[blockIdx.x].rpn_ce)[threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+    if (threadIdx.x == 4) slots[blockIdx.x].rpn_valid = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // out[0..4] = total, rpn_cls, rpn_reg, head_cls, head_reg ; out[5] = 1/n_valid, out[6] = 1/R (gradient scales)
-__global__ void det_loss_finalize_kernel(const LossAcc *__restrict__ acc, int R, float *__restrict__ out)
+__global__ __launch_bounds__(64) void det_loss_finalize_kernel(const LossAcc *__restrict__ slots, int n_slots, int R, float *__restrict__ out)
 {
-    const float nv = (float)acc->rpn_valid, fr = (float)R;
-    const float l1 = acc->rpn_ce / nv, l2 = acc->rpn_sl1 / nv, l3 = acc->head_ce / fr, l4 = acc->head_sl1 / fr;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int nvi = 0;
+    for (int b = threadIdx.x; b < n_slots; b += 64) {                  // fixed assignment + fixed shuffle tree: deterministic
+        a[0] += slots[b].rpn_ce; a[1] += slots[b].rpn_sl1; a[2] += slots[b].head_ce; a[3] += slots[b].head_sl1;
+        nvi += slots[b].rpn_valid;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] = wave_sum(a[q]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nvi += __shfl_xor(nvi, o);
+    if (threadIdx.x != 0) return;
+    const float nv = (float)nvi, fr = (float)R;
+    const float l1 = a[0] / nv, l2 = a[1] / nv, l3 = a[2] / fr, l4 = a[3] / fr;
     out[1] = l1; out[2] = l2; out[3] = l3; out[4] = l4;
     out[0] = l1 + l2 + l3 + l4;
     out[5] = 1.0f / nv;
@@ -110,15 +134,17 @@ FRCNN_EXPORT int frcnn_detection_loss(const float *rpn_cls, const float *rpn_reg
     FRCNN_REQUIRE(rpn_cls && rpn_reg && t_rpn_cls && t_rpn_reg && head_cls && head_reg && t_cls && t_reg && out7 && g_rpn_cls && g_rpn_reg &&
                       g_head_cls && g_head_reg && workspace,
                   "detection_loss: NULL pointer");
-    if (workspace_bytes < sizeof(LossAcc)) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "detection_loss: workspace %zu < %zu bytes", workspace_bytes, sizeof(LossAcc));
+    const int nb_rpn = (int)((N + 255) / 256 < LOSS_MAX_BLOCKS ? (N + 255) / 256 : LOSS_MAX_BLOCKS);
+    const int nb_head = (int)((R + 3) / 4 < LOSS_MAX_BLOCKS ? (R + 3) / 4 : LOSS_MAX_BLOCKS);
+    const size_t need = (size_t)(nb_rpn + nb_head) * sizeof(LossAcc);
+    if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "detection_loss: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
-    LossAcc *acc = (LossAcc *)workspace;
-    if (hipMemsetAsync(acc, 0, sizeof(LossAcc), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "detection_loss: memset failed");
-    FRCNN_LAUNCH(KID_DET_LOSS, det_loss_kernel, dim3((unsigned)((N + R + 255) / 256)), dim3(256), 0, s, (const float2 *)rpn_cls, (const float4 *)rpn_reg,
+    LossAcc *slots = (LossAcc *)workspace;
+    FRCNN_LAUNCH(KID_DET_LOSS, det_loss_kernel, dim3((unsigned)(nb_rpn + nb_head)), dim3(256), 0, s, (const float2 *)rpn_cls, (const float4 *)rpn_reg,
                  t_rpn_cls, (const float4 *)t_rpn_reg, (int)N, head_cls, (const float4 *)head_reg, t_cls, (const float4 *)t_reg, (int)R, NC,
-                 (float2 *)g_rpn_cls, (float4 *)g_rpn_reg, g_head_cls, (float4 *)g_head_reg, acc);
+                 (float2 *)g_rpn_cls, (float4 *)g_rpn_reg, g_head_cls, (float4 *)g_head_reg, slots, nb_rpn);
     FRCNN_CHECK_LAUNCH("det_loss_kernel");
-    hipLaunchKernelGGL(det_loss_finalize_kernel, dim3(1), dim3(1), 0, s, acc, (int)R, out7);
+    FRCNN_LAUNCH(KID_DET_LOSS, det_loss_finalize_kernel, dim3(1), dim3(64), 0, s, slots, nb_rpn + nb_head, (int)R, out7);
     FRCNN_CHECK_LAUNCH("det_loss_finalize_kernel");
     return FRCNN_OK;
 }

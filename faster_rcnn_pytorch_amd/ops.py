@@ -446,10 +446,10 @@ class _DetLossFn(torch.autograd.Function):
         dev = rc.device
         out = torch.empty((7,), dtype=torch.float32, device=dev)
         g = [torch.empty_like(t) for t in (rc, rr, hc, hr)]
-        ws = _workspace(dev, 256)
+        ws = _workspace(dev, 16384)
         with torch.cuda.device(dev):
             check(lib.frcnn_detection_loss(_ptr(rc), _ptr(rr), _ptr(trc), _ptr(trr), N, _ptr(hc), _ptr(hr), _ptr(tc), _ptr(tr), R, NC,
-                                           _ptr(out), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(ws), 256, _stream()), "detection_loss")
+                                           _ptr(out), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(ws), 16384, _stream()), "detection_loss")
         ctx.save_for_backward(out, *g)
         ctx.shapes = shapes
         return out[0], out[1], out[2], out[3], out[4]

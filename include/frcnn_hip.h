@@ -205,7 +205,7 @@ int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host,
 /* ---- detection losses (losses/loss.py:5-85) ------------------------------------------------- */
 /* FRCNNLoss forward AND the un-normalised input gradients in one pass.  out7 (device): total, rpn_cls, rpn_reg,
  * head_cls, head_reg losses, then 1/#(rpn label >= 0) and 1/R (the scales backward multiplies the gradients by).
- * g_* have the shapes of the predictions.  workspace >= 32 bytes.                                                  */
+ * g_* have the shapes of the predictions.  workspace >= 16 KiB.                                                    */
 int frcnn_detection_loss(const float *rpn_cls /*[N,2]*/, const float *rpn_reg /*[N,4]*/, const int64_t *t_rpn_cls /*[N]*/,
                          const float *t_rpn_reg /*[N,4]*/, int64_t N,
                          const float *head_cls /*[R,NC]*/, const float *head_reg /*[R,4]*/, const int64_t *t_cls /*[R]*/,
