@@ -18,6 +18,7 @@
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include <cstdlib>
+#include <cstring>
 
 struct MsLevels {
     int n_levels;
@@ -389,6 +390,184 @@ __global__ __launch_bounds__(256) void roi_align_bwd77_kernel(MsLevels L, int C,
     }
 }
 
+// ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
+// A workgroup owns a 16 x 32 pixel tile of ONE level for 32 channels (lane = (column, channel mod 8), 4 channel sub-groups
+// x 16 row accumulators in registers) and writes it exactly once.  It scans the RoI list (level + footprint recomputed from the box: ~150 instructions per RoI,
+// 2 RoIs per lane at R = 512), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot compaction, so the
+// fp32 sum order is fixed: bit-reproducible gradients), and for each of them
+//   A: stores the prefetched dOut[r][8 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
+//      Wy[16][7] and Wx[32][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
+//   B: lane = (channel, column) forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds
+//      sum_ph Wy[y][ph] * T[ph] to its 16 row accumulators (registers) -- one barrier per RoI, LDS tables double-buffered.
+#define RT_TH 16
+#define RT_TW 32
+#ifndef RT_NS
+#define RT_NS 1                          // channel sub-groups of 8 per workgroup (lane = (column, channel within sub-group))
+#endif
+#define RT_CB (8 * RT_NS)
+#define RT_LIST 256                      // RoIs are scanned in chunks of this many
+#define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
+
+struct TileLevels { int tile0[FRCNN_MAX_LEVELS + 1]; int tiles_x[FRCNN_MAX_LEVELS]; };
+struct RoiEnt { int r; float sh, sw, bh, bw; };
+
+template <typename TOUT> __device__ __forceinline__ void store_grad(TOUT *p, float v);
+template <> __device__ __forceinline__ void store_grad<float>(float *p, float v) { *p = v; }
+
+template <typename TOUT>
+__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, int C, const float4 *__restrict__ rois, int R, int aligned,
+                                                                 int k_min, float s0, int k0, const float *__restrict__ grad_out, int n_cg)
+{
+    __shared__ RoiEnt s_list[RT_LIST];
+    __shared__ int s_n;
+    __shared__ int s_woff[5];
+    __shared__ float s_g[2][RT_CB * 49];
+    __shared__ __attribute__((aligned(16))) float s_wy[2][RT_TH * 8];
+    __shared__ float s_wx[2][RT_TW * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // block -> (tile, channel group); groups pinned to XCDs when there are 8 k of them
+    int tile, cg;
+    if ((n_cg & 7) == 0) { const int j = blockIdx.x >> 3; const int q8 = n_cg >> 3; cg = (j % q8) * 8 + (blockIdx.x & 7); tile = j / q8; }
+    else { cg = blockIdx.x % n_cg; tile = blockIdx.x / n_cg; }
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
+    const int tl = tile - TL.tile0[l];
+    const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
+    const int H = L.H[l], W = L.W[l];
+    const float scale = L.scale[l];
+    const int cx = t & (RT_TW - 1), cc = t >> 5;          // phase B: lane -> (column cx, channel cc + 8 s of the group)
+    const int c0 = cg * RT_CB;
+    const int nc = min(RT_CB, C - c0);
+    const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
+
+    float acc[RT_NS][RT_TH];
+#pragma unroll
+    for (int sg = 0; sg < RT_NS; ++sg)
+#pragma unroll
+        for (int y = 0; y < RT_TH; ++y) acc[sg][y] = 0.0f;
+
+    for (int rbase = 0; rbase < R; rbase += RT_LIST) {
+        // ---- scan RT_LIST RoIs: which of them touch this tile?
+        __syncthreads();                                   // the previous chunk's readers of s_list are done
+        const int r = rbase + t;
+        bool hit = false;
+        RoiEnt e;
+        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f;
+        if (r < R) {
+            const float4 b = rois[r];
+            const int lr = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
+            if (lr == l) {
+                const AlignGeom g = align_geom(b, scale, 7, 7, 2, aligned != 0);
+                const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
+                const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
+                const int y0 = min(ya.lo, yb.lo), y1 = max(ya.hi, yb.hi), x0 = min(xa.lo, xb.lo), x1 = max(xa.hi, xb.hi);
+                hit = y0 < ty0 + RT_TH && y1 >= ty0 && x0 < tx0 + RT_TW && x1 >= tx0;
+                e.sh = g.sh; e.sw = g.sw; e.bh = g.bh; e.bw = g.bw;
+            }
+        }
+        const unsigned long long bm = __ballot(hit);
+        if (lane == 0) s_woff[wave + 1] = __builtin_popcountll(bm);
+        __syncthreads();
+        if (t == 0) { s_woff[0] = 0; for (int q = 1; q <= 4; ++q) s_woff[q] += s_woff[q - 1]; s_n = s_woff[4]; }
+        __syncthreads();
+        if (hit) s_list[s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
+        __syncthreads();
+        const int n = s_n;
+        // ---- the RoIs of this chunk that touch the tile, in index order
+        float pg[RT_PF];                                   // prefetched dOut elements t + 256 u of the next RoI
+#pragma unroll
+        for (int u = 0; u < RT_PF; ++u) pg[u] = 0.0f;
+        if (n > 0) {
+            const float *src = grad_out + ((size_t)s_list[0].r * C + c0) * 49;
+#pragma unroll
+            for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
+        }
+        for (int i = 0; i < n; ++i) {
+            const int buf = i & 1;
+            const RoiEnt en = s_list[i];
+            // A: dOut tile -> LDS (zero-padded to RT_CB channels), weight tables of this RoI restricted to the tile
+#pragma unroll
+            for (int u = 0; u < RT_PF; ++u)
+                if (t + 256 * u < RT_CB * 49) s_g[buf][t + 256 * u] = t + 256 * u < ne ? pg[u] : 0.0f;
+            if (i + 1 < n) {
+                const float *src = grad_out + ((size_t)s_list[i + 1].r * C + c0) * 49;
+#pragma unroll
+                for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
+            }
+            {
+                // lanes 0..223: (col = t / 7, bin = t % 7) of Wx ; lanes 0..111 additionally (row, bin) of Wy
+                const int bin = t % 7, rc = t / 7;
+                if (rc < RT_TW) {
+                    const int x = tx0 + rc;
+                    float wv = 0.0f;
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
+                        if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
+                    }
+                    s_wx[buf][rc * 8 + bin] = wv;
+                }
+                if (rc < RT_TH) {
+                    const int y = ty0 + rc;
+                    float wv = 0.0f;
+#pragma unroll
+                    for (int iy = 0; iy < 2; ++iy) {
+                        const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
+                        if (q.ok) wv += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
+                    }
+                    s_wy[buf][rc * 8 + bin] = 0.25f * wv;
+                }
+            }
+            __syncthreads();
+            // B: per channel sub-group: T[ph] for (cc + 8 sg, cx), then the tile rows the footprint reaches (uniform bounds)
+            const Lin fa = lin_setup(H, en.sh + 0.5f * en.bh / 2.0f), fb = lin_setup(H, en.sh + 6.0f * en.bh + 1.5f * en.bh / 2.0f);
+            const int ya = __builtin_amdgcn_readfirstlane(max(min(fa.lo, fb.lo) - ty0, 0));
+            const int yb = __builtin_amdgcn_readfirstlane(min(max(fa.hi, fb.hi) - ty0, RT_TH - 1));
+            float wx[7];
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) wx[pw] = s_wx[buf][cx * 8 + pw];
+#pragma unroll
+            for (int sg = 0; sg < RT_NS; ++sg) {
+                if (RT_NS > 1) asm volatile("" ::: "memory");   // re-read the (broadcast) tables per sub-group instead of pinning 300 registers
+                const float *gch = &s_g[buf][(cc + 8 * sg) * 49];
+                float T[7];
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph) {
+                    float a = gch[ph * 7] * wx[0];
+#pragma unroll
+                    for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
+                    T[ph] = a;
+                }
+#pragma unroll
+                for (int y = 0; y < RT_TH; ++y) {
+                    if (y >= ya && y <= yb) {                 // scalar branch
+                        const float4 w0 = *(const float4 *)&s_wy[buf][y * 8], w1 = *(const float4 *)&s_wy[buf][y * 8 + 4];
+                        float a = acc[sg][y];
+                        a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
+                        a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
+                        acc[sg][y] = __builtin_fmaf(w1.z, T[6], a);
+                    }
+                }
+            }
+            // no barrier here: the next A writes the OTHER buffers; the one after that is fenced by the next barrier
+        }
+    }
+    // ---- the tile is complete: one coalesced store per row and channel
+    if (tx0 + cx < W) {
+#pragma unroll
+        for (int sg = 0; sg < RT_NS; ++sg) {
+            const int c = cc + 8 * sg;
+            if (c < nc) {
+                TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + ty0) * W + tx0 + cx;
+#pragma unroll
+                for (int y = 0; y < RT_TH; ++y)
+                    if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[sg][y]);
+            }
+        }
+    }
+}
+
 FRCNN_EXPORT int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, int k_max, float s0, int k0, float eps, int32_t *out_level,
                                      void *stream)
 {
@@ -451,13 +630,33 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
                                         int k_min, float s0, int k0, void *stream)
 {
     FRCNN_REQUIRE(C > 0 && PH > 0 && PW > 0 && R >= 0 && sampling_ratio >= 0 && s0 > 0.f, "ms_roi_align_bwd: bad argument");
-    if (R == 0) return FRCNN_OK;
-    FRCNN_REQUIRE(rois && grad_out, "ms_roi_align_bwd: NULL pointer");
+    FRCNN_REQUIRE((R == 0 || (rois && grad_out)), "ms_roi_align_bwd: NULL pointer");
     MsLevels L;
     int rc = fill_levels(&L, nullptr, grad_feats, H, W, scales, n_levels);
     if (rc) return rc;
     const int64_t total = R * C * PH * PW;
     hipStream_t s = (hipStream_t)stream;
+    static const bool scatter77 = [] { const char *e = getenv("FRCNN_RA_BWD"); return e && !strcmp(e, "scatter"); }();   // tests / comparison
+    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24) && !scatter77) {
+        TileLevels TL;
+        int tiles = 0;
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+            TL.tile0[l] = tiles;
+            TL.tiles_x[l] = (L.W[l] + RT_TW - 1) / RT_TW;
+            if (l < n_levels) tiles += TL.tiles_x[l] * ((L.H[l] + RT_TH - 1) / RT_TH);
+        }
+        TL.tile0[FRCNN_MAX_LEVELS] = tiles;
+        const int n_quads = (C + RT_CB - 1) / RT_CB;
+        FRCNN_REQUIRE((int64_t)tiles * n_quads < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(tiles * n_quads)), dim3(256), 0, s, L, TL, C,
+                     (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_quads);
+        FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
+        return FRCNN_OK;
+    }
+    for (int l = 0; l < n_levels; ++l)                  // the scatter kernels accumulate: clear the planes first
+        if (hipMemsetAsync(L.grad[l], 0, (size_t)C * L.H[l] * L.W[l] * sizeof(float), s) != hipSuccess)
+            return frcnn_set_error(FRCNN_ERR_LAUNCH, "ms_roi_align_bwd: memset failed");
+    if (R == 0) return FRCNN_OK;
     if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
         const int n_cg = (C + RA_BWD_CB - 1) / RA_BWD_CB;
         FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, roi_align_bwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,

@@ -566,7 +566,7 @@ class _MsRoIAlignFn(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         PH, PW, sampling_ratio, aligned, scales, k_min, s0, k0, shapes = ctx.meta
         grad_out = _req(grad_out, name="grad_out")
-        grads = [torch.zeros(s, dtype=torch.float32, device=grad_out.device) for s in shapes]
+        grads = [torch.empty(s, dtype=torch.float32, device=grad_out.device) for s in shapes]     # overwritten by the library
         ptrs, H, W, sc = _level_tables(grads, scales)
         with torch.cuda.device(grad_out.device):
             check(lib.frcnn_ms_roi_align_bwd(_ptr(grad_out), ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(grads), shapes[0][1], _ptr(rois),

@@ -197,7 +197,9 @@ int frcnn_ms_roi_align_fwd(const float *const *feats_host /*[n_levels] device pt
                            const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
                            int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0,
                            float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/, void *stream);
-/* grad_feats[l] [C,H_l,W_l] are ACCUMULATED into with fp32 atomics; the caller zeroes them. */
+/* grad_feats[l] [C,H_l,W_l] are OVERWRITTEN with the gradient of every level (zero where no RoI reaches); the caller does
+ * not clear them.  7x7 / sampling_ratio 2: tile-owner gather, no atomics, bit-reproducible; other shapes: memset + fp32
+ * atomics inside the library (sum order not fixed, tolerance 1e-4).                                        */
 int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host, const int *H_host, const int *W_host,
                            const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
                            int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0, void *stream);

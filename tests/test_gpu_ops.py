@@ -502,6 +502,36 @@ def test_single_level_roi_align_big_footprints_and_generic_shapes(ops, PH, SR):
     assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=2e-4)
 
 
+def test_ms_roi_align_bwd_tile_gather_is_reproducible_and_overwrites(ops):
+    """The 7x7 / sampling-ratio-2 backward owns tiles instead of scattering atomics: two runs give identical bits, stale
+    contents of the gradient buffers do not leak (the library overwrites), clustered RoIs (64 on one spot) and R = 0 work."""
+    from faster_rcnn_pytorch_amd import _lib
+    import ctypes as C
+    rng = np.random.RandomState(3)
+    shapes = [(256, 100, 168), (256, 50, 84), (256, 25, 42), (256, 13, 21)]
+    rois = rand_boxes(rng, 300, 0.02, 0.6) * np.array([672, 400, 672, 400], np.float32)
+    rois[:64] = rois[0] + rng.randn(64, 4).astype(np.float32) * 2.0               # a pile of near-identical RoIs on one tile
+    go = rng.randn(300, 256, 7, 7).astype(np.float32)
+    lv = orc.roi_level_map(rois)
+    H = np.array([s[1] for s in shapes], np.int32); W = np.array([s[2] for s in shapes], np.int32)
+    sc = np.array([0.25, 0.125, 0.0625, 0.03125], np.float32)
+
+    def run(fill, R):
+        grads = [torch.full(s, fill, dtype=torch.float32, device=DEV) for s in shapes]
+        ptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in grads])
+        _lib.check(_lib.lib.frcnn_ms_roi_align_bwd(T(go).data_ptr(), ptrs, H.ctypes.data, W.ctypes.data, sc.ctypes.data, 4, 256, T(rois).data_ptr(), R,
+                                                   7, 7, 2, 0, 2, 224.0, 4, None), "bwd")
+        torch.cuda.synchronize()
+        return [g.cpu().numpy() for g in grads]
+    a, b = run(0.0, 300), run(123.0, 300)
+    for l in range(4):
+        assert np.array_equal(a[l], b[l])                                          # overwritten + bit-reproducible
+        ref = orc.roi_align_bwd(go, shapes[l], rois, float(sc[l]), 2, False, lv, l)
+        assert np.allclose(a[l], ref, rtol=1e-4, atol=2e-4)
+    z = run(7.0, 0)
+    assert all((g == 0).all() for g in z)                                          # no RoIs: zero gradient, not stale memory
+
+
 # ------------------------------------------------------------------------------------------ RPN head tail (MFMA)
 @pytest.mark.parametrize("C,fh,fw,A", [(512, 37, 62, 9), (256, 50, 84, 3), (64, 5, 7, 9)])
 def test_rpn_head_tail_vs_torch_fp32(ops, C, fh, fw, A):
