@@ -391,20 +391,26 @@ __global__ __launch_bounds__(256) void roi_align_bwd77_kernel(MsLevels L, int C,
 }
 
 // ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
-// A workgroup owns a 16 x 32 pixel tile of ONE level for 32 channels (lane = (column, channel mod 8), 4 channel sub-groups
-// x 16 row accumulators in registers) and writes it exactly once.  It scans the RoI list (level + footprint recomputed from the box: ~150 instructions per RoI,
+// A workgroup owns a 16 x 8 pixel tile of ONE level for 32 channels (lane = (column, channel), 16 row accumulators in
+// registers) and writes it exactly once.  (Measured 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch
+// 89/178 -- micro-benchmark / FPN step: narrow tiles keep the per-tile RoI chain short.)  It scans the RoI list (level + footprint recomputed from the box: ~150 instructions per RoI,
 // 2 RoIs per lane at R = 512), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot compaction, so the
 // fp32 sum order is fixed: bit-reproducible gradients), and for each of them
-//   A: stores the prefetched dOut[r][8 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
-//      Wy[16][7] and Wx[32][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
+//   A: stores the prefetched dOut[r][32 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
+//      Wy[16][7] and Wx[8][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
 //   B: lane = (channel, column) forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds
 //      sum_ph Wy[y][ph] * T[ph] to its 16 row accumulators (registers) -- one barrier per RoI, LDS tables double-buffered.
+#ifndef RT_TH
 #define RT_TH 16
-#define RT_TW 32
+#endif
+#ifndef RT_TW
+#define RT_TW 8
+#endif
+#define RT_CPS (256 / RT_TW)              // channels per sub-group: lane = (column, channel)
 #ifndef RT_NS
 #define RT_NS 1                          // channel sub-groups of 8 per workgroup (lane = (column, channel within sub-group))
 #endif
-#define RT_CB (8 * RT_NS)
+#define RT_CB (RT_CPS * RT_NS)
 #define RT_LIST 256                      // RoIs are scanned in chunks of this many
 #define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
 
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
     const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
     const int H = L.H[l], W = L.W[l];
     const float scale = L.scale[l];
-    const int cx = t & (RT_TW - 1), cc = t >> 5;          // phase B: lane -> (column cx, channel cc + 8 s of the group)
+    const int cx = t % RT_TW, cc = t / RT_TW;             // phase B: lane -> (column cx, channel cc + RT_CPS s of the group)
     const int c0 = cg * RT_CB;
     const int nc = min(RT_CB, C - c0);
     const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
 #pragma unroll
             for (int sg = 0; sg < RT_NS; ++sg) {
                 if (RT_NS > 1) asm volatile("" ::: "memory");   // re-read the (broadcast) tables per sub-group instead of pinning 300 registers
-                const float *gch = &s_g[buf][(cc + 8 * sg) * 49];
+                const float *gch = &s_g[buf][(cc + RT_CPS * sg) * 49];
                 float T[7];
 #pragma unroll
                 for (int ph = 0; ph < 7; ++ph) {
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
     if (tx0 + cx < W) {
 #pragma unroll
         for (int sg = 0; sg < RT_NS; ++sg) {
-            const int c = cc + 8 * sg;
+            const int c = cc + RT_CPS * sg;
             if (c < nc) {
                 TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + ty0) * W + tx0 + cx;
 #pragma unroll
