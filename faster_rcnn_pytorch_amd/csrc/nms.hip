@@ -31,6 +31,10 @@
 #include <cstring>
 
 #define NMS_MAX_BLOCKS 4096            // K <= 262144
+#ifndef NMS_TNEAR
+#define NMS_TNEAR 7
+#endif
+//                    // transposed tiles are kept for column block - row block <= NMS_TNEAR
 #define NMS_FAST_MAX_BLOCKS 192        // pipelined scan: 3 far words per lane
 #define NMS_WS_PAD 256                 // the prefetchers read up to 7 words past a row's last word
 
@@ -82,7 +86,7 @@ __device__ __forceinline__ unsigned mask_half(float4 a, float area_a, const floa
 
 template <bool CLS>
 __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev, int K,
-                                                       float thr, int nblk, u64 *__restrict__ mask, u64 *__restrict__ rowmask)
+                                                       float thr, int nblk, u64 *__restrict__ mask, u64 *__restrict__ rowmask, u64 *__restrict__ diagT)
 {
     __shared__ float4 s_box[4][64];
     __shared__ float s_area[4][64];
@@ -128,6 +132,18 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
         }
     }
     if (row < K) mask[(size_t)row * nblk + cb] = bits;
+    if (cb - rb <= NMS_TNEAR) {
+        // transposes of the tiles on the main diagonal and the NMS_TNEAR next ones: tileT[(cb * (NMS_TNEAR + 1) + d) * 64 + i], d = cb - rb,
+        // has bit j set iff row j of block rb suppresses row i of block cb.  The scan PULLS with them (lane i tests its column
+        // word against the kept masks of the last blocks: 3 VALU per diagonal) instead of walking rows and pushing words.
+        u64 t = 0ull;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+            const u64 bal = __ballot((bits >> c) & 1ull);
+            if (lane == c) t = bal;
+        }
+        diagT[((size_t)cb * (NMS_TNEAR + 1) + (cb - rb)) * 64 + lane] = t;
+    }
     // which rows of this tile have any bit: lets the scan skip the (typically all-zero) far words of kept rows
     const u64 any = __ballot(bits != 0ull && row < K);
     if (lane == 0) rowmask[(size_t)rb * nblk + cb] = any;
@@ -345,25 +361,48 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
-// dataflow scan (K <= 12288): same roles as above but NO workgroup barrier inside the loop.  The resolver (wave 0),
-// two prefetchers (waves 1-2, even / odd blocks) and 13 block-owning helpers (waves 3-15) run free and hand data to
-// each other through LDS words (progress counter, per-block ready / done flags), polled with s_sleep.  The resolver's
-// per-block time is then its own scalar work only; every other latency (near-word prefetch, far-word fetch of the
-// kept rows) is overlapped by waves that are several blocks ahead of / behind it.
-//   resolver  b : needs ring_ready[b] (prefetcher) and fdone[b - FLOW_LAG] (far words of all blocks <= b - FLOW_LAG)
-//   prefetcher j: fills ring slot j % FLOW_RING once progress >= j - FLOW_AHEAD
-//   helper    c : waits progress > c, emits the kept positions of block c, fetches its far words (>= c + FLOW_LAG + 1... see code),
-//                 ORs them into `removed`, sets fdone[c]
-// Every spin is bounded (FLOW_SPIN_MAX polls): on overflow the kernel aborts with out_count = -1 instead of hanging.
+// dataflow scan (K <= 12288): ONE workgroup, no barrier inside the loop.  The resolver (wave 0), FLOW_PF prefetchers and
+// 15 - FLOW_PF block-owning helpers run free and hand data to each other through LDS words (progress counter, per-block
+// ready / done flags).  A single wave issues about one instruction every 4-8 cycles, so the scan rate is
+// (instructions the resolver executes per 64-row block) x that -- everything is arranged to keep that stream short:
+//   * near suppression is PULLED: lane i holds the transposed words "which rows of block b-d suppress my row" (d = 0..7,
+//     written by nms_mask) and ANDs them with the kept masks of the last 7 blocks (SGPRs): 3 VALU per diagonal, no row walk,
+//     no LDS atomics;
+//   * the in-block greedy pass is a fixpoint  K <- alive & ~suppressed_by(K)  over the transposed diagonal tile: two
+//     straight-line ballot steps, then a convergence test (exact: by induction over the row index a fixpoint IS the
+//     sequential result; chains longer than 2 just take more steps);
+//   * the LDS round trip of block b+1 (words, far-removed mask, both flags) is issued before the work of block b; flags are
+//     plain loads behind a compiler barrier, consumed after the work (atomic or volatile flag loads each get their own
+//     s_waitcnt -- volatile ones even become FLAT loads, ~800 cycles per block);
+//   * far words (blocks >= c + 8) are pushed by the helpers, which fetch them SPECULATIVELY FLOW_SPEC blocks before block c
+//     resolves, for every row not removed yet, and filter by the kept mask when it arrives.
+//   resolver  b : needs ring_ready[b] (prefetcher) and fdone[b - FLOW_NEAR - 1] (far words of all blocks <= that)
+//   prefetcher j: fills ring slot j % FLOW_RT / j % FLOW_RM once progress >= j - FLOW_AHEAD
+//   helper    c : phase 1 at progress >= c - FLOW_SPEC (candidate far words -> registers), phase 2 at progress > c (emit the
+//                 kept positions of block c, OR the kept rows' words into `removed`, set fdone[c])
+// Measured on the untrained-RPN frame of bench.py (188 blocks, 1395 kept): 147 us with row-walk resolver + pushed near words
+// + volatile flags -> 76 us (0.40 us per block).  Every spin is bounded: on overflow the kernel aborts with out_count = -1.
 // ------------------------------------------------------------------------------------------------
-#define FLOW_NEAR 3                     // near words handled by the resolver itself: blocks b+1 .. b+FLOW_NEAR
-#define FLOW_RING 16
-#define FLOW_AHEAD 7                    // <= FLOW_RING - FLOW_NEAR - 2: a ring slot is recycled only after its helper has set fdone
+#define FLOW_NEAR NMS_TNEAR                     // near words handled by the resolver itself: blocks b+1 .. b+FLOW_NEAR
+#define FLOW_RT 12                      // ring of transposed words (read by the resolver only): FLOW_RT - FLOW_AHEAD >= 1
+#define FLOW_RM (FLOW_AHEAD + FLOW_NEAR + 4)   // ring of row masks (read by the helpers' speculative phase): >= FLOW_AHEAD + FLOW_NEAR + 2
+#ifndef FLOW_SPEC
+#define FLOW_SPEC 5                     // helpers fetch the far words of block c speculatively once block c - FLOW_SPEC is resolved
+#endif
+#define FLOW_AHEAD (FLOW_SPEC + 3)      // how far the prefetchers run ahead of the resolver
 #define FLOW_Q 8
-#define FLOW_HELPERS 13
+#ifndef FLOW_PF
+#define FLOW_PF 4                       // prefetcher waves: each has ONE block's loads in flight (~1.1 us), so PF / 1.1 us bounds the scan rate
+#endif
+#define FLOW_HELPERS (15 - FLOW_PF)
 #define FLOW_SPIN_MAX (1 << 22)
 
-__device__ __forceinline__ int lds_ld(const volatile int *p) { return *p; }
+// Flag / counter accesses of the dataflow scan.  NOT `volatile`: LLVM's address-space inference leaves volatile accesses
+// through a generic pointer as FLAT instructions (flat_load_dword sc0 sc1 + s_waitcnt vmcnt(0) lgkmcnt(0)): every poll then
+// costs hundreds of cycles and also waits for the wave's global loads in flight.  Relaxed workgroup-scope atomics are
+// re-executed on every evaluation just the same and lower to plain ds_read_b32 / ds_write_b32.
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // OR-reduction over the 64 lanes; the result is valid in lane 63 (LLVM's DPP scan sequence: row_shr 1,2,4,8 inside
 // the four 16-lane rows, then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3)
@@ -378,32 +417,49 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v)
     return v;
 }
 
+#define FLOW_FIN (1 << 20)
+#ifndef FLOW_SLEEP
+#define FLOW_SLEEP 2
+#endif
+// Wait until the resolver has resolved NEED blocks or is done.  ONE LDS read per spin and a 128-cycle nap: fifteen waves poll,
+// and the LDS pipe they poll through is the resolver's critical resource.  ST = state word, or -1 after an abort.
+#define FLOW_WAIT_PROGRESS(ST, NEED)                                                                                 \
+    {                                                                                                                \
+        int spins_ = 0;                                                                                              \
+        for (;;) {                                                                                                   \
+            ST = lds_ld(&s_state);                                                                                   \
+            if (((ST) & (FLOW_FIN - 1)) >= (NEED) || ((ST) & FLOW_FIN)) break;                                       \
+            __builtin_amdgcn_s_sleep(FLOW_SLEEP);                                                                    \
+            if ((++spins_ & 15) == 0 && (spins_ > FLOW_SPIN_MAX || lds_ld(&s_abort))) { lds_st(&s_abort, 1); ST = -1; break; } \
+        }                                                                                                            \
+        asm volatile("" ::: "memory");                                                                               \
+    }
 #define FLOW_WAIT(COND)                                                                                              \
     {                                                                                                                \
         int spins_ = 0;                                                                                              \
         while (!(COND)) {                                                                                            \
             __builtin_amdgcn_s_sleep(1);                                                                             \
-            if (++spins_ > FLOW_SPIN_MAX || lds_ld(&s_abort)) { s_abort = 1; break; }                                \
+            if (++spins_ > FLOW_SPIN_MAX || lds_ld(&s_abort)) { lds_st(&s_abort, 1); break; }                                \
         }                                                                                                            \
         asm volatile("" ::: "memory");                                                                               \
     }
 
 __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
                                                              int nblk, const u64 *__restrict__ mask, const u64 *__restrict__ rowmask,
-                                                             int post_k, int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
-                                                             const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
-                                                             int32_t *__restrict__ out_count)
+                                                             const u64 *__restrict__ diagT, int post_k, int64_t *__restrict__ out_keep,
+                                                             float4 *__restrict__ out_rois, const int64_t *__restrict__ src_map,
+                                                             int64_t *__restrict__ out_src, int32_t *__restrict__ out_count)
 {
     __shared__ u64 removed[NMS_FAST_MAX_BLOCKS + 8];
-    __shared__ u64 ring[FLOW_RING][1 + FLOW_NEAR][64];                  // 64 KB
-    __shared__ u64 rm_ring[FLOW_RING][NMS_FAST_MAX_BLOCKS + 8];         // 25 KB
+    extern __shared__ u64 flow_smem[];                                  // > 64 KB of rings: dynamic LDS
+    u64 (*ring)[1 + FLOW_NEAR][64] = (u64 (*)[1 + FLOW_NEAR][64])flow_smem;                                   // [FLOW_RT]
+    u64 (*rm_ring)[NMS_FAST_MAX_BLOCKS + 8] = (u64 (*)[NMS_FAST_MAX_BLOCKS + 8])(flow_smem + FLOW_RT * (1 + FLOW_NEAR) * 64);   // [FLOW_RM]
     __shared__ u64 s_kept[NMS_FAST_MAX_BLOCKS];
     __shared__ int s_base[NMS_FAST_MAX_BLOCKS];
-    __shared__ volatile int ring_ready[NMS_FAST_MAX_BLOCKS];            // 1 once block j's ring slot is filled
-    __shared__ volatile int fdone[NMS_FAST_MAX_BLOCKS];                 // 1 once block c's far words are in `removed`
-    __shared__ volatile int s_progress;                                 // blocks resolved so far
-    __shared__ volatile int s_finished;                                 // resolver done (end of boxes or post_k reached)
-    __shared__ volatile int s_abort;
+    __shared__ int ring_ready[NMS_FAST_MAX_BLOCKS];            // 1 once block j's ring slot is filled
+    __shared__ int fdone[NMS_FAST_MAX_BLOCKS];                 // 1 once block c's far words are in `removed`
+    __shared__ int s_state;                                    // blocks resolved so far | FLOW_FIN once the resolver is done
+    __shared__ int s_abort;
     __shared__ int s_total_out;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -411,9 +467,9 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
     const int nb = (n + 63) >> 6;
 
     for (int w = tid; w < NMS_FAST_MAX_BLOCKS + 8; w += 1024) removed[w] = 0ull;
-    for (int w = tid; w < FLOW_RING * (NMS_FAST_MAX_BLOCKS + 8); w += 1024) (&rm_ring[0][0])[w] = 0ull;
+    for (int w = tid; w < FLOW_RM * (NMS_FAST_MAX_BLOCKS + 8); w += 1024) (&rm_ring[0][0])[w] = 0ull;
     for (int w = tid; w < NMS_FAST_MAX_BLOCKS; w += 1024) { ring_ready[w] = 0; fdone[w] = 0; }
-    if (tid == 0) { s_progress = 0; s_finished = 0; s_abort = 0; s_total_out = 0; }
+    if (tid == 0) { s_state = 0; s_abort = 0; s_total_out = 0; }
     __syncthreads();
 
     if (wave == 0) {
@@ -422,28 +478,53 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
         // them, and the only LDS round trip a block has to wait for is the batch {removed[b], near words, row masks};
         // the flags of block b+1 are sampled while block b resolves and re-polled only if they were not set yet.
         int total = 0;
-        if (nb > 0) FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)           // nb == 0: no live box, nothing will ever be prefetched
-        for (int b = 0; b < nb && !lds_ld(&s_abort); ++b) {
-            const int slot = b % FLOW_RING;
-            const int nxt_far = b + 1 - FLOW_NEAR - 1;                  // far words of blocks <= nxt_far must be in before block b+1
-            const int f_ring = b + 1 < nb ? lds_ld(&ring_ready[b + 1]) : 1;
-            const int f_far = nxt_far >= 0 ? lds_ld(&fdone[nxt_far]) : 1;
-            u64 nw[1 + FLOW_NEAR];
+        u64 kprev[FLOW_NEAR];                                           // kept masks of blocks b-1, b-2, .. (wave-uniform)
 #pragma unroll
-            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = ring[slot][d][lane];
-            const u64 rmv = rm_ring[slot][b];                           // which rows have any bit in the diagonal tile
-            const u64 rem = removed[b];
+        for (int d = 0; d < FLOW_NEAR; ++d) kprev[d] = 0ull;
+        if (nb > 0) FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)           // nb == 0: no live box, nothing will ever be prefetched
+        u64 nw[1 + FLOW_NEAR], nx[1 + FLOW_NEAR];                       // my column words for this block / the next one
+        u64 rem = 0ull, remx = 0ull;
+        if (nb > 0) {
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = ring[0][d][lane];
+        }
+        for (int b = 0; b < nb; ++b) {
+            // The LDS round trip of block b+1 overlaps the work of block b: its two flags are read FIRST (plain loads behind a
+            // compiler barrier; the LDS executes a wave's operations in order), then its words and far-removed mask.  If both
+            // flags were already set the data read behind them is final; otherwise the slow path below polls and re-reads.
+            asm volatile("" ::: "memory");
+            const int nxt_far = b + 1 - FLOW_NEAR - 1;                  // far words of blocks <= nxt_far must be in before block b+1
+            const int fr_raw = ring_ready[min(b + 1, nb - 1)];          // unconditional loads, consumed only after this block's
+            const int ff_raw = fdone[max(nxt_far, 0)];                  // work: no s_waitcnt of their own on the critical path
+            asm volatile("" ::: "memory");
+            const int xslot = (b + 1) % FLOW_RT;
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) nx[d] = ring[xslot][d][lane];
+            remx = removed[b + 1];
             const int live = n - b * 64;
             const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);
-            u64 alive = ~(((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem)) & valid;
+            u64 alive;
             {
-                const unsigned dl = (unsigned)nw[0], dh = (unsigned)(nw[0] >> 32);
-                u64 act = alive & (((u64)RFL((unsigned)(rmv >> 32)) << 32) | (u64)RFL((unsigned)rmv));
-                while (act != 0ull) {                                   // only live rows with a bit in the diagonal tile
-                    const int i = __builtin_ctzll(act);
-                    act &= act - 1ull;
-                    if ((alive >> i) & 1ull) alive &= ~RL64(dl, dh, i);
+                // rows of this block still alive: not removed by far words (`removed`, pushed by the helpers), not suppressed by a
+                // kept row of the FLOW_NEAR previous blocks (pulled: my column word & that block's kept mask) ...
+                u64 hitn = 0ull;
+#pragma unroll
+                for (int d = 1; d <= FLOW_NEAR; ++d) hitn |= nw[d] & kprev[d - 1];
+                const u64 remu = ((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem);
+                const bool a_i = (((valid & ~remu) >> lane) & 1ull) & (hitn == 0ull);
+                // ... and the in-block greedy pass as a fixpoint over the transposed diagonal tile:  K <- { i alive : no j in K
+                // suppresses i }, from K = alive.  By induction over the row index a fixpoint is exactly the sequential result;
+                // it is reached after (longest suppression chain + 1) wave-wide steps.
+                // (ballots of the vector compare only, AND-ed with the alive mask on the scalar unit; two steps straight-line --
+                // most blocks need exactly two -- before the first convergence test)
+                const u64 A = __ballot(a_i);
+                u64 Kp = __ballot((nw[0] & A) == 0ull) & A;
+                u64 Kc = __ballot((nw[0] & Kp) == 0ull) & A;
+                for (int it = 0; it < 64 && Kc != Kp; ++it) {
+                    Kp = Kc;
+                    Kc = __ballot((nw[0] & Kp) == 0ull) & A;
                 }
+                alive = Kc;
             }
             u64 kept = alive;
             int cnt = __builtin_popcountll(kept);
@@ -453,81 +534,118 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
                 for (int q = 0; q < cnt; ++q) t &= t - 1ull;
                 kept &= ~t;
             }
-            if (lane == 0) { s_kept[b] = kept; s_base[b] = total; s_progress = b + 1; }   // in-order: data lands before the counter
+            if (lane == 0) { s_kept[b] = kept; s_base[b] = total; asm volatile("" ::: "memory"); lds_st(&s_state, b + 1); }   // in-order: data lands before the counter
             total += cnt;
             if (total >= post_k) break;
-            // near words: every kept lane whose word is non-zero ORs it straight into `removed` (ds_or_b64); this wave's
-            // next read of removed[b+1] is queued behind them, and no helper touches words < c + FLOW_NEAR + 1
-            const bool mine = (kept >> lane) & 1ull;
 #pragma unroll
-            for (int d = 1; d <= FLOW_NEAR; ++d)
-                if (b + d < nb && mine && nw[d] != 0ull) atomicOr(&removed[b + d], nw[d]);
-            if (!f_ring) FLOW_WAIT(lds_ld(&ring_ready[b + 1]) != 0)
-            if (!f_far) FLOW_WAIT(lds_ld(&fdone[nxt_far]) != 0)
+            for (int d = FLOW_NEAR - 1; d > 0; --d) kprev[d] = kprev[d - 1];
+            kprev[0] = kept;
+            const bool f_ring = (b + 1 >= nb) | (fr_raw != 0), f_far = (nxt_far < 0) | (ff_raw != 0);
+            if (!f_ring || !f_far) {                                    // slow path: poll, re-read, and leave if somebody timed out
+                if (!f_ring) FLOW_WAIT(lds_ld(&ring_ready[b + 1]) != 0)
+                if (!f_far) FLOW_WAIT(lds_ld(&fdone[nxt_far]) != 0)
+                if (lds_ld(&s_abort)) break;
+#pragma unroll
+                for (int d = 0; d <= FLOW_NEAR; ++d) nx[d] = ring[xslot][d][lane];
+                remx = removed[b + 1];
+            }
+#pragma unroll
+            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = nx[d];
+            rem = remx;
         }
-        if (lane == 0) { s_total_out = total; s_finished = 1; }
-    } else if (wave <= 2) {
-        // ------------------------------------------------ prefetchers: wave 1 even blocks, wave 2 odd blocks
-        for (int j = wave - 1; j < nb; j += 2) {
-            FLOW_WAIT(lds_ld(&s_progress) >= j - FLOW_AHEAD || lds_ld(&s_finished))
-            if (lds_ld(&s_finished) || lds_ld(&s_abort)) break;
-            const int row = min(j * 64 + lane, K - 1);
-            const u64 *p = mask + (size_t)row * nblk + j;
+        if (lane == 0) { s_total_out = total; lds_st(&s_state, (lds_ld(&s_state) & (FLOW_FIN - 1)) | FLOW_FIN); }
+    } else if (wave <= FLOW_PF) {
+        // ------------------------------------------------ prefetchers: wave w takes blocks j = w - 1 (mod FLOW_PF)
+        for (int j = wave - 1; j < nb; j += FLOW_PF) {
+            int st;
+            FLOW_WAIT_PROGRESS(st, j - FLOW_AHEAD)
+            if (st < 0 || (st & FLOW_FIN)) break;
             u64 v[1 + FLOW_NEAR];
 #pragma unroll
-            for (int d = 0; d <= FLOW_NEAR; ++d) v[d] = p[d];          // 64 contiguous bytes of my row (padded workspace)
+            for (int d = 0; d <= FLOW_NEAR; ++d)                        // column words of my row against blocks j, j-1, .., j-FLOW_NEAR
+                v[d] = d <= j ? diagT[((size_t)j * (NMS_TNEAR + 1) + d) * 64 + lane] : 0ull;
             const u64 *q = rowmask + (size_t)j * nblk;
             u64 rmw[3];
 #pragma unroll
             for (int m = 0; m < 3; ++m) rmw[m] = (lane + 64 * m < nblk) ? q[lane + 64 * m] : 0ull;
-            const int slot = j % FLOW_RING;
 #pragma unroll
-            for (int d = 0; d <= FLOW_NEAR; ++d) ring[slot][d][lane] = v[d];
+            for (int d = 0; d <= FLOW_NEAR; ++d) ring[j % FLOW_RT][d][lane] = v[d];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = rmw[m];
+            for (int m = 0; m < 3; ++m) rm_ring[j % FLOW_RM][lane + 64 * m] = rmw[m];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) ring_ready[j] = 1;
+            if (lane == 0) lds_st(&ring_ready[j], 1);
         }
     } else {
-        // ------------------------------------------------ helpers: block c, c + 13, ...
-        for (int c = wave - 3; c < nb; c += FLOW_HELPERS) {
-            FLOW_WAIT(lds_ld(&s_progress) > c || lds_ld(&s_finished))
-            if (lds_ld(&s_abort) || lds_ld(&s_progress) <= c) break;    // finished before block c was resolved
+        // ------------------------------------------------ helpers: block c, c + FLOW_HELPERS, ...
+        // The far words of block c can only be APPLIED once its kept rows are known, but waiting for that to issue the loads
+        // puts a full HBM/L2 latency (~3.5 us) on a path the resolver crosses every FLOW_NEAR + 1 blocks (= the former
+        // 0.95 us per block).  So they are fetched speculatively FLOW_SPEC blocks early for every row that is not removed
+        // YET (a superset of the rows that will be kept: `removed` only grows), tagged with their row, and filtered by the
+        // kept mask when it arrives.  Rows beyond the FLOW_Q register slots of a word take the exact path afterwards.
+        for (int c = wave - 1 - FLOW_PF; c < nb; c += FLOW_HELPERS) {
+            int st;
+            FLOW_WAIT_PROGRESS(st, c - FLOW_SPEC)
+            if (st < 0 || ((st & FLOW_FIN) && (st & (FLOW_FIN - 1)) <= c)) break;
+            FLOW_WAIT(lds_ld(&ring_ready[c]) != 0)                      // set FLOW_AHEAD - FLOW_SPEC blocks earlier: normally no spin
+            if (lds_ld(&s_abort)) break;
+            const int w0 = c + FLOW_NEAR + 1;                           // first far word
+            const size_t rb0 = (size_t)c * 64;
+            const int cslot = c % FLOW_RM;
+            u64 v[3][FLOW_Q], tags[3], rest[3];
+            {
+                const u64 remv = removed[c];
+                const u64 cand = ~(((u64)RFL((unsigned)(remv >> 32)) << 32) | (u64)RFL((unsigned)remv));
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const int w = lane + 64 * m;
+                    u64 need = (w >= w0 && w < nb) ? (rm_ring[cslot][w] & cand) : 0ull;
+                    tags[m] = 0ull;
+#pragma unroll
+                    for (int q = 0; q < FLOW_Q; ++q) {
+                        v[m][q] = 0ull;
+                        if (need != 0ull) {
+                            const int i = __builtin_ctzll(need);
+                            need &= need - 1ull;
+                            tags[m] |= (u64)i << (8 * q);
+                            v[m][q] = mask[(rb0 + i) * nblk + w];
+                        }
+                    }
+                    rest[m] = need;
+                }
+            }
+            FLOW_WAIT_PROGRESS(st, c + 1)
+            if (st < 0 || (st & (FLOW_FIN - 1)) <= c) break;            // finished before block c was resolved
             const u64 kcv = s_kept[c];
             const u64 kc = ((u64)RFL((unsigned)(kcv >> 32)) << 32) | (u64)RFL((unsigned)kcv);
             if ((kc >> lane) & 1ull)
                 out_keep[s_base[c] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane);
-            const int w0 = c + FLOW_NEAR + 1;                           // first far word
             if (w0 < nb && kc != 0ull) {
-                const size_t rb0 = (size_t)c * 64;
-                const int cslot = c % FLOW_RING;
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
                     const int w = lane + 64 * m;
-                    u64 need = (w >= w0 && w < nb) ? (rm_ring[cslot][w] & kc) : 0ull;
-                    u64 v[FLOW_Q];
-#pragma unroll
-                    for (int q = 0; q < FLOW_Q; ++q) {
-                        v[q] = 0ull;
-                        if (need != 0ull) {
-                            const int i = __builtin_ctzll(need);
-                            need &= need - 1ull;
-                            v[q] = mask[(rb0 + i) * nblk + w];
-                        }
-                    }
                     u64 acc = 0ull;
-                    while (need != 0ull) {                              // rare: more than FLOW_Q suppressing rows for one word
-                        const int i = __builtin_ctzll(need);
-                        need &= need - 1ull;
-                        acc |= mask[(rb0 + i) * nblk + w];
-                    }
 #pragma unroll
-                    for (int q = 0; q < FLOW_Q; ++q) acc |= v[q];
+                    for (int q = 0; q < FLOW_Q; ++q)
+                        if (v[m][q] != 0ull && ((kc >> ((tags[m] >> (8 * q)) & 63ull)) & 1ull)) acc |= v[m][q];
+                    u64 need = rest[m] & kc;
+                    while (need != 0ull) {                              // more than FLOW_Q candidate rows for this word: the kept ones among
+                        u64 x[4];                                       // the rest, four loads in flight at a time
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x[q] = 0ull;
+                            if (need != 0ull) {
+                                const int i = __builtin_ctzll(need);
+                                need &= need - 1ull;
+                                x[q] = mask[(rb0 + i) * nblk + w];
+                            }
+                        }
+                        acc |= (x[0] | x[1]) | (x[2] | x[3]);
+                    }
                     if (acc) atomicOr(&removed[w], acc);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my ORs are in LDS before the flag
-            if (lane == 0) fdone[c] = 1;
+            if (lane == 0) lds_st(&fdone[c], 1);
         }
     }
     __syncthreads();                                                  // everybody out of the dataflow; out_keep complete
@@ -613,7 +731,7 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(const float4 *__restrict
 size_t frcnn_ws_nms(int64_t K)
 {
     const int64_t nblk = (K + 63) / 64;
-    return align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256) + align_up((size_t)nblk * (size_t)nblk * 8, 256);
+    return align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256) + align_up((size_t)nblk * (size_t)nblk * 8, 256) + align_up((size_t)nblk * (NMS_TNEAR + 1) * 64 * 8, 256);
 }
 
 int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
@@ -626,17 +744,21 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     if (nblk > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
     u64 *mask = (u64 *)ws;
     u64 *rowmask = (u64 *)((char *)ws + align_up((size_t)K * (size_t)nblk * 8 + NMS_WS_PAD, 256));
+    u64 *diagT = (u64 *)((char *)rowmask + align_up((size_t)nblk * (size_t)nblk * 8, 256));
     if (cls)
         FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel<true>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
-                     (int)K, thr, nblk, mask, rowmask);
+                     (int)K, thr, nblk, mask, rowmask, diagT);
     else
         FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel<false>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
-                     (int)K, thr, nblk, mask, rowmask);
+                     (int)K, thr, nblk, mask, rowmask, diagT);
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
     static const bool use_pipe = getenv("FRCNN_NMS_SCAN") && !strcmp(getenv("FRCNN_NMS_SCAN"), "pipe");
     if (nblk <= NMS_FAST_MAX_BLOCKS && !use_pipe) {
-        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_flow_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
-                     rowmask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
+        const size_t flow_lds = ((size_t)FLOW_RT * (1 + FLOW_NEAR) * 64 + (size_t)FLOW_RM * (NMS_FAST_MAX_BLOCKS + 8)) * sizeof(u64);
+        static const hipError_t attr_rc = hipFuncSetAttribute((const void *)nms_scan_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds);
+        if (attr_rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: cannot reserve %zu bytes of LDS: %s", flow_lds, hipGetErrorString(attr_rc));
+        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_flow_kernel, dim3(1), dim3(1024), flow_lds, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
+                     rowmask, diagT, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
         FRCNN_CHECK_LAUNCH("nms_scan_flow_kernel");
     } else if (nblk <= NMS_FAST_MAX_BLOCKS) {
         FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_fast_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
