@@ -157,6 +157,22 @@ def box_iou(boxes1, boxes2):
     return iou, union
 
 
+def box_area(boxes):
+    """torchvision.ops.boxes.box_area as imported at util/box_ops.py:6: (x2 - x1) * (y2 - y1)."""
+    boxes = _req(boxes, name="boxes")
+    return (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+
+
+def box_cxcywh_to_xyxy(x):
+    """util/box_ops.py:9-13 (same arithmetic as utils/util.py cxcy_to_xy)."""
+    return cxcy_to_xy(x)
+
+
+def box_xyxy_to_cxcywh(x):
+    """util/box_ops.py:16-20 (same arithmetic as utils/util.py xy_to_cxcy)."""
+    return xy_to_cxcy(x)
+
+
 # --------------------------------------------------------------------------------------------
 # proposal stage (models/model.py:12-58)
 # --------------------------------------------------------------------------------------------
