@@ -16,7 +16,7 @@
 #define ROI_FWD_CB 4
 #endif
 #ifndef ROI_FWD_RB
-#define ROI_FWD_RB 16
+#define ROI_FWD_RB 20
 #endif
 #ifndef ROI_BWD_CB
 #define ROI_BWD_CB 1
@@ -105,8 +105,11 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_atomic_kernel(const float *_
 // (roi, channel, bin) with the window scan served from LDS.  For one RoI the CB*49 outputs of the
 // block are contiguous in memory (784 B at CB = 4): the stores stay coalesced.
 // ------------------------------------------------------------------------------------------------
+#ifndef ROI_FWD_BS
+#define ROI_FWD_BS 512
+#endif
 template <int CB, int PH, int PW>
-__global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__restrict__ feat, int C, int H, int W,
+__global__ __launch_bounds__(ROI_FWD_BS) void roi_pool_fwd_lds_kernel(const float *__restrict__ feat, int C, int H, int W,
                                                                const float4 *__restrict__ rois, int R, int RB, float scale,
                                                                float *__restrict__ out, int32_t *__restrict__ argmax)
 {
@@ -116,8 +119,8 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
     int *tab = (int *)(smem + CB * HW);                          // [RB][PH + PW]: (hs | he << 16) x PH, (ws | we << 16) x PW
     constexpr int BINS = PH * PW;
     constexpr int TW = PH + PW;
-    constexpr int GROUPS = 256 / BINS;                           // RoIs processed concurrently by the block
-    static_assert(GROUPS >= 1, "PH * PW must fit one 256-thread block");
+    constexpr int GROUPS = ROI_FWD_BS / BINS;                           // RoIs processed concurrently by the block
+    static_assert(GROUPS >= 1, "PH * PW must fit one block");
     const int c0 = blockIdx.x * CB;
     const int r0 = blockIdx.y * RB;
     const int nr = min(RB, R - r0);
@@ -125,21 +128,21 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_lds_kernel(const float *__re
     const float *src = feat + (size_t)c0 * HW;
     {   // stage the planes: 8 independent loads in flight per lane
         const int n_stage = nch * HW;
-        for (int base = 0; base < n_stage; base += 256 * 8) {
+        for (int base = 0; base < n_stage; base += ROI_FWD_BS * 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + threadIdx.x;
+                const int i = base + u * ROI_FWD_BS + threadIdx.x;
                 v[u] = src[min(i, n_stage - 1)];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256 + threadIdx.x;
+                const int i = base + u * ROI_FWD_BS + threadIdx.x;
                 if (i < n_stage) planes[i] = v[u];
             }
         }
     }
-    for (int t = threadIdx.x; t < nr * TW; t += 256) {
+    for (int t = threadIdx.x; t < nr * TW; t += ROI_FWD_BS) {
         const int rl = t / TW, k = t - rl * TW;
         const RoiBins g = roi_bins(rois[r0 + rl], scale, PH, PW);
         if (k < PH) {
@@ -243,7 +246,7 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24)) {
         const int RB = ROI_FWD_RB;
         const size_t shmem = plane_bytes + (size_t)RB * (7 + 7) * 4;
-        FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<CB, 7, 7>), dim3((C + CB - 1) / CB, (unsigned)((R + RB - 1) / RB)), dim3(256),
+        FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<CB, 7, 7>), dim3((C + CB - 1) / CB, (unsigned)((R + RB - 1) / RB)), dim3(ROI_FWD_BS),
                      shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
         FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");
         return FRCNN_OK;
