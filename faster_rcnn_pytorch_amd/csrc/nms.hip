@@ -10,21 +10,12 @@
 //      decided; only inside the band is the exact division evaluated, so results are bit-identical to
 //      the oracle.  Boxes must be NaN-free (v_max/v_min drop NaNs where std::max would keep one).
 //
-//  nms_scan_fast_kernel (K <= 12288) : one 1024-thread workgroup, software-pipelined so that the
-//      sequential resolver never waits for global memory:
-//        wave 0  resolver: per 64-box block, scalar loop (s_ff1 + v_readlane) over the surviving rows;
-//                the same loop ORs the rows' words for the NEXT THREE blocks (near words), so the
-//                dependency block b -> b+1..b+3 never leaves registers / LDS.
-//        wave 1  prefetcher: streams each block's diagonal word + 3 near words (32 contiguous bytes
-//                per row) into an LDS ring four blocks ahead of the resolver; loads stay in flight
-//                across two barriers.
-//        waves 2-15 helpers: for the rows kept in block c they fetch the FAR words (>= c+4) from the
-//                row-major mask and ds_or them into the LDS-resident `removed` vector; the loads are
-//                issued one iteration after the block resolves and applied two iterations later, so
-//                their latency is hidden behind the resolver.
-//      One s_barrier per block.  Emits the first post_k kept positions, their boxes, their source
-//      indices and the count; stops as soon as post_k boxes are kept.
-//  nms_scan_kernel : the simple unpipelined form, used for K > 12288.
+//      For the 8 tiles next to the diagonal the wave also stores the TRANSPOSED tile (64 ballots): the scan pulls from those.
+//
+//  nms_scan_flow_kernel (K <= 12288) : one 1024-thread workgroup, barrier-free dataflow between a resolver wave, prefetcher
+//      waves and block-owning helper waves through LDS flags; see the comment block in front of it.  Emits the first post_k
+//      kept positions, their boxes, their source indices and the count; stops as soon as post_k boxes are kept.
+//  nms_scan_kernel : the simple multi-pass form, used for K > 12288.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include <cstdlib>
@@ -32,10 +23,9 @@
 
 #define NMS_MAX_BLOCKS 4096            // K <= 262144
 #ifndef NMS_TNEAR
-#define NMS_TNEAR 7
+#define NMS_TNEAR 7                    // transposed tiles are kept for column block - row block <= NMS_TNEAR
 #endif
-//                    // transposed tiles are kept for column block - row block <= NMS_TNEAR
-#define NMS_FAST_MAX_BLOCKS 192        // pipelined scan: 3 far words per lane
+#define NMS_FAST_MAX_BLOCKS 192        // dataflow scan: 3 far words per helper lane
 #define NMS_WS_PAD 256                 // the prefetchers read up to 7 words past a row's last word
 
 typedef unsigned long long u64;
@@ -149,216 +139,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const float4 *__restrict_
     if (lane == 0) rowmask[(size_t)rb * nblk + cb] = any;
 }
 
-// ------------------------------------------------------------------------------------------------
-// pipelined scan (K <= 12288)
-// ------------------------------------------------------------------------------------------------
 #define RL(v, i) ((unsigned)__builtin_amdgcn_readlane((v), (i)))          // builtin returns int: cast before widening
 #define RFL(v) ((unsigned)__builtin_amdgcn_readfirstlane((v)))
-
-#define SCAN_RING 8
-#define SCAN_PF 4
-#define SCAN_HELPERS 14
-#define SCAN_Q 8                       // far-word loads kept in flight per lane and 64-word chunk
-
-struct NearWords { u64 w[4]; u64 rm[3]; };   // diag, +1, +2, +3 words of my row; row-mask words lane, lane+64, lane+128
-
-__device__ __forceinline__ NearWords load_near(const u64 *__restrict__ mask, const u64 *__restrict__ rowmask, int nblk, int K, int blk, int lane)
-{
-    // 32 contiguous bytes of row (64*blk + lane): words blk .. blk+3 (may run past the row end: padded workspace)
-    const int row = min(blk * 64 + lane, K - 1);
-    const u64 *p = mask + (size_t)row * nblk + blk;
-    NearWords r;
-    r.w[0] = p[0]; r.w[1] = p[1]; r.w[2] = p[2]; r.w[3] = p[3];
-    const u64 *q = rowmask + (size_t)blk * nblk;
-#pragma unroll
-    for (int m = 0; m < 3; ++m) r.rm[m] = (lane + 64 * m < nblk) ? q[lane + 64 * m] : 0ull;
-    return r;
-}
-
-// workgroup barrier that only drains LDS traffic: __syncthreads() would add s_waitcnt vmcnt(0) and wait for the
-// prefetcher's / helpers' global loads (and the output stores) at every block
-#define SCAN_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define RL64(lo, hi, i) ((u64)RL((lo), (i)) | ((u64)RL((hi), (i)) << 32))
-
-__global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
-                                                             int nblk, const u64 *__restrict__ mask, const u64 *__restrict__ rowmask,
-                                                             int post_k, int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
-                                                             const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
-                                                             int32_t *__restrict__ out_count)
-{
-    __shared__ u64 removed[NMS_FAST_MAX_BLOCKS + 4];
-    __shared__ u64 ring[SCAN_RING][4][64];
-    __shared__ u64 rm_ring[SCAN_RING][NMS_FAST_MAX_BLOCKS + 4];
-    __shared__ u64 s_kept[4];
-    __shared__ int s_base[4];
-    __shared__ int s_total[2];                   // by block parity: a fast wave may already be one iteration ahead
-    const int tid = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int n = n_dev ? min(*n_dev, K) : K;
-    const int nb = (n + 63) >> 6;
-
-    for (int w = tid; w < NMS_FAST_MAX_BLOCKS + 4; w += 1024) removed[w] = 0ull;
-    for (int w = tid; w < SCAN_RING * (NMS_FAST_MAX_BLOCKS + 4); w += 1024) (&rm_ring[0][0])[w] = 0ull;
-    if (tid < 4) s_kept[tid] = 0ull;
-    if (tid < 2) s_total[tid] = 0;
-    __syncthreads();
-    // In-flight state.  Roles are per wave but registers are per kernel, so the prefetcher's two generations (7 words
-    // each) and the block-owning helper's 3 x SCAN_Q far words share one array.
-    u64 st[3 * SCAN_Q];
-#pragma unroll
-    for (int k = 0; k < 3 * SCAN_Q; ++k) st[k] = 0ull;
-#define PF_LOAD(G, BLK) { const NearWords t_ = load_near(mask, rowmask, nblk, K, (BLK), lane);                       \
-        st[(G) * 8 + 0] = t_.w[0]; st[(G) * 8 + 1] = t_.w[1]; st[(G) * 8 + 2] = t_.w[2]; st[(G) * 8 + 3] = t_.w[3]; \
-        st[(G) * 8 + 4] = t_.rm[0]; st[(G) * 8 + 5] = t_.rm[1]; st[(G) * 8 + 6] = t_.rm[2]; }
-    if (wave == 1) {
-        for (int blk = 0; blk < SCAN_PF && blk < nb; ++blk) {
-            const NearWords t = load_near(mask, rowmask, nblk, K, blk, lane);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) ring[blk % SCAN_RING][d][lane] = t.w[d];
-#pragma unroll
-            for (int m = 0; m < 3; ++m) rm_ring[blk % SCAN_RING][lane + 64 * m] = t.rm[m];
-        }
-        if (SCAN_PF + 0 < nb) PF_LOAD(0, SCAN_PF + 0)
-        if (SCAN_PF + 1 < nb) PF_LOAD(1, SCAN_PF + 1)
-    }
-    __syncthreads();
-
-    int total = 0;
-    int pend_c = -1;                             // helper: block whose far words are in flight
-
-#define SCAN_ITER(B, G)                                                                                              \
-    {                                                                                                                \
-        const int b = (B);                                                                                           \
-        if (wave == 0) {                                                                                             \
-            /* ---- resolver ---- */                                                                                 \
-            const int slot = b % SCAN_RING;                                                                          \
-            const u64 d0 = ring[slot][0][lane], u1 = ring[slot][1][lane], u2 = ring[slot][2][lane], u3 = ring[slot][3][lane]; \
-            const u64 rmv = rm_ring[slot][b + (lane & 3)];      /* lanes 0..3: which rows have bits in words b..b+3 */ \
-            const u64 rem = removed[b];                                                                              \
-            const unsigned d0l = (unsigned)d0, d0h = (unsigned)(d0 >> 32);                                           \
-            const unsigned u1l = (unsigned)u1, u1h = (unsigned)(u1 >> 32);                                           \
-            const unsigned u2l = (unsigned)u2, u2h = (unsigned)(u2 >> 32);                                           \
-            const unsigned u3l = (unsigned)u3, u3h = (unsigned)(u3 >> 32);                                           \
-            const unsigned rml = (unsigned)rmv, rmh = (unsigned)(rmv >> 32);                                         \
-            const int live = n - b * 64;                                                                             \
-            const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);                                   \
-            u64 alive = ~(((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem)) & valid;               \
-            /* in-block resolution: only live rows that have any bit in the diagonal tile are visited */               \
-            u64 act = alive & RL64(rml, rmh, 0);                                                                     \
-            while (act != 0ull) {                                                                                    \
-                const int i = __builtin_ctzll(act);                                                                  \
-                act &= act - 1ull;                                                                                   \
-                if ((alive >> i) & 1ull) alive &= ~RL64(d0l, d0h, i);                                                \
-            }                                                                                                        \
-            u64 kept = alive;                                                                                        \
-            int cnt = __builtin_popcountll(kept);                                                                    \
-            if (total + cnt > post_k) {                     /* keep only the first post_k - total survivors */       \
-                cnt = post_k - total;                                                                                \
-                u64 t = kept;                                                                                        \
-                for (int q = 0; q < cnt; ++q) t &= t - 1ull;                                                         \
-                kept &= ~t;                                                                                          \
-            }                                                                                                        \
-            /* near words: OR over the kept rows that have any bit there (row masks keep this scalar) */             \
-            u64 r1 = 0ull, r2 = 0ull, r3 = 0ull;                                                                     \
-            for (u64 nd = (b + 1 < nb) ? (kept & RL64(rml, rmh, 1)) : 0ull; nd != 0ull; nd &= nd - 1ull) {           \
-                const int i = __builtin_ctzll(nd);                                                                   \
-                r1 |= RL64(u1l, u1h, i);                                                                             \
-            }                                                                                                        \
-            for (u64 nd = (b + 2 < nb) ? (kept & RL64(rml, rmh, 2)) : 0ull; nd != 0ull; nd &= nd - 1ull) {           \
-                const int i = __builtin_ctzll(nd);                                                                   \
-                r2 |= RL64(u2l, u2h, i);                                                                             \
-            }                                                                                                        \
-            for (u64 nd = (b + 3 < nb) ? (kept & RL64(rml, rmh, 3)) : 0ull; nd != 0ull; nd &= nd - 1ull) {           \
-                const int i = __builtin_ctzll(nd);                                                                   \
-                r3 |= RL64(u3l, u3h, i);                                                                             \
-            }                                                                                                        \
-            if (lane == 0) {                                                                                         \
-                s_kept[b & 3] = kept;                                                                                \
-                s_base[b & 3] = total;                                                                               \
-                s_total[b & 1] = total + cnt;                                                                        \
-                if (r1) atomicOr(&removed[b + 1], r1);                                                               \
-                if (r2) atomicOr(&removed[b + 2], r2);                                                               \
-                if (r3) atomicOr(&removed[b + 3], r3);                                                               \
-            }                                                                                                        \
-        } else if (wave == 1) {                                                                                      \
-            /* ---- prefetcher: rings <- block b+PF (issued two iterations ago); re-issue for block b+PF+2 ---- */   \
-            if (b + SCAN_PF < nb) {                                                                                  \
-                const int slot = (b + SCAN_PF) % SCAN_RING;                                                          \
-                _Pragma("unroll") for (int d = 0; d < 4; ++d) ring[slot][d][lane] = st[(G) * 8 + d];                 \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) rm_ring[slot][lane + 64 * m] = st[(G) * 8 + 4 + m];    \
-            }                                                                                                        \
-            if (b + SCAN_PF + 2 < nb) PF_LOAD(G, b + SCAN_PF + 2)                                                    \
-        } else {                                                                                                     \
-            /* ---- helpers: ONE wave owns a whole block (c % 14 == wave-2); lane = far word (3 chunks of 64).       \
-               Up to SCAN_Q suppressing kept rows per word are fetched at iteration c+1 and OR-ed into `removed`     \
-               at iteration c+3; the other 13 helpers only pass the barrier, so they never compete for the SIMDs. */ \
-            if (pend_c >= 0 && b == pend_c + 3) {                                                                    \
-                _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                      \
-                    u64 acc = 0ull;                                                                                  \
-                    _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q) { acc |= st[m * SCAN_Q + q]; st[m * SCAN_Q + q] = 0ull; } \
-                    if (acc) atomicOr(&removed[lane + 64 * m], acc);                                                 \
-                }                                                                                                    \
-                pend_c = -1;                                                                                         \
-            }                                                                                                        \
-            const int c = b - 1;                                                                                     \
-            if (c >= 0 && (c % SCAN_HELPERS) == wave - 2) {                                                          \
-                const u64 kcv = s_kept[c & 3];                                                                       \
-                const u64 kc = ((u64)RFL((unsigned)(kcv >> 32)) << 32) | (u64)RFL((unsigned)kcv);                    \
-                /* kept positions of block c (boxes / source ids are gathered after the scan) */                     \
-                if ((kc >> lane) & 1ull)                                                                             \
-                    out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane); \
-                if (c + 4 < nb && kc != 0ull) {                                                                      \
-                    const size_t rb0 = (size_t)c * 64;                                                               \
-                    const int cslot = c % SCAN_RING;                                                                 \
-                    _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                  \
-                        const int w = lane + 64 * m;                                                                 \
-                        u64 need = (w >= c + 4 && w < nb) ? (rm_ring[cslot][w] & kc) : 0ull;                         \
-                        _Pragma("unroll") for (int q = 0; q < SCAN_Q; ++q)                                           \
-                            if (need != 0ull) {                                                                      \
-                                const int i = __builtin_ctzll(need);                                                 \
-                                need &= need - 1ull;                                                                 \
-                                st[m * SCAN_Q + q] = mask[(rb0 + i) * nblk + w];                                     \
-                            }                                                                                        \
-                        while (need != 0ull) {              /* rare: more than SCAN_Q suppressing rows for a word */ \
-                            const int i = __builtin_ctzll(need);                                                     \
-                            need &= need - 1ull;                                                                     \
-                            st[m * SCAN_Q] |= mask[(rb0 + i) * nblk + w];                                            \
-                        }                                                                                            \
-                    }                                                                                                \
-                    pend_c = c;                                                                                      \
-                }                                                                                                    \
-            }                                                                                                        \
-        }                                                                                                            \
-        SCAN_BARRIER();                                                                                              \
-        total = s_total[b & 1];                                                                                      \
-    }
-
-    int last_b = -1;
-    for (int b0 = 0; b0 < nb && total < post_k; b0 += 2) {
-        SCAN_ITER(b0, 0)
-        last_b = b0;
-        if (b0 + 1 >= nb || total >= post_k) break;
-        SCAN_ITER(b0 + 1, 1)
-        last_b = b0 + 1;
-    }
-#undef SCAN_ITER
-#undef PF_LOAD
-    if (wave == 2 && last_b >= 0) {                             // the last resolved block was never emitted
-        const int c = last_b;
-        const u64 kc = s_kept[c & 3];
-        if ((kc >> lane) & 1ull)
-            out_keep[s_base[c & 3] + __builtin_popcountll(kc & ((1ull << lane) - 1ull))] = (int64_t)(c * 64 + lane);
-    }
-    __syncthreads();                                            // out_keep complete and visible to the whole workgroup
-    const int n_out = total < post_k ? total : post_k;
-    if (out_rois || out_src)
-        for (int p = tid; p < n_out; p += 1024) {
-            const int64_t row = out_keep[p];
-            if (out_rois) out_rois[p] = boxes[row];
-            if (out_src) out_src[p] = src_map ? src_map[row] : row;
-        }
-    if (tid == 0) *out_count = n_out;
-}
 
 // ------------------------------------------------------------------------------------------------
 // dataflow scan (K <= 12288): ONE workgroup, no barrier inside the loop.  The resolver (wave 0), FLOW_PF prefetchers and
@@ -374,23 +156,27 @@ __global__ __launch_bounds__(1024) void nms_scan_fast_kernel(const float4 *__res
 //   * the LDS round trip of block b+1 (words, far-removed mask, both flags) is issued before the work of block b; flags are
 //     plain loads behind a compiler barrier, consumed after the work (atomic or volatile flag loads each get their own
 //     s_waitcnt -- volatile ones even become FLAT loads, ~800 cycles per block);
-//   * far words (blocks >= c + 8) are pushed by the helpers, which fetch them SPECULATIVELY FLOW_SPEC blocks before block c
-//     resolves, for every row not removed yet, and filter by the kept mask when it arrives.
+//   * far words (blocks >= c + 8) are pushed by the helpers; the first FLOW_Q candidate rows of every word are fetched
+//     SPECULATIVELY FLOW_SPEC blocks before block c resolves (rows not removed yet) and filtered by the kept mask when it
+//     arrives, the rest is fetched then, four loads in flight.  (With 8 pulled diagonals the helpers have 8 block times of
+//     slack and deep speculation stopped paying: Q = 8 / 4 / 2 / 1 -> 73.7 / 70.3 / 69.8 / 69.5 us.)
 //   resolver  b : needs ring_ready[b] (prefetcher) and fdone[b - FLOW_NEAR - 1] (far words of all blocks <= that)
 //   prefetcher j: fills ring slot j % FLOW_RT / j % FLOW_RM once progress >= j - FLOW_AHEAD
 //   helper    c : phase 1 at progress >= c - FLOW_SPEC (candidate far words -> registers), phase 2 at progress > c (emit the
 //                 kept positions of block c, OR the kept rows' words into `removed`, set fdone[c])
 // Measured on the untrained-RPN frame of bench.py (188 blocks, 1395 kept): 147 us with row-walk resolver + pushed near words
-// + volatile flags -> 76 us (0.40 us per block).  Every spin is bounded: on overflow the kernel aborts with out_count = -1.
+// + volatile flags -> 70 us (0.37 us per block).  Every spin is bounded: on overflow the kernel aborts with out_count = -1.
 // ------------------------------------------------------------------------------------------------
 #define FLOW_NEAR NMS_TNEAR                     // near words handled by the resolver itself: blocks b+1 .. b+FLOW_NEAR
 #define FLOW_RT 12                      // ring of transposed words (read by the resolver only): FLOW_RT - FLOW_AHEAD >= 1
 #define FLOW_RM (FLOW_AHEAD + FLOW_NEAR + 4)   // ring of row masks (read by the helpers' speculative phase): >= FLOW_AHEAD + FLOW_NEAR + 2
 #ifndef FLOW_SPEC
-#define FLOW_SPEC 5                     // helpers fetch the far words of block c speculatively once block c - FLOW_SPEC is resolved
+#define FLOW_SPEC 2                     // helpers fetch the far words of block c speculatively once block c - FLOW_SPEC is resolved
 #endif
 #define FLOW_AHEAD (FLOW_SPEC + 3)      // how far the prefetchers run ahead of the resolver
-#define FLOW_Q 8
+#ifndef FLOW_Q
+#define FLOW_Q 2                        // speculative register slots per far word (tags are packed 8 bits each: <= 8)
+#endif
 #ifndef FLOW_PF
 #define FLOW_PF 4                       // prefetcher waves: each has ONE block's loads in flight (~1.1 us), so PF / 1.1 us bounds the scan rate
 #endif
@@ -444,6 +230,8 @@ __device__ __forceinline__ unsigned wave_or_u32(unsigned v)
         asm volatile("" ::: "memory");                                                                               \
     }
 
+template <int P> struct FlowPhase { static constexpr int value = P; };
+
 __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K,
                                                              int nblk, const u64 *__restrict__ mask, const u64 *__restrict__ rowmask,
                                                              const u64 *__restrict__ diagT, int post_k, int64_t *__restrict__ out_keep,
@@ -478,17 +266,25 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
         // them, and the only LDS round trip a block has to wait for is the batch {removed[b], near words, row masks};
         // the flags of block b+1 are sampled while block b resolves and re-polled only if they were not set yet.
         int total = 0;
-        u64 kprev[FLOW_NEAR];                                           // kept masks of blocks b-1, b-2, .. (wave-uniform)
+        // The loop is unrolled by FLOW_NEAR + 1 phases so that nothing has to be MOVED between blocks: kring[p] is the kept mask
+        // of the latest block with b % 8 == p (the other seven entries are exactly blocks b-1 .. b-7), and the column words of
+        // this / the next block ping-pong between W[0] and W[1].  (Rolling copies cost 30 of ~95 instructions per block.)
+        static_assert(FLOW_NEAR + 1 == 8, "the resolver is unrolled over 8 phases");
+        static_assert(FLOW_Q >= 1 && FLOW_Q <= 8, "row tags of the speculative slots are packed 8 x 8 bits");
+        u64 kring[FLOW_NEAR + 1];
 #pragma unroll
-        for (int d = 0; d < FLOW_NEAR; ++d) kprev[d] = 0ull;
-        if (nb > 0) FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)           // nb == 0: no live box, nothing will ever be prefetched
-        u64 nw[1 + FLOW_NEAR], nx[1 + FLOW_NEAR];                       // my column words for this block / the next one
-        u64 rem = 0ull, remx = 0ull;
+        for (int d = 0; d <= FLOW_NEAR; ++d) kring[d] = 0ull;
+        u64 W[2][1 + FLOW_NEAR];                                        // my column words: W[b & 1] for block b
+        u64 R2[2] = {0ull, 0ull};                                       // far-removed mask of block b in R2[b & 1]
         if (nb > 0) {
+            FLOW_WAIT(lds_ld(&ring_ready[0]) != 0)                     // nb == 0: no live box, nothing will ever be prefetched
 #pragma unroll
-            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = ring[0][d][lane];
+            for (int d = 0; d <= FLOW_NEAR; ++d) W[0][d] = ring[0][d][lane];
         }
-        for (int b = 0; b < nb; ++b) {
+        auto step = [&](auto phase, const int b) -> bool {              // resolves block b; true = the scan is over
+            constexpr int PH = decltype(phase)::value;
+            u64 (&nw)[1 + FLOW_NEAR] = W[PH & 1];
+            u64 (&nx)[1 + FLOW_NEAR] = W[(PH + 1) & 1];
             // The LDS round trip of block b+1 overlaps the work of block b: its two flags are read FIRST (plain loads behind a
             // compiler barrier; the LDS executes a wave's operations in order), then its words and far-removed mask.  If both
             // flags were already set the data read behind them is final; otherwise the slow path below polls and re-reads.
@@ -500,33 +296,29 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
             const int xslot = (b + 1) % FLOW_RT;
 #pragma unroll
             for (int d = 0; d <= FLOW_NEAR; ++d) nx[d] = ring[xslot][d][lane];
-            remx = removed[b + 1];
+            R2[(PH + 1) & 1] = removed[b + 1];
             const int live = n - b * 64;
             const u64 valid = live >= 64 ? ~0ull : ((1ull << (live & 63)) - 1ull);
-            u64 alive;
-            {
-                // rows of this block still alive: not removed by far words (`removed`, pushed by the helpers), not suppressed by a
-                // kept row of the FLOW_NEAR previous blocks (pulled: my column word & that block's kept mask) ...
-                u64 hitn = 0ull;
+            // rows of this block still alive: not removed by far words (`removed`, pushed by the helpers), not suppressed by a
+            // kept row of the FLOW_NEAR previous blocks (pulled: my column word & that block's kept mask) ...
+            u64 hitn = 0ull;
 #pragma unroll
-                for (int d = 1; d <= FLOW_NEAR; ++d) hitn |= nw[d] & kprev[d - 1];
-                const u64 remu = ((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem);
-                const bool a_i = (((valid & ~remu) >> lane) & 1ull) & (hitn == 0ull);
-                // ... and the in-block greedy pass as a fixpoint over the transposed diagonal tile:  K <- { i alive : no j in K
-                // suppresses i }, from K = alive.  By induction over the row index a fixpoint is exactly the sequential result;
-                // it is reached after (longest suppression chain + 1) wave-wide steps.
-                // (ballots of the vector compare only, AND-ed with the alive mask on the scalar unit; two steps straight-line --
-                // most blocks need exactly two -- before the first convergence test)
-                const u64 A = __ballot(a_i);
-                u64 Kp = __ballot((nw[0] & A) == 0ull) & A;
-                u64 Kc = __ballot((nw[0] & Kp) == 0ull) & A;
-                for (int it = 0; it < 64 && Kc != Kp; ++it) {
-                    Kp = Kc;
-                    Kc = __ballot((nw[0] & Kp) == 0ull) & A;
-                }
-                alive = Kc;
+            for (int d = 1; d <= FLOW_NEAR; ++d) hitn |= nw[d] & kring[(PH + 8 - d) & 7];
+            const u64 rem = R2[PH & 1];
+            const u64 remu = ((u64)RFL((unsigned)(rem >> 32)) << 32) | (u64)RFL((unsigned)rem);
+            const bool a_i = (((valid & ~remu) >> lane) & 1ull) & (hitn == 0ull);
+            // ... and the in-block greedy pass as a fixpoint over the transposed diagonal tile:  K <- { i alive : no j in K
+            // suppresses i }, from K = alive.  By induction over the row index a fixpoint is exactly the sequential result; it
+            // is reached after (longest suppression chain + 1) wave-wide steps.  Ballots of the vector compare only, AND-ed with
+            // the alive mask on the scalar unit; two steps straight-line (most blocks need exactly two) before the first test.
+            const u64 A = __ballot(a_i);
+            u64 Kp = __ballot((nw[0] & A) == 0ull) & A;
+            u64 Kc = __ballot((nw[0] & Kp) == 0ull) & A;
+            for (int it = 0; it < 64 && Kc != Kp; ++it) {
+                Kp = Kc;
+                Kc = __ballot((nw[0] & Kp) == 0ull) & A;
             }
-            u64 kept = alive;
+            u64 kept = Kc;
             int cnt = __builtin_popcountll(kept);
             if (total + cnt > post_k) {                                 // keep only the first post_k - total survivors
                 cnt = post_k - total;
@@ -536,22 +328,28 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
             }
             if (lane == 0) { s_kept[b] = kept; s_base[b] = total; asm volatile("" ::: "memory"); lds_st(&s_state, b + 1); }   // in-order: data lands before the counter
             total += cnt;
-            if (total >= post_k) break;
-#pragma unroll
-            for (int d = FLOW_NEAR - 1; d > 0; --d) kprev[d] = kprev[d - 1];
-            kprev[0] = kept;
+            if (total >= post_k) return true;
+            kring[PH] = kept;
             const bool f_ring = (b + 1 >= nb) | (fr_raw != 0), f_far = (nxt_far < 0) | (ff_raw != 0);
             if (!f_ring || !f_far) {                                    // slow path: poll, re-read, and leave if somebody timed out
                 if (!f_ring) FLOW_WAIT(lds_ld(&ring_ready[b + 1]) != 0)
                 if (!f_far) FLOW_WAIT(lds_ld(&fdone[nxt_far]) != 0)
-                if (lds_ld(&s_abort)) break;
+                if (lds_ld(&s_abort)) return true;
 #pragma unroll
                 for (int d = 0; d <= FLOW_NEAR; ++d) nx[d] = ring[xslot][d][lane];
-                remx = removed[b + 1];
+                R2[(PH + 1) & 1] = removed[b + 1];
             }
-#pragma unroll
-            for (int d = 0; d <= FLOW_NEAR; ++d) nw[d] = nx[d];
-            rem = remx;
+            return b + 1 >= nb;
+        };
+        for (int b0 = 0; b0 < nb; b0 += 8) {
+            if (step(FlowPhase<0>{}, b0)) break;
+            if (step(FlowPhase<1>{}, b0 + 1)) break;
+            if (step(FlowPhase<2>{}, b0 + 2)) break;
+            if (step(FlowPhase<3>{}, b0 + 3)) break;
+            if (step(FlowPhase<4>{}, b0 + 4)) break;
+            if (step(FlowPhase<5>{}, b0 + 5)) break;
+            if (step(FlowPhase<6>{}, b0 + 6)) break;
+            if (step(FlowPhase<7>{}, b0 + 7)) break;
         }
         if (lane == 0) { s_total_out = total; lds_st(&s_state, (lds_ld(&s_state) & (FLOW_FIN - 1)) | FLOW_FIN); }
     } else if (wave <= FLOW_PF) {
@@ -586,8 +384,10 @@ __global__ __launch_bounds__(1024) void nms_scan_flow_kernel(const float4 *__res
             int st;
             FLOW_WAIT_PROGRESS(st, c - FLOW_SPEC)
             if (st < 0 || ((st & FLOW_FIN) && (st & (FLOW_FIN - 1)) <= c)) break;
-            FLOW_WAIT(lds_ld(&ring_ready[c]) != 0)                      // set FLOW_AHEAD - FLOW_SPEC blocks earlier: normally no spin
-            if (lds_ld(&s_abort)) break;
+            // set FLOW_AHEAD - FLOW_SPEC blocks earlier: normally no spin.  A prefetcher that sees the scan finished leaves
+            // without filling its remaining blocks, so this wait must end on FLOW_FIN as well.
+            FLOW_WAIT(lds_ld(&ring_ready[c]) != 0 || (lds_ld(&s_state) & FLOW_FIN) != 0)
+            if (lds_ld(&s_abort) || lds_ld(&ring_ready[c]) == 0) break;
             const int w0 = c + FLOW_NEAR + 1;                           // first far word
             const size_t rb0 = (size_t)c * 64;
             const int cslot = c % FLOW_RM;
@@ -752,18 +552,13 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
         FRCNN_LAUNCH(KID_NMS_MASK, nms_mask_kernel<false>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
                      (int)K, thr, nblk, mask, rowmask, diagT);
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
-    static const bool use_pipe = getenv("FRCNN_NMS_SCAN") && !strcmp(getenv("FRCNN_NMS_SCAN"), "pipe");
-    if (nblk <= NMS_FAST_MAX_BLOCKS && !use_pipe) {
+    if (nblk <= NMS_FAST_MAX_BLOCKS) {
         const size_t flow_lds = ((size_t)FLOW_RT * (1 + FLOW_NEAR) * 64 + (size_t)FLOW_RM * (NMS_FAST_MAX_BLOCKS + 8)) * sizeof(u64);
         static const hipError_t attr_rc = hipFuncSetAttribute((const void *)nms_scan_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds);
         if (attr_rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: cannot reserve %zu bytes of LDS: %s", flow_lds, hipGetErrorString(attr_rc));
         FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_flow_kernel, dim3(1), dim3(1024), flow_lds, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
                      rowmask, diagT, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
         FRCNN_CHECK_LAUNCH("nms_scan_flow_kernel");
-    } else if (nblk <= NMS_FAST_MAX_BLOCKS) {
-        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_fast_kernel, dim3(1), dim3(1024), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
-                     rowmask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
-        FRCNN_CHECK_LAUNCH("nms_scan_fast_kernel");
     } else {
         FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_kernel, dim3(1), dim3(1024), (size_t)nblk * 8, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk,
                      mask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
