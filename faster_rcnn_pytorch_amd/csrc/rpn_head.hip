@@ -6,7 +6,7 @@
 // copies (10-12 launches, ~60 us on MI355X); here the 1x1 heads are a [P x C] . [C x (2A+4A)] contraction on the
 // matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32: D = fma chain in k order, no reduced precision), the
 // bias + ReLU of the 3x3 output is applied while the A operand is loaded, and the epilogue stores NHWC.
-//   block = 4 waves = one tile of 32 positions; wave w takes the k-quarter [w*C/4, (w+1)*C/4); the four partial
+//   block = 8 waves (4 if C % 128 != 0) = one tile of 32 positions; wave w takes the k-slice [w*C/8, (w+1)*C/8); the partial
 //   accumulators are summed through LDS.  A operand: lane l reads raw[k0 + (l>>5)][pos0 + (l&31)] (two 128-B
 //   segments per wave-load, straight from the NCHW conv output); B operand: lane l reads W[j = l&31][k0 + (l>>5)]
 //   (each lane streams along its own weight row: L1-resident lines).
@@ -42,13 +42,13 @@ __device__ __forceinline__ short to_bf16_rne(float f)
 // TIN: element type of the 3x3 output (float, or unsigned short = bf16 bits).  NT: number of 32-wide output tiles (1 when
 // n_cls + n_reg <= 32, the FPN head with A = 3).  BF16MM: contract on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16,
 // fp32 accumulate, fp32 bias and outputs -- the mixed-precision configuration) instead of the exact-fp32 32x32x2 MFMA.
-template <typename TIN, int NT, bool BF16MM>
-__global__ __launch_bounds__(256) void rpn_head_tail_kernel(HeadLevels L, int C, const float *__restrict__ b3,
+template <typename TIN, int NT, bool BF16MM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rpn_head_tail_kernel(HeadLevels L, int C, const float *__restrict__ b3,
                                                             const float *__restrict__ w_cls, const float *__restrict__ b_cls, int n_cls,
                                                             const float *__restrict__ w_reg, const float *__restrict__ b_reg, int n_reg,
                                                             float *__restrict__ out_cls, float *__restrict__ out_reg)
 {
-    __shared__ float s_acc[3][16 * NT][64];               // partial accumulators of waves 1..3: [wave-1][reg][lane]
+    __shared__ float s_acc[WAVES - 1][16 * NT][64];       // partial accumulators of waves 1..: [wave-1][reg][lane]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int lvl = 0;
 #pragma unroll
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void rpn_head_tail_kernel(HeadLevels L, int C,
     const int p0 = ((int)blockIdx.x - L.tile0[lvl]) * 32;
     const int li = lane & 31, lk = lane >> 5;
     const int pos = min(p0 + li, P - 1);
-    const int kq = C / 4;
+    const int kq = C / WAVES;
     const int kbeg = wave * kq, kend = kbeg + kq;
     // weight rows of this lane for the output tiles (j = li, 32 + li); rows >= n_cls + n_reg contribute zeros
     const float *wrow[NT];
@@ -72,19 +72,30 @@ __global__ __launch_bounds__(256) void rpn_head_tail_kernel(HeadLevels L, int C,
     for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
     if constexpr (!BF16MM) {
         for (int k0 = kbeg; k0 < kend; k0 += 16) {
-            float a[8], bw[NT][8];
+            // channel of MFMA step u, k-half lk:  k0 + 8 lk + u  (any bijection works as long as A and B agree): the eight
+            // weights of a lane are then contiguous -> two 16-byte loads per tile instead of eight scalar ones
+            float a[8];
+            float4 bw[NT][2];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {                 // 8 * (1 + NT) independent loads in flight before the first MFMA
-                const int k = k0 + 2 * u + lk;            // A lane l: A[i = l & 31][k = l >> 5]
+            for (int u = 0; u < 8; ++u) {                 // 8 + 2 NT independent loads in flight before the first MFMA
+                const int k = k0 + 8 * lk + u;
                 a[u] = load_raw(raw, (size_t)k * P + pos) + b3[k];
+            }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bw[t][u] = wrow[t] ? wrow[t][k] : 0.0f;
+            for (int t = 0; t < NT; ++t) {
+                const float4 *wp = (const float4 *)(wrow[t] ? wrow[t] + k0 + 8 * lk : nullptr);
+                bw[t][0] = wp ? wp[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bw[t][1] = wp ? wp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float h = a[u] > 0.0f ? a[u] : 0.0f;    // ReLU of the 3x3 output (bias already added)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(h, bw[t][u], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const float4 q = bw[t][u >> 2];
+                    const float w = (u & 3) == 0 ? q.x : ((u & 3) == 1 ? q.y : ((u & 3) == 2 ? q.z : q.w));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(h, w, acc[t], 0, 0, 0);
+                }
             }
         }
     } else {
@@ -97,9 +108,12 @@ __global__ __launch_bounds__(256) void rpn_head_tail_kernel(HeadLevels L, int C,
                 a[u] = load_raw(raw, (size_t)k * P + pos) + b3[k];
             }
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) bv[t][u] = wrow[t] ? to_bf16_rne(wrow[t][k0 + 8 * lk + u]) : (short)0;
+            for (int t = 0; t < NT; ++t) {
+                const float4 *wp = (const float4 *)(wrow[t] ? wrow[t] + k0 + 8 * lk : nullptr);
+                const float4 q0 = wp ? wp[0] : make_float4(0.f, 0.f, 0.f, 0.f), q1 = wp ? wp[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[t][0] = to_bf16_rne(q0.x); bv[t][1] = to_bf16_rne(q0.y); bv[t][2] = to_bf16_rne(q0.z); bv[t][3] = to_bf16_rne(q0.w);
+                bv[t][4] = to_bf16_rne(q1.x); bv[t][5] = to_bf16_rne(q1.y); bv[t][6] = to_bf16_rne(q1.z); bv[t][7] = to_bf16_rne(q1.w);
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) av[u] = to_bf16_rne(a[u] > 0.0f ? a[u] : 0.0f);
 #pragma unroll
@@ -124,7 +138,10 @@ __global__ __launch_bounds__(256) void rpn_head_tail_kernel(HeadLevels L, int C,
                 // C/D layout of the 32x32 MFMA: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const int p = p0 + i;
-                const float v = acc[t][r] + s_acc[0][16 * t + r][lane] + s_acc[1][16 * t + r][lane] + s_acc[2][16 * t + r][lane] + bias;
+                float v = acc[t][r];
+#pragma unroll
+                for (int w = 0; w < WAVES - 1; ++w) v += s_acc[w][16 * t + r][lane];
+                v += bias;
                 if (p < P) {
                     if (j < n_cls) oc[(size_t)p * n_cls + j] = v;
                     else if (j < n_cls + n_reg) orr[(size_t)p * n_reg + (j - n_cls)] = v;
@@ -138,12 +155,14 @@ template <typename TIN, bool BF16MM>
 static void launch_head(int nt, const HeadLevels &L, int tiles, int C, const float *b3, const float *w_cls, const float *b_cls, int n_cls,
                         const float *w_reg, const float *b_reg, int n_reg, float *out_cls, float *out_reg, hipStream_t s)
 {
-    if (nt == 1)
-        FRCNN_LAUNCH(KID_RPN_HEAD_TAIL, (rpn_head_tail_kernel<TIN, 1, BF16MM>), dim3((unsigned)tiles), dim3(256), 0, s, L, C, b3, w_cls, b_cls, n_cls,
-                     w_reg, b_reg, n_reg, out_cls, out_reg);
-    else
-        FRCNN_LAUNCH(KID_RPN_HEAD_TAIL, (rpn_head_tail_kernel<TIN, 2, BF16MM>), dim3((unsigned)tiles), dim3(256), 0, s, L, C, b3, w_cls, b_cls, n_cls,
-                     w_reg, b_reg, n_reg, out_cls, out_reg);
+    // 8 waves per 32-position tile when the K slice stays a multiple of 16 (C % 128 == 0): half the dependent load rounds
+#define HEAD_LAUNCH(NT_, W_)                                                                                                            \
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL, (rpn_head_tail_kernel<TIN, NT_, BF16MM, W_>), dim3((unsigned)tiles), dim3(64 * W_), 0, s, L, C, b3, w_cls, \
+                 b_cls, n_cls, w_reg, b_reg, n_reg, out_cls, out_reg)
+    const bool w8 = (C % 128) == 0;
+    if (nt == 1) { if (w8) HEAD_LAUNCH(1, 8); else HEAD_LAUNCH(1, 4); }
+    else { if (w8) HEAD_LAUNCH(2, 8); else HEAD_LAUNCH(2, 4); }
+#undef HEAD_LAUNCH
 }
 
 FRCNN_EXPORT int frcnn_rpn_head_tail_ml_fwd(const void *const *conv_raw_levels, int dtype, int mfma, int C, const int64_t *P_levels, int n_levels,
