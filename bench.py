@@ -25,6 +25,7 @@ import torch  # noqa: E402
 
 H, W = 600, 1000                      # BASELINE.json configs[1]
 NUM_CLASSES = 21                      # VOC: 20 + background (models/model.py:141)
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9        # wave64 VALU issue: lanes per second, one op each (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -171,12 +172,20 @@ def main():
             if k.startswith(stem):
                 return v["traffic_bytes"]
         return None
+    # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
+    # peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s): pair IoUs x ~21 VALU ops, rank compares x 2
+    valu_ops = {"nms_mask_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21, "topk_rank_kernel": shape["N"] * shape["N"] * 2}
     per_kernel = {}
     for name, (ms, n) in kernels.items():
         us = ms / n * 1e3
         ab = algorithmic_bytes(name, **shape)
         per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
                             "GB_s": round(ab / us * 1e-3, 2) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+        if name in valu_ops:
+            per_kernel[name]["valu_lane_ops"] = valu_ops[name]
+            per_kernel[name]["valu_frac_of_39.3T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
+        if name == "nms_mask_kernel":
+            per_kernel[name]["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (us * 1e-6), 0)
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
