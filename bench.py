@@ -151,6 +151,7 @@ def main():
     kernels = {} if args.no_kernel_events else _lib.prof_report()
 
     if rank != 0:
+        parallel.shutdown()
         return
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
@@ -216,6 +217,7 @@ def main():
         "final_loss": round(final_loss, 4),
     }
     print(json.dumps(out), flush=True)
+    parallel.shutdown()
 
 
 def cpu_baseline(steps, lr):

@@ -34,6 +34,13 @@ def init_for_distributed(backend=None):
     return rank, local_rank, world, device
 
 
+def shutdown():
+    """Tear the process group down (quiet exit under torchrun); no-op for a single process."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def shard_indices(n_items, rank, world):
     """DistributedSampler-style partition (new_datasets/build.py:72): rank r takes r, r+W, r+2W, ..."""
     return list(range(rank, n_items, world))
