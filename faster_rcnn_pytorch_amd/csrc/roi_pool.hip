@@ -197,7 +197,11 @@ __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__re
                                                                int R, int C, int HW, int bins, float *__restrict__ grad_feat)
 {
     extern __shared__ float plane[];                 // [CB][HW]
-    const int c0 = blockIdx.x * CB;
+    // adjacent channels share the cache lines at the ends of their 196-byte runs: keep neighbours on ONE XCD (workgroups are
+    // dealt round-robin to the 8 XCDs) so that the second touch of such a line is an L2 hit instead of another HBM fetch
+    const int nb = gridDim.x;
+    const int bx = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int c0 = bx * CB;
     const int nch = min(CB, C - c0);
     for (int i = threadIdx.x; i < nch * HW; i += 512) plane[i] = 0.0f;
     __syncthreads();
