@@ -75,7 +75,7 @@ class RegionProposal(nn.Module):
     def forward(self, cls, reg, anchor, mode):
         """Reference signature: returns roi_tensor [n,4] (variable length -> one host sync for n)."""
         rois, cnt, _ = self.propose(cls, reg, anchor, mode)
-        return rois[:int(cnt.item())]
+        return rois[:ops.host_count(cnt, 'region_proposal')]
 
 
 class RegionProposalNetwork(nn.Module):
@@ -259,7 +259,7 @@ class FRCNN(nn.Module):
         pred_rpn_cls, pred_rpn_reg = self.rpn(features)
         rois, n_rois, _ = self.rp.propose(pred_rpn_cls.squeeze(0), pred_rpn_reg.squeeze(0), None, "test",
                                           grid=self.anchor_maker.grid_desc(hw))
-        rois = rois[:int(n_rois.item())]
+        rois = rois[:ops.host_count(n_rois, 'region_proposal')]
         pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.fast_rcnn_head(features, rois)
         pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)                    # model.py:369
         pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4)

@@ -206,7 +206,7 @@ class RegionProposalNetwork(nn.Module):
 
     def forward(self, x, features, mode):
         pred_rpn_cls, pred_rpn_reg, rois, cnt, anchor = self.propose(x, features, mode)
-        return pred_rpn_cls, pred_rpn_reg, rois[:int(cnt.item())], anchor
+        return pred_rpn_cls, pred_rpn_reg, rois[:ops.host_count(cnt, 'region_proposal')], anchor
 
 
 class FRCNNHead(nn.Module):
@@ -311,7 +311,7 @@ class FRCNN(nn.Module):
         threshold = float(getattr(opts, "thres", opts))
         features = self.backbone(x)
         _, _, rois, n_rois, _ = self.rpn.propose(x, features, "test")
-        rois = rois[:int(n_rois.item())]
+        rois = rois[:ops.host_count(n_rois, 'region_proposal')]
         pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.frcnn_head(features, rois, x.shape[2:])
         pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)
         pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4) * torch.tensor([0.1, 0.1, 0.2, 0.2], device=x.device)

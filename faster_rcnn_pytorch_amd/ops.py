@@ -247,7 +247,7 @@ def nms(boxes, scores, iou_threshold):
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     idx, _, sboxes, _ = topk_sorted(scores, boxes.shape[0], boxes, all_live=True)
     keep, _, cnt = nms_sorted(sboxes, iou_threshold)
-    n = int(cnt.item())
+    n = host_count(cnt)
     return idx[keep[:n]]
 
 
@@ -273,7 +273,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     with torch.cuda.device(dev):
         check(lib.frcnn_nms_classed(_ptr(sboxes), _ptr(scls), None, n, float(iou_threshold), n, _ptr(keep), None, _ptr(cnt), _ptr(ws), nb,
                                     _stream()), "nms_classed")
-    return order[keep[:int(cnt.item())]]
+    return order[keep[:host_count(cnt)]]
 
 
 def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_threshold, post_nms_top_k, grid=None, want_src=False):
@@ -392,6 +392,15 @@ def rpn_head_tail_levels(conv_raws, b3, w_cls, b_cls, w_reg, b_reg, mfma="f32"):
 # --------------------------------------------------------------------------------------------
 # target makers
 # --------------------------------------------------------------------------------------------
+def host_count(cnt, what="nms"):
+    """Read a device-side count on the host (a sync).  The library reports an aborted scan (a bounded spin ran out: should never
+    happen, see nms.hip) as -1: fail loudly instead of slicing with it."""
+    n = int(cnt.item())
+    if n < 0:
+        raise _lib.FrcnnError("%s: the device-side scan aborted (count = %d); results are invalid" % (what, n))
+    return n
+
+
 def _perm(p, dev):
     if p is None:
         return None, 0
