@@ -1,72 +1,44 @@
-"""Detection losses -- mirror of the reference's losses/loss.py:5-85.
+"""Detection loss with the interface of the reference's losses/loss.py:64-85 (`FRCNNLoss(opts)(pred, target)` -> the
+5-tuple total, rpn_cls, rpn_reg, fast_rcnn_cls, fast_rcnn_reg), SURVEY 8(f) rank 1.
 
-Same classes and values (SmoothL1Loss, RPNLoss, FastRCNNLoss, FRCNNLoss), but the reference's
-boolean-mask indexing `pred_reg[target_cls > 0]` (loss.py:33,56), which forces a nonzero() host
-sync on every step, is replaced by the algebraically identical masked sum, so the whole training
-step stays asynchronous.  Plain torch ops: these are a handful of tiny launches next to the path.
+On fp32 HIP tensors the four terms AND their gradients come from one fused kernel (`ops.detection_loss`,
+csrc/loss.hip).  Anything else (CPU tensors in the gloo tests, non-fp32 predictions) takes `detection_loss_torch`, which
+states the same four formulas (loss.py:20-40 RPN, :43-61 head) once, as masked sums: the reference's boolean-mask indexing
+`pred_reg[target_cls > 0]` forces a nonzero() host sync per step and is algebraically the same thing.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
-class SmoothL1Loss(nn.Module):
-    def __init__(self, beta=1.):
-        super().__init__()
-        self.beta = beta
-
-    def forward(self, pred, target):
-        x = (pred - target).abs()
-        l1 = x - 0.5 * self.beta
-        l2 = 0.5 * x ** 2 / self.beta
-        return torch.where(x >= self.beta, l1, l2)
+def _masked_smooth_l1(pred, target, labels, beta):
+    """sum over the rows with label > 0 of smooth-L1(pred - target; beta), divided by the number of rows with label >= 0."""
+    d = (pred - target).abs()
+    per_elem = torch.where(d >= beta, d - 0.5 * beta, d * d * (0.5 / beta))
+    positive = (labels > 0).to(per_elem.dtype)[:, None]
+    return (per_elem * positive).sum() / (labels >= 0).sum()
 
 
-class RPNLoss(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.smooth_l1_loss = SmoothL1Loss(beta=1 / 9)
-        self.rpn_lambda = 10          # defined but unused in the reference too
-
-    def forward(self, pred_cls, pred_reg, target_cls, target_reg):
-        rpn_cls_loss = F.cross_entropy(pred_cls.squeeze(0), target_cls, ignore_index=-1)
-        pos = (target_cls > 0).to(pred_reg.dtype).unsqueeze(-1)
-        reg = self.smooth_l1_loss(pred_reg.squeeze(0), target_reg) * pos
-        rpn_reg_loss = reg.sum() / (target_cls >= 0).sum()
-        return rpn_cls_loss, rpn_reg_loss
-
-
-class FastRCNNLoss(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.smooth_l1_loss = SmoothL1Loss(1)
-
-    def forward(self, pred_cls, pred_reg, target_cls, target_reg):
-        cls_loss = F.cross_entropy(pred_cls.squeeze(0), target_cls)
-        pos = (target_cls > 0).to(pred_reg.dtype).unsqueeze(-1)
-        reg = self.smooth_l1_loss(pred_reg.squeeze(0), target_reg) * pos
-        reg_loss = reg.sum() / (target_cls >= 0).sum()
-        return cls_loss, reg_loss
+def detection_loss_torch(pred, target):
+    rpn_cls, rpn_reg, head_cls, head_reg = (p.squeeze(0) if p.dim() == 3 else p for p in pred)
+    t_rpn_cls, t_rpn_reg, t_head_cls, t_head_reg = target
+    l_rpn_cls = F.cross_entropy(rpn_cls, t_rpn_cls, ignore_index=-1)          # anchors labelled -1 are not sampled
+    l_rpn_reg = _masked_smooth_l1(rpn_reg, t_rpn_reg, t_rpn_cls, 1.0 / 9.0)     # beta 1/9, normalised by #(label >= 0)
+    l_head_cls = F.cross_entropy(head_cls, t_head_cls)
+    l_head_reg = _masked_smooth_l1(head_reg, t_head_reg, t_head_cls, 1.0)       # beta 1, normalised by R
+    return l_rpn_cls + l_rpn_reg + l_head_cls + l_head_reg, l_rpn_cls, l_rpn_reg, l_head_cls, l_head_reg
 
 
 class FRCNNLoss(nn.Module):
     def __init__(self, opts=None):
         super().__init__()
         self.opts = opts
-        self.rpn_loss = RPNLoss()
-        self.fast_rcnn_loss = FastRCNNLoss()
 
     def forward(self, pred, target):
         if all(t.is_cuda and t.dtype == torch.float32 for t in pred):
-            from . import ops                                   # fused HIP kernel: 3 launches instead of ~15
-            return ops.detection_loss(pred, target)
-        pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg = pred
-        target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg = target
-        rpn_cls_loss, rpn_reg_loss = self.rpn_loss(pred_rpn_cls, pred_rpn_reg, target_rpn_cls, target_rpn_reg)
-        fast_rcnn_cls_loss, fast_rcnn_reg_loss = self.fast_rcnn_loss(pred_fast_rcnn_cls, pred_fast_rcnn_reg,
-                                                                     target_fast_rcnn_cls, target_fast_rcnn_reg)
-        total_loss = rpn_cls_loss + rpn_reg_loss + fast_rcnn_cls_loss + fast_rcnn_reg_loss
-        return total_loss, rpn_cls_loss, rpn_reg_loss, fast_rcnn_cls_loss, fast_rcnn_reg_loss
+            from . import ops
+            return ops.detection_loss(pred, target)                             # 2 launches instead of ~15 + two host syncs
+        return detection_loss_torch(pred, target)
 
 
 def build_loss(opts=None):
