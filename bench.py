@@ -213,9 +213,14 @@ def main():
         "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * 2000, 1),
                      # BASELINE.json's second figure: NMS (mask + scan) + RoI pooling forward/backward, HIP-event us per image
                      "nms_plus_roi_us_per_img": round(sum(v["avg_us"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
+                     # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
+                     "proposal_stage_us_per_img": round(sum(v["avg_us"] for k, v in per_kernel.items()
+                                                            if k.startswith(("proposal_prologue", "topk_", "nms_"))), 1),
                      "kernels": per_kernel},
         "final_loss": round(final_loss, 4),
     }
+    st = out["hot_path"]["proposal_stage_us_per_img"]
+    out["hot_path"]["proposal_stage_proposals_per_s"] = round(2000 / (st * 1e-6), 0) if st else None
     print(json.dumps(out), flush=True)
     parallel.shutdown()
 
