@@ -127,7 +127,13 @@ def main():
         opt.step()
         return loss
 
-    log("model + %d frames resident; warm-up" % len(frames))
+    # Initialisation pass, outside the W / K accounting: the first steps of a process select and compile MIOpen kernels, grow the
+    # caching allocator and the library workspaces (seconds, not steady state).  The W warm-up steps below then run warm.
+    log("model + %d frames resident; initialisation pass" % len(frames))
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    log("warm-up")
     for i in range(args.warmup):
         step(i)
         torch.cuda.synchronize()
