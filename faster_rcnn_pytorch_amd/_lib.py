@@ -11,6 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
+ABI_VERSION = 2
+HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
 OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS = 1, 2, 3, 4, 5, 6
 
 _vp, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -35,7 +37,7 @@ SIGNATURES = {
     "frcnn_rpn_head_tail_ml_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64,
-                                _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_roi_pool_fwd": (_i, [_vp, _i, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "frcnn_roi_pool_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "frcnn_roi_level_map": (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp]),
@@ -50,6 +52,7 @@ SIGNATURES = {
     "frcnn_prof_num_kernels": (_i, []),
     "frcnn_prof_kernel_name": (C.c_char_p, [_i]),
     "frcnn_prof_get": (_i, [_i, _vp, _vp]),
+    "frcnn_prof_get_samples": (_i64, [_i, _vp, _i64]),
 }
 
 
@@ -67,8 +70,9 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.frcnn_abi_version() != 1:
-        raise ImportError("libfrcnn_hip.so ABI version %d, expected 1" % lib.frcnn_abi_version())
+    if lib.frcnn_abi_version() != ABI_VERSION:
+        raise ImportError("libfrcnn_hip.so ABI version %d, expected %d (rebuild: make -C faster_rcnn_pytorch_amd/csrc)"
+                          % (lib.frcnn_abi_version(), ABI_VERSION))
     return lib
 
 
@@ -102,4 +106,17 @@ def prof_report():
         check(lib.frcnn_prof_get(k, C.byref(ms), C.byref(n)))
         if n.value:
             out[lib.frcnn_prof_kernel_name(k).decode()] = (ms.value, n.value)
+    return out
+
+
+def prof_samples():
+    """{kernel_name: [per-launch ms, ...]} since the last reset (syncs the events)."""
+    check(lib.frcnn_prof_collect())
+    out = {}
+    for k in range(lib.frcnn_prof_num_kernels()):
+        n = int(lib.frcnn_prof_get_samples(k, None, 0))
+        if n > 0:
+            buf = (C.c_float * n)()
+            lib.frcnn_prof_get_samples(k, buf, n)
+            out[lib.frcnn_prof_kernel_name(k).decode()] = list(buf)
     return out

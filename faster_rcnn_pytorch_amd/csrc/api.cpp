@@ -81,9 +81,9 @@ FRCNN_EXPORT int frcnn_tv_base_anchors_host(float size, const float *ratios, int
 // ---- per-kernel timing with HIP events on the launch stream ----
 static const char *const g_kernel_names[KID_COUNT] = {
     "anchor_grid_kernel", "box_codec_kernel", "pairwise_iou_kernel", "proposal_prologue_kernel",
-    "topk_rank_kernel", "topk_scatter_kernel", "nms_mask_kernel", "nms_scan_kernel",
+    "topk_rank_kernel", "topk_scatter_kernel", "nms_mask_kernel", "nms_scan_flow_kernel",
     "rpn_colmax_kernel", "rpn_label_kernel", "rpn_sample_kernel", "head_targets_kernel",
-    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel"};
+    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_scan_kernel"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
@@ -92,6 +92,7 @@ static std::vector<ProfRec> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_free;
 static double g_prof_ms[KID_COUNT];
 static int64_t g_prof_n[KID_COUNT];
+static std::vector<float> g_prof_samples[KID_COUNT];      // per-launch durations (ms): median / percentiles for bench.py
 
 bool frcnn_prof_on() { return g_prof_enabled; }
 
@@ -133,6 +134,7 @@ FRCNN_EXPORT int frcnn_prof_collect(void)
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             g_prof_ms[r.kid] += ms;
             g_prof_n[r.kid] += 1;
+            if (g_prof_samples[r.kid].size() < (size_t)1 << 20) g_prof_samples[r.kid].push_back(ms);
         }
         g_prof_free.push_back(r.a);
         g_prof_free.push_back(r.b);
@@ -145,7 +147,7 @@ FRCNN_EXPORT int frcnn_prof_reset(void)
 {
     frcnn_prof_collect();
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (int i = 0; i < KID_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
+    for (int i = 0; i < KID_COUNT; ++i) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; g_prof_samples[i].clear(); }
     return FRCNN_OK;
 }
 
@@ -158,4 +160,15 @@ FRCNN_EXPORT int frcnn_prof_get(int kid, double *total_ms, int64_t *launches)
     *total_ms = g_prof_ms[kid];
     *launches = g_prof_n[kid];
     return FRCNN_OK;
+}
+
+// per-launch samples of one kernel id, in launch order: copies min(cap, n) values (ms) and returns n (negative = error)
+FRCNN_EXPORT int64_t frcnn_prof_get_samples(int kid, float *out_ms, int64_t cap)
+{
+    if (kid < 0 || kid >= KID_COUNT || cap < 0 || (cap > 0 && !out_ms)) return frcnn_set_error(FRCNN_ERR_INVALID_ARG, "prof_get_samples: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const std::vector<float> &v = g_prof_samples[kid];
+    const int64_t n = (int64_t)v.size();
+    for (int64_t i = 0; i < n && i < cap; ++i) out_ms[i] = v[(size_t)i];
+    return n;
 }

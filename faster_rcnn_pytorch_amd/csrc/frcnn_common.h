@@ -31,6 +31,7 @@ enum FrcnnKernelId {
     KID_RPN_HEAD_TAIL,
     KID_DET_LOSS,
     KID_PREPROCESS,
+    KID_NMS_SCAN_SIMPLE,
     KID_COUNT
 };
 

@@ -1,6 +1,7 @@
 // loss.hip -- FRCNNLoss (losses/loss.py:5-85) as one streaming kernel + a one-thread finalize.
 //   RPN : CE(ignore -1) over [N,2] + SmoothL1(beta 1/9) over the positives, both / #(label >= 0)     (loss.py:20-40)
 //   head: CE over [R,C]            + SmoothL1(beta 1)   over the positives, both / R                   (loss.py:43-61)
+// A head class outside [0, C) (the failure mark of frcnn_head_targets) makes the head CE, hence the total, NaN.
 // The reference spends ~15 eager launches and two boolean-mask host syncs (loss.py:33,56) per forward and about as
 // many per backward.  Here one pass over the predictions produces the four sums AND the un-normalised gradients
 // (softmax - onehot, SmoothL1'), so backward is four scalar multiplies.  RPN rows: one lane per anchor, grid-stride over at
@@ -83,7 +84,9 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float2 *__restrict_
             float *g = g_head_cls + (size_t)r * NC;
             for (int c = lane; c < NC; c += 64) g[c] = expf(row[c] - m) / s - (c == t ? 1.f : 0.f);
             if (lane == 0) {
-                hce += m + logf(s) - row[t];
+                // a class outside [0, NC) is the target maker's failure mark (targets.hip: upstream NMS abort, or fewer than R
+                // samples): the loss becomes NaN instead of reading out of bounds, so the failure shows at the caller's loss.item()
+                hce += (t >= 0 && t < NC) ? m + logf(s) - row[t] : __builtin_nanf("");
                 float4 gr = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (t > 0) {
                     const float4 p = head_reg[r], q = t_reg[r];

@@ -18,6 +18,7 @@
 //  nms_scan_kernel : the simple multi-pass form, used for K > 12288.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -554,13 +555,21 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     FRCNN_CHECK_LAUNCH("nms_mask_kernel");
     if (nblk <= NMS_FAST_MAX_BLOCKS) {
         const size_t flow_lds = ((size_t)FLOW_RT * (1 + FLOW_NEAR) * 64 + (size_t)FLOW_RM * (NMS_FAST_MAX_BLOCKS + 8)) * sizeof(u64);
-        static const hipError_t attr_rc = hipFuncSetAttribute((const void *)nms_scan_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds);
-        if (attr_rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: cannot reserve %zu bytes of LDS: %s", flow_lds, hipGetErrorString(attr_rc));
+        // The > 64 KB dynamic-LDS opt-in is a property of the function ON THE CURRENT DEVICE: remember it per device ordinal (a
+        // process may drive several GPUs, e.g. DataParallel as in the reference's models/build.py:18), and do not cache failures.
+        static std::atomic<unsigned char> attr_done[64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: no current device");
+        if (dev >= 64 || !attr_done[dev].load(std::memory_order_acquire)) {
+            const hipError_t attr_rc = hipFuncSetAttribute((const void *)nms_scan_flow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flow_lds);
+            if (attr_rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: cannot reserve %zu bytes of LDS: %s", flow_lds, hipGetErrorString(attr_rc));
+            if (dev < 64) attr_done[dev].store(1, std::memory_order_release);
+        }
         FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_flow_kernel, dim3(1), dim3(1024), flow_lds, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk, mask,
                      rowmask, diagT, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
         FRCNN_CHECK_LAUNCH("nms_scan_flow_kernel");
     } else {
-        FRCNN_LAUNCH(KID_NMS_SCAN, nms_scan_kernel, dim3(1), dim3(1024), (size_t)nblk * 8, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk,
+        FRCNN_LAUNCH(KID_NMS_SCAN_SIMPLE, nms_scan_kernel, dim3(1), dim3(1024), (size_t)nblk * 8, s, (const float4 *)boxes, n_boxes_dev, (int)K, nblk,
                      mask, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
         FRCNN_CHECK_LAUNCH("nms_scan_kernel");
     }

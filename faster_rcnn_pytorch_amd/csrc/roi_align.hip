@@ -9,11 +9,11 @@
 //             25 KB of LDS with coalesced row loads, then a lane owns one bin, sets up its 4 samples x 4 taps ONCE
 //             and walks the staged channels (same operation order as the oracle: bit-identical outputs).  Channel groups are pinned to XCDs (blockIdx & 7) so that each XCD's L2 only ever
 //             holds its own eighth of the pyramid instead of all 91 MB streaming through all eight.
-//   backward: bilinear scatter is separable,  dF = Wy^T (7 x fh) . dOut (7x7) . Wx (7 x fw)  over the RoI's footprint,
-//             so a workgroup (RoI, 16 channels) builds the two small weight tables in LDS, forms T = dOut . Wx per
-//             64-column chunk, and each lane then produces finished footprint pixels: ONE global fp32 atomic per
-//             footprint pixel, contiguous along x, instead of 16 scattered atomics per bin (784 per RoI-channel).
-// Any other bin/sampling shape takes the generic one-lane-per-output kernels below (fp32 atomics in backward;
+//   backward: tile-owner GATHER (roi_align_bwd_tile_kernel): bilinear scatter is separable,
+//             dF = Wy^T (fh x 7) . dOut (7x7) . Wx (7 x fw), so a workgroup that owns a 16 x 8 pixel tile of one level for 32
+//             channels walks the RoIs whose footprint meets the tile IN INDEX ORDER and accumulates the tile in registers;
+//             every gradient pixel is written exactly once: no atomics, no memset, bit-reproducible.
+// Any other bin/sampling shape takes the generic one-lane-per-output kernels below (memset + fp32 atomics in backward;
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
@@ -282,114 +282,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
     }
 }
 
-#ifndef RA_BWD_CB
-#define RA_BWD_CB 16
-#endif
-#ifndef RA_BWD_XC
-#define RA_BWD_XC 64
-#endif
-#define RA_BWD_MAXROWS 256
-// generic scatter of one (RoI, channel range) -- used when the RoI's footprint is taller than the LDS row table
-__device__ void roi_align_bwd_scatter(const MsLevels &L, int l, int C, int r, int c0, int c1, const AlignGeom &g,
-                                      const float *__restrict__ grad_out)
-{
-    const int H = L.H[l], W = L.W[l];
-    for (int e = threadIdx.x; e < (c1 - c0) * 49; e += 256) {
-        const int c = c0 + e / 49, bin = e % 49, ph = bin / 7, pw = bin % 7;
-        float *pl = L.grad[l] + (size_t)c * H * W;
-        const float go = grad_out[((size_t)r * C + c) * 49 + bin] / g.cnt;
-        for (int iy = 0; iy < 2; ++iy)
-            for (int ix = 0; ix < 2; ++ix) {
-                const float y = g.sh + (float)ph * g.bh + ((float)iy + 0.5f) * g.bh / 2.0f;
-                const float x = g.sw + (float)pw * g.bw + ((float)ix + 0.5f) * g.bw / 2.0f;
-                const Bilin s = bilin_setup(H, W, y, x);
-                if (!s.ok) continue;
-                atomicAdd(pl + s.yl * W + s.xl, go * s.w1);
-                atomicAdd(pl + s.yl * W + s.xh, go * s.w2);
-                atomicAdd(pl + s.yh * W + s.xl, go * s.w3);
-                atomicAdd(pl + s.yh * W + s.xh, go * s.w4);
-            }
-    }
-}
-
-__global__ __launch_bounds__(256) void roi_align_bwd77_kernel(MsLevels L, int C, const float4 *__restrict__ rois, int R, int aligned, int k_min,
-                                                              float s0, int k0, const float *__restrict__ grad_out, int n_cg)
-{
-    __shared__ float s_g[RA_BWD_CB * 49];                // dOut tile [c][ph][pw]
-    __shared__ float s_wy[RA_BWD_MAXROWS * 7];           // Wy[y - y0][ph]  (x 1/4)
-    __shared__ float s_wx[RA_BWD_XC * 7];                // Wx[x - xc0][pw]
-    __shared__ float s_t[RA_BWD_CB * 7 * RA_BWD_XC];     // T[c][ph][x - xc0]
-    int cg, r;
-    tile_of_block(blockIdx.x, R, n_cg, &cg, &r);
-    const int t = threadIdx.x;
-    const float4 b = rois[r];
-    const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
-    const int H = L.H[l], W = L.W[l];
-    const AlignGeom g = align_geom(b, L.scale[l], 7, 7, 2, aligned != 0);
-    const int c0 = cg * RA_BWD_CB, c1 = min(C, c0 + RA_BWD_CB), nc = c1 - c0;
-    // footprint: sample coordinates are monotonic, so the first / last samples bound it
-    const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
-    const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
-    const int y0 = ya.lo, y1 = yb.hi, x0 = xa.lo, x1 = xb.hi;
-    const int fh = y1 - y0 + 1;
-    if (fh > RA_BWD_MAXROWS || fh < 1 || x1 < x0) {       // uniform
-        roi_align_bwd_scatter(L, l, C, r, c0, c1, g, grad_out);
-        return;
-    }
-    for (int e = t; e < nc * 49; e += 256) s_g[e] = grad_out[((size_t)r * C + c0) * 49 + e];
-    for (int e = t; e < fh * 7; e += 256) s_wy[e] = 0.0f;
-    __syncthreads();
-    if (t < 7) {
-#pragma unroll
-        for (int iy = 0; iy < 2; ++iy) {
-            const Lin s = lin_setup(H, g.sh + (float)t * g.bh + ((float)iy + 0.5f) * g.bh / 2.0f);
-            if (s.ok) {
-                s_wy[(s.lo - y0) * 7 + t] += 0.25f * s.wlo;
-                s_wy[(s.hi - y0) * 7 + t] += 0.25f * s.whi;
-            }
-        }
-    }
-    float *gl = L.grad[l] + (size_t)c0 * H * W;
-    for (int xc0 = x0; xc0 <= x1; xc0 += RA_BWD_XC) {
-        const int cw = min(RA_BWD_XC, x1 - xc0 + 1);
-        __syncthreads();                                   // previous chunk's readers of s_wx / s_t are done (and s_wy is built)
-        for (int e = t; e < cw * 7; e += 256) s_wx[e] = 0.0f;
-        __syncthreads();
-        if (t < 7) {
-#pragma unroll
-            for (int ix = 0; ix < 2; ++ix) {
-                const Lin s = lin_setup(W, g.sw + (float)t * g.bw + ((float)ix + 0.5f) * g.bw / 2.0f);
-                if (s.ok) {
-                    if (s.lo >= xc0 && s.lo < xc0 + cw) s_wx[(s.lo - xc0) * 7 + t] += s.wlo;
-                    if (s.hi >= xc0 && s.hi < xc0 + cw) s_wx[(s.hi - xc0) * 7 + t] += s.whi;
-                }
-            }
-        }
-        __syncthreads();
-        for (int e = t; e < nc * 7 * cw; e += 256) {        // T[c][ph][x] = sum_pw dOut[c][ph][pw] * Wx[x][pw]
-            const int x = e % cw, cp = e / cw;              // cp = c * 7 + ph
-            float a = 0.0f;
-#pragma unroll
-            for (int pw = 0; pw < 7; ++pw) a += s_g[cp * 7 + pw] * s_wx[x * 7 + pw];
-            s_t[cp * RA_BWD_XC + x] = a;
-        }
-        __syncthreads();
-        for (int e = t; e < nc * cw; e += 256) {            // lane -> (channel, column); walk the footprint rows
-            const int x = e % cw, c = e / cw;
-            float tc[7];
-#pragma unroll
-            for (int ph = 0; ph < 7; ++ph) tc[ph] = s_t[(c * 7 + ph) * RA_BWD_XC + x];
-            float *px = gl + (size_t)c * H * W + (size_t)y0 * W + xc0 + x;
-            for (int y = 0; y < fh; ++y) {
-                float a = 0.0f;
-#pragma unroll
-                for (int ph = 0; ph < 7; ++ph) a += s_wy[y * 7 + ph] * tc[ph];
-                if (a != 0.0f) atomicAdd(px + (size_t)y * W, a);
-            }
-        }
-    }
-}
-
 // ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
 // A workgroup owns a 16 x 8 pixel tile of ONE level for 32 channels (lane = (column, channel), 16 row accumulators in
 // registers) and writes it exactly once.  (Measured 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch
@@ -642,8 +534,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
     if (rc) return rc;
     const int64_t total = R * C * PH * PW;
     hipStream_t s = (hipStream_t)stream;
-    static const bool scatter77 = [] { const char *e = getenv("FRCNN_RA_BWD"); return e && !strcmp(e, "scatter"); }();   // tests / comparison
-    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24) && !scatter77) {
+    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
         TileLevels TL;
         int tiles = 0;
         for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
@@ -663,13 +554,6 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         if (hipMemsetAsync(L.grad[l], 0, (size_t)C * L.H[l] * L.W[l] * sizeof(float), s) != hipSuccess)
             return frcnn_set_error(FRCNN_ERR_LAUNCH, "ms_roi_align_bwd: memset failed");
     if (R == 0) return FRCNN_OK;
-    if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
-        const int n_cg = (C + RA_BWD_CB - 1) / RA_BWD_CB;
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, roi_align_bwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,
-                     aligned, k_min, s0, k0, grad_out, n_cg);
-        FRCNN_CHECK_LAUNCH("roi_align_bwd77_kernel");
-        return FRCNN_OK;
-    }
     FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, roi_align_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, C, (const float4 *)rois,
                  total, PH, PW, sampling_ratio, aligned, k_min, s0, k0, grad_out);
     FRCNN_CHECK_LAUNCH("roi_align_bwd_kernel");

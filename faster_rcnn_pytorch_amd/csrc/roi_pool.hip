@@ -1,12 +1,12 @@
 // roi_pool.hip -- torchvision.ops.RoIPool forward / backward as called at models/model.py:97,113 (gfx950).
 //
-// forward : one lane per output element, pw-minor, so the two stores (value + int32 argmax, the
-//           25.7 MB that dominate the kernel at R=128, C=512) are perfectly coalesced; the RoI window
-//           reads hit L1/L2 (one 37x62 fp32 channel plane is 9 KB).
-// backward: one workgroup per channel; the channel's gradient plane lives in LDS, every
-//           (roi, bin) of that channel is accumulated with ds_add_f32 and the plane is written
-//           once with coalesced stores: no global atomics, no pre-zeroing of grad_feat.
-//           Planes larger than the LDS budget fall back to zero-fill + global fp32 atomics.
+// forward : (7x7, planes that fit LDS -- the shape the reference runs) roi_pool_fwd_lds_kernel: a workgroup stages CB
+//           adjacent channel planes in LDS with one coalesced pass, builds the bin tables of its RoIs once, and each lane
+//           = (RoI, bin) scans its window in LDS for the CB channels; out + int32 argmax (the 25.7 MB that dominate at
+//           R=128, C=512) leave in contiguous CB*49-element runs.  Other shapes: one lane per output element, windows from L1/L2.
+// backward: one workgroup per channel group; the gradient planes live in LDS, every (roi, bin) is accumulated with
+//           ds_add_f32 and each plane is written once with coalesced stores: no global atomics, no pre-zeroing of
+//           grad_feat.  Planes larger than the LDS budget fall back to zero-fill + global fp32 atomics.
 // Algorithmic bytes: fwd 4*C*H*W + 16R + 8*R*C*PH*PW; bwd the same.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
                                                             unsigned long long seed, unsigned long long offset,
                                                             int64_t *__restrict__ out_cls, float4 *__restrict__ out_reg,
                                                             float4 *__restrict__ out_rois, int64_t *__restrict__ out_keep,
-                                                            int32_t *__restrict__ counts)
+                                                            int32_t *__restrict__ counts, int32_t *__restrict__ sticky)
 {
     __shared__ int s_w[17];
     __shared__ short s_arg[HT_MAX];
@@ -495,7 +495,12 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     __shared__ unsigned s_pref[4];
     __shared__ int s_nsel;
     const int tid = threadIdx.x;
-    const int n_rois = n_rois_dev ? min(max(*n_rois_dev, 0), P_cap) : P_cap;
+    // A negative device count is the upstream proposal stage reporting an aborted NMS scan (nms.hip): it must not silently
+    // become "no proposals" (the step would train on the ground-truth boxes alone).  It is carried into counts[3] / the sticky
+    // status word and every row gets the out-of-range class -1, which the loss turns into NaN (loss.hip).
+    const int n_rois_raw = n_rois_dev ? *n_rois_dev : P_cap;
+    const bool upstream_abort = n_rois_raw < 0;
+    const int n_rois = min(max(n_rois_raw, 0), P_cap);
     const int n = n_rois + G;
 
     for (int j = tid; j < total; j += 1024) s_row[j] = -1;
@@ -583,8 +588,11 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     for (int j = tid; j < total; j += 1024) {
         const int k = s_row[j];
         float4 box = make_float4(0.f, 0.f, 0.f, 0.f), reg = box;
-        int64_t cls = 0;
-        if (k >= 0) {
+        // rows that could not be sampled (fewer than `total` candidates: the reference throws at model.py:340 / asserts at
+        // new_model.py:182) are marked with the out-of-range class -1 instead of posing as background samples
+        int64_t cls = -1;
+        if (k >= 0 && !upstream_abort) {
+            cls = 0;
             box = k < n_rois ? rois[k] : gt[k - n_rois];
             const int arg = s_arg[k];
             if (j < n_pos) cls = gt_label[arg] + label_offset;
@@ -596,7 +604,13 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
         out_rois[j] = box;
         if (out_keep) out_keep[j] = k;
     }
-    if (tid == 0) { const int err = s_err; counts[0] = npc; counts[1] = nnc; counts[2] = err ? 0 : n_pos + n_neg; counts[3] = err; }
+    if (tid == 0) {
+        int err = s_err;                                            // FRCNN_HT_ERR_* bits (include/frcnn_hip.h)
+        if (upstream_abort) err |= FRCNN_HT_ERR_UPSTREAM_ABORT;
+        if (n_pos + n_neg < total) err |= FRCNN_HT_ERR_SHORT;
+        counts[0] = npc; counts[1] = nnc; counts[2] = (err & 3) ? 0 : n_pos + n_neg; counts[3] = err;
+        if (sticky && err) atomicOr(sticky, err);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -661,9 +675,8 @@ FRCNN_EXPORT int frcnn_head_targets(int variant, const float *rois, const int32_
                                     const int64_t *gt_label, int64_t G, int64_t label_offset, int64_t max_pos, int64_t total,
                                     const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
                                     uint64_t seed, uint64_t offset, int64_t *out_cls, float *out_reg, float *out_rois,
-                                    int64_t *out_keep_index, int32_t *out_counts, void *workspace, size_t workspace_bytes, void *stream)
+                                    int64_t *out_keep_index, int32_t *out_counts, int32_t *sticky_status, void *stream)
 {
-    (void)workspace; (void)workspace_bytes;
     FRCNN_REQUIRE(variant == 0 || variant == 1, "head_targets: variant must be 0 (VGG) or 1 (FPN)");
     FRCNN_REQUIRE(P_cap >= 0 && G > 0, "head_targets: need P_cap >= 0 and G >= 1");
     if (P_cap + G > HT_MAX) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "head_targets: P+G=%lld above limit %d", (long long)(P_cap + G), HT_MAX);
@@ -674,7 +687,7 @@ FRCNN_EXPORT int frcnn_head_targets(int variant, const float *rois, const int32_
     FRCNN_LAUNCH(KID_HEAD_TARGETS, head_targets_kernel, dim3(1), dim3(1024), 0, s, variant, (const float4 *)rois, n_rois_dev, (int)P_cap,
                  (const float4 *)gt, gt_label, (int)G, (int)label_offset, (int)max_pos, (int)total, perm_pos, (int)n_perm_pos, perm_neg,
                  (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, out_cls, (float4 *)out_reg, (float4 *)out_rois,
-                 out_keep_index, out_counts);
+                 out_keep_index, out_counts, sticky_status);
     FRCNN_CHECK_LAUNCH("head_targets_kernel");
     return FRCNN_OK;
 }

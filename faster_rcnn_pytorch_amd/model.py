@@ -138,6 +138,9 @@ class _Sampler(object):
         self.sampling = sampling
         self.seed = int(seed)
         self.offset = 0
+        # sticky device-side error word: the sync-free ('device') target makers OR their failure bits into it; the training
+        # loop reads it where it syncs anyway (FRCNN.check_device_status()).  The same failures also make the loss NaN.
+        self.status = ops.DeviceStatus()
 
     def next_offset(self):
         self.offset += 1
@@ -163,7 +166,8 @@ class FastRcnnTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 128:
                 raise RuntimeError("FastRcnnTargetMaker: fewer than 128 samples (the reference fails here too, model_.py:340)")
         else:
-            cls, reg, srois, _, _ = ops.head_targets(rois, bbox, label, n_rois=n_rois, seed=s.seed, offset=s.next_offset())
+            cls, reg, srois, _, _ = ops.head_targets(rois, bbox, label, n_rois=n_rois, seed=s.seed, offset=s.next_offset(),
+                                                     status=s.status.word(rois.device))
         return cls, reg, srois
 
 
@@ -211,6 +215,13 @@ class FRCNN(nn.Module):
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def check_device_status(self):
+        """Raises if a device-side failure was recorded since the last call (an aborted NMS scan upstream of the head target
+        maker, or fewer than 128 RoI samples -- where the reference throws, model.py:340).  One host sync: call it at the
+        logging / checkpoint interval.  The same failures turn the step's loss into NaN, so a caller that prints loss.item()
+        sees them even without this call."""
+        self.sampler.status.check()
 
     def _side_stream(self, device):
         st = self._streams.get(device)

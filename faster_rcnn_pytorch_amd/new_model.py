@@ -250,7 +250,8 @@ class FRCNNTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 512:
                 raise RuntimeError("FRCNNTargetMaker: fewer than 512 samples (assert at new_model.py:183)")
         else:
-            cls, reg, srois, _, _ = ops.head_targets(rois, boxes, labels, seed=s.seed, offset=s.next_offset(), **kw)
+            cls, reg, srois, _, _ = ops.head_targets(rois, boxes, labels, seed=s.seed, offset=s.next_offset(),
+                                                     status=s.status.word(rois.device), **kw)
         return cls, reg, srois
 
 
@@ -293,6 +294,11 @@ class FRCNN(nn.Module):
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def check_device_status(self):
+        """As models.model.FRCNN.check_device_status: raises if a device-side failure (aborted NMS scan, fewer than 512 RoI
+        samples -- the reference asserts there, new_model.py:182) was recorded since the last call; one host sync."""
+        self.sampler.status.check()
 
     def forward(self, x, boxes, labels):
         features = self.backbone(x)                                                # new_model.py:394

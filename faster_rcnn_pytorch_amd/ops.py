@@ -401,6 +401,37 @@ def host_count(cnt, what="nms"):
     return n
 
 
+def describe_status(bits):
+    """Names of the _lib.HT_ERR_* bits set in a status word."""
+    names = ((_lib.HT_ERR_PERM_LENGTH, "permutation length mismatch"), (_lib.HT_ERR_PERM_RANGE, "permutation entry out of range"),
+             (_lib.HT_ERR_UPSTREAM_ABORT, "the proposal stage reported an aborted NMS scan (count < 0)"),
+             (_lib.HT_ERR_SHORT, "fewer RoI samples than requested (the reference throws here)"))
+    return [n for b, n in names if bits & b]
+
+
+class DeviceStatus(object):
+    """Sticky device-side error word of one model (one int32 per device): target makers OR their error bits into it without a
+    host sync; `check()` reads it (a sync -- call it where the training loop syncs anyway: logging / checkpoint interval)."""
+
+    def __init__(self):
+        self._words = {}
+
+    def word(self, device):
+        w = self._words.get(device)
+        if w is None:
+            w = torch.zeros((1,), dtype=torch.int32, device=device)
+            self._words[device] = w
+        return w
+
+    def check(self, reset=True):
+        for dev, w in self._words.items():
+            bits = int(w.item())
+            if bits:
+                if reset:
+                    w.zero_()
+                raise _lib.FrcnnError("device status %d on %s since the last check: %s" % (bits, dev, "; ".join(describe_status(bits))))
+
+
 def _perm(p, dev):
     if p is None:
         return None, 0
@@ -428,8 +459,9 @@ def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, of
 
 
 def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max_pos=32, total=128,
-                 perm_pos=None, perm_neg=None, seed=0, offset=0, want_keep=False):
-    """FastRcnnTargetMaker.forward.  Returns (cls[total] i64, reg[total,4], sample_rois[total,4], keep|None, counts int32[4])."""
+                 perm_pos=None, perm_neg=None, seed=0, offset=0, want_keep=False, status=None):
+    """FastRcnnTargetMaker.forward.  Returns (cls[total] i64, reg[total,4], sample_rois[total,4], keep|None, counts int32[4]).
+    counts[3] holds the _lib.HT_ERR_* bits; they are also OR-ed into `status` (device int32[1], sticky across steps) if given."""
     rois = _req(rois, name="rois").reshape(-1, 4)
     gt = _req(gt, name="gt").reshape(-1, 4)
     gt_label = _req(gt_label, torch.int64, "gt_label").reshape(-1)
@@ -443,10 +475,12 @@ def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max
     counts = torch.empty((4,), dtype=torch.int32, device=dev)
     pp, npp = _perm(perm_pos, dev)
     pn, npn = _perm(perm_neg, dev)
+    if status is not None:
+        status = _req(status, torch.int32, "status")
     with torch.cuda.device(dev):
         check(lib.frcnn_head_targets(int(variant), _ptr(rois), _ptr(n_rois), rois.shape[0], _ptr(gt), _ptr(gt_label), gt.shape[0],
                                      int(label_offset), int(max_pos), int(total), _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
-                                     _ptr(cls), _ptr(reg), _ptr(srois), _ptr(keep), _ptr(counts), None, 0, _stream()), "head_targets")
+                                     _ptr(cls), _ptr(reg), _ptr(srois), _ptr(keep), _ptr(counts), _ptr(status), _stream()), "head_targets")
     return cls, reg, srois, keep, counts
 
 
@@ -610,18 +644,45 @@ def ms_roi_align(feats, rois, output_size=7, sampling_ratio=2, scales=(0.25, 0.1
                                float(canonical_scale), int(canonical_level), *feats)
 
 
+def infer_scales_like_torchvision(feat_shapes, image_shapes):
+    """torchvision.ops.poolers: `_setup_scales` / `_infer_scale` as published (>= 0.13):
+        original = (max over images of shape[0], max over images of shape[1])     # torchvision MEANS (h, w)
+        scale_l  = 2 ** round(log2(feat_l.shape[-2] / original[0]))               # only the FIRST axis decides
+    The reference passes image_shapes = [(w, h)] (models/new_model.py:143), so under torchvision the FEATURE
+    HEIGHT is divided by the IMAGE WIDTH: an 800x1344 frame gives 200/1344 -> 2^-3, i.e. levels 1/8 .. 1/64 and k_min = 3
+    instead of 1/4 .. 1/32 and k_min = 2.  Pure host arithmetic on shapes (fp32 log2 / round like torch.tensor(x).log2().round())."""
+    o0 = max(int(sh[0]) for sh in image_shapes)
+    scales = []
+    for fh, _fw in feat_shapes:
+        approx = np.float32(float(fh) / float(o0))
+        scales.append(2.0 ** float(np.round(np.log2(approx))))
+    return tuple(scales)
+
+
 class MultiScaleRoIAlign(torch.nn.Module):
     """torchvision.ops.MultiScaleRoIAlign(featmap_names, output_size, sampling_ratio) with the call convention of
     models/new_model.py:143: forward(features: dict, [rois in image pixels], image_shapes).
-    The per-level scales are explicit (default 1/4 .. 1/32): the reference passes (w, h) where torchvision
-    expects (h, w), so scale inference from image_shapes is deliberately not reproduced."""
+
+    scales=None (default): the per-level scales are the true strides 1/4 .. 1/32 whatever image_shapes says.  The reference
+        passes (w, h) where torchvision expects (h, w), so torchvision's inference from image_shapes picks the
+        WRONG pyramid level scales for non-square frames; the default corrects that.
+    scales='reference': reproduce what the reference actually computes under torchvision, i.e. infer the scales (and with
+        them the level mapper's k_min / k_max) from image_shapes exactly as torchvision does, swapped axes included
+        (`infer_scales_like_torchvision`).  Needed to evaluate checkpoints TRAINED with the reference on non-square frames
+        at the pooling geometry they were trained with.
+    scales=(s0, s1, ...): explicit."""
 
     def __init__(self, featmap_names, output_size, sampling_ratio, scales=None):
         super().__init__()
         self.featmap_names = list(featmap_names)
         self.output_size = output_size
         self.sampling_ratio = sampling_ratio
-        self.scales = tuple(scales) if scales is not None else tuple(2.0 ** -(2 + i) for i in range(len(self.featmap_names)))
+        if isinstance(scales, str):
+            if scales != "reference":
+                raise ValueError("scales must be None, 'reference' or a tuple of floats")
+            self.scales = "reference"
+        else:
+            self.scales = tuple(scales) if scales is not None else tuple(2.0 ** -(2 + i) for i in range(len(self.featmap_names)))
 
     def forward(self, x, boxes, image_shapes=None):
         if isinstance(boxes, (list, tuple)):
@@ -629,16 +690,37 @@ class MultiScaleRoIAlign(torch.nn.Module):
                 raise ValueError("MultiScaleRoIAlign: one image per call (batch 1 per GPU)")
             boxes = boxes[0]
         feats = [x[k] for k in self.featmap_names]
-        return ms_roi_align(feats, boxes, self.output_size, self.sampling_ratio, self.scales)
+        scales = self.scales
+        if scales == "reference":
+            if not image_shapes:
+                raise ValueError("MultiScaleRoIAlign(scales='reference') needs image_shapes (as passed at new_model.py:143)")
+            scales = infer_scales_like_torchvision([tuple(f.shape[-2:]) for f in feats], image_shapes)
+        return ms_roi_align(feats, boxes, self.output_size, self.sampling_ratio, scales)
 
 
 # --------------------------------------------------------------------------------------------
 # AnchorGenerator (models/new_model.py:23-25,46)
 # --------------------------------------------------------------------------------------------
+class ImageList(object):
+    """torchvision.models.detection.image_list.ImageList as the reference builds it at models/new_model.py:46:
+    ImageList(x, [(w, h)]).  AnchorGenerator reads only `.tensors` (strides come from the padded batch tensor's shape),
+    so the swapped (w, h) in `.image_sizes` is harmless there."""
+
+    def __init__(self, tensors, image_sizes):
+        self.tensors = tensors
+        self.image_sizes = image_sizes
+
+    def to(self, device):
+        return ImageList(self.tensors.to(device), self.image_sizes)
+
+
 class AnchorGenerator(torch.nn.Module):
     """torchvision.models.detection.rpn.AnchorGenerator(sizes, aspect_ratios) restricted to what the reference
-    uses: one size per level, a shared ratio tuple.  __call__(image_hw, feature_maps) -> [anchors[N,4] in pixels].
-    Anchors depend only on shapes, so they are cached per (image, feature) shape and stay resident in HBM."""
+    uses: one size per level, a shared ratio tuple.  Called as the reference does (models/new_model.py:46):
+    anchor_generator(ImageList(x, [(w, h)]), features) -> [anchors[N,4] in pixels]; `features` may be the backbone's
+    OrderedDict or a list of maps; an (H, W) pair is accepted in place of the ImageList.
+    Anchors depend only on shapes, so they are cached per (image, feature) shape and stay resident in HBM.  The reference
+    divides the returned tensor IN PLACE by (w, h, w, h) (new_model.py:47): the list therefore holds a clone of the cached grid."""
 
     def __init__(self, sizes=((32,), (64,), (128,), (256,), (512,)), aspect_ratios=((0.5, 1.0, 2.0),) * 5):
         super().__init__()
@@ -662,6 +744,16 @@ class AnchorGenerator(torch.nn.Module):
             self._cache[key] = a
         return a
 
-    def forward(self, image_hw, feature_maps):
+    def forward(self, image_list, feature_maps):
+        if hasattr(feature_maps, "values"):
+            feature_maps = list(feature_maps.values())
+        if hasattr(image_list, "tensors"):                       # ImageList-shaped (torchvision's, or ops.ImageList)
+            t = image_list.tensors
+            image_hw = tuple(t.shape[-2:])
+            sizes = getattr(image_list, "image_sizes", None)
+            n_img = len(sizes) if sizes is not None else (t.shape[0] if t.dim() == 4 else 1)     # one anchor set per image, as torchvision
+        else:
+            image_hw, n_img = tuple(int(v) for v in image_list), 1
         shapes = [tuple(f.shape[-2:]) for f in feature_maps]
-        return [self.grid(image_hw, shapes, feature_maps[0].device)]
+        a = self.grid(image_hw, shapes, feature_maps[0].device)
+        return [a.clone() for _ in range(n_img)]

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 1
+#define FRCNN_ABI_VERSION 2
 
 typedef enum {
     FRCNN_OK = 0,
@@ -168,8 +168,16 @@ int frcnn_rpn_targets(int variant, const float *anchors /*[N,4]*/, int64_t N, co
 /* FastRcnnTargetMaker.forward (models/model_.py:127-179; FPN: models/new_model.py:157-206).
  * rois [P_cap,4] with a device count n_rois_dev (NULL = P_cap rows are live); candidates = cat(rois, gt).
  * variant 0: find_jaccard_overlap(roi, gt) eps 1e-5; 1: box_iou(gt, roi).  label_offset 1 (VGG) / 0 (FPN);
- * max_pos 32 / 128; total 128 / 512.  Rows beyond the number actually sampled (the reference throws in
- * that case) are filled with class 0, zero boxes; out_counts = {#pos cand, #neg cand, rows written, error}. */
+ * max_pos 32 / 128; total 128 / 512.  out_counts = {#pos cand, #neg cand, rows written, error bits}.
+ * Failure is never silent and never needs a host sync: rows beyond the number actually sampled (the reference throws
+ * there, model.py:340 / new_model.py:182) get the out-of-range class -1 and zero boxes, and a NEGATIVE *n_rois_dev (the
+ * proposal stage reporting an aborted NMS scan) marks every row that way; frcnn_detection_loss turns an out-of-range
+ * class into a NaN loss.  The error bits are also OR-ed into *sticky_status (device int32, may be NULL), which the
+ * caller reads whenever it syncs anyway (logging / checkpoint interval). */
+#define FRCNN_HT_ERR_PERM_LENGTH 1      /* perm_pos / perm_neg length != candidate count (parity mode) */
+#define FRCNN_HT_ERR_PERM_RANGE 2       /* a permutation entry is out of range */
+#define FRCNN_HT_ERR_UPSTREAM_ABORT 4   /* *n_rois_dev < 0 */
+#define FRCNN_HT_ERR_SHORT 8            /* fewer than `total` rows could be sampled */
 int frcnn_head_targets(int variant, const float *rois, const int32_t *n_rois_dev, int64_t P_cap,
                        const float *gt, const int64_t *gt_label, int64_t G,
                        int64_t label_offset, int64_t max_pos, int64_t total,
@@ -177,7 +185,7 @@ int frcnn_head_targets(int variant, const float *rois, const int32_t *n_rois_dev
                        uint64_t seed, uint64_t offset,
                        int64_t *out_cls /*[total]*/, float *out_reg /*[total,4]*/, float *out_rois /*[total,4]*/,
                        int64_t *out_keep_index /*[total] or NULL*/, int32_t *out_counts /*[4]*/,
-                       void *workspace, size_t workspace_bytes, void *stream);
+                       int32_t *sticky_status /* device int32 or NULL */, void *stream);
 
 /* ---- RoI pooling ---------------------------------------------------------------------------------- */
 /* torchvision.ops.RoIPool((PH,PW), spatial_scale) forward/backward (models/model.py:97,113); one image,
@@ -238,6 +246,8 @@ int frcnn_prof_reset(void);
 int frcnn_prof_num_kernels(void);
 const char *frcnn_prof_kernel_name(int kernel_id);
 int frcnn_prof_get(int kernel_id, double *total_ms, int64_t *launches);
+/* per-launch durations (ms, launch order) of one kernel since the last reset: copies min(cap, n), returns n. */
+int64_t frcnn_prof_get_samples(int kernel_id, float *out_ms, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -632,14 +632,99 @@ def test_empty_and_degenerate_inputs(ops):
     cls = np.zeros((N, 2), np.float32)
     rois, cnt, _ = ops.region_proposal(T(reg), T(cls), T(anchor), 1 / 1000, 12000, 0.7, 2000)
     assert int(cnt.item()) == 0 and orc.region_proposal(reg, cls, anchor, 1 / 1000, 12000, 0.7, 2000)[0].shape[0] == 0
-    # head targets with zero live proposals: candidates are the GT boxes alone (model_.py:135), rows padded to 128
+    # head targets with zero live proposals: candidates are the GT boxes alone (model_.py:135): 3 rows of 128.  The reference
+    # throws here (model.py:340); the library flags it (SHORT) and marks the unfilled rows with the out-of-range class -1
+    from faster_rcnn_pytorch_amd import _lib
     gt = _gt(np.random.RandomState(0), 3)
     lab = np.array([1, 2, 3], np.int64)
     cls_t, reg_t, srois, keep, counts = ops.head_targets(rois, T(gt), T(lab), n_rois=cnt, seed=1, want_keep=True)
     c = counts.cpu().tolist()
-    assert c[0] == 3 and c[1] == 0 and c[2] == 3 and c[3] == 0
+    assert c[0] == 3 and c[1] == 0 and c[2] == 3 and c[3] == _lib.HT_ERR_SHORT
     k = keep.cpu().numpy()
-    assert sorted(k[:3].tolist()) == [0, 1, 2] and (k[3:] == -1).all() and (cls_t.cpu().numpy()[3:] == 0).all()
+    assert sorted(k[:3].tolist()) == [0, 1, 2] and (k[3:] == -1).all() and (cls_t.cpu().numpy()[3:] == -1).all()
+    assert (cls_t.cpu().numpy()[:3] >= 1).all()
+
+
+def test_upstream_abort_and_short_samples_surface_without_a_sync(ops, golden):
+    """VERDICT r1 #7 / ADVICE r1: a scan abort upstream (device count -1) or fewer than `total` samples must not silently
+    become a GT-only / fake-background step.  Forged counts (no real abort is provoked): error bits in counts[3], sticky
+    status word, class -1 rows, NaN loss, DeviceStatus.check() raises."""
+    from faster_rcnn_pytorch_amd import _lib
+    rng = np.random.RandomState(5)
+    gt = _gt(rng, 3)
+    lab = np.array([4, 5, 6], np.int64)
+    rois = rand_boxes(rng, 2000, 0.05, 0.5)
+    st = ops.DeviceStatus()
+    word = st.word(torch.device(DEV))
+    # 1. healthy call: no bits, word stays clean
+    out = ops.head_targets(T(rois), T(gt), T(lab), n_rois=T(np.array([2000], np.int32)), seed=1, status=word)
+    assert out[4].cpu().tolist()[3] == 0 and int(word.item()) == 0 and (out[0].cpu().numpy() >= 0).all()
+    st.check()
+    # 2. forged upstream abort
+    out = ops.head_targets(T(rois), T(gt), T(lab), n_rois=T(np.array([-1], np.int32)), seed=1, status=word)
+    c = out[4].cpu().tolist()
+    assert c[3] & _lib.HT_ERR_UPSTREAM_ABORT
+    assert (out[0].cpu().numpy() == -1).all()                                 # every row carries the failure mark
+    assert int(word.item()) & _lib.HT_ERR_UPSTREAM_ABORT
+    # ... a later healthy step does not clear the sticky word
+    ops.head_targets(T(rois), T(gt), T(lab), n_rois=T(np.array([2000], np.int32)), seed=2, status=word)
+    assert int(word.item()) & _lib.HT_ERR_UPSTREAM_ABORT
+    with pytest.raises(_lib.FrcnnError, match="aborted NMS scan"):
+        st.check()
+    st.check()                                                                # cleared by the raise
+    # 3. the loss of such a step is NaN (total and head CE), found at the caller's loss.item()
+    g = golden("loss")
+    pred = tuple(T(g[k]) for k in ("p_rpn_cls", "p_rpn_reg", "p_head_cls", "p_head_reg"))
+    tgt = [T(g[k]) for k in ("t_rpn_cls", "t_rpn_reg", "t_head_cls", "t_head_reg")]
+    ok = ops.detection_loss(pred, tgt)
+    assert all(np.isfinite(float(v)) for v in ok)
+    tgt[2] = torch.full_like(tgt[2], -1)
+    bad = ops.detection_loss(pred, tgt)
+    assert np.isnan(float(bad[0])) and np.isnan(float(bad[3])) and np.isfinite(float(bad[1]))
+    tgt[2] = T(g["t_head_cls"]).clone()
+    tgt[2][7] = 21                                                            # one row out of range (NC = 21) is enough
+    assert np.isnan(float(ops.detection_loss(pred, tgt)[0]))
+    # 4. fewer candidates than `total`: P + G < 128
+    out = ops.head_targets(T(rois[:40]), T(gt), T(lab), seed=1, status=word, want_keep=True)
+    c = out[4].cpu().tolist()
+    assert c[3] == _lib.HT_ERR_SHORT and c[2] == c[0] + c[1] < 128
+    cls = out[0].cpu().numpy()
+    assert (cls[:c[2]] >= 0).all() and (cls[c[2]:] == -1).all()
+    with pytest.raises(_lib.FrcnnError, match="fewer RoI samples"):
+        st.check()
+
+
+def test_anchor_generator_call_convention_of_the_reference(ops):
+    """models/new_model.py:46-47: anchor = self.anchor_generator(ImageList(x, [(w, h)]), features)[0]; anchor /= (w, h, w, h)."""
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    feats = {str(i): torch.zeros(1, 2, fh, fw, device=DEV) for i, (fh, fw) in enumerate(shapes)}
+    x = torch.zeros(1, 3, 800, 1344, device=DEV)
+    ag = ops.AnchorGenerator()
+    a = ag(ops.ImageList(x, [(1344, 800)]), feats)[0]
+    want = orc.tv_anchor_grid(800, 1344, shapes, normalise=False)
+    assert np.array_equal(a.cpu().numpy(), want)
+    a /= torch.tensor([1344, 800, 1344, 800], dtype=torch.float32, device=DEV)      # the reference's in-place normalisation
+    assert np.array_equal(a.cpu().numpy(), orc.tv_anchor_grid(800, 1344, shapes, normalise=True))
+    # ... must not have touched the cached grid: a second call still returns pixels
+    assert np.array_equal(ag(ops.ImageList(x, [(1344, 800)]), list(feats.values()))[0].cpu().numpy(), want)
+    assert np.array_equal(ag((800, 1344), list(feats.values()))[0].cpu().numpy(), want)
+
+
+def test_ms_roi_align_reference_scale_mode(ops):
+    """scales='reference' = torchvision's scale inference fed with the reference's swapped [(w, h)] (new_model.py:143): on an
+    800x1344 frame the four maps are pooled at 1/8 .. 1/64 with level mapper k_min 3."""
+    rng = np.random.RandomState(3)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    feats = [rng.randn(1, 8, fh, fw).astype(np.float32) for fh, fw in shapes]
+    fd = {str(i): T(f) for i, f in enumerate(feats)}
+    rois = rand_boxes(rng, 64, 0.03, 0.9) * np.array([1344, 800, 1344, 800], np.float32)
+    got = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2, scales="reference")(fd, [T(rois)], [(1344, 800)]).cpu().numpy()
+    sc = (1 / 8, 1 / 16, 1 / 32, 1 / 64)
+    want, lv = orc.ms_roi_align([f[0] for f in feats], rois, scales=sc)
+    assert len(np.unique(lv)) >= 3
+    assert np.abs(got - want).max() < 1e-5
+    dflt = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)(fd, [T(rois)], [(1344, 800)]).cpu().numpy()
+    assert np.abs(dflt - got).max() > 1e-3                                   # the two conventions really differ on this frame
 
 
 def test_nms_all_identical_boxes_and_single_survivor(ops):

@@ -89,3 +89,39 @@ def test_ddp_gloo_world2_gradient_average_and_timing_rule():
         model(xs[list(range(r, 4, 2))]).pow(2).mean().backward()
         gs.append(model[0].weight.grad.clone())
     assert np.allclose(res[0][1], ((gs[0] + gs[1]) / 2).numpy(), atol=1e-6)
+
+
+def test_torchvision_scale_inference_with_the_references_swapped_shapes():
+    """models/new_model.py:143 passes image_shapes=[(w, h)] where torchvision's pooler reads (h, w): under
+    torchvision the FEATURE HEIGHT is divided by the IMAGE WIDTH.  ops.MultiScaleRoIAlign(scales='reference') reproduces that."""
+    from faster_rcnn_pytorch_amd import ops
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    # landscape COCO frame 800 x 1344 as the reference passes it: [(w, h)] = [(1344, 800)] -> 200/1344 = 0.149 -> 2^-3
+    assert ops.infer_scales_like_torchvision(shapes, [(1344, 800)]) == (1 / 8, 1 / 16, 1 / 32, 1 / 64)
+    # the same frame with the axes the way torchvision means them: the true strides
+    assert ops.infer_scales_like_torchvision(shapes, [(800, 1344)]) == (1 / 4, 1 / 8, 1 / 16, 1 / 32)
+    # square frames are unaffected by the swap
+    sq = [(200, 200), (100, 100), (50, 50), (25, 25)]
+    assert ops.infer_scales_like_torchvision(sq, [(800, 800)]) == (1 / 4, 1 / 8, 1 / 16, 1 / 32)
+    # portrait 1344 x 800 passed as (w, h) = (800, 1344): 336/800 = 0.42 -> 2^-1
+    pt = [(336, 200), (168, 100), (84, 50), (42, 25)]
+    assert ops.infer_scales_like_torchvision(pt, [(800, 1344)]) == (1 / 2, 1 / 4, 1 / 8, 1 / 16)
+    m = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    assert m.scales == (1 / 4, 1 / 8, 1 / 16, 1 / 32)
+    assert ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2, scales="reference").scales == "reference"
+    with pytest.raises(ValueError):
+        ops.MultiScaleRoIAlign(["0"], 7, 2, scales="torchvision")
+
+
+def test_device_status_names():
+    from faster_rcnn_pytorch_amd import _lib, ops
+    assert ops.describe_status(0) == []
+    names = ops.describe_status(_lib.HT_ERR_UPSTREAM_ABORT | _lib.HT_ERR_SHORT)
+    assert len(names) == 2 and "aborted NMS scan" in names[0] and "fewer RoI samples" in names[1]
+    st = ops.DeviceStatus()
+    w = st.word(torch.device("cpu"))
+    st.check()                                                             # clean: no raise
+    w |= _lib.HT_ERR_UPSTREAM_ABORT
+    with pytest.raises(_lib.FrcnnError, match="aborted NMS scan"):
+        st.check()
+    st.check()                                                             # check() cleared the word
