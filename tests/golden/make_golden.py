@@ -152,7 +152,72 @@ def main():
                         p_rpn_cls=p_rc.numpy(), p_rpn_reg=p_rr.numpy(), p_head_cls=p_hc.numpy(), p_head_reg=p_hr.numpy(),
                         t_rpn_cls=t_rc.numpy(), t_rpn_reg=t_rr.numpy(), t_head_cls=t_hc.numpy(), t_head_reg=t_hr.numpy(),
                         losses=np.array([float(o) for o in out], dtype=np.float32))
+    make_full_size_proposal_goldens(am)
     print("golden vectors written to", OUT)
+
+
+# ---- FULL-SIZE pre-NMS proposal bodies (VERDICT r1 "next" 1a): models/model_.py:19-49 at 600x1000 (N = 20 646,
+#      K = 12 000) and models/new_model.py:49-76 at 800x1344 (N = 268 569, K = 4 000), executed with the REFERENCE's own
+#      decode / xy_to_cxcy / cxcy_to_xy + torch.softmax / clamp / sort, in both synthetic RPN-output regimes of SURVEY 8d.
+#      Inputs are not stored: tests regenerate them from the seed (torch CPU generator) and check their sha256.
+FULL_CASES = [
+    # name, (H, W), seed, regime, K, min_size (model_.py:15 -> 1; new_model.py:21 -> 10)
+    ("V_init", (600, 1000), 101, "init", 12000, 1),
+    ("V_trained", (600, 1000), 102, "trained", 12000, 1),
+    ("V_trained_test", (600, 1000), 105, "trained", 6000, 1),
+    ("F_init", (800, 1344), 104, "init", 4000, 10),
+    ("F_trained", (800, 1344), 103, "trained", 4000, 10),
+]
+FPN_SHAPES = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+
+
+def full_case_inputs(seed, regime, N):
+    """SURVEY 8d regimes.  init: what normal_init(., 0.01) heads produce; trained: fg-bg logit ~ N(-2, 2), deltas N(0, .1/.2)."""
+    g = torch.Generator().manual_seed(seed)
+    if regime == "init":
+        reg = torch.randn(N, 4, generator=g) * 0.02
+        cls = torch.randn(N, 2, generator=g) * 0.02
+    else:
+        reg = torch.randn(N, 4, generator=g) * torch.tensor([0.1, 0.1, 0.2, 0.2])
+        d = torch.randn(N, generator=g) * 2 - 2
+        cls = torch.stack([torch.zeros(N), d], 1)
+    return reg.contiguous(), cls.contiguous()
+
+
+def make_full_size_proposal_goldens(am):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from oracle import oracle as orc      # ONLY for the FPN anchor grid: torchvision's AnchorGenerator is not importable
+    d = {}
+    for name, (H, W), seed, regime, K, min_size in FULL_CASES:
+        if name.startswith("V"):
+            anchor = torch.from_numpy(am._enumerate_shifted_anchor((H, W)))                 # anchor.py:34-55 (reference)
+        else:
+            anchor = torch.from_numpy(orc.tv_anchor_grid(H, W, FPN_SHAPES, normalise=True))  # input of this fixture, not pinned by it
+        N = anchor.shape[0]
+        reg, cls = full_case_inputs(seed, regime, N)
+        score = torch.softmax(cls, dim=-1)[..., 1]                                          # model_.py:20
+        roi = cxcy_to_xy(decode(reg, xy_to_cxcy(anchor))).clamp(0, 1)                       # model_.py:31-33
+        ws = roi[:, 2] - roi[:, 0]
+        hs = roi[:, 3] - roi[:, 1]
+        keep = (hs >= (min_size / 1000)) & (ws >= (min_size / 1000))                        # model_.py:36-38
+        roi_k, sc_k = roi[keep], score[keep]
+        ssc, sidx = sc_k.sort(descending=True)                                              # model_.py:44 (unstable; ties: see tests)
+        k = min(K, len(sidx))
+        orig_idx = torch.arange(N)[keep][sidx[:k]]
+        d[name + "_meta"] = np.array([H, W, seed, K, min_size, N, int(keep.sum()), k], np.int64)
+        d[name + "_regime"] = np.array(regime)
+        d[name + "_sha_reg"] = np.array(sha(reg.numpy()))
+        d[name + "_sha_cls"] = np.array(sha(cls.numpy()))
+        d[name + "_sha_anchor"] = np.array(sha(anchor.numpy()))
+        d[name + "_sha_keep"] = np.array(sha(keep.numpy()))
+        d[name + "_top_idx"] = orig_idx.numpy().astype(np.int32)
+        d[name + "_top_score"] = ssc[:k].numpy()
+        d[name + "_top_roi_s16"] = roi_k[sidx[:k]][::16].numpy()
+        d[name + "_roi_all_s101"] = roi[::101].numpy()
+        d[name + "_score_all_s101"] = score[::101].numpy()
+        d[name + "_n_distinct_top_scores"] = np.array(int(torch.unique(ssc[:k]).numel()))
+        print(name, "N", N, "kept", int(keep.sum()), "k", k, "distinct top scores", int(torch.unique(ssc[:k]).numel()))
+    np.savez_compressed(os.path.join(OUT, "proposal_full.npz"), **d)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,92 @@
+"""Full-size index parity with the REFERENCE (VERDICT r1 "next" 1a/1b): the pre-NMS body of RegionProposal.forward
+(models/model_.py:19-49 at 600x1000, N = 20 646, K = 12 000 / 6 000; models/new_model.py:49-76 at 800x1344, N = 268 569,
+K = 4 000) was executed with the reference's own functions by tests/golden/make_golden.py; here the CPU oracle (not gpu) and
+the HIP kernels (gpu) run on the same regenerated inputs and the number of top-K positions that differ is REPORTED
+(printed, and written to gpurun_out/parity_index_report.json on the GPU box) and bounded:
+    other          == 0     a differing position whose two candidates are neither an exact nor a near tie in the reference's scores
+    near_tie       <= 32    swaps of scores within 4e-7 (last-bit differences between torch's exp and the deterministic exp)
+    set_difference <= 8     members of the top-K set that differ (only possible through a near tie at the K boundary)
+    exact_tie      any      the reference's torch.sort is unstable: its order inside a run of equal scores is arbitrary
+Measured in the build container (oracle): V_init 289 differing = 279 exact + 10 near; V_trained 6 = 2 + 4; V_trained_test 6 = 6 + 0;
+F_init 102 = 100 + 2; F_trained 10 = 10 + 0; other = 0 and set_difference = 0 everywhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import full_cases as fc
+from oracle import oracle as orc
+
+NEAR_CAP, SET_CAP = 32, 8
+
+
+def _anchors(g, name, m):
+    a = orc.anchor_grid(m["H"], m["W"]) if name.startswith("V") else orc.tv_anchor_grid(m["H"], m["W"], fc.FPN_SHAPES, normalise=True)
+    assert fc.sha(a) == str(g[name + "_sha_anchor"])
+    return a
+
+
+def _check(g, name, m, boxes, scores, n_valid, idx, top_scores, top_boxes, cls):
+    # element-wise stage outputs vs the reference run (fp32 tolerance of the north star is 1e-4; measured 1.2e-7)
+    assert n_valid == m["n_keep"]
+    assert fc.sha(scores >= 0) == str(g[name + "_sha_keep"])                          # min-size filter: identical keep mask
+    assert np.abs(boxes[::101] - g[name + "_roi_all_s101"]).max() < 1e-6
+    live = scores[::101] >= 0
+    assert np.abs(scores[::101][live] - g[name + "_score_all_s101"][live]).max() < 2e-7
+    assert np.abs(top_scores - g[name + "_top_score"]).max() < 2e-7
+    rep = fc.index_parity_report(g[name + "_top_idx"], idx, fc.reference_scores(g, name, cls))
+    rep["case"] = name
+    print("\nindex parity vs reference:", json.dumps(rep))
+    assert rep["other"] == 0, rep
+    assert rep["near_tie"] <= NEAR_CAP and rep["set_difference"] <= SET_CAP, rep
+    if top_boxes is not None:                                                          # gathered boxes of the agreeing positions
+        same16 = (np.asarray(idx) == g[name + "_top_idx"])[::16]
+        assert np.abs(top_boxes[::16][same16] - g[name + "_top_roi_s16"][same16]).max() < 1e-6
+    return rep
+
+
+@pytest.mark.parametrize("name", fc.CASES)
+def test_oracle_full_size_index_parity_with_reference(golden, name):
+    g = golden("proposal_full")
+    m = fc.meta(g, name)
+    reg, cls = fc.inputs(g, name)
+    anchor = _anchors(g, name, m)
+    boxes, scores, nv = orc.proposal_prologue(reg, cls, anchor, m["min_size"] / 1000)
+    idx, sc = orc.topk_sorted(scores, m["K"])
+    _check(g, name, m, boxes, scores, nv, idx, sc, boxes[idx], cls)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", fc.CASES)
+def test_hip_full_size_index_parity_with_reference(golden, name):
+    import torch
+    from faster_rcnn_pytorch_amd import ops
+    g = golden("proposal_full")
+    m = fc.meta(g, name)
+    reg, cls = fc.inputs(g, name)
+    anchor = _anchors(g, name, m)
+    dev = "cuda:0"
+    boxes, scores = ops.proposal_prologue(torch.from_numpy(reg).to(dev), torch.from_numpy(cls).to(dev), torch.from_numpy(anchor).to(dev),
+                                          m["min_size"] / 1000)
+    idx, ssc, sbx, cnt = ops.topk_sorted(scores, m["K"], boxes)
+    assert int(cnt.item()) == m["k"]
+    sc_h = scores.cpu().numpy()
+    rep = _check(g, name, m, boxes.cpu().numpy(), sc_h, int((sc_h >= 0).sum()), idx.cpu().numpy(), ssc.cpu().numpy(), sbx.cpu().numpy(), cls)
+    # HIP == oracle bit for bit on the same inputs (the build's own determinism claim), at full size
+    bo, so, _ = orc.proposal_prologue(reg, cls, anchor, m["min_size"] / 1000)
+    io, _ = orc.topk_sorted(so, m["K"])
+    assert np.array_equal(boxes.cpu().numpy(), bo) and np.array_equal(sc_h, so) and np.array_equal(idx.cpu().numpy(), io)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "parity_index_report.json")
+        allr = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                allr = json.load(f)
+        allr[name] = rep
+        with open(path, "w") as f:
+            json.dump(allr, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
