@@ -1,18 +1,24 @@
 #!/usr/bin/env python
-"""bench.py -- BASELINE.json's metric on its config[1]/[2]: training images/sec of VGG16 Faster R-CNN on
-synthetic 600x1000 frames, batch 1 per GPU, the proposal / RoI-head path on the hand-written HIP kernels.
+"""bench.py -- BASELINE.json's metric: training images/sec of Faster R-CNN on synthetic frames, batch 1 per GPU, the
+proposal / RoI-head path on the hand-written HIP kernels.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                          # configs[1]: VGG16, 600x1000, 1 GPU (the headline configuration)
+    python bench.py --config fpn             # configs[3]: ResNet-50-FPN, 800x1344 (COCO shape padded to /32), fp32
+    python bench.py --config fpn --amp bf16  # configs[4]: bf16 autocast on the torch layers + bf16 MFMA RPN head, fp32 box path
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = forward (backbone -> RPN -> proposals -> targets -> RoIPool -> head) + loss + backward + SGD on one
+One step = forward (backbone -> RPN -> proposals -> targets -> RoIPool / RoIAlign -> head) + loss + backward + SGD on one
 frame per GPU.  Frames and boxes are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
-`roofline` describes the dominant hand-written kernel of the hot path, timed live with HIP events on the launch
-stream (libfrcnn_hip's frcnn_prof_* facility) inside the timed region; `cpu_baseline` is the oracle's CPU
-restatement of the same training step (oracle/model_ref.py) on a bounded number of steps.
+  roofline     : the hand-written kernel with the largest average launch time in the timed region, timed live with HIP events
+                 on its launch stream (libfrcnn_hip's frcnn_prof_* facility); `bound` says what actually bounds it ("latency" for
+                 the single-workgroup sequential kernels, "valu" for the pair-IoU / rank kernels whose compulsory bytes are
+                 negligible, "hbm" for the streaming ones); `hbm_kernel` is the largest HBM-bound kernel beside it.
+  cpu_baseline : the oracle's CPU restatement of the same training step (oracle/model_ref.py) on a bounded number of steps.
+  hot_path     : per-kernel mean / median / p10 / p90 launch time, bytes, GB/s, PMC traffic.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -23,25 +29,49 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-H, W = 600, 1000                      # BASELINE.json configs[1]
-NUM_CLASSES = 21                      # VOC: 20 + background (models/model.py:141)
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9        # wave64 VALU issue: lanes per second, one op each (MI355X_MICROARCH.md)
-HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+# MI355X_MICROARCH.md:53-54,473: 256 CUs x 4 SIMDs, each SIMD a 32-lane fp32 datapath (a wave64 v_fma_f32 issues in 2 cycles),
+# 2.4 GHz -> 256 * 4 * 32 * 2.4e9 = 78.6 T lane-ops/s (= the 157.3 TFLOP/s fp32 vector peak / 2 flops per FMA).
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E spec (6.29 TB/s measured copy ceiling)
+
+CONFIGS = {
+    "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
+                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62),
+                metric="train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)",
+                workload="VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
+                         "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)"),
+    "fpn": dict(H=800, W=1344, num_classes=91, label_lo=1, label_hi=91,          # raw COCO ids 1..90
+                shape=dict(N=268569, K=4000, P=1000, R=512, C=256, G=8,
+                           feat_bytes=4 * 256 * (200 * 336 + 100 * 168 + 50 * 84 + 25 * 42), A=3,
+                           P_head=200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21),
+                metric="train images/sec (ResNet-50-FPN Faster R-CNN, 800x1344, bs=1/GPU)",
+                workload="ResNet-50-FPN Faster R-CNN train step, synthetic 800x1344 frames (COCO 800x1333 padded to /32), bs=1/GPU, "
+                         "HIP proposal/RoI path (N=268569 anchors over 5 levels, pre/post NMS 4000/1000, 512 RoIs, "
+                         "MultiScaleRoIAlign 7x7 on 256 x {200x336,100x168,50x84,25x42})"),
+}
+
+# what bounds each hand-written kernel
+BOUND = {"nms_scan_flow_kernel": "latency", "nms_scan_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
+         "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency", "topk_scatter_kernel": "latency",
+         "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
+         "nms_mask_kernel": "valu", "topk_rank_kernel": "valu",
+         "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
+         "rpn_conv3x3_kernel": "mfma"}
 
 
-def synth_frame(rank, step):
-    """x ~ randn(1,3,600,1000); G ~ U{1..8}; centres U(.15,.85)^2, sides U(.08,.6); labels U{0..19}."""
+def synth_frame(cfg, rank, step):
+    """x ~ randn(1,3,H,W); G ~ U{1..8}; centres U(.15,.85)^2, sides U(.08,.6); labels uniform over the classes."""
     g = torch.Generator().manual_seed(1000 + rank * 10 ** 6 + step)
-    x = torch.randn(1, 3, H, W, generator=g)
+    x = torch.randn(1, 3, cfg["H"], cfg["W"], generator=g)
     G = int(torch.randint(1, 9, (1,), generator=g))
     c = torch.rand(G, 2, generator=g) * 0.7 + 0.15
     wh = torch.rand(G, 2, generator=g) * 0.52 + 0.08
     boxes = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1)
-    labels = torch.randint(0, 20, (G,), generator=g)
+    labels = torch.randint(cfg["label_lo"], cfg["label_hi"], (G,), generator=g)
     return x, boxes, labels
 
 
-def algorithmic_bytes(kernel, N, K, P, R, C, fh, fw, G):
+def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels')."""
     nblk = (K + 63) // 64
     return {
@@ -49,15 +79,27 @@ def algorithmic_bytes(kernel, N, K, P, R, C, fh, fw, G):
         "topk_rank_kernel": 4 * N,                                        # scores in (partials are workspace traffic)
         "topk_scatter_kernel": 4 * N + 16 * N + 28 * K,                   # scores + boxes in, idx/score/box out
         "nms_mask_kernel": 16 * K + 8 * K * nblk // 2,                    # boxes in + upper-triangle mask out
-        "nms_scan_kernel": 16 * K + 8 * P + 16 * P,                       # compulsory: boxes in, keep + rois out
+        "nms_scan_flow_kernel": 16 * K + 8 * P + 16 * P,                  # compulsory: boxes in, keep + rois out
+        "nms_scan_kernel": 16 * K + 8 * P + 16 * P,
         "rpn_colmax_kernel": 16 * (N + G),
         "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
         "rpn_sample_kernel": 9 * N,
         "head_targets_kernel": 16 * (P + G) + 44 * R,
-        "roi_pool_fwd_kernel": 4 * C * fh * fw + 16 * R + 8 * R * C * 49,  # features + rois in, out + argmax out
-        "roi_pool_bwd_kernel": 8 * R * C * 49 + 4 * C * fh * fw,           # grad_out + argmax in, grad_feat out
-        "rpn_head_tail_kernel": 4 * C * fh * fw + 4 * 54 * C + 4 * 54 * fh * fw,   # conv output + weights in, cls + reg out
+        "roi_pool_fwd_kernel": feat_bytes + 16 * R + 8 * R * C * 49,      # features + rois in, out + argmax out
+        "roi_pool_bwd_kernel": 8 * R * C * 49 + feat_bytes,               # grad_out + argmax in, grad_feat out
+        "roi_align_fwd_kernel": 4 * R * C * 49 + feat_bytes,              # out + (at most) the four pooled levels in
+        "roi_align_bwd_kernel": 4 * R * C * 49 + feat_bytes,              # grad_out in + every gradient pixel written once
+        "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
     }.get(kernel)
+
+
+def percentiles(v):
+    v = sorted(v)
+    n = len(v)
+    if n == 0:
+        return None, None, None
+    q = lambda f: v[min(n - 1, max(0, int(round(f * (n - 1)))))]      # noqa: E731
+    return q(0.5), q(0.1), q(0.9)
 
 
 T0 = time.perf_counter()
@@ -68,9 +110,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--config", default="vgg", choices=sorted(CONFIGS), help="vgg = BASELINE configs[1]/[2] (headline); fpn = configs[3]/[4]")
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
     ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
@@ -79,10 +122,10 @@ def main():
     ap.add_argument("--amp", default="none", choices=["none", "bf16"],
                     help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     from faster_rcnn_pytorch_amd import _lib, parallel
     from faster_rcnn_pytorch_amd.loss import FRCNNLoss
-    from faster_rcnn_pytorch_amd.model import FRCNN
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
@@ -96,17 +139,22 @@ def main():
             print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
 
     torch.manual_seed(0)
-    model = FRCNN(num_classes=NUM_CLASSES, sampling="device", seed=1234 + rank).to(device)
+    if args.config == "vgg":
+        from faster_rcnn_pytorch_amd.model import FRCNN
+    else:
+        from faster_rcnn_pytorch_amd.new_model import FRCNN
+    model = FRCNN(num_classes=cfg["num_classes"], sampling="device", seed=1234 + rank).to(device)
     if args.channels_last:
-        model.extractor = model.extractor.to(memory_format=torch.channels_last)
+        bb = "extractor" if args.config == "vgg" else "backbone"
+        setattr(model, bb, getattr(model, bb).to(memory_format=torch.channels_last))
     net = parallel.wrap_ddp(model, device)
     crit = FRCNNLoss(None)
-    opt = torch.optim.SGD(net.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4,        # main.py:55-60
+    opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=args.lr, momentum=0.9, weight_decay=1e-4,   # main.py:55-60
                           fused=not args.no_fused_sgd)   # same update rule, one multi-tensor kernel
 
     frames = []
     for i in range(args.frames):
-        x, b, l = synth_frame(rank, i)
+        x, b, l = synth_frame(cfg, rank, i)
         x = x.to(device)
         if args.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
@@ -129,7 +177,7 @@ def main():
 
     # Initialisation pass, outside the W / K accounting: the first steps of a process select and compile MIOpen kernels, grow the
     # caching allocator and the library workspaces (seconds, not steady state).  The W warm-up steps below then run warm.
-    log("model + %d frames resident; initialisation pass" % len(frames))
+    log("%s model + %d frames resident; initialisation pass" % (args.config, len(frames)))
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
@@ -141,37 +189,48 @@ def main():
     if not args.no_kernel_events:
         _lib.prof_reset()
         _lib.prof_enable(True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the main stream (no sync)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        marks[i].record()
         loss = step(args.warmup + i)
+    marks[args.steps].record()
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     _lib.prof_enable(False)
-    dt = parallel.max_over_ranks(dt, device)
+    dt = parallel.max_over_ranks(dt_local, device)
+    per_rank_ms = [round(v / args.steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
     final_loss = float(loss.detach())
-    kernels = {} if args.no_kernel_events else _lib.prof_report()
+    model.check_device_status()                      # sticky device-side error word (aborted scan / short sample): raises if set
+    samples = {} if args.no_kernel_events else _lib.prof_samples()
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    backend = torch.distributed.get_backend() if world > 1 else None
+    world_seen = torch.distributed.get_world_size() if world > 1 else 1
 
     if rank != 0:
         parallel.shutdown()
         return
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
-    N = (H // 16) * (W // 16) * 9
-    fh, fw = H // 16, W // 16
-    shape = dict(N=N, K=12000, P=2000, R=128, C=512, fh=fh, fw=fw, G=8)
-    # HBM traffic per launch from the rocprofv3 PMC passes (tools/pmc_traffic.sh; separate FETCH_SIZE / WRITE_SIZE runs,
-    # gfx950 fetch correction): measured once per round on the same shapes and committed under profiles/
-    pmc = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hotpath_pmc_traffic.json")) as f:
-            pmc = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        pmc = {}
+    shape = cfg["shape"]
+    # HBM traffic per launch from the rocprofv3 PMC passes over THIS command (tools/pmc_traffic.sh: separate FETCH_SIZE /
+    # WRITE_SIZE runs of bench.py itself, gfx950 fetch correction); measured per round and committed under profiles/
+    pmc, pmc_src = {}, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.config)))
+    if not cands and args.config == "vgg":
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_hotpath_pmc_traffic.json")))
+    if cands:
+        try:
+            with open(cands[-1]) as f:
+                pmc = json.load(f)["kernels"]
+            pmc_src = os.path.relpath(cands[-1], ROOT)
+        except (OSError, ValueError, KeyError):
+            pmc = {}
 
     def pmc_traffic(name):
         stem = name[:-len("_kernel")] if name.endswith("_kernel") else name
@@ -180,72 +239,101 @@ def main():
                 return v["traffic_bytes"]
         return None
     # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
-    # peak (256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T lane-ops/s): pair IoUs x ~21 VALU ops, rank compares x 2
-    valu_ops = {"nms_mask_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21, "topk_rank_kernel": shape["N"] * shape["N"] * 2}
+    # peak (VALU_PEAK_LANE_OPS above): pair IoUs x ~21 VALU ops (counted in the ISA), rank compares x 2
+    valu_ops = {"nms_mask_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
+    if args.config == "vgg":
+        valu_ops["topk_rank_kernel"] = None          # depends on the path taken (full rank sort vs radix pre-filter): see DESIGN.md
     per_kernel = {}
-    for name, (ms, n) in kernels.items():
-        us = ms / n * 1e3
+    for name, v in samples.items():
+        n = len(v)
+        us = sum(v) / n * 1e3
+        med, p10, p90 = (x * 1e3 for x in percentiles(v))
         ab = algorithmic_bytes(name, **shape)
-        per_kernel[name] = {"avg_us": round(us, 2), "launches": n, "algorithmic_bytes": ab,
-                            "GB_s": round(ab / us * 1e-3, 2) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
-        if name in valu_ops:
+        per_kernel[name] = {"bound": BOUND.get(name, "latency"), "avg_us": round(us, 2), "median_us": round(med, 2), "p10_us": round(p10, 2),
+                            "p90_us": round(p90, 2), "launches": n, "us_per_img": round(sum(v) * 1e3 / args.steps, 2),
+                            "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
+                            "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+        if valu_ops.get(name):
             per_kernel[name]["valu_lane_ops"] = valu_ops[name]
-            per_kernel[name]["valu_frac_of_39.3T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
+            per_kernel[name]["valu_frac_of_78.6T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
         if name == "nms_mask_kernel":
             per_kernel[name]["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (us * 1e-6), 0)
+
+    def roofline_of(name):
+        d = per_kernel[name]
+        return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
     roofline = None
     if per_kernel:
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
-        d = per_kernel[dom]
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(d["GB_s"] / HBM_PEAK_GBS, 5) if d["GB_s"] else None, "traffic": pmc_traffic(dom),
-                    "traffic_source": "profiles/r01_hotpath_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                    "avg_launch_us": d["avg_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
-    hot_us = sum(v["avg_us"] for v in per_kernel.values())
+        roofline = roofline_of(dom)
+        roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
+        if roofline["bound"] != "hbm":
+            roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
+                                "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
+        hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm"]
+        if hbm:
+            roofline["hbm_kernel"] = roofline_of(max(hbm, key=lambda k: per_kernel[k]["avg_us"]))
+    hot_us = sum(v["us_per_img"] for v in per_kernel.values())
+    smed, sp10, sp90 = percentiles(step_ms)
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline(args.cpu_steps, args.lr)
+        cpu = cpu_baseline(args.config, cfg, args.cpu_steps, args.lr)
 
+    P = shape["P"]
     out = {
-        "metric": "train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)", "value": round(value, 3), "unit": "images/s",
+        "metric": cfg["metric"], "value": round(value, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.amp == "none" else "bf16(torch layers)+f32(hot path)", "data": "synthetic",
-        "config": {"workload": "VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
-                               "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)",
-                   "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * 2000, 1),
+        "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3),
+                    "source": "HIP events at the step boundaries on the main stream (rank 0)"},
+        "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
+                        "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms)},
+        "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * P, 1),
                      # BASELINE.json's second figure: NMS (mask + scan) + RoI pooling forward/backward, HIP-event us per image
-                     "nms_plus_roi_us_per_img": round(sum(v["avg_us"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
+                     "nms_plus_roi_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
                      # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
-                     "proposal_stage_us_per_img": round(sum(v["avg_us"] for k, v in per_kernel.items()
+                     "proposal_stage_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items()
                                                             if k.startswith(("proposal_prologue", "topk_", "nms_"))), 1),
                      "kernels": per_kernel},
-        "final_loss": round(final_loss, 4),
+        "final_loss": round(final_loss, 4), "device_status": 0,
     }
     st = out["hot_path"]["proposal_stage_us_per_img"]
-    out["hot_path"]["proposal_stage_proposals_per_s"] = round(2000 / (st * 1e-6), 0) if st else None
+    out["hot_path"]["proposal_stage_proposals_per_s"] = round(P / (st * 1e-6), 0) if st else None
     print(json.dumps(out), flush=True)
     parallel.shutdown()
 
 
-def cpu_baseline(steps, lr):
+def cpu_baseline(config, cfg, steps, lr):
     """The oracle's CPU restatement of the same training step (kind 'port'), bounded sample."""
     from oracle import oracle as orc
-    from oracle.model_ref import RefFRCNN, ref_loss
+    from oracle import model_ref
     orc.build()
     torch.manual_seed(0)
-    ref = RefFRCNN(NUM_CLASSES)
-    for m in ref.modules():
-        if isinstance(m, torch.nn.Conv2d):
-            torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-            torch.nn.init.zeros_(m.bias)
-    for m in (ref.rpn.inter_layer, ref.rpn.cls_layer, ref.rpn.reg_layer):
+    if config == "vgg":
+        ref = model_ref.RefFRCNN(cfg["num_classes"])
+        heads = (ref.rpn.inter_layer, ref.rpn.cls_layer, ref.rpn.reg_layer)
+        steps = 8 if steps is None else steps
+    else:
+        from faster_rcnn_pytorch_amd.new_model import BackboneWithFPN      # the backbone is plain torch on both sides
+        ref = model_ref.RefFRCNNFPN(BackboneWithFPN(trainable_layers=3), cfg["num_classes"])
+        heads = (ref.rpn_head.inter_layer, ref.rpn_head.cls_layer, ref.rpn_head.reg_layer)
+        steps = 4 if steps is None else steps
+    if config == "vgg":
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                torch.nn.init.zeros_(m.bias)
+    for m in heads:
         m.weight.data.normal_(0, 0.01)
         m.bias.data.zero_()
-    opt = torch.optim.SGD(ref.parameters(), lr=lr, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD([p for p in ref.parameters() if p.requires_grad], lr=lr, momentum=0.9, weight_decay=1e-4)
     # the GPU box gives one GPU's share of the host: 16 cores; more threads than that oversubscribes the cgroup
     try:
         avail = len(os.sched_getaffinity(0))
@@ -256,9 +344,9 @@ def cpu_baseline(steps, lr):
     print("[bench] cpu baseline on %d threads (affinity %d, cpu_count %s)" % (cores, avail, os.cpu_count()), file=sys.stderr, flush=True)
 
     def one(i):
-        x, b, l = synth_frame(0, i)
+        x, b, l = synth_frame(cfg, 0, i)
         pred, target = ref(x, [b], [l])
-        loss = ref_loss(pred, target)[0]
+        loss = model_ref.ref_loss(pred, target)[0]
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -269,9 +357,10 @@ def cpu_baseline(steps, lr):
         one(1 + i)
         print("[bench] cpu baseline step %d done (%.1f s)" % (i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
+    name = "RefFRCNN" if config == "vgg" else "RefFRCNNFPN"
     return {"value": round(steps / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d full training steps (fwd+loss+bwd+SGD) of oracle/model_ref.RefFRCNN on the same synthetic 600x1000 "
-                      "frames, torch CPU %d threads + oracle C path, %.1f s" % (steps, cores, dt)}
+            "sample": "%d full training steps (fwd+loss+bwd+SGD) of oracle/model_ref.%s on the same synthetic %dx%d "
+                      "frames, torch CPU %d threads + oracle C path, %.1f s" % (steps, name, cfg["H"], cfg["W"], cores, dt)}
 
 
 if __name__ == "__main__":

@@ -64,6 +64,16 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
+def gather_over_ranks(value, device):
+    """The python float of every rank, as a list indexed by rank (bench.py prints per-rank step times)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def sum_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)

@@ -128,6 +128,65 @@ class RefFRCNN(nn.Module):
                (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
 
 
+class _RefMsRoIAlign(torch.autograd.Function):
+    """MultiScaleRoIAlign (models/new_model.py:127,143) through the C oracle, with its backward (per level scatter)."""
+
+    @staticmethod
+    def forward(ctx, rois, *feats):
+        fs = [f.detach().numpy()[0] for f in feats]
+        out, lv = orc.ms_roi_align(fs, rois.numpy())
+        ctx.rois, ctx.lv, ctx.shapes = rois.numpy(), lv, [f.shape for f in fs]
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, go):
+        g = go.contiguous().numpy()
+        scales = (0.25, 0.125, 0.0625, 0.03125)
+        grads = [torch.from_numpy(orc.roi_align_bwd(g, ctx.shapes[l], ctx.rois, scales[l], 2, False, ctx.lv, l))[None] for l in range(len(ctx.shapes))]
+        return (None,) + tuple(grads)
+
+
+class RefFRCNNFPN(nn.Module):
+    """CPU restatement of models/new_model.py:366-418 (ResNet-50-FPN training forward).  The backbone is handed in (a plain
+    torch module, e.g. resnet_fpn_backbone or the build's from-scratch definition of it): conv layers are torch on both sides,
+    only the path stages go through the oracle."""
+
+    def __init__(self, backbone, num_classes=91):
+        super().__init__()
+        self.num_classes = num_classes
+        self.backbone = backbone
+        self.classifier = nn.Sequential(nn.Linear(12544, 1024), nn.ReLU(inplace=True), nn.Linear(1024, 1024), nn.ReLU(inplace=True))
+        self.rpn_head = nn.Module()
+        self.rpn_head.inter_layer = nn.Conv2d(256, 256, 3, padding=1)
+        self.rpn_head.cls_layer = nn.Conv2d(256, 6, 1)
+        self.rpn_head.reg_layer = nn.Conv2d(256, 12, 1)
+        self.cls_head = nn.Linear(1024, num_classes)
+        self.reg_head = nn.Linear(1024, num_classes * 4)
+
+    def forward(self, x, boxes, labels):
+        features = self.backbone(x)                                             # new_model.py:394
+        feats = list(features.values())
+        cls, reg = [], []
+        for f in feats:                                                         # new_model.py:37-44
+            h = torch.relu(self.rpn_head.inter_layer(f))
+            cls.append(self.rpn_head.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
+            reg.append(self.rpn_head.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
+        pred_cls, pred_reg = torch.cat(cls, dim=1), torch.cat(reg, dim=1)
+        boxes = boxes[0] if isinstance(boxes, (list, tuple)) else boxes
+        labels = labels[0] if isinstance(labels, (list, tuple)) else labels
+        H, W = x.shape[2:]
+        p = fpn_path([f.detach().numpy()[0] for f in feats[:4]], [tuple(f.shape[-2:]) for f in feats], pred_cls.detach().numpy()[0],
+                     pred_reg.detach().numpy()[0], boxes.numpy(), labels.numpy().astype(np.int64), (H, W))
+        scaled = torch.from_numpy(p["sample_rois"] * np.array([W, H, W, H], np.float32))
+        pool = _RefMsRoIAlign.apply(scaled, *feats[:4])
+        z = self.classifier(pool.view(pool.size(0), -1))
+        head_cls = self.cls_head(z)
+        t_cls = torch.from_numpy(p["t_cls"])
+        head_reg = self.reg_head(z).reshape(512, -1, 4)[torch.arange(512), t_cls]
+        return (pred_cls, pred_reg, head_cls, head_reg), \
+               (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
+
+
 def ref_loss(pred, target):
     """losses/loss.py:5-85 in torch (CPU), written as the reference writes it (boolean-mask indexing)."""
     import torch.nn.functional as F

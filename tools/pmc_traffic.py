@@ -21,6 +21,9 @@ def load(dirname, counter):
 
 def main():
     out = sys.argv[1]
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "vgg"
+    shapes = {"vgg": "config V: N=20646 K=12000 P=2000 R=128 C=512 37x62 (bench.py frames)",
+              "fpn": "config F: N=268569 K=4000 P=1000 R=512 C=256, 4 RoIAlign levels of 800x1344 (bench.py --config fpn frames)"}
     fetch = load(out + "/fetch", "FETCH_SIZE")
     write = load(out + "/write", "WRITE_SIZE")
     res = {}
@@ -34,7 +37,8 @@ def main():
         res[k] = {"launches": max(len(f), len(w)), "fetch_bytes_raw": round(fk * 1024), "fetch_bytes_x2": round(2 * fk * 1024),
                   "write_bytes": round(wk * 1024), "traffic_bytes": round((2 * fk + wk) * 1024)}
     print(json.dumps({"note": "per launch; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 fetch correction applied",
-                      "shape": "config V: N=20646 K=12000 P=2000 R=128 C=512 37x62", "kernels": res}, indent=1))
+                      "command": "bench.py --config %s --steps 4 --warmup 1 (all launches of the process, incl. the 3 initialisation steps)" % cfg,
+                      "shape": shapes.get(cfg, cfg), "kernels": res}, indent=1))
 
 
 if __name__ == "__main__":
