@@ -51,10 +51,10 @@ CONFIGS = {
 }
 
 # what bounds each hand-written kernel
-BOUND = {"nms_scan_flow_kernel": "latency", "nms_scan_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
+BOUND = {"nms_resolve_kernel": "latency", "nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
          "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency", "topk_scatter_kernel": "latency",
          "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
-         "nms_mask_kernel": "valu", "topk_rank_kernel": "valu",
+         "nms_sup_kernel": "valu", "topk_rank_kernel": "valu",
          "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
          "rpn_conv3x3_kernel": "mfma"}
 
@@ -78,9 +78,9 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "proposal_prologue_kernel": 44 * N,                               # reg 16N + cls 8N in, boxes 16N + scores 4N out
         "topk_rank_kernel": 4 * N,                                        # scores in (partials are workspace traffic)
         "topk_scatter_kernel": 4 * N + 16 * N + 28 * K,                   # scores + boxes in, idx/score/box out
-        "nms_mask_kernel": 16 * K + 8 * K * nblk // 2,                    # boxes in + upper-triangle mask out
-        "nms_scan_flow_kernel": 16 * K + 8 * P + 16 * P,                  # compulsory: boxes in, keep + rois out
-        "nms_scan_kernel": 16 * K + 8 * P + 16 * P,
+        "nms_sup_kernel": 16 * K + 8 * K * nblk // 2,                     # boxes in + (at most) the lower-triangle relation out
+        "nms_resolve_kernel": 8 * K + 8 * 2 * nblk,                       # compulsory: one relation word per box + the two bitmaps
+        "nms_emit_kernel": 8 * nblk + 16 * P + 8 * P + 16 * P,            # bitmap + kept boxes in, keep + rois out
         "rpn_colmax_kernel": 16 * (N + G),
         "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
         "rpn_sample_kernel": 9 * N,
@@ -240,7 +240,7 @@ def main():
         return None
     # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
     # peak (VALU_PEAK_LANE_OPS above): pair IoUs x ~21 VALU ops (counted in the ISA), rank compares x 2
-    valu_ops = {"nms_mask_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
+    valu_ops = {"nms_sup_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
     if args.config == "vgg":
         valu_ops["topk_rank_kernel"] = None          # depends on the path taken (full rank sort vs radix pre-filter): see DESIGN.md
     per_kernel = {}
@@ -256,7 +256,7 @@ def main():
         if valu_ops.get(name):
             per_kernel[name]["valu_lane_ops"] = valu_ops[name]
             per_kernel[name]["valu_frac_of_78.6T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
-        if name == "nms_mask_kernel":
+        if name == "nms_sup_kernel":
             per_kernel[name]["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (us * 1e-6), 0)
 
     def roofline_of(name):

@@ -140,17 +140,19 @@ FRCNN_EXPORT int frcnn_pairwise_iou(const float *set1, int64_t n1, const float *
 //   keep  = (h >= m) & (w >= m); filtered (and NaN) scores are written as -1.
 // HAS_ANCHORS = false regenerates the anchor from the level table in registers.
 // Algorithmic bytes per anchor: 16 (reg) + 8 (cls) [+16 anchors] in, 16 (box) + 4 (score) out.
-// Thread 0 of block 0 also clears the pipeline's control words (topk count, nms count).
+// The first lanes also clear the pipeline's control words (topk count, nms count) and the NMS stage's pull counters.
 // ------------------------------------------------------------------------------------------
 template <bool HAS_ANCHORS>
 __global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__restrict__ reg, const float2 *__restrict__ cls,
                                                                 const float4 *__restrict__ anchors, AnchorDesc d, int64_t N,
                                                                 float min_size, float4 *__restrict__ out_boxes,
                                                                 float *__restrict__ out_scores, int32_t *__restrict__ ctrl_zero,
-                                                                int n_ctrl)
+                                                                int n_ctrl, int32_t *__restrict__ zero2, int n_zero2)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (ctrl_zero && i < n_ctrl) ctrl_zero[i] = 0;
+    if (zero2)                                                  // second region: the NMS stage's per-box pull counters + flags
+        for (int64_t j = i; j < n_zero2; j += (int64_t)gridDim.x * 256) zero2[j] = 0;
     if (i >= N) return;
     const float4 t = reg[i];
     const float2 c = cls[i];
@@ -168,16 +170,17 @@ __global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__
 }
 
 int frcnn_launch_prologue(const float *reg, const float *cls, const float *anchors, const AnchorDesc *d, int64_t N,
-                          float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, hipStream_t s)
+                          float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, int32_t *zero2, int n_zero2,
+                          hipStream_t s)
 {
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
     if (anchors) {
         AnchorDesc dummy = {};
         FRCNN_LAUNCH(KID_PROLOGUE, proposal_prologue_kernel<true>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
-                     (const float4 *)anchors, dummy, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl);
+                     (const float4 *)anchors, dummy, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
     } else {
         FRCNN_LAUNCH(KID_PROLOGUE, proposal_prologue_kernel<false>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
-                     (const float4 *)nullptr, *d, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl);
+                     (const float4 *)nullptr, *d, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
     }
     FRCNN_CHECK_LAUNCH("proposal_prologue_kernel");
     return FRCNN_OK;
@@ -190,5 +193,5 @@ FRCNN_EXPORT int frcnn_proposal_prologue(const float *reg, const float *cls, con
     if (N == 0) return FRCNN_OK;
     FRCNN_REQUIRE(reg && cls && anchors && out_boxes && out_scores, "prologue: NULL pointer");
     FRCNN_REQUIRE(N < ((int64_t)1 << 31), "prologue: N too large");
-    return frcnn_launch_prologue(reg, cls, anchors, nullptr, N, min_size_norm, out_boxes, out_scores, nullptr, 0, (hipStream_t)stream);
+    return frcnn_launch_prologue(reg, cls, anchors, nullptr, N, min_size_norm, out_boxes, out_scores, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }

@@ -17,8 +17,8 @@ enum FrcnnKernelId {
     KID_PROLOGUE,
     KID_TOPK_RANK,
     KID_TOPK_SCATTER,
-    KID_NMS_MASK,
-    KID_NMS_SCAN,
+    KID_NMS_MASK,        // nms_sup_kernel
+    KID_NMS_SCAN,        // nms_resolve_kernel
     KID_RPN_COLMAX,
     KID_RPN_LABEL,
     KID_RPN_SAMPLE,
@@ -31,7 +31,7 @@ enum FrcnnKernelId {
     KID_RPN_HEAD_TAIL,
     KID_DET_LOSS,
     KID_PREPROCESS,
-    KID_NMS_SCAN_SIMPLE,
+    KID_NMS_SCAN_SIMPLE, // nms_emit_kernel
     KID_COUNT
 };
 

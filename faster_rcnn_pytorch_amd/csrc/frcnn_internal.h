@@ -18,7 +18,8 @@ int frcnn_fill_anchor_desc(AnchorDesc *d, int n_levels, const int *fh, const int
                            const float *base, int A, float div_w, float div_h, int64_t *n_total);
 
 int frcnn_launch_prologue(const float *reg, const float *cls, const float *anchors, const AnchorDesc *d, int64_t N,
-                          float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, hipStream_t s);
+                          float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, int32_t *zero2, int n_zero2,
+                          hipStream_t s);
 
 // top-K: count must be zero before topk_scatter runs; zero_count = true lets the rank kernel clear it.
 size_t frcnn_ws_topk(int64_t N);
@@ -27,6 +28,9 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
                       void *ws, size_t ws_bytes, hipStream_t s);
 
 size_t frcnn_ws_nms(int64_t K);
+// pre_zeroed: the caller has already cleared the region frcnn_nms_zero_region() describes (e.g. inside an earlier kernel of the
+// same stream); otherwise frcnn_launch_nms clears it with a memset node.
 int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
                      int64_t *out_keep, float *out_rois, const int64_t *src_map, int64_t *out_src, int32_t *out_count,
-                     void *ws, size_t ws_bytes, hipStream_t s);
+                     void *ws, size_t ws_bytes, bool pre_zeroed, hipStream_t s);
+void frcnn_nms_zero_region(void *ws, int64_t K, int32_t **ptr, int *n_ints);

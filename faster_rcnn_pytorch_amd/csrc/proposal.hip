@@ -60,10 +60,13 @@ FRCNN_EXPORT int frcnn_region_proposal(const float *reg, const float *cls, const
         if (rc) return rc;
         FRCNN_REQUIRE(n == N, "region_proposal: grid describes %lld anchors, N=%lld", (long long)n, (long long)N);
     }
-    int rc = frcnn_launch_prologue(reg, cls, anchors, &d, N, min_size_norm, w.boxes, w.scores, w.ctrl, 8, s);
+    int32_t *nz_ptr = nullptr;
+    int nz_n = 0;
+    frcnn_nms_zero_region(w.nms_ws, K, &nz_ptr, &nz_n);            // cleared by the prologue kernel: no memset node in the pipeline
+    int rc = frcnn_launch_prologue(reg, cls, anchors, &d, N, min_size_norm, w.boxes, w.scores, w.ctrl, 8, nz_ptr, nz_n, s);
     if (rc) return rc;
     rc = frcnn_launch_topk(w.scores, w.boxes, N, K, 1, w.sidx, w.sscores, w.sboxes, w.ctrl, w.topk_ws, w.topk_bytes, s);
     if (rc) return rc;
     return frcnn_launch_nms(w.sboxes, nullptr, w.ctrl, K, iou_threshold, P < K ? P : K, w.keep, out_rois, w.sidx, out_src_idx, out_count, w.nms_ws,
-                            w.nms_bytes, s);
+                            w.nms_bytes, true, s);
 }
