@@ -52,9 +52,9 @@ CONFIGS = {
 
 # what bounds each hand-written kernel
 BOUND = {"nms_resolve_kernel": "latency", "nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
-         "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency", "topk_scatter_kernel": "latency",
+         "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency",
          "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
-         "nms_sup_kernel": "valu", "topk_rank_kernel": "valu",
+         "nms_sup_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
          "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
          "rpn_conv3x3_kernel": "mfma"}
 
@@ -76,8 +76,8 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     nblk = (K + 63) // 64
     return {
         "proposal_prologue_kernel": 44 * N,                               # reg 16N + cls 8N in, boxes 16N + scores 4N out
-        "topk_rank_kernel": 4 * N,                                        # scores in (partials are workspace traffic)
-        "topk_scatter_kernel": 4 * N + 16 * N + 28 * K,                   # scores + boxes in, idx/score/box out
+        "topk_partition_kernels": 4 * N,                                  # per launch (sample / count / place): scores in
+        "topk_bucket_kernel": 8 * N + 16 * K + 28 * K,                    # placed keys + the K gathered boxes in, idx/score/box out
         "nms_sup_kernel": 16 * K + 8 * K * nblk // 2,                     # boxes in + (at most) the lower-triangle relation out
         "nms_resolve_kernel": 8 * K + 8 * 2 * nblk,                       # compulsory: one relation word per box + the two bitmaps
         "nms_emit_kernel": 8 * nblk + 16 * P + 8 * P + 16 * P,            # bitmap + kept boxes in, keep + rois out
@@ -241,8 +241,6 @@ def main():
     # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
     # peak (VALU_PEAK_LANE_OPS above): pair IoUs x ~21 VALU ops (counted in the ISA), rank compares x 2
     valu_ops = {"nms_sup_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
-    if args.config == "vgg":
-        valu_ops["topk_rank_kernel"] = None          # depends on the path taken (full rank sort vs radix pre-filter): see DESIGN.md
     per_kernel = {}
     for name, v in samples.items():
         n = len(v)

@@ -15,8 +15,8 @@ enum FrcnnKernelId {
     KID_BOX_CODEC,
     KID_PAIRWISE_IOU,
     KID_PROLOGUE,
-    KID_TOPK_RANK,
-    KID_TOPK_SCATTER,
+    KID_TOPK_RANK,       // topk_sample / topk_count / topk_place kernels (N >= 4096), topk_rank_kernel below
+    KID_TOPK_SCATTER,    // topk_bucket_kernel (N >= 4096), topk_scatter_kernel below
     KID_NMS_MASK,        // nms_sup_kernel
     KID_NMS_SCAN,        // nms_resolve_kernel
     KID_RPN_COLMAX,

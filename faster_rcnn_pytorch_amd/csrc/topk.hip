@@ -12,7 +12,7 @@
 //   index tie-break costs nothing; only the diagonal chunk evaluates it per lane.
 // Kernel 2 (topk_scatter_kernel): sums the per-segment partial ranks and scatters index, score and
 //   (optionally) the box to position rank(i) if rank(i) < K: the gather at model.py:48 is fused.
-// Work: N^2 pair compares (426 M at N = 20 646 -> ~11 us of VALU on 1024 SIMDs).
+// Work: N^2 pair compares -- used for N < 4096 only; larger N take the sample sort further down.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 
@@ -109,172 +109,225 @@ __global__ __launch_bounds__(256) void topk_scatter_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large N with K << N (FPN: N = 268 569, K = 4000): the O(N^2) rank sort would be ~72 G compares, so a two-level
-// radix histogram (11 + 11 bits of the order-preserving key) first finds a 22-bit prefix threshold that at least K
-// keys reach; those M >= K candidates (M - K = ties inside one 2^-13-relative score band, typically tens) are
-// compacted and rank-sorted among themselves with the explicit (key desc, index asc) order.
-//   topk_hist_kernel<0>  ->  topk_hist_kernel<1>  ->  topk_compact_kernel  ->  topk_rank_cand_kernel  ->  topk_scatter_cand_kernel
-// Every kernel re-derives what it needs from the previous histogram in its prologue (2048 bins, one block scan), so
-// there is no single-block "pick the digit" launch in between.
+// N >= 4096: SAMPLE SORT on the composite key  key64 = f2key(score) << 32 | ~index  (all keys distinct, order = score descending,
+// index ascending, so ties need no special case and cannot unbalance anything):
+//   topk_sample_kernel   one workgroup rank-sorts 512 / 1024 evenly spaced samples and keeps every stride-th as a splitter (255);
+//   topk_count_kernel    every key finds its bucket (binary search over the splitters in LDS) -> 256 bucket sizes, #valid;
+//   topk_place_kernel    exclusive scan of the sizes (recomputed per block) + one atomic slot per key: buckets become contiguous
+//                        segments of a scratch array (order inside a segment is arbitrary);
+//   topk_bucket_kernel   one workgroup per bucket whose first rank is < K: rank inside the bucket (~80^2 compares at N = 20 646;
+//                        the keys are staged in LDS) + the bucket's base = the exact rank; index, score and box are scattered to
+//                        that position (the gather at model.py:48 stays fused).
+// Work N * (8 + N / 256) compares instead of N^2: the chip-wide rank sort above took 34 us + 11 us (scatter) at N = 20 646 and
+// the radix-select pre-filter of round 1 57 us + 6 us at N = 268 569 (four histogram / compaction launches before its rank sort).
 // ------------------------------------------------------------------------------------------------
-#define SEL_BINS 2048
+#define SS_BUCKETS 256
+#define SS_MIN_N 4096
+#define SS_PER_THREAD 4                                            // keys per thread of the placing kernel
 
-struct SelCtl { unsigned hist1[SEL_BINS]; unsigned hist2[SEL_BINS]; int m; int pad[15]; };
+typedef unsigned long long u64;
+struct SsCtl { u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; };
 
-// descending search: returns the bin holding the `want`-th largest key (1-based) and the number of keys in higher bins;
-// if the histogram holds fewer than `want` keys, returns bin 0 (everything qualifies).  256 threads.
-__device__ __forceinline__ void sel_find_bin(const unsigned *__restrict__ hist, int want, int *s_tmp /*[8]*/, int *bin, int *above)
+__device__ __forceinline__ u64 ss_key(float sc, int idx) { return ((u64)f2key(sc) << 32) | (u64)(uint32_t)(~idx); }
+
+// S evenly spaced samples, rank-sorted by S threads (32-bit keys; the sample position breaks ties exactly like the index would:
+// positions grow with the index).  Splitter q (1..255) = the sample of rank q * stride: stride 4 (S = 1024) / 2 (S = 512) covers the
+// whole distribution; a smaller stride concentrates the 255 splitters on the best-scored part when K << N (buckets past rank K are
+// never ranked), keeping the buckets that matter at ~N / S * stride keys.
+template <int S>
+__global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ scores, int N, int stride, SsCtl *__restrict__ ctl)
 {
-    const int t = threadIdx.x;                       // thread t owns descending bins d = 8t .. 8t+7  (bin = 2047 - d)
-    unsigned c[8];
-    int local = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { c[q] = hist[SEL_BINS - 1 - (8 * t + q)]; local += (int)c[q]; }
-    // block-wide exclusive scan of `local` over 256 threads
-    const int lane = t & 63, wave = t >> 6;
-    int inc = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(inc, o);
-        if (lane >= o) inc += v;
-    }
+    // S / 64 workgroups; each ranks 64 samples against ALL S sample keys (staged in LDS), its four waves taking every fourth
+    // 64-key chunk.  (All samples in one workgroup: 9 us at S = 512, 21 us at S = 1024 -- one CU's VALU; one lone wave per 64
+    // samples: 9 / 15 us -- a lone wave issues one instruction every 4-8 cycles.)
+    __shared__ uint4 s_k4[S / 4];
+    __shared__ int s_part[4][64];
+    uint32_t *s_k = (uint32_t *)s_k4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rb = blockIdx.x;                                       // my 64 samples = chunk rb
+    const int t = rb * 64 + lane;
+    for (int tq = threadIdx.x; tq < S; tq += 256) s_k[tq] = f2key(scores[(int)(((long long)tq * N) / S)]);
+    const int idx = (int)(((long long)t * N) / S);
+    const float sc = scores[idx];
+    const uint32_t k = f2key(sc);
+    if (blockIdx.x == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->split[0] = ~0ull; } }
     __syncthreads();
-    if (lane == 63) s_tmp[wave] = inc;
-    if (t == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
+    // rank among the samples, (key desc, position asc): whole 64-sample chunks before / after my own chunk need no tie-break
+    // (>= / >), only the own chunk evaluates it per lane (same scheme as topk_rank_kernel)
+    int rank = 0;
+    for (int c = wave; c < S / 64; c += 4) {
+        const uint4 *p = s_k4 + c * 16;
+        if (c < rb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const uint4 v = p[q]; rank += (v.x >= k) + (v.y >= k) + (v.z >= k) + (v.w >= k); }
+        } else if (c > rb) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const uint4 v = p[q]; rank += (v.x > k) + (v.y > k) + (v.z > k) + (v.w > k); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint4 v = p[q];
+                rank += (v.x > k) || (v.x == k && 4 * q + 0 < lane);
+                rank += (v.y > k) || (v.y == k && 4 * q + 1 < lane);
+                rank += (v.z > k) || (v.z == k && 4 * q + 2 < lane);
+                rank += (v.w > k) || (v.w == k && 4 * q + 3 < lane);
+            }
+        }
+    }
+    s_part[wave][lane] = rank;
+    __syncthreads();
+    if (wave != 0) return;
+    rank = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
+    // bucket b holds the keys x with split[b] > x >= split[b + 1] (split[0] = +inf, split[256] = -inf): descending ranges
+    if (rank > 0 && rank % stride == 0 && rank / stride < SS_BUCKETS) ctl->split[rank / stride] = ss_key(sc, idx);
+}
+
+// number of splitters 1..255 that are > k  =  the bucket of k
+__device__ __forceinline__ int ss_bucket(const u64 *s_split, u64 k)
+{
+    int lo = 0;
+#pragma unroll
+    for (int step = SS_BUCKETS / 2; step > 0; step >>= 1)
+        if (s_split[lo + step] > k) lo += step;
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void topk_count_kernel(const float *__restrict__ scores, int N, int proposal_mode, SsCtl *__restrict__ ctl)
+{
+    __shared__ u64 s_split[SS_BUCKETS];
+    __shared__ int s_cnt[SS_BUCKETS];
+    __shared__ int s_valid;
+    s_split[threadIdx.x] = ctl->split[threadIdx.x];
+    s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    int valid = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
+        const float sc = scores[i];
+        valid += (!proposal_mode || sc >= 0.0f) ? 1 : 0;
+        atomicAdd(&s_cnt[ss_bucket(s_split, ss_key(sc, i))], 1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    if (s_cnt[threadIdx.x]) atomicAdd(&ctl->cnt[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl->n_valid, s_valid);
+}
+
+// exclusive scan of 256 bucket sizes by 256 threads; returns this thread's base
+__device__ __forceinline__ int ss_scan256(int v, int *s_w /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    if (lane == 63) s_w[wave] = inc;
     __syncthreads();
     int base = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) if (w < wave) base += s_tmp[w];
-    const int excl = base + inc - local;
-    if (excl < want && want <= excl + local) {       // exactly one thread (if the total reaches `want`)
-        int acc = excl, q = 0;
-        for (; q < 7; ++q) {
-            if (acc + (int)c[q] >= want) break;
-            acc += (int)c[q];
-        }
-        s_tmp[4] = SEL_BINS - 1 - (8 * t + q);
-        s_tmp[5] = acc;
-        s_tmp[6] = 1;
-    }
-    __syncthreads();
-    *bin = s_tmp[6] ? s_tmp[4] : 0;
-    *above = s_tmp[6] ? s_tmp[5] : 0;
-    __syncthreads();
+    for (int q = 0; q < 4; ++q) base += q < wave ? s_w[q] : 0;
+    return base + inc - v;
 }
 
-template <int LEVEL>
-__global__ __launch_bounds__(256) void topk_hist_kernel(const float *__restrict__ scores, int N, int K, int proposal_mode, SelCtl *__restrict__ ctl)
+// Buckets become contiguous segments of `sorted`.  A block first counts its own 1024 keys per bucket in LDS (the returned value
+// is the key's slot inside the block's share), reserves the block's share of every non-empty bucket with ONE global atomic per
+// bucket, then writes: N / 1024 * (<= 256) global atomics instead of N on 256 hot words.
+__global__ __launch_bounds__(256) void topk_place_kernel(const float *__restrict__ scores, int N, SsCtl *__restrict__ ctl, u64 *__restrict__ sorted)
 {
-    __shared__ unsigned s_hist[SEL_BINS];
-    __shared__ int s_tmp[8];
-    int bin1 = 0, above1 = 0;
-    if (LEVEL == 1) sel_find_bin(ctl->hist1, K, s_tmp, &bin1, &above1);
-    for (int i = threadIdx.x; i < SEL_BINS; i += 256) s_hist[i] = 0u;
+    __shared__ u64 s_split[SS_BUCKETS];
+    __shared__ int s_base[SS_BUCKETS], s_cnt[SS_BUCKETS];
+    __shared__ int s_w[4];
+    s_split[threadIdx.x] = ctl->split[threadIdx.x];
+    s_cnt[threadIdx.x] = 0;
+    s_base[threadIdx.x] = ss_scan256(ctl->cnt[threadIdx.x], s_w);
     __syncthreads();
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < N; i += gridDim.x * 256) {
-        const float sc = scores[i];
-        if (proposal_mode && !(sc >= 0.0f)) continue;
-        const uint32_t k = f2key(sc);
-        if (LEVEL == 0) atomicAdd(&s_hist[k >> 21], 1u);
-        else if ((int)(k >> 21) == bin1) atomicAdd(&s_hist[(k >> 10) & (SEL_BINS - 1)], 1u);
-    }
-    __syncthreads();
-    unsigned *dst = LEVEL == 0 ? ctl->hist1 : ctl->hist2;
-    for (int i = threadIdx.x; i < SEL_BINS; i += 256)
-        if (s_hist[i]) atomicAdd(&dst[i], s_hist[i]);
-}
-
-__global__ __launch_bounds__(256) void topk_compact_kernel(const float *__restrict__ scores, int N, int K, int proposal_mode,
-                                                           SelCtl *__restrict__ ctl, uint32_t *__restrict__ cand_key,
-                                                           int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_rank)
-{
-    __shared__ int s_tmp[8];
-    int bin1, above1, bin2, above2;
-    sel_find_bin(ctl->hist1, K, s_tmp, &bin1, &above1);
-    sel_find_bin(ctl->hist2, K - above1, s_tmp, &bin2, &above2);
-    const uint32_t thr22 = ((uint32_t)bin1 << 11) | (uint32_t)bin2;      // keep keys whose top 22 bits reach this
-    for (int i0 = blockIdx.x * 256; i0 < N; i0 += gridDim.x * 256) {
-        const int i = i0 + threadIdx.x;
-        bool c = false;
-        uint32_t k = 0u;
+    u64 k[SS_PER_THREAD];
+    int bk[SS_PER_THREAD], slot[SS_PER_THREAD];
+#pragma unroll
+    for (int e = 0; e < SS_PER_THREAD; ++e) {
+        const int i = (blockIdx.x * SS_PER_THREAD + e) * 256 + threadIdx.x;
+        bk[e] = -1;
         if (i < N) {
-            const float sc = scores[i];
-            k = f2key(sc);
-            c = (!proposal_mode || sc >= 0.0f) && (k >> 10) >= thr22;
-        }
-        const unsigned long long bm = __ballot(c);
-        if (bm != 0ull) {
-            int base = 0;
-            if ((threadIdx.x & 63) == 0) base = atomicAdd(&ctl->m, __builtin_popcountll(bm));
-            base = __shfl(base, 0);
-            if (c) {
-                const int slot = base + __builtin_popcountll(bm & ((1ull << (threadIdx.x & 63)) - 1ull));
-                cand_key[slot] = k;
-                cand_idx[slot] = i;
-                cand_rank[slot] = 0;
-            }
+            k[e] = ss_key(scores[i], i);
+            bk[e] = ss_bucket(s_split, k[e]);
+            slot[e] = atomicAdd(&s_cnt[bk[e]], 1);
         }
     }
+    __syncthreads();
+    const int c = s_cnt[threadIdx.x];
+    if (c) s_base[threadIdx.x] += atomicAdd(&ctl->cursor[threadIdx.x], c);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < SS_PER_THREAD; ++e)
+        if (bk[e] >= 0) sorted[s_base[bk[e]] + slot[e]] = k[e];
 }
 
-// rank among the M candidates (M on the device); persistent grid over (256-row block) x (1024-column segment) tiles
-__global__ __launch_bounds__(256) void topk_rank_cand_kernel(const SelCtl *__restrict__ ctl, const uint32_t *__restrict__ cand_key,
-                                                             const int32_t *__restrict__ cand_idx, int32_t *__restrict__ cand_rank)
+__global__ __launch_bounds__(256) void topk_bucket_kernel(const float *__restrict__ scores, const float4 *__restrict__ boxes_in, int N, int K,
+                                                          const SsCtl *__restrict__ ctl, const u64 *__restrict__ sorted,
+                                                          int64_t *__restrict__ out_idx, float *__restrict__ out_scores,
+                                                          float4 *__restrict__ out_boxes, int32_t *__restrict__ out_count)
 {
-    __shared__ uint32_t s_k[TOPK_SEG];
-    __shared__ int32_t s_i[TOPK_SEG];
-    const int M = ctl->m;
-    const int nrow = (M + TOPK_ROWS - 1) / TOPK_ROWS, nseg = (M + TOPK_SEG - 1) / TOPK_SEG;
-    for (int tile = blockIdx.x; tile < nrow * nseg; tile += gridDim.x) {
-        const int rb = tile / nseg, sg = tile - rb * nseg;
-        const int c0 = sg * TOPK_SEG;
-        const int cn = min(TOPK_SEG, M - c0);
-        __syncthreads();
-        for (int t = threadIdx.x; t < cn; t += 256) { s_k[t] = cand_key[c0 + t]; s_i[t] = cand_idx[c0 + t]; }
-        __syncthreads();
-        const int r = rb * TOPK_ROWS + threadIdx.x;
-        if (r < M) {
-            const uint32_t kr = cand_key[r];
-            const int32_t ir = cand_idx[r];
-            int rank = 0;
-            for (int t = 0; t < cn; ++t) {
-                const uint32_t k = s_k[t];
-                rank += (k > kr) || (k == kr && s_i[t] < ir);
-            }
-            if (rank) atomicAdd(&cand_rank[r], rank);
+    __shared__ u64 s_k[1024];
+    __shared__ int s_w[4];
+    __shared__ int s_b[2];
+    const int bkt = blockIdx.x;
+    const int part = blockIdx.y, nparts = gridDim.y;                // the bucket's keys (rows) are split over nparts workgroups
+    const int mine = ctl->cnt[threadIdx.x];
+    const int excl = ss_scan256(mine, s_w);
+    if (threadIdx.x == bkt) { s_b[0] = excl; s_b[1] = mine; }
+    __syncthreads();
+    const int base = s_b[0], m = s_b[1];
+    const int n_valid = ctl->n_valid;
+    const int n_out = n_valid < K ? n_valid : K;
+    if (bkt == 0 && part == 0 && threadIdx.x == 0) *out_count = n_out;
+    if (base >= n_out || m == 0) return;
+    const u64 *seg = sorted + base;
+    const int per = (m + nparts - 1) / nparts;
+    const int e0 = part * per, e1 = min(m, e0 + per);              // my rows
+    if (e0 >= e1) return;
+    auto emit = [&](u64 k, int r) {
+        const int rank = base + r;
+        if (rank < n_out) {
+            const int idx = (int)(~(uint32_t)k);
+            out_idx[rank] = idx;
+            out_scores[rank] = scores[idx];
+            if (out_boxes) out_boxes[rank] = boxes_in[idx];
         }
+    };
+    if (m <= 1024) {                                               // the usual case: the whole bucket in LDS, one pass
+        for (int t = threadIdx.x; t < m; t += 256) s_k[t] = seg[t];
+        __syncthreads();
+        for (int e = e0 + threadIdx.x; e < e1; e += 256) {         // (waves without a row skip the loop)
+            const u64 k = s_k[e];
+            int r = 0;
+#pragma unroll 8
+            for (int j = 0; j < m; ++j) r += s_k[j] > k;           // broadcast ds_read_b64
+            emit(k, r);
+        }
+        return;
+    }
+    for (int r0 = e0; r0 < e1; r0 += 256) {                        // an unlucky sample: row groups x 1024-key chunks
+        const int e = r0 + threadIdx.x;
+        const u64 k = e < e1 ? seg[e] : 0ull;
+        int r = 0;
+        for (int c0 = 0; c0 < m; c0 += 1024) {
+            const int cn = min(1024, m - c0);
+            __syncthreads();
+            for (int t = threadIdx.x; t < cn; t += 256) s_k[t] = seg[c0 + t];
+            __syncthreads();
+#pragma unroll 8
+            for (int j = 0; j < cn; ++j) r += s_k[j] > k;
+        }
+        if (e < e1) emit(k, r);
     }
 }
-
-__global__ __launch_bounds__(256) void topk_scatter_cand_kernel(const SelCtl *__restrict__ ctl, const float *__restrict__ scores,
-                                                                const float4 *__restrict__ boxes_in, const int32_t *__restrict__ cand_idx,
-                                                                const int32_t *__restrict__ cand_rank, int K, int64_t *__restrict__ out_idx,
-                                                                float *__restrict__ out_scores, float4 *__restrict__ out_boxes,
-                                                                int32_t *__restrict__ out_count)
-{
-    const int M = ctl->m;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = M < K ? M : K;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
-        const int rank = cand_rank[r];
-        if (rank < K) {
-            const int i = cand_idx[r];
-            out_idx[rank] = i;
-            out_scores[rank] = scores[i];
-            if (out_boxes) out_boxes[rank] = boxes_in[i];
-        }
-    }
-}
-
-static inline bool topk_use_select(int64_t N, int64_t K) { return N > 32768 && K * 4 <= N; }
 
 size_t frcnn_ws_topk(int64_t N)
 {
     const int64_t nseg = (N + TOPK_SEG - 1) / TOPK_SEG;
-    const size_t direct = N > 32768 ? 0 : align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
-    const size_t direct_big = align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
-    const size_t select = align_up(sizeof(SelCtl), 256) + 3 * align_up((size_t)N * 4, 256);
-    // N > 32768: the select path needs `select`; the direct path (K close to N) needs `direct_big`
-    return N > 32768 ? (direct_big > select ? direct_big : select) : direct;
+    if (N >= SS_MIN_N) return align_up(sizeof(SsCtl), 256) + align_up((size_t)N * 8, 256);
+    return align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
 }
 
 int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int64_t K, int proposal_mode,
@@ -283,26 +336,26 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
 {
     if (ws_bytes < frcnn_ws_topk(N))
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "topk: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_topk(N));
-    if (topk_use_select(N, K)) {
-        char *p = (char *)ws;
-        SelCtl *ctl = (SelCtl *)p; p += align_up(sizeof(SelCtl), 256);
-        uint32_t *cand_key = (uint32_t *)p; p += align_up((size_t)N * 4, 256);
-        int32_t *cand_idx = (int32_t *)p; p += align_up((size_t)N * 4, 256);
-        int32_t *cand_rank = (int32_t *)p;
-        if (hipMemsetAsync(ctl, 0, sizeof(SelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "topk: memset failed");
-        const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_hist_kernel<0>, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl);
-        FRCNN_CHECK_LAUNCH("topk_hist_kernel<0>");
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_hist_kernel<1>, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl);
-        FRCNN_CHECK_LAUNCH("topk_hist_kernel<1>");
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_compact_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, (int)K, proposal_mode, ctl, cand_key,
-                     cand_idx, cand_rank);
-        FRCNN_CHECK_LAUNCH("topk_compact_kernel");
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_rank_cand_kernel, dim3(1024), dim3(256), 0, s, ctl, cand_key, cand_idx, cand_rank);
-        FRCNN_CHECK_LAUNCH("topk_rank_cand_kernel");
-        FRCNN_LAUNCH(KID_TOPK_SCATTER, topk_scatter_cand_kernel, dim3(256), dim3(256), 0, s, ctl, scores, (const float4 *)boxes_in, cand_idx,
-                     cand_rank, (int)K, out_idx, out_scores, (float4 *)out_boxes, out_count);
-        FRCNN_CHECK_LAUNCH("topk_scatter_cand_kernel");
+    if (N >= SS_MIN_N) {
+        SsCtl *ctl = (SsCtl *)ws;
+        u64 *sorted = (u64 *)((char *)ws + align_up(sizeof(SsCtl), 256));
+        const int gb = (int)((N + 256 * SS_PER_THREAD - 1) / (256 * SS_PER_THREAD));
+        // 512 samples for the sizes of one feature map, 2048 above; the splitter stride covers ranks up to ~1.5 K (at least), the
+        // whole distribution at most
+        const int S = N < 65536 ? 512 : 2048;
+        const int full = S / SS_BUCKETS;                                        // stride that spreads 255 splitters over all S samples
+        int stride = (int)((3 * K * S + 2 * (SS_BUCKETS - 1) * N - 1) / (2 * (SS_BUCKETS - 1) * N));     // ceil(1.5 K S / (255 N))
+        stride = stride < 1 ? 1 : (stride > full ? full : stride);
+        if (S == 512) FRCNN_LAUNCH(KID_TOPK_RANK, topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+        else FRCNN_LAUNCH(KID_TOPK_RANK, topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+        FRCNN_CHECK_LAUNCH("topk_sample_kernel");
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);
+        FRCNN_CHECK_LAUNCH("topk_count_kernel");
+        FRCNN_LAUNCH(KID_TOPK_RANK, topk_place_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, ctl, sorted);
+        FRCNN_CHECK_LAUNCH("topk_place_kernel");
+        FRCNN_LAUNCH(KID_TOPK_SCATTER, topk_bucket_kernel, dim3(SS_BUCKETS, N < 65536 ? 4 : 8), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, ctl,
+                     sorted, out_idx, out_scores, (float4 *)out_boxes, out_count);
+        FRCNN_CHECK_LAUNCH("topk_bucket_kernel");
         return FRCNN_OK;
     }
     const int nseg = (int)((N + TOPK_SEG - 1) / TOPK_SEG);
