@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's first-call search times every applicable solver, including the naive reference convolutions (seconds per layer at these
+# shapes, and never the winner).  Leaving them out only shortens the initialisation pass; the steady state is unchanged.
+for _k in ("FWD", "BWD", "WRW"):
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
 
 import torch  # noqa: E402
 

@@ -40,6 +40,8 @@ SIGNATURES = {
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_roi_pool_fwd": (_i, [_vp, _i, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "frcnn_roi_pool_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "frcnn_roi_pool_fwd_a16": (_i, [_vp, _i, _i, _i, _vp, _i64, _f, _vp, _vp, _vp]),
+    "frcnn_roi_pool_bwd_a16": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "frcnn_roi_level_map": (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp]),
     "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "frcnn_ms_roi_align_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp]),

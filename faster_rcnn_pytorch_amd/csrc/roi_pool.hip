@@ -12,14 +12,11 @@
 #include "frcnn_internal.h"
 #include <cfloat>
 
-#ifndef ROI_FWD_CB
-#define ROI_FWD_CB 4
-#endif
 #ifndef ROI_FWD_RB
 #define ROI_FWD_RB 20
 #endif
 #ifndef ROI_BWD_CB
-#define ROI_BWD_CB 1
+#define ROI_BWD_CB 2
 #endif
 
 struct RoiBins { int sw, sh; float bw, bh; };
@@ -99,34 +96,45 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_atomic_kernel(const float *_
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-staged forward (the shape the reference runs: PHxPW = 7x7, plane <= 64 KB / CB):
-// grid (ceil(C/CB), ceil(R/RB)); a block stages CB adjacent channel planes in LDS with one coalesced
-// pass, builds the bin-boundary table of its RB RoIs once, then every lane produces outputs
-// (roi, channel, bin) with the window scan served from LDS.  For one RoI the CB*49 outputs of the
-// block are contiguous in memory (784 B at CB = 4): the stores stay coalesced.
+// LDS-staged forward (the shape the reference runs: PHxPW = 7x7, 4 planes <= 48 KB):
+// grid (ceil(C/4), ceil(R/RB)); a block stages FOUR adjacent channel planes in LDS, INTERLEAVED per pixel (float4 = the four
+// channels of one pixel), builds the bin-boundary table of its RB RoIs once, then every lane produces outputs (roi, bin) x 4
+// channels: one ds_read_b128 per window pixel serves all four channels (round 1 kept the planes separate: four ds_read_b32 and
+// ~8 instructions per pixel and channel; the kernel was bound by instruction issue at 18 us).  For one RoI the 4*49 outputs of
+// the block are contiguous in memory (784 B): the stores stay coalesced.
+// AT = the argmax element: int32_t (the torchvision-shaped ABI) or uint16_t (library-private, planes < 65535 pixels: 6.4 MB less
+// to write and, in backward, to read at R = 128, C = 512; 0xFFFF = empty bin).
 // ------------------------------------------------------------------------------------------------
 #ifndef ROI_FWD_BS
 #define ROI_FWD_BS 512
 #endif
-template <int CB, int PH, int PW>
+template <typename AT> __device__ __forceinline__ AT roi_arg_enc(int mi);
+template <> __device__ __forceinline__ int32_t roi_arg_enc<int32_t>(int mi) { return mi; }
+template <> __device__ __forceinline__ uint16_t roi_arg_enc<uint16_t>(int mi) { return (uint16_t)(mi < 0 ? 0xFFFF : mi); }
+template <typename AT> __device__ __forceinline__ int roi_arg_dec(AT a);
+template <> __device__ __forceinline__ int roi_arg_dec<int32_t>(int32_t a) { return a; }
+template <> __device__ __forceinline__ int roi_arg_dec<uint16_t>(uint16_t a) { return a == 0xFFFF ? -1 : (int)a; }
+
+template <int PH, int PW, typename AT>
 __global__ __launch_bounds__(ROI_FWD_BS) void roi_pool_fwd_lds_kernel(const float *__restrict__ feat, int C, int H, int W,
                                                                const float4 *__restrict__ rois, int R, int RB, float scale,
-                                                               float *__restrict__ out, int32_t *__restrict__ argmax)
+                                                               float *__restrict__ out, AT *__restrict__ argmax)
 {
-    extern __shared__ float smem[];
+    constexpr int CB = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int HW = H * W;
-    float *planes = smem;                                        // [CB][HW]
+    float4 *px = (float4 *)smem;                                 // [HW]: the four channels of a pixel
     int *tab = (int *)(smem + CB * HW);                          // [RB][PH + PW]: (hs | he << 16) x PH, (ws | we << 16) x PW
     constexpr int BINS = PH * PW;
     constexpr int TW = PH + PW;
-    constexpr int GROUPS = ROI_FWD_BS / BINS;                           // RoIs processed concurrently by the block
+    constexpr int GROUPS = ROI_FWD_BS / BINS;                    // RoIs processed concurrently by the block
     static_assert(GROUPS >= 1, "PH * PW must fit one block");
     const int c0 = blockIdx.x * CB;
     const int r0 = blockIdx.y * RB;
     const int nr = min(RB, R - r0);
     const int nch = min(CB, C - c0);
     const float *src = feat + (size_t)c0 * HW;
-    {   // stage the planes: 8 independent loads in flight per lane
+    {   // stage the planes (coalesced per plane, 8 independent loads in flight per lane), interleaving them per pixel
         const int n_stage = nch * HW;
         for (int base = 0; base < n_stage; base += ROI_FWD_BS * 8) {
             float v[8];
@@ -138,9 +146,12 @@ __global__ __launch_bounds__(ROI_FWD_BS) void roi_pool_fwd_lds_kernel(const floa
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * ROI_FWD_BS + threadIdx.x;
-                if (i < n_stage) planes[i] = v[u];
+                if (i < n_stage) { const int c = i / HW, p = i - c * HW; smem[p * CB + c] = v[u]; }
             }
         }
+        if (nch < CB)                                            // missing channels of the last group: never stored, keep them finite
+            for (int i = threadIdx.x; i < HW; i += ROI_FWD_BS)
+                for (int c = nch; c < CB; ++c) smem[i * CB + c] = 0.0f;
     }
     for (int t = threadIdx.x; t < nr * TW; t += ROI_FWD_BS) {
         const int rl = t / TW, k = t - rl * TW;
@@ -155,8 +166,6 @@ __global__ __launch_bounds__(ROI_FWD_BS) void roi_pool_fwd_lds_kernel(const floa
         }
     }
     __syncthreads();
-    // lane -> fixed (RoI group, bin); the CB channels of the block are an INNER loop, so the window geometry, the loop
-    // control and the clamps are paid once per CB outputs and the CB LDS reads of a pixel are independent
     const int grp = threadIdx.x / BINS;
     const int p = threadIdx.x - grp * BINS;
     const int ph = p / PW, pw = p - ph * PW;
@@ -167,37 +176,39 @@ __global__ __launch_bounds__(ROI_FWD_BS) void roi_pool_fwd_lds_kernel(const floa
         const int th = tab[rl * TW + ph], tw = tab[rl * TW + PH + pw];
         const int hs = th & 0xFFFF, he = th >> 16, ws = tw & 0xFFFF, we = tw >> 16;
         const bool empty = (he <= hs) || (we <= ws);
-        float mv[CB];
-        int mi[CB];
-#pragma unroll
-        for (int c = 0; c < CB; ++c) { mv[c] = empty ? 0.0f : -FLT_MAX; mi[c] = -1; }
+        const float init = empty ? 0.0f : -FLT_MAX;
+        float m0 = init, m1 = init, m2 = init, m3 = init;
+        int i0 = -1, i1 = -1, i2 = -1, i3 = -1;
         for (int h = hs; h < he; ++h) {
             const int rowoff = h * W;
-            for (int w = ws; w < we; w += 2) {                   // 2 pixels x CB planes = 2*CB independent LDS reads in flight
+            for (int w = ws; w < we; w += 2) {                   // two pixels = two independent ds_read_b128 in flight
                 const int w1 = min(w + 1, we - 1);               // a clamped duplicate can never be > the running max
-                float v0[CB], v1[CB];
-#pragma unroll
-                for (int c = 0; c < CB; ++c) { v0[c] = planes[c * HW + rowoff + w]; v1[c] = planes[c * HW + rowoff + w1]; }
-#pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    if (v0[c] > mv[c]) { mv[c] = v0[c]; mi[c] = rowoff + w; }
-                    if (v1[c] > mv[c]) { mv[c] = v1[c]; mi[c] = rowoff + w1; }
-                }
+                const float4 a = px[rowoff + w], b = px[rowoff + w1];
+                const int ia = rowoff + w, ib = rowoff + w1;
+                if (a.x > m0) { m0 = a.x; i0 = ia; }
+                if (a.y > m1) { m1 = a.y; i1 = ia; }
+                if (a.z > m2) { m2 = a.z; i2 = ia; }
+                if (a.w > m3) { m3 = a.w; i3 = ia; }
+                if (b.x > m0) { m0 = b.x; i0 = ib; }
+                if (b.y > m1) { m1 = b.y; i1 = ib; }
+                if (b.z > m2) { m2 = b.z; i2 = ib; }
+                if (b.w > m3) { m3 = b.w; i3 = ib; }
             }
         }
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-            if (c < nch) { out[e + (size_t)c * BINS] = mv[c]; argmax[e + (size_t)c * BINS] = mi[c]; }
+        out[e] = m0; argmax[e] = roi_arg_enc<AT>(i0);
+        if (nch > 1) { out[e + BINS] = m1; argmax[e + BINS] = roi_arg_enc<AT>(i1); }
+        if (nch > 2) { out[e + 2 * BINS] = m2; argmax[e + 2 * BINS] = roi_arg_enc<AT>(i2); }
+        if (nch > 3) { out[e + 3 * BINS] = m3; argmax[e + 3 * BINS] = roi_arg_enc<AT>(i3); }
     }
 }
 
 // LDS-accumulating backward, CB adjacent channels per block (contiguous CB*bins runs of grad_out / argmax)
-template <int CB>
-__global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
+template <int CB, typename AT>
+__global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__restrict__ grad_out, const AT *__restrict__ argmax,
                                                                int R, int C, int HW, int bins, float *__restrict__ grad_feat)
 {
     extern __shared__ float plane[];                 // [CB][HW]
-    // adjacent channels share the cache lines at the ends of their 196-byte runs: keep neighbours on ONE XCD (workgroups are
+    // adjacent channels share the cache lines at the ends of their runs: keep neighbours on ONE XCD (workgroups are
     // dealt round-robin to the 8 XCDs) so that the second touch of such a line is an L2 hit instead of another HBM fetch
     const int nb = gridDim.x;
     const int bx = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__re
             for (int u = 0; u < U; ++u) {
                 const int r = r0 + u * rpp;
                 const size_t idx = ((size_t)min(r, R - 1) * C + c0) * bins + rem;
-                a[u] = __builtin_nontemporal_load(argmax + idx);
+                a[u] = roi_arg_dec<AT>(__builtin_nontemporal_load(argmax + idx));
                 g[u] = __builtin_nontemporal_load(grad_out + idx);
                 if (r >= R) a[u] = -1;
             }
@@ -235,6 +246,56 @@ __global__ __launch_bounds__(512) void roi_pool_bwd_lds_kernel(const float *__re
     for (int i = threadIdx.x; i < nch * HW; i += 512) dst[i] = plane[i];
 }
 
+template <typename AT>
+static int roi_pool_fwd_launch(const float *feat, int C, int H, int W, const float *rois, int64_t R, int PH, int PW, float spatial_scale,
+                               float *out, AT *argmax, hipStream_t s)
+{
+    const int RB = ROI_FWD_RB;
+    const size_t shmem = (size_t)4 * H * W * 4 + (size_t)RB * (7 + 7) * 4;
+    FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<7, 7, AT>), dim3((C + 3) / 4, (unsigned)((R + RB - 1) / RB)), dim3(ROI_FWD_BS),
+                 shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
+    FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");
+    return FRCNN_OK;
+}
+
+template <typename AT>
+static int roi_pool_bwd_launch(const float *grad_out, const AT *argmax, int64_t R, int C, int64_t HW, int bins, float *grad_feat, hipStream_t s)
+{
+    FRCNN_LAUNCH(KID_ROI_POOL_BWD, (roi_pool_bwd_lds_kernel<ROI_BWD_CB, AT>), dim3((C + ROI_BWD_CB - 1) / ROI_BWD_CB), dim3(512), (size_t)HW * 4 * ROI_BWD_CB, s,
+                 grad_out, argmax, (int)R, C, (int)HW, bins, grad_feat);
+    FRCNN_CHECK_LAUNCH("roi_pool_bwd_lds_kernel");
+    return FRCNN_OK;
+}
+
+// Library-private 16-bit argmax pair (the autograd path of the host layer): same results as the int32 entry points.
+FRCNN_EXPORT int frcnn_roi_pool_fwd_a16(const float *feat, int C, int H, int W, const float *rois, int64_t R, float spatial_scale,
+                                        float *out, uint16_t *argmax16, void *stream)
+{
+    FRCNN_REQUIRE(C > 0 && H > 0 && W > 0 && R >= 0, "roi_pool_fwd_a16: bad shape");
+    if (R == 0) return FRCNN_OK;
+    FRCNN_REQUIRE(feat && rois && out && argmax16, "roi_pool_fwd_a16: NULL pointer");
+    FRCNN_REQUIRE((int64_t)H * W < 65535 && (size_t)4 * H * W * 4 <= 48 * 1024 && R < (1 << 24),
+                  "roi_pool_fwd_a16: plane %dx%d does not fit the 16-bit argmax / LDS path (use frcnn_roi_pool_fwd)", H, W);
+    return roi_pool_fwd_launch<uint16_t>(feat, C, H, W, rois, R, 7, 7, spatial_scale, out, argmax16, (hipStream_t)stream);
+}
+
+FRCNN_EXPORT int frcnn_roi_pool_bwd_a16(const float *grad_out, const uint16_t *argmax16, int64_t R, int C, int H, int W, float *grad_feat,
+                                        void *stream)
+{
+    FRCNN_REQUIRE(C > 0 && H > 0 && W > 0 && R >= 0, "roi_pool_bwd_a16: bad shape");
+    FRCNN_REQUIRE(grad_feat, "roi_pool_bwd_a16: NULL grad_feat");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t HW = (int64_t)H * W;
+    FRCNN_REQUIRE(HW < 65535 && HW * 4 * ROI_BWD_CB <= 64 * 1024, "roi_pool_bwd_a16: plane does not fit the 16-bit argmax / LDS path");
+    if (R == 0) {
+        if (hipMemsetAsync(grad_feat, 0, (size_t)C * HW * 4, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "roi_pool_bwd_a16: memset failed");
+        return FRCNN_OK;
+    }
+    FRCNN_REQUIRE(grad_out && argmax16, "roi_pool_bwd_a16: NULL pointer");
+    FRCNN_REQUIRE(R * 49 < ((int64_t)1 << 31), "roi_pool_bwd_a16: R*bins too large");
+    return roi_pool_bwd_launch<uint16_t>(grad_out, argmax16, R, C, HW, 49, grad_feat, s);
+}
+
 FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, const float *rois, int64_t R, int PH, int PW,
                                     float spatial_scale, float *out, int32_t *argmax, void *stream)
 {
@@ -245,16 +306,13 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     const int64_t total = R * C * PH * PW;
     FRCNN_REQUIRE(total < ((int64_t)1 << 38), "roi_pool_fwd: output too large");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int CB = ROI_FWD_CB;
-    const size_t plane_bytes = (size_t)CB * H * W * 4;
-    if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24)) {
-        const int RB = ROI_FWD_RB;
-        const size_t shmem = plane_bytes + (size_t)RB * (7 + 7) * 4;
-        FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<CB, 7, 7>), dim3((C + CB - 1) / CB, (unsigned)((R + RB - 1) / RB)), dim3(ROI_FWD_BS),
-                     shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
-        FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");
-        return FRCNN_OK;
-    }
+    const size_t plane_bytes = (size_t)4 * H * W * 4;
+#ifdef ROI_FWD_FORCE_DIRECT
+    if (false)
+#else
+    if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24))
+#endif
+        return roi_pool_fwd_launch<int32_t>(feat, C, H, W, rois, R, PH, PW, spatial_scale, out, argmax, s);
     FRCNN_LAUNCH(KID_ROI_POOL_FWD, roi_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, C, H, W,
                  (const float4 *)rois, total, PH, PW, spatial_scale, out, argmax);
     FRCNN_CHECK_LAUNCH("roi_pool_fwd_kernel");
@@ -275,9 +333,7 @@ FRCNN_EXPORT int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax
     FRCNN_REQUIRE(grad_out && argmax, "roi_pool_bwd: NULL pointer");
     FRCNN_REQUIRE(R * PH * PW < ((int64_t)1 << 31), "roi_pool_bwd: R*bins too large");
     if (HW * 4 * ROI_BWD_CB <= 64 * 1024) {
-        FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_lds_kernel<ROI_BWD_CB>, dim3((C + ROI_BWD_CB - 1) / ROI_BWD_CB), dim3(512), (size_t)HW * 4 * ROI_BWD_CB, s, grad_out, argmax, (int)R, C,
-                     (int)HW, PH * PW, grad_feat);
-        FRCNN_CHECK_LAUNCH("roi_pool_bwd_lds_kernel");
+        return roi_pool_bwd_launch<int32_t>(grad_out, argmax, R, C, HW, PH * PW, grad_feat, s);
     } else if (HW * 4 <= 64 * 1024) {
         FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_kernel, dim3(C), dim3(256), (size_t)HW * 4, s, grad_out, argmax, (int)R, C, (int)HW,
                      PH * PW, grad_feat);

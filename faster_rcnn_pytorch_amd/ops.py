@@ -540,10 +540,15 @@ class _RoIPoolFn(torch.autograd.Function):
         _, Cc, H, W = feat.shape
         R = rois.shape[0]
         out = torch.empty((R, Cc, PH, PW), dtype=torch.float32, device=feat.device)
-        arg = torch.empty((R, Cc, PH, PW), dtype=torch.int32, device=feat.device)
+        # the argmax never leaves this Function: 16 bits are enough for planes below 65535 pixels (the library's private pair)
+        a16 = PH == 7 and PW == 7 and H * W < 65535 and 16 * H * W <= 48 * 1024 and R < (1 << 24)
+        arg = torch.empty((R, Cc, PH, PW), dtype=torch.uint16 if a16 else torch.int32, device=feat.device)
         with torch.cuda.device(feat.device):
-            check(lib.frcnn_roi_pool_fwd(_ptr(feat), Cc, H, W, _ptr(rois), R, PH, PW, float(scale), _ptr(out), _ptr(arg), _stream()),
-                  "roi_pool_fwd")
+            if a16:
+                check(lib.frcnn_roi_pool_fwd_a16(_ptr(feat), Cc, H, W, _ptr(rois), R, float(scale), _ptr(out), _ptr(arg), _stream()), "roi_pool_fwd_a16")
+            else:
+                check(lib.frcnn_roi_pool_fwd(_ptr(feat), Cc, H, W, _ptr(rois), R, PH, PW, float(scale), _ptr(out), _ptr(arg), _stream()),
+                      "roi_pool_fwd")
         ctx.save_for_backward(arg)
         ctx.shape = (Cc, H, W, PH, PW, R)
         return out
@@ -555,8 +560,25 @@ class _RoIPoolFn(torch.autograd.Function):
         grad_out = _req(grad_out, name="grad_out")
         gf = torch.empty((1, Cc, H, W), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
-            check(lib.frcnn_roi_pool_bwd(_ptr(grad_out), _ptr(arg), R, Cc, H, W, PH, PW, _ptr(gf), _stream()), "roi_pool_bwd")
+            if arg.dtype == torch.uint16:
+                check(lib.frcnn_roi_pool_bwd_a16(_ptr(grad_out), _ptr(arg), R, Cc, H, W, _ptr(gf), _stream()), "roi_pool_bwd_a16")
+            else:
+                check(lib.frcnn_roi_pool_bwd(_ptr(grad_out), _ptr(arg), R, Cc, H, W, PH, PW, _ptr(gf), _stream()), "roi_pool_bwd")
         return gf, None, None, None, None      # no gradient through box coordinates
+
+
+def roi_pool_with_argmax(features, rois, output_size=(7, 7), spatial_scale=1.0):
+    """The torchvision-shaped forward: (out [R,C,PH,PW], argmax int32 [R,C,PH,PW], -1 = empty bin), no autograd (tests, parity)."""
+    feat = _req(features, name="features")
+    rois = _req(rois, name="rois").reshape(-1, 4)
+    _, Cc, H, W = feat.shape
+    PH, PW = output_size
+    R = rois.shape[0]
+    out = torch.empty((R, Cc, PH, PW), dtype=torch.float32, device=feat.device)
+    arg = torch.empty((R, Cc, PH, PW), dtype=torch.int32, device=feat.device)
+    with torch.cuda.device(feat.device):
+        check(lib.frcnn_roi_pool_fwd(_ptr(feat), Cc, H, W, _ptr(rois), R, PH, PW, float(spatial_scale), _ptr(out), _ptr(arg), _stream()), "roi_pool_fwd")
+    return out, arg
 
 
 def roi_pool(features, rois, output_size=(7, 7), spatial_scale=1.0):

@@ -195,6 +195,13 @@ int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, const float *rois
 /* grad_feat [C,H,W] is fully overwritten (no pre-zeroing needed). */
 int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax, int64_t R, int C, int H, int W, int PH, int PW,
                        float *grad_feat, void *stream);
+/* The same 7x7 pooling with a library-private 16-bit argmax (0xFFFF = empty bin) for planes of fewer than 65535 pixels that
+ * fit the LDS-staged kernel (4*H*W*4 bytes <= 48 KB): what the host layer's autograd pair uses (models/model.py:113 never sees
+ * the argmax).  Same `out` / `grad_feat` as the int32 entry points; 2 bytes less per pooled element to write and to read back. */
+int frcnn_roi_pool_fwd_a16(const float *feat, int C, int H, int W, const float *rois, int64_t R, float spatial_scale,
+                           float *out /*[R,C,7,7]*/, uint16_t *argmax16 /*[R,C,7,7]*/, void *stream);
+int frcnn_roi_pool_bwd_a16(const float *grad_out, const uint16_t *argmax16, int64_t R, int C, int H, int W,
+                           float *grad_feat, void *stream);
 
 /* torchvision.ops.MultiScaleRoIAlign(names, PH, sampling_ratio) (models/new_model.py:127,143): level mapper
  * k = floor(k0 + log2(sqrt(area)/s0) + 1e-6) clamped to [k_min, k_min+n_levels-1]; per level roi_align

@@ -449,6 +449,19 @@ def test_roi_pool_fwd_bwd_vs_oracle(ops, C, H, W, R):
     assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-5, atol=1e-5)      # fp32 sum order differs: 1e-5
 
 
+@pytest.mark.parametrize("C,H,W,R", [(512, 37, 62, 128), (6, 9, 11, 5), (3, 70, 70, 9)])
+def test_roi_pool_int32_argmax_abi_bit_exact(ops, C, H, W, R):
+    """The torchvision-shaped entry points (int32 argmax, -1 = empty bin): values AND argmax bit-exact, backward from them."""
+    rng = np.random.RandomState(C * 7 + R)
+    f = rng.randn(C, H, W).astype(np.float32)
+    rois = rand_boxes(rng, R, 0.02, 0.9) * np.array([W, H, W, H], np.float32)
+    rois[0] = [W + 3, H + 3, W + 9, H + 9]                                          # outside: empty bins, argmax -1
+    out_o, arg_o = orc.roi_pool_fwd(f, rois, 7, 7, 1.0)
+    out, arg = ops.roi_pool_with_argmax(T(f[None]), T(rois), (7, 7), 1.0)
+    assert np.array_equal(out.cpu().numpy(), out_o) and np.array_equal(arg.cpu().numpy(), arg_o)
+    assert (arg_o[0] == -1).all()
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign
 def test_level_map_bit_exact(ops):
     rng = np.random.RandomState(0)

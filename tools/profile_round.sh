@@ -1,0 +1,24 @@
+#!/bin/bash
+# One round's tracked evidence (run on the GPU box from the repo root):  bash tools/profile_round.sh r02
+#   rocprofv3 --kernel-trace --stats of bench.py (VGG; FPN fp32; FPN bf16) -> per-step kernel summaries (tools/profile_summary.py)
+#   PMC FETCH_SIZE / WRITE_SIZE passes over the same commands (tools/pmc_traffic.sh)
+# Everything lands under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+set -e
+TAG=${1:-rXX}
+R=$(pwd)
+cd /tmp && export TMPDIR=/tmp
+prof() {   # name, bench args...
+    local name=$1; shift
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_prof_$name" -- python3 "$R/bench.py" "$@" --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-events > "$R/gpurun_out/${TAG}_prof_$name.log" 2>&1
+    python3 "$R/tools/profile_summary.py" $(ls "$R"/gpurun_out/${TAG}_prof_$name/*/*_kernel_trace.csv | head -1) --steps 10 > "$R/gpurun_out/${TAG}_${name}_kernel_summary.csv"
+    cp $(ls "$R"/gpurun_out/${TAG}_prof_$name/*/*_kernel_stats.csv | head -1) "$R/gpurun_out/${TAG}_${name}_rocprofv3_kernel_stats.csv"
+    tail -1 "$R/gpurun_out/${TAG}_prof_$name.log" > "$R/gpurun_out/${TAG}_${name}_bench_under_rocprof.json"
+    echo "$name done"
+}
+prof vgg
+prof fpn --config fpn
+prof fpn_bf16 --config fpn --amp bf16
+cd "$R"
+bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_vgg vgg > /dev/null
+bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_fpn fpn > /dev/null
+echo "pmc done"
