@@ -32,6 +32,7 @@ enum FrcnnKernelId {
     KID_DET_LOSS,
     KID_PREPROCESS,
     KID_NMS_SCAN_SIMPLE, // nms_emit_kernel
+    KID_RPN_HEAD_TAIL_BWD,
     KID_COUNT
 };
 

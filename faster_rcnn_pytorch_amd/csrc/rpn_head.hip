@@ -205,3 +205,226 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_fwd(const float *conv_raw, int C, int64_t P
     return frcnn_rpn_head_tail_ml_fwd(lv, FRCNN_DTYPE_F32, FRCNN_DTYPE_F32, C, &P, 1, b3, w_cls, b_cls, n_cls, w_reg, b_reg, n_reg, out_cls, out_reg,
                                       stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward of the tail in ONE kernel + a finalize (the reference gets it from autograd as ~8 eager launches per level: bias
+// gradients, two transposed 1x1 convolutions, the ReLU mask, the weight gradients, concatenations -- ~10 passes over the
+// 256-channel intermediate, 92 MB at FPN size).  With g = [g_cls | g_reg] in [P, J] (J = 2A + 4A <= 64), z = raw + b3, h = relu(z):
+//     dz[c, p] = (sum_j W[j, c] g[p, j]) * (z[c, p] > 0)        -> d_raw (the gradient of the bias-free 3x3 output), db3[c] = sum_p dz
+//     dW[j, c] = sum_p g[p, j] h[c, p],   db[j] = sum_p g[p, j]
+// Block = 8 waves, persistent over 32-position tiles; wave w owns the channels [w C/8, (w+1) C/8) (C % 256 == 0: one or two 32-wide
+// channel tiles).  Per tile: the g tile goes to LDS once; dz is a [C x J].[J x 32] product on v_mfma_f32_32x32x2f32 with the
+// W^T operand resident in registers for the whole kernel; the mask is applied in the accumulator layout (lane = position, registers =
+// 16 channels: raw is read and d_raw written as 128-byte row segments); h passes through a small per-wave LDS tile into the B
+// operand of the second product, dW += g^T h, whose accumulators stay in registers across all tiles of the block.  Per-block
+// partial sums (dW, db, db3) are added in block order by the finalize kernel: no atomics, bit-reproducible.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define HB_GS 65                          // row stride of the g tile in LDS (conflict-free column reads)
+#define HB_HS 33                          // row stride of the per-wave h tile
+
+struct HeadBwdLevels {
+    int n_levels;
+    const void *raw[FRCNN_MAX_LEVELS];
+    void *d_raw[FRCNN_MAX_LEVELS];
+    int P[FRCNN_MAX_LEVELS];
+    int tile0[FRCNN_MAX_LEVELS + 1];
+    int pos0[FRCNN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ void store_raw(float *p, size_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void store_raw(unsigned short *p, size_t i, float v) { p[i] = (unsigned short)to_bf16_rne(v); }
+
+template <typename TIN, int NJ, int CT>
+__global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L, int C, int n_tiles, const float *__restrict__ b3,
+                                                                const float *__restrict__ w_cls, int n_cls, const float *__restrict__ w_reg, int n_reg,
+                                                                const float *__restrict__ g_cls, const float *__restrict__ g_reg,
+                                                                float *__restrict__ part_dw, float *__restrict__ part_db3, float *__restrict__ part_db)
+{
+    __shared__ float s_g[32 * HB_GS];
+    __shared__ float s_h[8][32 * HB_HS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int li = lane & 31, lk = lane >> 5;
+    const int J = n_cls + n_reg;
+    const int cw = wave * 32 * CT;                                  // first channel of this wave
+    // W^T operand of the first product, resident for the whole kernel: A[m = c][k = j] = W[j][c], step s covers j = 2 s + lk
+    float wt[CT][NJ * 16];
+    float bias[CT][16];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = cw + 32 * ct + li;
+#pragma unroll
+        for (int s = 0; s < NJ * 16; ++s) {
+            const int j = 2 * s + lk;
+            wt[ct][s] = j < n_cls ? w_cls[(size_t)j * C + c] : (j < J ? w_reg[(size_t)(j - n_cls) * C + c] : 0.0f);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[ct][r] = b3[cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk];
+    }
+    f32x16 acc_w[NJ][CT];
+    float db3[CT][16];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt) acc_w[jt][ct] = (f32x16){0};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) db3[ct][r] = 0.0f;
+    }
+    float db = 0.0f;                                                // wave 0: lane = output column j
+    float *sh = s_h[wave];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int lvl = 0;
+#pragma unroll
+        for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && tile >= L.tile0[l]) ? 1 : 0;
+        const TIN *raw = (const TIN *)L.raw[lvl];
+        TIN *d_raw = (TIN *)L.d_raw[lvl];
+        const int P = L.P[lvl];
+        const int p0 = (tile - L.tile0[lvl]) * 32;
+        const size_t row0 = (size_t)L.pos0[lvl] + p0;               // first row of this tile in the concatenated g tensors
+        __syncthreads();                                            // the previous tile's readers of s_g are done
+        for (int e = threadIdx.x; e < 32 * 64; e += 512) {          // g tile -> LDS, zero-padded (columns >= J, rows >= P)
+            const int p = e >> 6, j = e & 63;
+            float v = 0.0f;
+            if (p0 + p < P) {
+                if (j < n_cls) v = g_cls[(row0 + p) * n_cls + j];
+                else if (j < J) v = g_reg[(row0 + p) * n_reg + (j - n_cls)];
+            }
+            s_g[p * HB_GS + j] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll 8
+            for (int p = 0; p < 32; ++p) db += s_g[p * HB_GS + lane];
+        }
+        const int pos = min(p0 + li, P - 1);
+        const bool pv = p0 + li < P;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            // ---- dz = W^T g (accumulator: lane = position li, registers = 16 channels)
+            f32x16 acc = (f32x16){0};
+#pragma unroll
+            for (int s = 0; s < NJ * 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ct][s], s_g[li * HB_GS + 2 * s + lk], acc, 0, 0, 0);
+            // ---- ReLU mask, d_raw, db3, h -> LDS
+            float zr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int c = cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                zr[r] = load_raw(raw, (size_t)c * P + pos) + bias[ct][r];
+            }
+            __builtin_amdgcn_wave_barrier();                        // the previous c-tile's readers of my h tile are done
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float dz = zr[r] > 0.0f ? acc[r] : 0.0f;
+                if (pv) { store_raw(d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
+                sh[cl * HB_HS + li] = zr[r] > 0.0f ? zr[r] : 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- dW += g^T h : A[m = j][k = p] = g[p][j], B[k = p][n = c] = h[c][p], step s covers p = 2 s + lk
+#pragma unroll
+            for (int jt = 0; jt < NJ; ++jt) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc_w[jt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_g[(2 * s + lk) * HB_GS + 32 * jt + li], sh[li * HB_HS + 2 * s + lk], acc_w[jt][ct], 0, 0, 0);
+            }
+        }
+    }
+    // ---- per-block partial sums
+    float *pw = part_dw + (size_t)blockIdx.x * 64 * C;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int jt = 0; jt < NJ; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                pw[(size_t)j * C + cw + 32 * ct + li] = acc_w[jt][ct][r];
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = db3[ct][r];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);   // over the 32 positions of my half-wave
+            if (li == 0) part_db3[(size_t)blockIdx.x * C + cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk] = v;
+        }
+    }
+    if (wave == 0) part_db[(size_t)blockIdx.x * 64 + lane] = db;
+}
+
+// sums the per-block partials in block order: dW rows -> dw_cls / dw_reg, db -> db_cls / db_reg, db3
+__global__ __launch_bounds__(256) void rpn_head_tail_bwd_finalize_kernel(const float *__restrict__ part_dw, const float *__restrict__ part_db3,
+                                                                         const float *__restrict__ part_db, int nblk, int C, int n_cls, int n_reg,
+                                                                         float *__restrict__ dw_cls, float *__restrict__ db_cls,
+                                                                         float *__restrict__ dw_reg, float *__restrict__ db_reg, float *__restrict__ db3)
+{
+    const int J = n_cls + n_reg;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < J * C) {
+        const int j = e / C, c = e - j * C;
+        float v = 0.0f;
+        for (int b = 0; b < nblk; ++b) v += part_dw[((size_t)b * 64 + j) * C + c];
+        if (j < n_cls) dw_cls[(size_t)j * C + c] = v; else dw_reg[(size_t)(j - n_cls) * C + c] = v;
+    } else if (e < J * C + C) {
+        const int c = e - J * C;
+        float v = 0.0f;
+        for (int b = 0; b < nblk; ++b) v += part_db3[(size_t)b * C + c];
+        db3[c] = v;
+    } else if (e < J * C + C + J) {
+        const int j = e - J * C - C;
+        float v = 0.0f;
+        for (int b = 0; b < nblk; ++b) v += part_db[(size_t)b * 64 + j];
+        if (j < n_cls) db_cls[j] = v; else db_reg[j - n_cls] = v;
+    }
+}
+
+#define HEAD_BWD_MAX_BLOCKS 256
+size_t frcnn_ws_head_bwd(int64_t C) { return (size_t)HEAD_BWD_MAX_BLOCKS * ((size_t)64 * C + C + 64) * sizeof(float); }
+
+FRCNN_EXPORT int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, void *const *d_raw_levels, int dtype, int C, const int64_t *P_levels,
+                                            int n_levels, const float *b3, const float *w_cls, int n_cls, const float *w_reg, int n_reg,
+                                            const float *g_cls, const float *g_reg, float *dw_cls, float *db_cls, float *dw_reg, float *db_reg,
+                                            float *db3, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FRCNN_REQUIRE(C > 0 && C % 256 == 0 && C <= 512, "rpn_head_tail_bwd: C=%d must be 256 or 512", C);
+    FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS && conv_raw_levels && d_raw_levels && P_levels, "rpn_head_tail_bwd: bad level table");
+    FRCNN_REQUIRE(dtype == FRCNN_DTYPE_F32 || dtype == FRCNN_DTYPE_BF16, "rpn_head_tail_bwd: dtype %d (0 = f32, 1 = bf16)", dtype);
+    FRCNN_REQUIRE(n_cls > 0 && n_reg > 0 && n_cls + n_reg <= 64, "rpn_head_tail_bwd: n_cls + n_reg = %d must be in (0, 64]", n_cls + n_reg);
+    FRCNN_REQUIRE(b3 && w_cls && w_reg && g_cls && g_reg && dw_cls && db_cls && dw_reg && db_reg && db3 && workspace, "rpn_head_tail_bwd: NULL pointer");
+    if (workspace_bytes < frcnn_ws_head_bwd(C))
+        return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_head_tail_bwd: workspace %zu < %zu bytes", workspace_bytes, frcnn_ws_head_bwd(C));
+    HeadBwdLevels L;
+    L.n_levels = n_levels;
+    int64_t tiles = 0, pos = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        const int k = l < n_levels ? l : 0;
+        FRCNN_REQUIRE(conv_raw_levels[k] && d_raw_levels[k] && P_levels[k] > 0 && P_levels[k] < ((int64_t)1 << 30), "rpn_head_tail_bwd: bad level %d", k);
+        L.raw[l] = conv_raw_levels[k]; L.d_raw[l] = d_raw_levels[k]; L.P[l] = (int)P_levels[k];
+        L.tile0[l] = (int)tiles; L.pos0[l] = (int)pos;
+        if (l < n_levels) { tiles += (P_levels[k] + 31) / 32; pos += P_levels[k]; }
+    }
+    L.tile0[FRCNN_MAX_LEVELS] = (int)tiles;
+    FRCNN_REQUIRE(tiles < ((int64_t)1 << 30), "rpn_head_tail_bwd: too many positions");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (int)(tiles < HEAD_BWD_MAX_BLOCKS ? tiles : HEAD_BWD_MAX_BLOCKS);
+    float *part_dw = (float *)workspace;
+    float *part_db3 = part_dw + (size_t)HEAD_BWD_MAX_BLOCKS * 64 * C;
+    float *part_db = part_db3 + (size_t)HEAD_BWD_MAX_BLOCKS * C;
+    const int nj = n_cls + n_reg <= 32 ? 1 : 2;
+    const int ct = C / 256;
+#define HEAD_BWD_LAUNCH(T_, NJ_, CT_)                                                                                                       \
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, CT_>), dim3((unsigned)nblk), dim3(512), 0, s, L, C, (int)tiles, b3, w_cls, \
+                 n_cls, w_reg, n_reg, g_cls, g_reg, part_dw, part_db3, part_db)
+    if (dtype == FRCNN_DTYPE_F32) {
+        if (nj == 1 && ct == 1) HEAD_BWD_LAUNCH(float, 1, 1); else if (nj == 1) HEAD_BWD_LAUNCH(float, 1, 2);
+        else if (ct == 1) HEAD_BWD_LAUNCH(float, 2, 1); else HEAD_BWD_LAUNCH(float, 2, 2);
+    } else {
+        if (nj == 1 && ct == 1) HEAD_BWD_LAUNCH(unsigned short, 1, 1); else if (nj == 1) HEAD_BWD_LAUNCH(unsigned short, 1, 2);
+        else if (ct == 1) HEAD_BWD_LAUNCH(unsigned short, 2, 1); else HEAD_BWD_LAUNCH(unsigned short, 2, 2);
+    }
+#undef HEAD_BWD_LAUNCH
+    FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_kernel");
+    const int n_out = (n_cls + n_reg) * C + C + n_cls + n_reg;
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, rpn_head_tail_bwd_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, part_dw, part_db3, part_db,
+                 nblk, C, n_cls, n_reg, dw_cls, db_cls, dw_reg, db_reg, db3);
+    FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_finalize_kernel");
+    return FRCNN_OK;
+}

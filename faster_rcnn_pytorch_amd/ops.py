@@ -355,6 +355,35 @@ class _RPNHeadTailFn(torch.autograd.Function):
         raws = ctx.saved_tensors[3:]
         n_cls, n_reg = wc.shape[0], wr.shape[0]
         Cc = wc.shape[1]
+        dev = wc.device
+        if Cc in (256, 512):
+            # one fused MFMA kernel + a finalize for all levels (csrc/rpn_head.hip): d_raw, dW, db, db3
+            g_cls = _req(g_cls.reshape(-1, n_cls), name="grad_cls")
+            g_reg = _req(g_reg.reshape(-1, n_reg), name="grad_reg")
+            d_raws = [torch.empty_like(r) for r in raws]
+            dwc, dwr = torch.empty_like(wc), torch.empty_like(wr)
+            dbc = torch.empty((n_cls,), dtype=torch.float32, device=dev)
+            dbr = torch.empty((n_reg,), dtype=torch.float32, device=dev)
+            db3 = torch.empty((Cc,), dtype=torch.float32, device=dev)
+            nb = _lib.workspace_bytes(_lib.OP_HEAD_BWD, Cc)
+            ws = _workspace(dev, nb)
+            ptrs = (C.c_void_p * len(raws))(*[r.data_ptr() for r in raws])
+            dptrs = (C.c_void_p * len(raws))(*[r.data_ptr() for r in d_raws])
+            pl = (C.c_int64 * len(raws))(*[r.shape[2] * r.shape[3] for r in raws])
+            with torch.cuda.device(dev):
+                check(lib.frcnn_rpn_head_tail_ml_bwd(ptrs, dptrs, 1 if raws[0].dtype == torch.bfloat16 else 0, Cc, pl, len(raws), _ptr(b3), _ptr(wc),
+                                                     n_cls, _ptr(wr), n_reg, _ptr(g_cls), _ptr(g_reg), _ptr(dwc), _ptr(dbc), _ptr(dwr), _ptr(dbr),
+                                                     _ptr(db3), _ptr(ws), nb, _stream()), "rpn_head_tail_ml_bwd")
+            return (None, db3, dwc.reshape(ctx.w_shapes[0]), dbc, dwr.reshape(ctx.w_shapes[1]), dbr, *d_raws)
+        return _RPNHeadTailFn._backward_torch(ctx, g_cls, g_reg)
+
+    @staticmethod
+    def _backward_torch(ctx, g_cls, g_reg):
+        """The same gradients as plain torch ops (other channel counts; also the fp32 reference of the fused kernel's test)."""
+        b3, wc, wr = ctx.saved_tensors[:3]
+        raws = ctx.saved_tensors[3:]
+        n_cls, n_reg = wc.shape[0], wr.shape[0]
+        Cc = wc.shape[1]
         w_all = torch.cat([wc, wr], dim=0)
         dW = torch.zeros((n_cls + n_reg, Cc), dtype=torch.float32, device=wc.device)
         db = torch.zeros((n_cls + n_reg,), dtype=torch.float32, device=wc.device)

@@ -53,7 +53,8 @@ typedef enum {
     FRCNN_OP_REGION_PROPOSAL = 3, /* n1 = N anchors, n2 = K */
     FRCNN_OP_RPN_TARGETS = 4,     /* n1 = N anchors, n2 = G */
     FRCNN_OP_HEAD_TARGETS = 5,    /* n1 = P + G candidates */
-    FRCNN_OP_PREPROCESS = 6       /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
+    FRCNN_OP_PREPROCESS = 6,      /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
+    FRCNN_OP_HEAD_BWD = 7         /* n1 = C (frcnn_rpn_head_tail_ml_bwd) */
 } frcnn_op;
 
 int frcnn_abi_version(void);
@@ -150,6 +151,16 @@ int frcnn_rpn_head_tail_fwd(const float *conv_raw, int C, int64_t P, const float
 int frcnn_rpn_head_tail_ml_fwd(const void *const *conv_raw_levels, int dtype, int mfma, int C, const int64_t *P_levels, int n_levels,
                                const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
                                const float *b_reg, int n_reg, float *out_cls, float *out_reg, void *stream);
+
+/* Backward of frcnn_rpn_head_tail_ml_fwd (what autograd derives from models/model.py:79-83 / new_model.py:109-113): given the
+ * gradients of the two outputs (g_cls [sum P_l, n_cls], g_reg [sum P_l, n_reg], the outputs' own layout) it writes
+ *   d_raw_levels[l] [C, P_l]  gradient of the bias-free 3x3 output (same dtype as conv_raw_levels: 0 = f32, 1 = bf16),
+ *   dw_cls [n_cls, C], db_cls [n_cls], dw_reg [n_reg, C], db_reg [n_reg], db3 [C]  (fp32, fully overwritten).
+ * C must be 256 or 512; workspace >= frcnn_workspace_bytes(FRCNN_OP_HEAD_BWD, C, 0).  Exact fp32 MFMA; sums in a fixed order. */
+int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, void *const *d_raw_levels, int dtype, int C, const int64_t *P_levels,
+                               int n_levels, const float *b3, const float *w_cls, int n_cls, const float *w_reg, int n_reg,
+                               const float *g_cls, const float *g_reg, float *dw_cls, float *db_cls, float *dw_reg, float *db_reg,
+                               float *db3, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

@@ -821,3 +821,44 @@ def test_detection_loss_matches_reference_golden_and_autograd(ops, golden):
     for a, b in zip(pred, ref_in):
         assert (a.grad.cpu() - b.grad).abs().max() < 1e-6
     assert np.allclose(orc.frcnn_loss([g[k] for k in names_p], [g[k] for k in names_t]), g["losses"], rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_rpn_head_tail_backward_full_fpn_size_fused_vs_torch(ops, dtype):
+    """The fused MFMA backward (csrc/rpn_head.hip) at the full FPN level shapes of 800x1344 (89 523 positions, C = 256, A = 3)
+    against the same gradients from plain torch ops in float64 on the GPU.  Tolerances: d_raw 1e-5 absolute (fp32) / bf16 rounding
+    (8 mantissa bits) of values ~0.05; dW / db / db3 are sums over 89 523 positions of terms ~1e-2: 1e-3 relative to their max."""
+    g = torch.Generator().manual_seed(5)
+    C_, A = 256, 3
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    raws = [torch.randn(1, C_, h, w, generator=g).to(DEV) for h, w in shapes]
+    if dtype == "bf16":
+        raws = [r.bfloat16() for r in raws]
+    b3 = (torch.randn(C_, generator=g) * 0.1).to(DEV)
+    wc, bc = (torch.randn(2 * A, C_, 1, 1, generator=g) * 0.02).to(DEV), (torch.randn(2 * A, generator=g) * 0.1).to(DEV)
+    wr, br = (torch.randn(4 * A, C_, 1, 1, generator=g) * 0.02).to(DEV), (torch.randn(4 * A, generator=g) * 0.1).to(DEV)
+    dr = [r.clone().requires_grad_(True) for r in raws]
+    params = [t.clone().requires_grad_(True) for t in (b3, wc, bc, wr, br)]
+    cls, reg = ops.rpn_head_tail_levels(dr, *params, mfma="f32")
+    gc, gr = torch.randn(cls.shape, generator=g).to(DEV), torch.randn(reg.shape, generator=g).to(DEV)
+    ((cls * gc).sum() + (reg * gr).sum()).backward()
+    # float64 reference on the same (possibly bf16-rounded) conv outputs
+    w_all = torch.cat([wc.reshape(2 * A, C_), wr.reshape(4 * A, C_)], 0).double()
+    dW = torch.zeros(6 * A, C_, dtype=torch.float64, device=DEV)
+    db = torch.zeros(6 * A, dtype=torch.float64, device=DEV)
+    db3 = torch.zeros(C_, dtype=torch.float64, device=DEV)
+    p0 = 0
+    for r, d in zip(raws, dr):
+        P = r.shape[2] * r.shape[3]
+        gg = torch.cat([gc.reshape(-1, 2 * A)[p0:p0 + P], gr.reshape(-1, 4 * A)[p0:p0 + P]], 1).double()
+        z = r.reshape(C_, P).double() + b3.double()[:, None]
+        dz = (w_all.t() @ gg.t()) * (z > 0)
+        dW += gg.t() @ torch.relu(z).t(); db += gg.sum(0); db3 += dz.sum(1)
+        tol = 1e-5 if dtype == "f32" else 4e-3 * float(dz.abs().max())
+        assert (d.grad.reshape(C_, P).double() - dz).abs().max() < tol
+        p0 += P
+    got_dW = torch.cat([params[1].grad.reshape(2 * A, C_), params[3].grad.reshape(4 * A, C_)], 0).double()
+    got_db = torch.cat([params[2].grad, params[4].grad]).double()
+    assert (got_dW - dW).abs().max() < 1e-3 * float(dW.abs().max())
+    assert (got_db - db).abs().max() < 1e-3 * float(db.abs().max())
+    assert (params[0].grad.double() - db3).abs().max() < 1e-3 * float(db3.abs().max())
