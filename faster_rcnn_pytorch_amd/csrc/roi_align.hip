@@ -9,10 +9,11 @@
 //             25 KB of LDS with coalesced row loads, then a lane owns one bin, sets up its 4 samples x 4 taps ONCE
 //             and walks the staged channels (same operation order as the oracle: bit-identical outputs).  Channel groups are pinned to XCDs (blockIdx & 7) so that each XCD's L2 only ever
 //             holds its own eighth of the pyramid instead of all 91 MB streaming through all eight.
-//   backward: tile-owner GATHER (roi_align_bwd_tile_kernel): bilinear scatter is separable,
-//             dF = Wy^T (fh x 7) . dOut (7x7) . Wx (7 x fw), so a workgroup that owns a 16 x 8 pixel tile of one level for 32
-//             channels walks the RoIs whose footprint meets the tile IN INDEX ORDER and accumulates the tile in registers;
-//             every gradient pixel is written exactly once: no atomics, no memset, bit-reproducible.
+//   backward: tile-owner GATHER: bilinear scatter is separable, dF = Wy^T (fh x 7) . dOut (7x7) . Wx (7 x fw), so a workgroup that
+//             owns a 16 x 8 pixel tile of one level walks the RoIs whose footprint meets the tile IN INDEX ORDER and accumulates
+//             the tile in registers; every gradient pixel is written exactly once: no atomics, no memset, bit-reproducible.
+//             Fine levels: roi_align_bwd_tile_kernel (32 channels per workgroup, one RoI at a time); coarse levels, where a tile's
+//             RoI list is long: roi_align_bwd_coarse_kernel (16 channels, eight RoIs in flight, combined in a fixed order).
 // Any other bin/sampling shape takes the generic one-lane-per-output kernels below (memset + fp32 atomics in backward;
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
@@ -466,6 +467,201 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
     }
 }
 
+// ---- the same gather for the COARSE levels: 8 channels per workgroup, eight RoIs in flight ------------------------
+// (16 channels per workgroup, two sub-groups of 8 per lane.)
+// The coarse levels have few tiles and every large RoI touches all of them: with the kernel above (ONE RoI in flight per
+// workgroup, 32 channels) a coarse tile is a chain of ~200 RoIs x 0.5 us on an untrained frame -- 194 us in the FPN step against
+// 61 us in the micro-benchmark.  Here a workgroup owns a 16 x 8 pixel tile of one level for 16 channels and writes it exactly once.  It scans the RoI list (level +
+// footprint recomputed from the box, 2 RoIs per lane at R = 512), keeps the ones whose footprint meets the tile IN INDEX ORDER
+// (ballot compaction), and its EIGHT WAVES then walk that list concurrently, wave w taking entries w, w + 8, ... with no workgroup
+// barrier in between.  Per RoI a wave
+//   A: stores the prefetched dOut[r][8 ch][7][7] to its private LDS tile and builds the two separable weight tables restricted to the
+//      tile, Wy[16][7] and Wx[8][7] (lane = (row | col, bin): 1-D bilinear set-ups, gathered, no scatter / zero pass),
+//   B: lane = (column, channel) forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds
+//      sum_ph Wy[y][ph] * T[ph] to its 16 row accumulators (registers).
+// At the end the eight private accumulator tiles are added in wave order through LDS: every pixel is written once, the fp32 sum
+// order is fixed (bit-reproducible gradients), nothing is cleared beforehand.
+// (Used for every level it was 6x slower: 24 000 workgroups x 57 KB of LDS, each scanning the whole RoI list.  It only pays where
+// the lists are long.)
+#define RC_TH 16
+#define RC_TW 8
+#define RC_NS 2                          // channel sub-groups of 8 per lane
+#define RC_CB (8 * RC_NS)                // channels per workgroup: lane = (column 0..7, channel 0..7 of each sub-group)
+#define RC_WAVES 8                       // RoIs in flight per workgroup
+#define RC_LIST 512                      // RoIs are scanned in chunks of this many (one per thread)
+#define RC_GE (RC_CB * 49)               // dOut elements of one RoI for this channel group
+#define RC_PF ((RC_GE + 63) / 64)        // ... prefetched per lane
+
+
+template <typename TOUT>
+__global__ __launch_bounds__(64 * RC_WAVES) void roi_align_bwd_coarse_kernel(MsLevels L, TileLevels TL, int C, const float4 *__restrict__ rois, int R, int aligned,
+                                                                          int k_min, float s0, int k0, const float *__restrict__ grad_out, int n_cg)
+{
+    // the RoI list + the waves' dOut tiles (during the walk) and the waves' accumulator tiles (at the end) share one buffer
+    constexpr int U_WALK = (int)sizeof(RoiEnt) / 4 * RC_LIST + RC_WAVES * (RC_GE + 8), U_ACC = (RC_WAVES - 1) * RC_CB * RC_TH * RC_TW;
+    __shared__ __attribute__((aligned(16))) float s_u[U_WALK > U_ACC ? U_WALK : U_ACC];
+    RoiEnt *s_list = (RoiEnt *)s_u;
+    float (*s_g)[RC_GE + 8] = (float (*)[RC_GE + 8])(s_u + sizeof(RoiEnt) / 4 * RC_LIST);
+    float (*s_acc)[RC_CB * RC_TH * RC_TW] = (float (*)[RC_CB * RC_TH * RC_TW])s_u;
+    __shared__ int s_n;
+    __shared__ int s_woff[RC_WAVES + 1];
+    __shared__ __attribute__((aligned(16))) float s_wy[RC_WAVES][RC_TH * 8];
+    __shared__ float s_wx[RC_WAVES][RC_TW * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // block -> (tile, channel group); groups pinned to XCDs when there are 8 k of them
+    int tile, cg;
+    if ((n_cg & 7) == 0) { const int j = blockIdx.x >> 3; const int q8 = n_cg >> 3; cg = (j % q8) * 8 + (blockIdx.x & 7); tile = j / q8; }
+    else { cg = blockIdx.x % n_cg; tile = blockIdx.x / n_cg; }
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
+    const int tl = tile - TL.tile0[l];
+    const int ty0 = (tl / TL.tiles_x[l]) * RC_TH, tx0 = (tl % TL.tiles_x[l]) * RC_TW;
+    const int H = L.H[l], W = L.W[l];
+    const float scale = L.scale[l];
+    const int cx = lane & 7, cc = lane >> 3;              // phase B: lane -> (column cx, channel cc of the group)
+    const int c0 = cg * RC_CB;
+    const int nc = min(RC_CB, C - c0);
+    const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
+    float *my_g = s_g[wave], *my_wy = s_wy[wave], *my_wx = s_wx[wave];
+
+    float acc[RC_NS][RC_TH];
+#pragma unroll
+    for (int sg = 0; sg < RC_NS; ++sg)
+#pragma unroll
+        for (int y = 0; y < RC_TH; ++y) acc[sg][y] = 0.0f;
+
+    for (int rbase = 0; rbase < R; rbase += RC_LIST) {
+        // ---- scan RC_LIST RoIs: which of them touch this tile?
+        __syncthreads();                                   // the previous chunk's readers of s_list are done
+        const int r = rbase + t;
+        bool hit = false;
+        RoiEnt e;
+        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f;
+        if (r < R) {
+            const float4 b = rois[r];
+            const int lr = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
+            if (lr == l) {
+                const AlignGeom g = align_geom(b, scale, 7, 7, 2, aligned != 0);
+                const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
+                const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
+                const int y0 = min(ya.lo, yb.lo), y1 = max(ya.hi, yb.hi), x0 = min(xa.lo, xb.lo), x1 = max(xa.hi, xb.hi);
+                hit = y0 < ty0 + RC_TH && y1 >= ty0 && x0 < tx0 + RC_TW && x1 >= tx0;
+                e.sh = g.sh; e.sw = g.sw; e.bh = g.bh; e.bw = g.bw;
+            }
+        }
+        const unsigned long long bm = __ballot(hit);
+        if (lane == 0) s_woff[wave + 1] = __builtin_popcountll(bm);
+        __syncthreads();
+        if (t == 0) { s_woff[0] = 0; for (int q = 1; q <= RC_WAVES; ++q) s_woff[q] += s_woff[q - 1]; s_n = s_woff[RC_WAVES]; }
+        __syncthreads();
+        if (hit) s_list[s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
+        __syncthreads();
+        const int n = s_n;
+        // ---- my share of the list: entries wave, wave + RC_WAVES, ... (index order inside the share)
+        float pg[RC_PF];                                   // prefetched dOut elements lane + 64 u of my next RoI
+#pragma unroll
+        for (int u = 0; u < RC_PF; ++u) pg[u] = 0.0f;
+        if (wave < n) {
+            const float *src = grad_out + ((size_t)s_list[wave].r * C + c0) * 49;
+#pragma unroll
+            for (int u = 0; u < RC_PF; ++u) if (lane + 64 * u < ne) pg[u] = src[lane + 64 * u];
+        }
+        for (int i = wave; i < n; i += RC_WAVES) {
+            const RoiEnt en = s_list[i];
+            __builtin_amdgcn_wave_barrier();               // my previous RoI's LDS reads are issued (a wave's ds ops run in order)
+            // A: dOut tile -> LDS (zero-padded to RC_CB channels), weight tables of this RoI restricted to the tile
+#pragma unroll
+            for (int u = 0; u < RC_PF; ++u)
+                if (lane + 64 * u < RC_GE) my_g[lane + 64 * u] = lane + 64 * u < ne ? pg[u] : 0.0f;
+            if (i + RC_WAVES < n) {
+                const float *src = grad_out + ((size_t)s_list[i + RC_WAVES].r * C + c0) * 49;
+#pragma unroll
+                for (int u = 0; u < RC_PF; ++u) if (lane + 64 * u < ne) pg[u] = src[lane + 64 * u];
+            }
+            {
+                // lanes 0..55: (col = lane / 7, bin = lane % 7) of Wx and rows 0..7 of Wy; then rows 8..15 of Wy
+                const int bin = lane % 7, rc = lane / 7;
+                if (rc < RC_TW) {
+                    const int x = tx0 + rc;
+                    float wv = 0.0f;
+#pragma unroll
+                    for (int ix = 0; ix < 2; ++ix) {
+                        const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
+                        if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
+                    }
+                    my_wx[rc * 8 + bin] = wv;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int yy = rc + 8 * half, y = ty0 + yy;
+                        float wy = 0.0f;
+#pragma unroll
+                        for (int iy = 0; iy < 2; ++iy) {
+                            const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
+                            if (q.ok) wy += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
+                        }
+                        my_wy[yy * 8 + bin] = 0.25f * wy;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // B: T[ph] for (cc, cx), then the tile rows the footprint reaches (uniform bounds)
+            const Lin fa = lin_setup(H, en.sh + 0.5f * en.bh / 2.0f), fb = lin_setup(H, en.sh + 6.0f * en.bh + 1.5f * en.bh / 2.0f);
+            const int ya = __builtin_amdgcn_readfirstlane(max(min(fa.lo, fb.lo) - ty0, 0));
+            const int yb = __builtin_amdgcn_readfirstlane(min(max(fa.hi, fb.hi) - ty0, RC_TH - 1));
+            float wx[7];
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) wx[pw] = my_wx[cx * 8 + pw];
+#pragma unroll
+            for (int sg = 0; sg < RC_NS; ++sg) {
+                const float *gch = &my_g[(cc + 8 * sg) * 49];
+                float T[7];
+#pragma unroll
+                for (int ph = 0; ph < 7; ++ph) {
+                    float a = gch[ph * 7] * wx[0];
+#pragma unroll
+                    for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
+                    T[ph] = a;
+                }
+#pragma unroll
+                for (int y = 0; y < RC_TH; ++y) {
+                    if (y >= ya && y <= yb) {             // scalar branch
+                        const float4 w0 = *(const float4 *)&my_wy[y * 8], w1 = *(const float4 *)&my_wy[y * 8 + 4];
+                        float a = acc[sg][y];
+                        a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
+                        a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
+                        acc[sg][y] = __builtin_fmaf(w1.z, T[6], a);
+                    }
+                }
+            }
+        }
+    }
+    // ---- add the eight private tiles in wave order, then one coalesced store per row and channel
+    __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+        for (int sg = 0; sg < RC_NS; ++sg)
+#pragma unroll
+            for (int y = 0; y < RC_TH; ++y) s_acc[wave - 1][((cc + 8 * sg) * RC_TH + y) * RC_TW + cx] = acc[sg][y];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int sg = 0; sg < RC_NS; ++sg) {
+        const int c = cc + 8 * sg;
+#pragma unroll
+        for (int w = 0; w < RC_WAVES - 1; ++w)
+#pragma unroll
+            for (int y = 0; y < RC_TH; ++y) acc[sg][y] += s_acc[w][(c * RC_TH + y) * RC_TW + cx];
+        if (tx0 + cx < W && c < nc) {
+            TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + ty0) * W + tx0 + cx;
+#pragma unroll
+            for (int y = 0; y < RC_TH; ++y)
+                if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[sg][y]);
+        }
+    }
+}
+
 FRCNN_EXPORT int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, int k_max, float s0, int k0, float eps, int32_t *out_level,
                                      void *stream)
 {
@@ -535,18 +731,34 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
     const int64_t total = R * C * PH * PW;
     hipStream_t s = (hipStream_t)stream;
     if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
-        TileLevels TL;
-        int tiles = 0;
-        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
-            TL.tile0[l] = tiles;
-            TL.tiles_x[l] = (L.W[l] + RT_TW - 1) / RT_TW;
-            if (l < n_levels) tiles += TL.tiles_x[l] * ((L.H[l] + RT_TH - 1) / RT_TH);
-        }
-        TL.tile0[FRCNN_MAX_LEVELS] = tiles;
-        const int n_quads = (C + RT_CB - 1) / RT_CB;
-        FRCNN_REQUIRE((int64_t)tiles * n_quads < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(tiles * n_quads)), dim3(256), 0, s, L, TL, C,
-                     (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_quads);
+        // fine levels: the 32-channel kernel; coarse levels (fewer than a sixth of the finest level's tiles): the 8-channel kernel
+        int real[FRCNN_MAX_LEVELS];
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l)
+            real[l] = l < n_levels ? ((L.W[l] + RT_TW - 1) / RT_TW) * ((L.H[l] + RT_TH - 1) / RT_TH) : 0;
+        int first_coarse = n_levels;
+        for (int l = n_levels - 1; l >= 1; --l)
+            if (real[l] * 6 <= real[0]) first_coarse = l; else break;
+        auto fill = [&](TileLevels &T, int lo, int hi) {             // tiles of the levels [lo, hi); the others get none
+            int tiles = 0;
+            for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+                T.tile0[l] = tiles;
+                T.tiles_x[l] = (L.W[l] + RT_TW - 1) / RT_TW;
+                if (l >= lo && l < hi) tiles += real[l];
+            }
+            T.tile0[FRCNN_MAX_LEVELS] = tiles;
+            return tiles;
+        };
+        static_assert(RT_TH == RC_TH && RT_TW == RC_TW, "both tile kernels use the same tile shape");
+        TileLevels TF, TC;
+        const int tiles_f = fill(TF, 0, first_coarse), tiles_c = fill(TC, first_coarse, n_levels);
+        const int n_quads = (C + RT_CB - 1) / RT_CB, n_oct = (C + RC_CB - 1) / RC_CB;
+        FRCNN_REQUIRE((int64_t)tiles_f * n_quads < ((int64_t)1 << 31) && (int64_t)tiles_c * n_oct < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        if (tiles_f > 0)
+            FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(tiles_f * n_quads)), dim3(256), 0, s, L, TF, C,
+                         (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_quads);
+        if (tiles_c > 0)
+            FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_coarse_kernel<float>), dim3((unsigned)(tiles_c * n_oct)), dim3(64 * RC_WAVES), 0, s, L, TC, C,
+                         (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_oct);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
         return FRCNN_OK;
     }

@@ -212,8 +212,9 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_fwd(const float *conv_raw, int C, int64_t P
 // 256-channel intermediate, 92 MB at FPN size).  With g = [g_cls | g_reg] in [P, J] (J = 2A + 4A <= 64), z = raw + b3, h = relu(z):
 //     dz[c, p] = (sum_j W[j, c] g[p, j]) * (z[c, p] > 0)        -> d_raw (the gradient of the bias-free 3x3 output), db3[c] = sum_p dz
 //     dW[j, c] = sum_p g[p, j] h[c, p],   db[j] = sum_p g[p, j]
-// Block = 8 waves, persistent over 32-position tiles; wave w owns the channels [w C/8, (w+1) C/8) (C % 256 == 0: one or two 32-wide
-// channel tiles).  Per tile: the g tile goes to LDS once; dz is a [C x J].[J x 32] product on v_mfma_f32_32x32x2f32 with the
+// Block = 8 waves, persistent over 32-position tiles, for 256 channels (blockIdx.y selects the half of a 512-channel head: two
+// 32-wide channel tiles per wave needed ~330 registers and spilled 100 of them to scratch -- 69 us for the 72 tiles of config V);
+// wave w owns the channels [256 y + 32 w, + 32).  Per tile: the g tile goes to LDS once; dz is a [C x J].[J x 32] product on v_mfma_f32_32x32x2f32 with the
 // W^T operand resident in registers for the whole kernel; the mask is applied in the accumulator layout (lane = position, registers =
 // 16 channels: raw is read and d_raw written as 128-byte row segments); h passes through a small per-wave LDS tile into the B
 // operand of the second product, dW += g^T h, whose accumulators stay in registers across all tiles of the block.  Per-block
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lk = lane >> 5;
     const int J = n_cls + n_reg;
-    const int cw = wave * 32 * CT;                                  // first channel of this wave
+    const int cw = (int)blockIdx.y * 256 * CT + wave * 32 * CT;     // first channel of this wave
     // W^T operand of the first product, resident for the whole kernel: A[m = c][k = j] = W[j][c], step s covers j = 2 s + lk
     float wt[CT][NJ * 16];
     float bias[CT][16];
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
             if (li == 0) part_db3[(size_t)blockIdx.x * C + cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk] = v;
         }
     }
-    if (wave == 0) part_db[(size_t)blockIdx.x * 64 + lane] = db;
+    if (wave == 0 && blockIdx.y == 0) part_db[(size_t)blockIdx.x * 64 + lane] = db;
 }
 
 // sums the per-block partials in block order: dW rows -> dw_cls / dw_reg, db -> db_cls / db_reg, db3
@@ -358,20 +359,29 @@ __global__ __launch_bounds__(256) void rpn_head_tail_bwd_finalize_kernel(const f
 {
     const int J = n_cls + n_reg;
     const int e = blockIdx.x * 256 + threadIdx.x;
+    // one thread per output, neighbouring threads read neighbouring words of a partial; eight partials in flight per thread
+    // (one load after the other cost 63 us for 256 partials).  The summation order is fixed: bit-reproducible.
+    const float *src = nullptr;
+    size_t stride = 0;
+    if (e < J * C) { src = part_dw + e; stride = (size_t)64 * C; }
+    else if (e < J * C + C) { src = part_db3 + (e - J * C); stride = (size_t)C; }
+    else if (e < J * C + C + J) { src = part_db + (e - J * C - C); stride = 64; }
+    if (!src) return;
+    float v = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = b0 + u < nblk ? src[(size_t)(b0 + u) * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
     if (e < J * C) {
         const int j = e / C, c = e - j * C;
-        float v = 0.0f;
-        for (int b = 0; b < nblk; ++b) v += part_dw[((size_t)b * 64 + j) * C + c];
         if (j < n_cls) dw_cls[(size_t)j * C + c] = v; else dw_reg[(size_t)(j - n_cls) * C + c] = v;
     } else if (e < J * C + C) {
-        const int c = e - J * C;
-        float v = 0.0f;
-        for (int b = 0; b < nblk; ++b) v += part_db3[(size_t)b * C + c];
-        db3[c] = v;
-    } else if (e < J * C + C + J) {
+        db3[e - J * C] = v;
+    } else {
         const int j = e - J * C - C;
-        float v = 0.0f;
-        for (int b = 0; b < nblk; ++b) v += part_db[(size_t)b * 64 + j];
         if (j < n_cls) db_cls[j] = v; else db_reg[j - n_cls] = v;
     }
 }
@@ -409,17 +419,11 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, 
     float *part_db3 = part_dw + (size_t)HEAD_BWD_MAX_BLOCKS * 64 * C;
     float *part_db = part_db3 + (size_t)HEAD_BWD_MAX_BLOCKS * C;
     const int nj = n_cls + n_reg <= 32 ? 1 : 2;
-    const int ct = C / 256;
-#define HEAD_BWD_LAUNCH(T_, NJ_, CT_)                                                                                                       \
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, CT_>), dim3((unsigned)nblk), dim3(512), 0, s, L, C, (int)tiles, b3, w_cls, \
-                 n_cls, w_reg, n_reg, g_cls, g_reg, part_dw, part_db3, part_db)
-    if (dtype == FRCNN_DTYPE_F32) {
-        if (nj == 1 && ct == 1) HEAD_BWD_LAUNCH(float, 1, 1); else if (nj == 1) HEAD_BWD_LAUNCH(float, 1, 2);
-        else if (ct == 1) HEAD_BWD_LAUNCH(float, 2, 1); else HEAD_BWD_LAUNCH(float, 2, 2);
-    } else {
-        if (nj == 1 && ct == 1) HEAD_BWD_LAUNCH(unsigned short, 1, 1); else if (nj == 1) HEAD_BWD_LAUNCH(unsigned short, 1, 2);
-        else if (ct == 1) HEAD_BWD_LAUNCH(unsigned short, 2, 1); else HEAD_BWD_LAUNCH(unsigned short, 2, 2);
-    }
+#define HEAD_BWD_LAUNCH(T_, NJ_)                                                                                                            \
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, 1>), dim3((unsigned)nblk, (unsigned)(C / 256)), dim3(512), 0, s, L, C, (int)tiles, \
+                 b3, w_cls, n_cls, w_reg, n_reg, g_cls, g_reg, part_dw, part_db3, part_db)
+    if (dtype == FRCNN_DTYPE_F32) { if (nj == 1) HEAD_BWD_LAUNCH(float, 1); else HEAD_BWD_LAUNCH(float, 2); }
+    else { if (nj == 1) HEAD_BWD_LAUNCH(unsigned short, 1); else HEAD_BWD_LAUNCH(unsigned short, 2); }
 #undef HEAD_BWD_LAUNCH
     FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_kernel");
     const int n_out = (n_cls + n_reg) * C + C + n_cls + n_reg;
