@@ -60,7 +60,7 @@ BOUND = {"nms_resolve_kernel": "latency", "nms_emit_kernel": "latency", "rpn_sam
          "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
          "nms_sup_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
          "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
-         "rpn_conv3x3_kernel": "mfma"}
+         "rpn_conv3x3_head_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
 
 
 def synth_frame(cfg, rank, step):

@@ -29,6 +29,7 @@ size_t frcnn_ws_head_targets(int64_t n);
 size_t frcnn_ws_region_proposal(int64_t N, int64_t K, int64_t P);
 size_t frcnn_ws_preprocess(int64_t in_hw, int64_t out_hw);
 size_t frcnn_ws_head_bwd(int64_t C);
+size_t frcnn_ws_rpn_conv(void);
 
 FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
 {
@@ -41,6 +42,7 @@ FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
     case FRCNN_OP_HEAD_TARGETS: return frcnn_ws_head_targets(n1);
     case FRCNN_OP_PREPROCESS: return frcnn_ws_preprocess(n1, n2);
     case FRCNN_OP_HEAD_BWD: return frcnn_ws_head_bwd(n1);
+    case FRCNN_OP_RPN_CONV: return frcnn_ws_rpn_conv();
     default: return 0;
     }
 }
@@ -85,7 +87,7 @@ static const char *const g_kernel_names[KID_COUNT] = {
     "anchor_grid_kernel", "box_codec_kernel", "pairwise_iou_kernel", "proposal_prologue_kernel",
     "topk_partition_kernels", "topk_bucket_kernel", "nms_sup_kernel", "nms_resolve_kernel",
     "rpn_colmax_kernel", "rpn_label_kernel", "rpn_sample_kernel", "head_targets_kernel",
-    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_emit_kernel", "rpn_head_tail_bwd_kernel"};
+    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_emit_kernel", "rpn_head_tail_bwd_kernel", "rpn_conv3x3_head_kernel", "rpn_conv_pack_kernel"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_prof_mu;

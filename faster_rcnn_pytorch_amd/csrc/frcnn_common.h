@@ -33,6 +33,8 @@ enum FrcnnKernelId {
     KID_PREPROCESS,
     KID_NMS_SCAN_SIMPLE, // nms_emit_kernel
     KID_RPN_HEAD_TAIL_BWD,
+    KID_RPN_CONV,
+    KID_RPN_CONV_PACK,
     KID_COUNT
 };
 

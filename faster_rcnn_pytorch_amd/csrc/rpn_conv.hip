@@ -1,0 +1,409 @@
+// rpn_conv.hip -- the whole RPN head of the FPN model (models/new_model.py:89-114) for the bf16 mixed-precision configuration
+// (BASELINE configs[4]) as ONE implicit-GEMM kernel on the bf16 matrix cores:
+//     raw = conv3x3(x, W3)            (256 -> 256, stride 1, pad 1, bf16 operands, fp32 accumulate, stored as bf16 for backward)
+//     h   = relu(raw + b3)            (fp32 bias; never leaves the registers)
+//     cls = Wc h + bc, reg = Wr h + br  (fp32 accumulate, fp32 outputs in the reference's permute(0,2,3,1).view(B,-1,2|4) layout)
+// for all pyramid levels in one launch.  MIOpen runs the five 3x3 convolutions at 11.6 % of the dense bf16 peak
+// (364 us for 105.6 GFLOP, profiles/r02b_fpn_bf16_kernel_summary.csv: igemm 160 us + NCHW<->NHWC transposes for the largest
+// level, im2col + GEMM for the others) and the 256-channel intermediate makes a round trip through HBM before the 1x1 heads.
+//
+// GEMM view per output tile: D[m = output channel][n = position] = sum_k W3[m][k] X[k][n], k = (input channel, tap).
+//   block = 256 threads = 4 waves, tile = 256 channels x (8 rows x 32 columns of one level); wave (wc, wp) owns channels
+//   [128 wc, +128) x tile rows [4 wp, +4): 4 x 4 v_mfma_f32_32x32x16_bf16 tiles = 256 accumulator registers per lane.
+//   K is walked as 16 input channels at a time (the 10 x 34 halo of the tile for those channels goes to LDS once, [pixel][16 ch],
+//   pixel stride 48 bytes: conflict-free ds_read_b128 of "8 consecutive channels of my pixel") x 9 taps (a tap is a shift of
+//   the halo address, and an 8 KB slice of the pre-packed weights W3p[chunk][tap][m][16] staged in LDS, row stride 48 bytes).
+//   One workgroup barrier per (chunk, kernel row) step = 48 MFMAs per wave; both LDS buffers are double-buffered and filled from
+//   registers that were loaded one step (weights) / one chunk (pixels) ahead.
+// Epilogue on the accumulators (C/D layout: lane = position, registers = 16 channels): round to bf16 = raw (stored as 64-byte row
+//   segments), add b3, ReLU, round to bf16 -- and those registers ARE the B operand of the second product (D2[j][n] += Wh[j][c] h[c][n]):
+//   for a 32-channel tile the lane's registers 8 s .. 8 s + 7 hold channels 16 s + {0..3, 8..11} (+4 for the upper half-wave), which
+//   is a permutation of a K = 16 slice; the head weights are pre-packed with the same permutation.  The two channel halves are
+//   added through LDS, the biases are added and cls / reg are written.
+#include "frcnn_common.h"
+#include "frcnn_internal.h"
+#include <atomic>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+#define RC3_C 256                       // input = output channels of the head
+#define RC3_TH 8
+#define RC3_TW 32
+#define RC3_HW (RC3_TW + 2)             // halo width
+#define RC3_HP ((RC3_TH + 2) * RC3_HW)  // halo pixels: 340
+#define RC3_PS 24                       // pixel / weight-row stride in LDS, in bf16 elements (48 bytes)
+#define RC3_XE ((RC3_HP * 16 + 255) / 256)   // halo elements per thread and chunk: 22
+
+struct ConvLevels {
+    int n_levels;
+    const unsigned short *x[FRCNN_MAX_LEVELS];     // [256, H, W] bf16
+    unsigned short *raw[FRCNN_MAX_LEVELS];         // [256, H, W] bf16 (bias-free 3x3 output)
+    int H[FRCNN_MAX_LEVELS], W[FRCNN_MAX_LEVELS];
+    int tile0[FRCNN_MAX_LEVELS + 1];               // first tile of level l
+    int tiles_x[FRCNN_MAX_LEVELS];
+    int pos0[FRCNN_MAX_LEVELS];                    // first output row of level l in the concatenated cls / reg tensors
+};
+
+__device__ __forceinline__ unsigned short f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // (HIP's uint4 is a struct around a union: arrays of it end up in scratch)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// (lo, hi) -> two bf16 in one dword, round to nearest even, NaN stays NaN: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
+{
+    const bf16x2_t r = __builtin_convertvector((f32x2_t){lo, hi}, bf16x2_t);
+    return *(const unsigned *)&r;
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
+// W3 [256 out][256 in][3][3] fp32 -> W3p[chunk 16][tap 9][out 256][16 in] bf16 ; Wc [n_cls][256], Wr [n_reg][256] fp32 ->
+// Whp[ct 8][s 2][j 32][g 2][e 8] bf16 with channel = 32 ct + 16 s + 4 g + (e & 3) + 8 (e >> 2), rows j >= n_cls + n_reg zero
+__global__ __launch_bounds__(256) void rpn_conv_pack_kernel(const float *__restrict__ w3, const float *__restrict__ w_cls, int n_cls,
+                                                            const float *__restrict__ w_reg, int n_reg, unsigned short *__restrict__ w3p,
+                                                            unsigned short *__restrict__ whp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 16 * 9 * 256 * 16) {
+        const int k = i & 15, m = (i >> 4) & 255, tap = (i >> 12) % 9, chunk = (i >> 12) / 9;
+        w3p[i] = f2bf(w3[((size_t)m * RC3_C + chunk * 16 + k) * 9 + tap]);
+    }
+    if (i < 8 * 2 * 32 * 2 * 8) {
+        const int e = i & 7, g = (i >> 3) & 1, j = (i >> 4) & 31, s = (i >> 9) & 1, ct = i >> 10;
+        const int c = 32 * ct + 16 * s + 4 * g + (e & 3) + 8 * (e >> 2);
+        float v = 0.0f;
+        if (j < n_cls) v = w_cls[(size_t)j * RC3_C + c];
+        else if (j < n_cls + n_reg) v = w_reg[(size_t)(j - n_cls) * RC3_C + c];
+        whp[i] = f2bf(v);
+    }
+}
+
+template <bool ODDW>
+__device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels &L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
+                                                               const unsigned short *__restrict__ whp, const float *__restrict__ b_cls, int n_cls,
+                                                               const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
+                                                               float *__restrict__ out_reg)
+{
+    // dynamic LDS (106 KB): [2][halo pixels x 24] (2 x 16 320 B), then [2][3 taps][256 rows x 24] (2 x 36 864 B); the epilogue reuses
+    // the first 32 KB.  The weights of a whole kernel ROW (3 taps) are staged per barrier: one barrier per tap (16 MFMAs per wave
+    // between barriers, one wave per SIMD) ran at 12 % of the matrix peak -- no better than MIOpen.
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_all[];
+    unsigned short (*s_x)[RC3_HP * RC3_PS] = (unsigned short (*)[RC3_HP * RC3_PS])s_all;
+    unsigned short (*s_w)[3 * RC3_C * RC3_PS] = (unsigned short (*)[3 * RC3_C * RC3_PS])(s_all + 2 * RC3_HP * RC3_PS);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const int wc = wave & 1, wp = wave >> 1;               // channel half, tile-row half
+    const int H = L.H[lvl], W = L.W[lvl];
+    const int tl = (int)blockIdx.x - L.tile0[lvl];
+    const int y0 = (tl / L.tiles_x[lvl]) * RC3_TH, x0 = (tl % L.tiles_x[lvl]) * RC3_TW;
+    const unsigned short *xin = L.x[lvl];
+    const size_t plane = (size_t)H * W;
+
+    // Pixel staging.  Sub-dword memory operations are slow (global_load_ushort / ds_write_b16 per halo element cost 90 us per round
+    // of tiles), so an item = (channel pair, halo row, aligned pixel pair): dword loads (channels 2q and 2q + 1, pixels 2w and
+    // 2w + 1 of the row, w counted from the even column x0 - 2), a 2 x 2 transpose in registers, two dword LDS stores
+    // ([pixel][channel pair]).  8 pairs x 10 rows x 18 words = 1440 items per 16-channel chunk, <= 6 per thread.
+    // The loads are UNCONDITIONAL (out-of-image items read element 0 and are masked at the store): a load under a lane-dependent
+    // branch makes the compiler's s_waitcnt bookkeeping give up, and every LDS store of the (earlier issued) weights then waits
+    // for the HBM latency of the pixel loads as well -- 35 us per tile.
+    // ODDW (a level of odd width, e.g. 13 x 21): element offsets can be odd, so each pair is cut out of the two aligned dwords
+    // around it (4 loads per item instead of 2).
+    constexpr int XI = (8 * (RC3_TH + 2) * 18 + 255) / 256;
+    constexpr int XL = ODDW ? 2 : 1;
+    unsigned x_off[XI];                                     // element offset of the even pixel inside the chunk (channel 2q); 0 if none
+    short x_lds[XI];                                        // LDS element index of (pixel 2w - 1 relative to the halo, channel 2q); see store_x
+    unsigned char x_ok[XI];                                 // bit 0 / 1: pixel 2w / 2w + 1 lies inside the image row; bit 2 / 3: inside the halo
+    const unsigned end = (unsigned)RC3_C * (unsigned)plane; // elements of the level (< 2^31, checked by the host)
+#pragma unroll
+    for (int u = 0; u < XI; ++u) {
+        const int e = t + 256 * u;
+        const int q = e / ((RC3_TH + 2) * 18), rem = e - q * ((RC3_TH + 2) * 18);
+        const int hy = rem / 18, w = rem - hy * 18;
+        const int yy = y0 + hy - 1, xe = x0 - 2 + 2 * w;    // even pixel of the pair (x0 is a multiple of 32)
+        const bool item = e < 8 * (RC3_TH + 2) * 18, row_in = yy >= 0 && yy < H;
+        x_off[u] = item && row_in && xe >= 0 && xe < W ? (unsigned)(2 * q) * (unsigned)plane + (unsigned)yy * (unsigned)W + (unsigned)xe : 0u;
+        // halo column of pixel xe is hx = xe - (x0 - 1) = 2 w - 1  (w = 0: only the odd pixel is in the halo; w = 17: hx = 33, 34: only the even one)
+        x_lds[u] = (short)(item ? (hy * RC3_HW + 2 * w - 1) * RC3_PS + 2 * q : 0);
+        x_ok[u] = (unsigned char)((item && row_in && xe >= 0 && xe < W ? 1 : 0) | (item && row_in && xe >= 0 && xe + 1 < W ? 2 : 0) |
+                                  (item && w >= 1 ? 4 : 0) | (item && w <= 16 ? 8 : 0));
+    }
+    struct XV { unsigned a[XL][XI], b[XL][XI]; };
+    auto load_x = [&](int chunk, XV &v) {
+        const unsigned cbase = (unsigned)chunk * 16u * (unsigned)plane;
+#pragma unroll
+        for (int u = 0; u < XI; ++u) {
+            const unsigned oa = cbase + x_off[u], ob = oa + (unsigned)plane;
+            if (!ODDW) {                                    // W even: every offset is even and the pair is one aligned dword
+                v.a[0][u] = *(const unsigned *)(xin + oa);
+                v.b[0][u] = *(const unsigned *)(xin + ob);
+            } else {                                        // the dwords at (o & ~1) and the next one, clamped to the last dword of the level
+                const unsigned ea = oa & ~1u, eb = ob & ~1u;
+                v.a[0][u] = *(const unsigned *)(xin + ea); v.a[XL - 1][u] = *(const unsigned *)(xin + min(ea + 2u, end - 2u));
+                v.b[0][u] = *(const unsigned *)(xin + eb); v.b[XL - 1][u] = *(const unsigned *)(xin + min(eb + 2u, end - 2u));
+            }
+        }
+    };
+    auto store_x = [&](int buf, int chunk, const XV &v) {
+        const unsigned cbase = (unsigned)chunk * 16u * (unsigned)plane;
+#pragma unroll
+        for (int u = 0; u < XI; ++u) {
+            unsigned va = v.a[0][u], vb = v.b[0][u];
+            if (ODDW) {
+                const unsigned oa = cbase + x_off[u], ob = oa + (unsigned)plane;
+                va = __builtin_amdgcn_alignbit(v.a[XL - 1][u], va, (oa & 1u) * 16u);
+                vb = __builtin_amdgcn_alignbit(v.b[XL - 1][u], vb, (ob & 1u) * 16u);
+            }
+            const unsigned a = (x_ok[u] & 1) ? (va & 0xFFFFu) : 0u, a1 = (x_ok[u] & 2) ? (va >> 16) : 0u;
+            const unsigned b = (x_ok[u] & 1) ? (vb & 0xFFFFu) : 0u, b1 = (x_ok[u] & 2) ? (vb >> 16) : 0u;
+            unsigned *dst = (unsigned *)(&s_x[buf][0]) + (x_lds[u] >> 1);           // element index is even (2 q): dword aligned
+            if (x_ok[u] & 4) dst[0] = a | (b << 16);                                  // pixel 2w     : channels (2q, 2q + 1)
+            if (x_ok[u] & 8) dst[RC3_PS / 2] = a1 | (b1 << 16);                       // pixel 2w + 1
+        }
+    };
+    // weights of one (chunk, kernel row) step: 3 taps x 256 rows x 16 bf16 = 24 KB contiguous in W3p; thread t moves row t of each tap
+    auto load_w = [&](int step, u32x4 (&v)[6]) {
+        const u32x4 *src = (const u32x4 *)(w3p + (size_t)step * 3 * RC3_C * 16 + (size_t)t * 16);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v[2 * k] = src[k * RC3_C * 2]; v[2 * k + 1] = src[k * RC3_C * 2 + 1]; }
+    };
+    auto store_w = [&](int buf, const u32x4 (&v)[6]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u32x4 *dst = (u32x4 *)(&s_w[buf][(k * RC3_C + t) * RC3_PS]);
+            dst[0] = v[2 * k]; dst[1] = v[2 * k + 1];
+        }
+    };
+
+    f32x16 acc[4][4];                                       // [channel tile][position tile]
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = (f32x16){0};
+
+    // Main loop: 48 steps = (chunk of 16 input channels) x (kernel row ky), 3 taps kx per step, 16 MFMAs per tap and wave.
+    // One wave per SIMD (512 registers), so nothing hides a latency unless the code does:
+    //  * the 8 fragments of tap kx + 1 are read from LDS into the OTHER fragment register set while the 16 MFMAs of tap kx run
+    //    (the compiler's own schedule reloaded the weight fragment after every 4 MFMAs and waited for it: 44 % MFMA duty);
+    //  * the barrier of a step sits before its LAST tap: the staging stores of step + 1 are done by then, so the fragments of
+    //    (step + 1, tap 0) are prefetched behind the barrier while the last 16 MFMAs run;
+    //  * global loads run two steps (weights) / two chunks (pixels) ahead of their LDS store, in the same registers: store, then
+    //    immediately reload.  The body is unrolled over (2 chunks) x (3 rows) with unconditional, clamped loads so that the
+    //    s_waitcnt before a weight store counts exactly the pixel loads issued after it.
+    bf16x8 fa[2][4], fb[2][4];
+    auto load_frags = [&](auto P, int chunk, int ky, int kx) {
+        constexpr int p = decltype(P)::value;
+        const unsigned short *sx = s_x[chunk & 1], *sw = s_w[(chunk * 3 + ky) & 1];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) fa[p][ct] = *(const bf16x8 *)(sw + (kx * RC3_C + 128 * wc + 32 * ct + li) * RC3_PS + 8 * g);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) fb[p][pt] = *(const bf16x8 *)(sx + ((4 * wp + pt + ky) * RC3_HW + li + kx) * RC3_PS + 8 * g);
+    };
+    auto mfma16 = [&](auto P) {
+        constexpr int p = decltype(P)::value;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][ct], fb[p][pt], acc[ct][pt], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+    XV xv;
+    u32x4 wv[6];
+    load_x(0, xv);
+    load_w(0, wv);
+    store_x(0, 0, xv);
+    store_w(0, wv);
+    load_w(1, wv);
+    load_x(1, xv);
+    __syncthreads();
+    load_frags(I0{}, 0, 0, 0);
+    auto do_step = [&](auto P, auto Q, auto KY, int chunk) {    // fragments of tap 0 are in set P on entry, and in set Q = 1 - P for the next step
+        constexpr int ky = decltype(KY)::value;
+        const int step = chunk * 3 + ky;
+        load_frags(Q, chunk, ky, 1);
+        mfma16(P);
+        load_frags(P, chunk, ky, 2);
+        mfma16(Q);
+#ifndef RC3_NO_STAGE
+        store_w((step + 1) & 1, wv);                        // (step 47 stores a clamped reload into the idle buffer: nobody reads it)
+        load_w(min(step + 2, 47), wv);
+        if (ky == 0) {
+            store_x((chunk + 1) & 1, min(chunk + 1, 15), xv);
+            load_x(min(chunk + 2, 15), xv);
+        }
+#endif
+        __syncthreads();
+        if (ky == 2) load_frags(Q, chunk + 1, 0, 0); else load_frags(Q, chunk, ky + 1, 0);
+        mfma16(P);
+    };
+    for (int chunk = 0; chunk < 16; chunk += 2) {
+        do_step(I0{}, I1{}, I0{}, chunk);
+        do_step(I1{}, I0{}, I1{}, chunk);
+        do_step(I0{}, I1{}, std::integral_constant<int, 2>{}, chunk);
+        do_step(I1{}, I0{}, I0{}, chunk + 1);
+        do_step(I0{}, I1{}, I1{}, chunk + 1);
+        do_step(I1{}, I0{}, std::integral_constant<int, 2>{}, chunk + 1);
+    }
+    __syncthreads();                                        // the stray staging stores of the last step are done before the epilogue reuses LDS
+#ifdef RC3_NO_EPI
+    {   // keep every accumulator alive
+        f32x16 sum = (f32x16){0};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < 4; ++pt) sum += acc[ct][pt];
+        float z = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z += sum[r];
+        if (z == 123.456f) L.raw[lvl][0] = 1;
+    }
+    return;
+#endif
+
+    // ---- epilogue: raw (bf16), h = relu(raw + b3) as the B operand of the heads' product.
+    // Accumulator register r of a lane is channel cb + (r & 3) + 8 (r >> 2) + 4 g at pixel (yy, x0 + li): registers (r, r + 1) are
+    // adjacent channels and convert as one v_cvt_pk_bf16_f32.  Stores of single bf16 are slow, so lanes (li, li ^ 1) swap halves:
+    // the even lane stores channel c of pixels (xx, xx + 1), the odd lane channel c + 1 of pixels (xx - 1, xx), one dword each.
+    unsigned short *rawp = L.raw[lvl];
+    const bool odd_lane = (li & 1) != 0, pair_ok = (W & 1) == 0;               // an odd W (13 x 21 level) breaks the dword alignment: bf16 stores
+    const unsigned sel = odd_lane ? 0x03020706u : 0x05040100u;                 // v_perm_b32 (a = neighbour, b = own): bytes of {a, b} = 7..4, 3..0
+    f32x16 acc2[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) acc2[pt] = (f32x16){0};
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        const int cb = 128 * wc + 32 * ct + 4 * g;
+        float bias[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = b3[cb + (r & 3) + 8 * (r >> 2)];
+        bf16x8 wa[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) wa[s] = *(const bf16x8 *)(whp + ((((size_t)(4 * wc + ct) * 2 + s) * 32 + li) * 2 + g) * 8);
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt) {
+            const int yy = y0 + 4 * wp + pt, xx = x0 + li;
+            const bool in = yy < H && xx < W;
+            const unsigned pix = (unsigned)yy * (unsigned)W + (unsigned)xx;
+            union { unsigned u[8]; bf16x8 v[2]; } hb;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = 2 * k, c = cb + (r & 3) + 8 * (r >> 2);          // registers r, r + 1 = channels c, c + 1
+                const unsigned own = cvt_pk_bf16(acc[ct][pt][r], acc[ct][pt][r + 1]);
+#ifdef RC3_NO_RAW
+                if (own == 0x12345678u)
+#endif
+                if (pair_ok) {
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                    const unsigned d = __builtin_amdgcn_perm(nb, own, sel);
+                    if (in) *(unsigned *)(rawp + (unsigned)(c + (odd_lane ? 1 : 0)) * (unsigned)plane + (pix & ~1u)) = d;
+                } else if (in) {
+                    rawp[(size_t)c * plane + pix] = (unsigned short)own;
+                    rawp[(size_t)(c + 1) * plane + pix] = (unsigned short)(own >> 16);
+                }
+                const float z0 = __uint_as_float(own << 16) + bias[r], z1 = __uint_as_float(own & 0xFFFF0000u) + bias[r + 1];
+                hb.u[k] = cvt_pk_bf16(z0 > 0.0f ? z0 : 0.0f, z1 > 0.0f ? z1 : 0.0f);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc2[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], hb.v[s], acc2[pt], 0, 0, 0);
+        }
+    }
+    // ---- add the two channel halves (through LDS: the staging buffers are free now), biases, store cls / reg
+    float *s_part = (float *)s_all;                           // [wp 2][pt 4][r 16][lane 64] floats = 32 KB of the 106 KB
+    if (wc == 1) {
+#pragma unroll
+        for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_part[((wp * 4 + pt) * 16 + r) * 64 + lane] = acc2[pt][r];
+    }
+    __syncthreads();
+    if (wc == 1) return;
+    const int J = n_cls + n_reg;
+    float *oc = out_cls + (size_t)L.pos0[lvl] * n_cls, *orr = out_reg + (size_t)L.pos0[lvl] * n_reg;
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+        const int yy = y0 + 4 * wp + pt, xx = x0 + li;
+        if (yy >= H || xx >= W) continue;
+        const size_t p = (size_t)yy * W + xx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (j < J) {
+                const float v = acc2[pt][r] + s_part[((wp * 4 + pt) * 16 + r) * 64 + lane] + (j < n_cls ? b_cls[j] : b_reg[j - n_cls]);
+                if (j < n_cls) oc[p * n_cls + j] = v; else orr[p * n_reg + (j - n_cls)] = v;
+            }
+        }
+    }
+}
+
+// One launch for all levels; a level of odd width takes the variant that cuts its pixel pairs out of two aligned dwords
+// (a workgroup-uniform branch: both variants need the same registers and LDS).
+__global__ __launch_bounds__(256) void rpn_conv3x3_head_kernel(ConvLevels L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
+                                                               const unsigned short *__restrict__ whp, const float *__restrict__ b_cls, int n_cls,
+                                                               const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
+                                                               float *__restrict__ out_reg)
+{
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && (int)blockIdx.x >= L.tile0[l]) ? 1 : 0;
+    if (L.W[lvl] & 1) rpn_conv3x3_head_tile<true>(lvl, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    else rpn_conv3x3_head_tile<false>(lvl, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+}
+
+size_t frcnn_ws_rpn_conv(void) { return (size_t)(16 * 9 * 256 * 16 + 8 * 2 * 32 * 2 * 8) * 2; }
+
+FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *raw_levels_bf16, const int *H, const int *W, int n_levels, int C,
+                                         const float *w3, const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
+                                         const float *b_reg, int n_reg, float *out_cls, float *out_reg, void *workspace, size_t workspace_bytes,
+                                         void *stream)
+{
+    FRCNN_REQUIRE(C == RC3_C, "rpn_conv_head: C=%d (this kernel is built for the FPN head: 256 channels)", C);
+    FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS && feat_levels_bf16 && raw_levels_bf16 && H && W, "rpn_conv_head: bad level table");
+    FRCNN_REQUIRE(n_cls > 0 && n_reg > 0 && n_cls + n_reg <= 32, "rpn_conv_head: n_cls + n_reg = %d must be in (0, 32]", n_cls + n_reg);
+    FRCNN_REQUIRE(w3 && b3 && w_cls && b_cls && w_reg && b_reg && out_cls && out_reg && workspace, "rpn_conv_head: NULL pointer");
+    if (workspace_bytes < frcnn_ws_rpn_conv()) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_conv_head: workspace %zu < %zu bytes", workspace_bytes, frcnn_ws_rpn_conv());
+    int64_t pos0[FRCNN_MAX_LEVELS + 1] = {0};
+    for (int k = 0; k < n_levels; ++k) {
+        FRCNN_REQUIRE(feat_levels_bf16[k] && raw_levels_bf16[k] && H[k] > 0 && W[k] > 0 && (int64_t)H[k] * W[k] * RC3_C < ((int64_t)1 << 31), "rpn_conv_head: bad level %d", k);
+        FRCNN_REQUIRE((((uintptr_t)feat_levels_bf16[k] | (uintptr_t)raw_levels_bf16[k]) & 3) == 0, "rpn_conv_head: level %d is not 4-byte aligned", k);
+        pos0[k + 1] = pos0[k] + (int64_t)H[k] * W[k];
+    }
+    FRCNN_REQUIRE(pos0[n_levels] < ((int64_t)1 << 31), "rpn_conv_head: too many positions");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short *w3p = (unsigned short *)workspace, *whp = w3p + 16 * 9 * 256 * 16;
+    FRCNN_LAUNCH(KID_RPN_CONV_PACK, rpn_conv_pack_kernel, dim3(16 * 9 * 256 * 16 / 256), dim3(256), 0, s, w3, w_cls, n_cls, w_reg, n_reg, w3p, whp);
+    FRCNN_CHECK_LAUNCH("rpn_conv_pack_kernel");
+    const size_t lds = (size_t)(2 * RC3_HP * RC3_PS + 2 * 3 * RC3_C * RC3_PS) * sizeof(unsigned short);
+    {   // > 64 KB of dynamic LDS is an opt-in per (function, device)
+        static std::atomic<unsigned char> done[64];
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_conv_head: no current device");
+        if (dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            const hipError_t rc = hipFuncSetAttribute((const void *)rpn_conv3x3_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_conv_head: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(rc));
+            if (dev < 64) done[dev].store(1, std::memory_order_release);
+        }
+    }
+    ConvLevels L;
+    int64_t tiles = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {              // unused slots repeat level 0 and start past the last tile
+        const int k = l < n_levels ? l : 0;
+        L.x[l] = (const unsigned short *)feat_levels_bf16[k]; L.raw[l] = (unsigned short *)raw_levels_bf16[k];
+        L.H[l] = H[k]; L.W[l] = W[k];
+        L.tiles_x[l] = (W[k] + RC3_TW - 1) / RC3_TW;
+        L.tile0[l] = (int)tiles; L.pos0[l] = (int)pos0[k];
+        if (l < n_levels) tiles += (int64_t)L.tiles_x[l] * ((H[k] + RC3_TH - 1) / RC3_TH);
+    }
+    L.tile0[FRCNN_MAX_LEVELS] = (int)tiles;
+    L.n_levels = n_levels;
+    FRCNN_REQUIRE(tiles < ((int64_t)1 << 30), "rpn_conv_head: too many tiles");
+    FRCNN_LAUNCH(KID_RPN_CONV, rpn_conv3x3_head_kernel, dim3((unsigned)tiles), dim3(256), lds, s, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    FRCNN_CHECK_LAUNCH("rpn_conv3x3_head_kernel");
+    return FRCNN_OK;
+}

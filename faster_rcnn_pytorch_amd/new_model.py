@@ -151,12 +151,20 @@ class RPNHead(nn.Module):
         normal_init(self.inter_layer, 0, 0.01)
         normal_init(self.cls_layer, 0, 0.01)
         normal_init(self.reg_layer, 0, 0.01)
+        self.fused_bf16_conv = True          # under bf16 autocast: the hand-written implicit-GEMM head (csrc/rpn_conv.hip) instead of MIOpen + tail
 
     def forward_levels(self, feats):
         """All levels at once: 3x3 per level on MIOpen without its bias, then ONE MFMA kernel for bias + ReLU + both 1x1 heads
         + the NHWC layout + the concatenation (new_model.py:37-44).  Under bf16 autocast the 3x3 outputs are bf16 and the
         heads contract on the bf16 matrix cores with fp32 accumulate; predictions (hence box regression) stay fp32."""
         f0 = feats[0]
+        n_out = self.cls_layer.out_channels + self.reg_layer.out_channels
+        if (self.fused_bf16_conv and f0.is_cuda and f0.size(0) == 1 and f0.size(1) == 256 and n_out <= 32 and torch.is_autocast_enabled()
+                and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+            # mixed-precision configuration: conv3x3 + bias + ReLU + both heads of all levels in ONE bf16 MFMA implicit-GEMM launch
+            with torch.autocast("cuda", enabled=False):
+                return ops.rpn_conv_head_levels([f.to(torch.bfloat16) for f in feats], self.inter_layer.weight, self.inter_layer.bias,
+                                                self.cls_layer.weight, self.cls_layer.bias, self.reg_layer.weight, self.reg_layer.bias)
         if f0.is_cuda and f0.size(0) == 1 and f0.dtype in (torch.float32, torch.bfloat16):
             raws = [torch.nn.functional.conv2d(f, self.inter_layer.weight, None, padding=1) for f in feats]
             if raws[0].dtype in (torch.float32, torch.bfloat16) and all(r.dtype == raws[0].dtype for r in raws):

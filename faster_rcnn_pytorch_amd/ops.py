@@ -404,6 +404,82 @@ class _RPNHeadTailFn(torch.autograd.Function):
         return (None, db3, dW[:n_cls].reshape(ctx.w_shapes[0]), db[:n_cls], dW[n_cls:].reshape(ctx.w_shapes[1]), db[n_cls:], *d_raws)
 
 
+class _RPNConvHeadFn(torch.autograd.Function):
+    """The whole FPN RPN head in the bf16 mixed-precision configuration (csrc/rpn_conv.hip): 3x3 conv + bias + ReLU + both 1x1
+    heads for all levels in one MFMA implicit-GEMM launch.  args: (w3, b3, w_cls, b_cls, w_reg, b_reg, *feats bf16 [1,256,h,w]).
+    Backward: the fused tail backward (d_raw, head gradients) + the convolution's own backward through aten (MIOpen)."""
+
+    @staticmethod
+    def forward(ctx, w3, b3, w_cls, b_cls, w_reg, b_reg, *feats):
+        feats = [_req(f, torch.bfloat16, "feature map") for f in feats]
+        Cc = feats[0].shape[1]
+        for f in feats:
+            if f.dim() != 4 or f.shape[0] != 1 or f.shape[1] != Cc:
+                raise ValueError("rpn_conv_head: every level must be [1,C,h,w] (batch 1 per GPU) with the same C")
+        w3c = _req(w3, name="w3")
+        b3, b_cls, b_reg = _req(b3, name="b3"), _req(b_cls, name="b_cls"), _req(b_reg, name="b_reg")
+        wc = _req(w_cls, name="w_cls").reshape(w_cls.shape[0], -1)
+        wr = _req(w_reg, name="w_reg").reshape(w_reg.shape[0], -1)
+        n_cls, n_reg = wc.shape[0], wr.shape[0]
+        dev = feats[0].device
+        raws = [torch.empty_like(f) for f in feats]
+        Pt = sum(f.shape[2] * f.shape[3] for f in feats)
+        out_cls = torch.empty((1, Pt * n_cls // 2, 2), dtype=torch.float32, device=dev)
+        out_reg = torch.empty((1, Pt * n_reg // 4, 4), dtype=torch.float32, device=dev)
+        H = _host_i32([f.shape[2] for f in feats])
+        W = _host_i32([f.shape[3] for f in feats])
+        fp = (C.c_void_p * len(feats))(*[f.data_ptr() for f in feats])
+        rp = (C.c_void_p * len(feats))(*[r.data_ptr() for r in raws])
+        nb = _lib.workspace_bytes(_lib.OP_RPN_CONV, 0)
+        ws = _workspace(dev, nb)
+        with torch.cuda.device(dev):
+            check(lib.frcnn_rpn_conv_head_fwd(fp, rp, _np_ptr(H), _np_ptr(W), len(feats), Cc, _ptr(w3c), _ptr(b3), _ptr(wc), _ptr(b_cls), n_cls,
+                                              _ptr(wr), _ptr(b_reg), n_reg, _ptr(out_cls), _ptr(out_reg), _ptr(ws), nb, _stream()), "rpn_conv_head_fwd")
+        ctx.save_for_backward(w3c, b3, wc, wr, *feats, *raws)
+        ctx.n = len(feats)
+        ctx.w_shapes = (w_cls.shape, w_reg.shape)
+        return out_cls, out_reg
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        w3, b3, wc, wr = ctx.saved_tensors[:4]
+        feats = ctx.saved_tensors[4:4 + ctx.n]
+        raws = ctx.saved_tensors[4 + ctx.n:]
+        n_cls, n_reg = wc.shape[0], wr.shape[0]
+        Cc = wc.shape[1]
+        dev = wc.device
+        g_cls = _req(g_cls.reshape(-1, n_cls), name="grad_cls")
+        g_reg = _req(g_reg.reshape(-1, n_reg), name="grad_reg")
+        d_raws = [torch.empty_like(r) for r in raws]
+        dwc, dwr = torch.empty_like(wc), torch.empty_like(wr)
+        dbc = torch.empty((n_cls,), dtype=torch.float32, device=dev)
+        dbr = torch.empty((n_reg,), dtype=torch.float32, device=dev)
+        db3 = torch.empty((Cc,), dtype=torch.float32, device=dev)
+        nb = _lib.workspace_bytes(_lib.OP_HEAD_BWD, Cc)
+        ws = _workspace(dev, nb)
+        ptrs = (C.c_void_p * len(raws))(*[r.data_ptr() for r in raws])
+        dptrs = (C.c_void_p * len(raws))(*[r.data_ptr() for r in d_raws])
+        pl = (C.c_int64 * len(raws))(*[r.shape[2] * r.shape[3] for r in raws])
+        with torch.cuda.device(dev):
+            check(lib.frcnn_rpn_head_tail_ml_bwd(ptrs, dptrs, 1, Cc, pl, len(raws), _ptr(b3), _ptr(wc), n_cls, _ptr(wr), n_reg, _ptr(g_cls), _ptr(g_reg),
+                                                 _ptr(dwc), _ptr(dbc), _ptr(dwr), _ptr(dbr), _ptr(db3), _ptr(ws), nb, _stream()), "rpn_head_tail_ml_bwd")
+        # the 3x3 convolution's backward stays on MIOpen (aten): data gradient per level, weight gradient accumulated in fp32
+        w3b = w3.to(torch.bfloat16)
+        dw3 = torch.zeros_like(w3)
+        d_feats = []
+        for f, d in zip(feats, d_raws):
+            gi, gw, _ = torch.ops.aten.convolution_backward(d, f, w3b, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [ctx.needs_input_grad[6], True, False])
+            d_feats.append(gi)
+            dw3 += gw.float()
+        return (dw3, db3, dwc.reshape(ctx.w_shapes[0]), dbc, dwr.reshape(ctx.w_shapes[1]), dbr, *d_feats)
+
+
+def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):
+    """(pred_cls [1, sum P_l * A, 2], pred_reg [1, sum P_l * A, 4]) of the shared FPN RPN head on bf16 feature maps (models/new_model.py:37-44,
+    89-114): one launch for conv3x3 + ReLU + both heads on the bf16 matrix cores; box regression outputs stay fp32."""
+    return _RPNConvHeadFn.apply(w3, b3, w_cls, b_cls, w_reg, b_reg, *feats)
+
+
 def rpn_head_tail(conv_raw, b3, w_cls, b_cls, w_reg, b_reg):
     """(pred_cls [1, P*A, 2], pred_reg [1, P*A, 4]) from the bias-free 3x3 output; see include/frcnn_hip.h."""
     return _RPNHeadTailFn.apply(False, b3, w_cls, b_cls, w_reg, b_reg, conv_raw)

@@ -54,7 +54,8 @@ typedef enum {
     FRCNN_OP_RPN_TARGETS = 4,     /* n1 = N anchors, n2 = G */
     FRCNN_OP_HEAD_TARGETS = 5,    /* n1 = P + G candidates */
     FRCNN_OP_PREPROCESS = 6,      /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
-    FRCNN_OP_HEAD_BWD = 7         /* n1 = C (frcnn_rpn_head_tail_ml_bwd) */
+    FRCNN_OP_HEAD_BWD = 7,        /* n1 = C (frcnn_rpn_head_tail_ml_bwd) */
+    FRCNN_OP_RPN_CONV = 8         /* frcnn_rpn_conv_head_fwd (packed bf16 weights) */
 } frcnn_op;
 
 int frcnn_abi_version(void);
@@ -161,6 +162,15 @@ int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, void *const *
                                int n_levels, const float *b3, const float *w_cls, int n_cls, const float *w_reg, int n_reg,
                                const float *g_cls, const float *g_reg, float *dw_cls, float *db_cls, float *dw_reg, float *db_reg,
                                float *db3, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The whole FPN RPN head (models/new_model.py:89-114) in the bf16 mixed-precision configuration as one MFMA implicit-GEMM kernel:
+ * 3x3 conv (256 -> 256, bf16 operands, fp32 accumulate) -> raw_levels (bf16, the bias-free conv output kept for backward) ->
+ * bias + ReLU + both 1x1 heads -> out_cls [sum P_l, n_cls], out_reg [sum P_l, n_reg] (fp32, the layout of frcnn_rpn_head_tail_ml_fwd).
+ * feat_levels / raw_levels: [256, H_l, W_l] bf16 NCHW; w3 [256,256,3,3], w_cls [n_cls,256], w_reg [n_reg,256], biases: fp32.
+ * workspace >= frcnn_workspace_bytes(FRCNN_OP_RPN_CONV, 0, 0) (the weights re-packed to bf16 on every call). */
+int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *raw_levels_bf16, const int *H_host, const int *W_host, int n_levels,
+                            int C, const float *w3, const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
+                            const float *b_reg, int n_reg, float *out_cls, float *out_reg, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

@@ -862,3 +862,54 @@ def test_rpn_head_tail_backward_full_fpn_size_fused_vs_torch(ops, dtype):
     assert (got_dW - dW).abs().max() < 1e-3 * float(dW.abs().max())
     assert (got_db - db).abs().max() < 1e-3 * float(db.abs().max())
     assert (params[0].grad.double() - db3).abs().max() < 1e-3 * float(db3.abs().max())
+
+
+@pytest.mark.parametrize("shapes", [[(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)], [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], [(9, 33)]])
+def test_rpn_conv_head_bf16_vs_torch(ops, shapes):
+    """The fused bf16 implicit-GEMM RPN head (csrc/rpn_conv.hip; BASELINE configs[4]) against the plain op chain of
+    models/new_model.py:109-113 in float64 on the SAME bf16-rounded inputs and weights.  Tolerances: raw is a K = 2304 bf16 dot
+    product accumulated in fp32 then rounded to bf16 (|raw| ~ 0.5: 2^-8 relative = 4e-3 absolute); cls / reg read that bf16 raw and
+    contract 256 bf16-rounded activations (2e-2 absolute, as the tail kernel's bf16 form).  Backward: against float64 autograd."""
+    g = torch.Generator().manual_seed(21)
+    C_, A = 256, 3
+    feats = [(torch.randn(1, C_, h, w, generator=g)).bfloat16().to(DEV) for h, w in shapes]
+    w3 = (torch.randn(C_, C_, 3, 3, generator=g) * 0.01).to(DEV)
+    b3 = (torch.randn(C_, generator=g) * 0.1).to(DEV)
+    wc, bc = (torch.randn(2 * A, C_, 1, 1, generator=g) * 0.02).to(DEV), (torch.randn(2 * A, generator=g) * 0.1).to(DEV)
+    wr, br = (torch.randn(4 * A, C_, 1, 1, generator=g) * 0.02).to(DEV), (torch.randn(4 * A, generator=g) * 0.1).to(DEV)
+    fin = [f.clone().requires_grad_(True) for f in feats]
+    params = [t.clone().requires_grad_(True) for t in (w3, b3, wc, bc, wr, br)]
+    cls, reg = ops.rpn_conv_head_levels(fin, *params)
+    # float64 reference on bf16-rounded operands
+    w3d = w3.bfloat16().double()
+    rin = [f.double().requires_grad_(True) for f in feats]
+    rp = [t.clone().double().requires_grad_(True) for t in (w3d, b3, wc.bfloat16().float(), bc, wr.bfloat16().float(), br)]
+    cc, rr = [], []
+    for f in rin:
+        raw = torch.nn.functional.conv2d(f, rp[0], None, padding=1)
+        h = torch.relu(raw + rp[1][None, :, None, None])
+        cc.append(torch.nn.functional.conv2d(h, rp[2], rp[3]).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
+        rr.append(torch.nn.functional.conv2d(h, rp[4], rp[5]).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
+    ref_c, ref_r = torch.cat(cc, 1), torch.cat(rr, 1)
+    assert cls.shape == ref_c.shape and reg.shape == ref_r.shape and cls.dtype == torch.float32
+    assert (cls.detach().double() - ref_c.detach()).abs().max() < 2e-2 and (reg.detach().double() - ref_r.detach()).abs().max() < 2e-2
+    gc, gr = torch.randn(cls.shape, generator=g).to(DEV), torch.randn(reg.shape, generator=g).to(DEV)
+    ((cls * gc).sum() + (reg * gr).sum()).backward()
+    ((ref_c * gc.double()).sum() + (ref_r * gr.double()).sum()).backward()
+    for a, b in zip(fin, rin):                                       # bf16 data gradients
+        assert (a.grad.double() - b.grad).abs().max() < 3e-2 * max(1.0, float(b.grad.abs().max()))
+    for i, (a, b) in enumerate(zip(params, rp)):
+        if i == 0:
+            continue                                                 # w3: checked against the unfused mixed-precision path below
+        # b3: the ReLU mask is decided on the bf16-rounded conv output, so a few positions with |raw + b3| < 2^-8 |raw| flip (8 %)
+        tol = (8e-2 if i == 1 else 3e-2) * max(1e-3, float(b.grad.abs().max()))
+        assert (a.grad.double() - b.grad).abs().max() < tol, (i, float((a.grad.double() - b.grad).abs().max()), float(b.grad.abs().max()))
+    # ... and the fused launch agrees with the unfused mixed-precision path (MIOpen bf16 conv + the tail kernel) it replaces.  The
+    # 3x3 weight gradient goes d_raw (bf16) -> MIOpen's bf16 weight-gradient kernel in BOTH paths; against float64 that carries up to
+    # ~10 % of the largest entry (0.87 on 19.6 at the first shape set, identically for both paths), so it is pinned path against path.
+    p2 = [t.clone().requires_grad_(True) for t in (w3, b3, wc, bc, wr, br)]
+    raws2 = [torch.nn.functional.conv2d(f, p2[0].bfloat16(), None, padding=1) for f in feats]
+    c2, r2 = ops.rpn_head_tail_levels(raws2, p2[1], p2[2], p2[3], p2[4], p2[5], mfma="bf16")
+    ((c2 * gc).sum() + (r2 * gr).sum()).backward()
+    assert (params[0].grad - p2[0].grad).abs().max() < 4e-2 * float(p2[0].grad.abs().max())       # a few bf16 ulps of the largest entry (MIOpen returns bf16)
+    assert (cls.detach() - c2.detach()).abs().max() < 1e-2 and (reg.detach() - r2.detach()).abs().max() < 1e-2
