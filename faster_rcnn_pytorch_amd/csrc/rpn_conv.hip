@@ -34,7 +34,9 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define RC3_HW (RC3_TW + 2)             // halo width
 #define RC3_HP ((RC3_TH + 2) * RC3_HW)  // halo pixels: 340
 #define RC3_PS 24                       // pixel / weight-row stride in LDS, in bf16 elements (48 bytes)
-#define RC3_XE ((RC3_HP * 16 + 255) / 256)   // halo elements per thread and chunk: 22
+#define RC3_STAGE_ELEMS (2 * RC3_HP * RC3_PS + 2 * 3 * RC3_C * RC3_PS)   // bf16 elements of the two double-buffered staging areas (106 KB)
+#define RC3_WH_ELEMS (8 * 2 * 32 * 2 * 8)                               // packed head weights (16 KB)
+#define RC3_LDS_BYTES ((size_t)(RC3_STAGE_ELEMS + RC3_WH_ELEMS) * 2 + RC3_C * 4)   // + b3 (1 KB): 123 KB of the CU's 160 KB
 
 struct ConvLevels {
     int n_levels;
@@ -85,24 +87,30 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_kernel(const float *__restr
     }
 }
 
-template <bool ODDW>
-__device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels &L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
+// NPT = position tiles (image rows) per wave: 4 = the full 8-row tile, 2 = a 4-row half tile (ysub = 0 / 4 inside the full tile)
+template <bool ODDW, int NPT>
+__device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysub, const ConvLevels &L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
                                                                const unsigned short *__restrict__ whp, const float *__restrict__ b_cls, int n_cls,
                                                                const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
                                                                float *__restrict__ out_reg)
 {
-    // dynamic LDS (106 KB): [2][halo pixels x 24] (2 x 16 320 B), then [2][3 taps][256 rows x 24] (2 x 36 864 B); the epilogue reuses
+    // dynamic LDS (123 KB): [2][halo pixels x 24] (2 x 16 320 B), then [2][3 taps][256 rows x 24] (2 x 36 864 B); the epilogue reuses
     // the first 32 KB.  The weights of a whole kernel ROW (3 taps) are staged per barrier: one barrier per tap (16 MFMAs per wave
     // between barriers, one wave per SIMD) ran at 12 % of the matrix peak -- no better than MIOpen.
     extern __shared__ __attribute__((aligned(16))) unsigned short s_all[];
     unsigned short (*s_x)[RC3_HP * RC3_PS] = (unsigned short (*)[RC3_HP * RC3_PS])s_all;
     unsigned short (*s_w)[3 * RC3_C * RC3_PS] = (unsigned short (*)[3 * RC3_C * RC3_PS])(s_all + 2 * RC3_HP * RC3_PS);
+    // behind them: the packed head weights and b3, copied once per tile so that the epilogue reads them at LDS latency
+    unsigned short *s_wh = s_all + RC3_STAGE_ELEMS;
+    float *s_b3 = (float *)(s_wh + RC3_WH_ELEMS);
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, g = lane >> 5;
     const int wc = wave & 1, wp = wave >> 1;               // channel half, tile-row half
     const int H = L.H[lvl], W = L.W[lvl];
-    const int tl = (int)blockIdx.x - L.tile0[lvl];
-    const int y0 = (tl / L.tiles_x[lvl]) * RC3_TH, x0 = (tl % L.tiles_x[lvl]) * RC3_TW;
+    constexpr int TH = 2 * NPT;                             // rows of this (half) tile
+    const int tl = tile - L.tile0[lvl];
+    const int y0 = (tl / L.tiles_x[lvl]) * RC3_TH + ysub, x0 = (tl % L.tiles_x[lvl]) * RC3_TW;
+    if (y0 >= H) return;                                    // the lower half of a tile that ends above it (whole workgroup)
     const unsigned short *xin = L.x[lvl];
     const size_t plane = (size_t)H * W;
 
@@ -115,7 +123,7 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
     // for the HBM latency of the pixel loads as well -- 35 us per tile.
     // ODDW (a level of odd width, e.g. 13 x 21): element offsets can be odd, so each pair is cut out of the two aligned dwords
     // around it (4 loads per item instead of 2).
-    constexpr int XI = (8 * (RC3_TH + 2) * 18 + 255) / 256;
+    constexpr int XI = (8 * (TH + 2) * 18 + 255) / 256;
     constexpr int XL = ODDW ? 2 : 1;
     unsigned x_off[XI];                                     // element offset of the even pixel inside the chunk (channel 2q); 0 if none
     short x_lds[XI];                                        // LDS element index of (pixel 2w - 1 relative to the halo, channel 2q); see store_x
@@ -124,10 +132,10 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
 #pragma unroll
     for (int u = 0; u < XI; ++u) {
         const int e = t + 256 * u;
-        const int q = e / ((RC3_TH + 2) * 18), rem = e - q * ((RC3_TH + 2) * 18);
+        const int q = e / ((TH + 2) * 18), rem = e - q * ((TH + 2) * 18);
         const int hy = rem / 18, w = rem - hy * 18;
         const int yy = y0 + hy - 1, xe = x0 - 2 + 2 * w;    // even pixel of the pair (x0 is a multiple of 32)
-        const bool item = e < 8 * (RC3_TH + 2) * 18, row_in = yy >= 0 && yy < H;
+        const bool item = e < 8 * (TH + 2) * 18, row_in = yy >= 0 && yy < H;
         x_off[u] = item && row_in && xe >= 0 && xe < W ? (unsigned)(2 * q) * (unsigned)plane + (unsigned)yy * (unsigned)W + (unsigned)xe : 0u;
         // halo column of pixel xe is hx = xe - (x0 - 1) = 2 w - 1  (w = 0: only the odd pixel is in the halo; w = 17: hx = 33, 34: only the even one)
         x_lds[u] = (short)(item ? (hy * RC3_HW + 2 * w - 1) * RC3_PS + 2 * q : 0);
@@ -181,11 +189,11 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
         }
     };
 
-    f32x16 acc[4][4];                                       // [channel tile][position tile]
+    f32x16 acc[4][NPT];                                      // [channel tile][position tile]
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = (f32x16){0};
+        for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = (f32x16){0};
 
     // Main loop: 48 steps = (chunk of 16 input channels) x (kernel row ky), 3 taps kx per step, 16 MFMAs per tap and wave.
     // One wave per SIMD (512 registers), so nothing hides a latency unless the code does:
@@ -196,21 +204,21 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
     //  * global loads run two steps (weights) / two chunks (pixels) ahead of their LDS store, in the same registers: store, then
     //    immediately reload.  The body is unrolled over (2 chunks) x (3 rows) with unconditional, clamped loads so that the
     //    s_waitcnt before a weight store counts exactly the pixel loads issued after it.
-    bf16x8 fa[2][4], fb[2][4];
+    bf16x8 fa[2][4], fb[2][NPT];
     auto load_frags = [&](auto P, int chunk, int ky, int kx) {
         constexpr int p = decltype(P)::value;
         const unsigned short *sx = s_x[chunk & 1], *sw = s_w[(chunk * 3 + ky) & 1];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) fa[p][ct] = *(const bf16x8 *)(sw + (kx * RC3_C + 128 * wc + 32 * ct + li) * RC3_PS + 8 * g);
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt) fb[p][pt] = *(const bf16x8 *)(sx + ((4 * wp + pt + ky) * RC3_HW + li + kx) * RC3_PS + 8 * g);
+        for (int pt = 0; pt < NPT; ++pt) fb[p][pt] = *(const bf16x8 *)(sx + ((NPT * wp + pt + ky) * RC3_HW + li + kx) * RC3_PS + 8 * g);
     };
     auto mfma16 = [&](auto P) {
         constexpr int p = decltype(P)::value;
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][ct], fb[p][pt], acc[ct][pt], 0, 0, 0);
+            for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][ct], fb[p][pt], acc[ct][pt], 0, 0, 0);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -218,6 +226,15 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
     u32x4 wv[6];
     load_x(0, xv);
     load_w(0, wv);
+    {
+        u32x4 hv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hv[k] = ((const u32x4 *)whp)[t + 256 * k];
+        const float bv = b3[t];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ((u32x4 *)s_wh)[t + 256 * k] = hv[k];
+        s_b3[t] = bv;
+    }
     store_x(0, 0, xv);
     store_w(0, wv);
     load_w(1, wv);
@@ -258,7 +275,7 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-            for (int pt = 0; pt < 4; ++pt) sum += acc[ct][pt];
+            for (int pt = 0; pt < NPT; ++pt) sum += acc[ct][pt];
         float z = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z += sum[r];
@@ -270,27 +287,24 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
     // ---- epilogue: raw (bf16), h = relu(raw + b3) as the B operand of the heads' product.
     // Accumulator register r of a lane is channel cb + (r & 3) + 8 (r >> 2) + 4 g at pixel (yy, x0 + li): registers (r, r + 1) are
     // adjacent channels and convert as one v_cvt_pk_bf16_f32.  Stores of single bf16 are slow, so lanes (li, li ^ 1) swap halves:
-    // the even lane stores channel c of pixels (xx, xx + 1), the odd lane channel c + 1 of pixels (xx - 1, xx), one dword each.
+    // the even lane stores channel c of pixels (xx, xx + 1), the odd lane channel c + 1 of pixels (xx - 1, xx), one dword each
+    // (an odd W breaks the dword alignment: that variant stores bf16 by bf16).
+    // Position tile by position tile, so that only ONE 16-register head accumulator is live next to the 256 conv accumulators; every
+    // wave leaves its 128-channel partial [32 outputs x 32 positions] in LDS (the staging buffers are free now).
     unsigned short *rawp = L.raw[lvl];
-    const bool odd_lane = (li & 1) != 0, pair_ok = (W & 1) == 0;               // an odd W (13 x 21 level) breaks the dword alignment: bf16 stores
+    const bool odd_lane = (li & 1) != 0;
+    constexpr bool pair_ok = !ODDW;
     const unsigned sel = odd_lane ? 0x03020706u : 0x05040100u;                 // v_perm_b32 (a = neighbour, b = own): bytes of {a, b} = 7..4, 3..0
-    f32x16 acc2[4];
+    float *s_part = (float *)s_all;                           // [wc 2][wp 2][pt 4][r 16][lane 64] floats = 64 KB of the 106 KB
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) acc2[pt] = (f32x16){0};
+    for (int pt = 0; pt < NPT; ++pt) {
+        const int yy = y0 + NPT * wp + pt, xx = x0 + li;
+        const bool in = yy < H && xx < W;
+        const unsigned pix = (unsigned)yy * (unsigned)W + (unsigned)xx;
+        f32x16 acc2 = (f32x16){0};
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        const int cb = 128 * wc + 32 * ct + 4 * g;
-        float bias[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = b3[cb + (r & 3) + 8 * (r >> 2)];
-        bf16x8 wa[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) wa[s] = *(const bf16x8 *)(whp + ((((size_t)(4 * wc + ct) * 2 + s) * 32 + li) * 2 + g) * 8);
-#pragma unroll
-        for (int pt = 0; pt < 4; ++pt) {
-            const int yy = y0 + 4 * wp + pt, xx = x0 + li;
-            const bool in = yy < H && xx < W;
-            const unsigned pix = (unsigned)yy * (unsigned)W + (unsigned)xx;
+        for (int ct = 0; ct < 4; ++ct) {
+            const int cb = 128 * wc + 32 * ct + 4 * g;
             union { unsigned u[8]; bf16x8 v[2]; } hb;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -299,61 +313,74 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, const ConvLevels 
 #ifdef RC3_NO_RAW
                 if (own == 0x12345678u)
 #endif
-                if (pair_ok) {
-                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-                    const unsigned d = __builtin_amdgcn_perm(nb, own, sel);
-                    if (in) *(unsigned *)(rawp + (unsigned)(c + (odd_lane ? 1 : 0)) * (unsigned)plane + (pix & ~1u)) = d;
-                } else if (in) {
-                    rawp[(size_t)c * plane + pix] = (unsigned short)own;
-                    rawp[(size_t)(c + 1) * plane + pix] = (unsigned short)(own >> 16);
+                {
+                    if (pair_ok) {
+                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                        const unsigned d = __builtin_amdgcn_perm(nb, own, sel);
+                        if (in) *(unsigned *)(rawp + (unsigned)(c + (odd_lane ? 1 : 0)) * (unsigned)plane + (pix & ~1u)) = d;
+                    } else if (in) {
+                        rawp[(size_t)c * plane + pix] = (unsigned short)own;
+                        rawp[(size_t)(c + 1) * plane + pix] = (unsigned short)(own >> 16);
+                    }
                 }
-                const float z0 = __uint_as_float(own << 16) + bias[r], z1 = __uint_as_float(own & 0xFFFF0000u) + bias[r + 1];
+                const float2 bias = *(const float2 *)(s_b3 + c);
+                const float z0 = __uint_as_float(own << 16) + bias.x, z1 = __uint_as_float(own & 0xFFFF0000u) + bias.y;
                 hb.u[k] = cvt_pk_bf16(z0 > 0.0f ? z0 : 0.0f, z1 > 0.0f ? z1 : 0.0f);
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc2[pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[s], hb.v[s], acc2[pt], 0, 0, 0);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 wa = *(const bf16x8 *)(s_wh + ((((4 * wc + ct) * 2 + s) * 32 + li) * 2 + g) * 8);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hb.v[s], acc2, 0, 0, 0);
+            }
         }
-    }
-    // ---- add the two channel halves (through LDS: the staging buffers are free now), biases, store cls / reg
-    float *s_part = (float *)s_all;                           // [wp 2][pt 4][r 16][lane 64] floats = 32 KB of the 106 KB
-    if (wc == 1) {
 #pragma unroll
-        for (int pt = 0; pt < 4; ++pt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_part[((wp * 4 + pt) * 16 + r) * 64 + lane] = acc2[pt][r];
+        for (int r = 0; r < 16; ++r) s_part[(((wc * 2 + wp) * NPT + pt) * 16 + r) * 64 + lane] = acc2[r];
     }
     __syncthreads();
-    if (wc == 1) return;
+    // ---- add the two channel halves and the biases, store cls / reg: wave (wc, wp) finishes its share (wc) of the position tiles of row half wp
     const int J = n_cls + n_reg;
     float *oc = out_cls + (size_t)L.pos0[lvl] * n_cls, *orr = out_reg + (size_t)L.pos0[lvl] * n_reg;
 #pragma unroll
-    for (int pt = 0; pt < 4; ++pt) {
-        const int yy = y0 + 4 * wp + pt, xx = x0 + li;
+    for (int q = 0; q < NPT / 2; ++q) {
+        const int pt = (NPT / 2) * wc + q;
+        const int yy = y0 + NPT * wp + pt, xx = x0 + li;
         if (yy >= H || xx >= W) continue;
         const size_t p = (size_t)yy * W + xx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = (r & 3) + 8 * (r >> 2) + 4 * g;
             if (j < J) {
-                const float v = acc2[pt][r] + s_part[((wp * 4 + pt) * 16 + r) * 64 + lane] + (j < n_cls ? b_cls[j] : b_reg[j - n_cls]);
+                const float v = s_part[(((0 * 2 + wp) * NPT + pt) * 16 + r) * 64 + lane] + s_part[(((1 * 2 + wp) * NPT + pt) * 16 + r) * 64 + lane] +
+                                (j < n_cls ? b_cls[j] : b_reg[j - n_cls]);
                 if (j < n_cls) oc[p * n_cls + j] = v; else orr[p * n_reg + (j - n_cls)] = v;
             }
         }
     }
 }
 
-// One launch for all levels; a level of odd width takes the variant that cuts its pixel pairs out of two aligned dwords
-// (a workgroup-uniform branch: both variants need the same registers and LDS).
-__global__ __launch_bounds__(256) void rpn_conv3x3_head_kernel(ConvLevels L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
-                                                               const unsigned short *__restrict__ whp, const float *__restrict__ b_cls, int n_cls,
-                                                               const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
-                                                               float *__restrict__ out_reg)
+// One launch for all levels.  Blocks [0, first_split) compute full 8 x 32 tiles; the remaining tiles are cut into two 4-row halves, one
+// block each: a tile takes ~80 us, so when the last round of tiles fills at most half of the CUs, halving those tiles halves that
+// round (FPN 800 x 1344: 384 tiles on 256 CUs = 256 full tiles + 256 half tiles).  A level of odd width takes the variant that cuts
+// its pixel pairs out of two aligned dwords (workgroup-uniform branches: all variants need the same registers and LDS).
+__global__ __launch_bounds__(256) void rpn_conv3x3_head_kernel(ConvLevels L, int first_split, const unsigned short *__restrict__ w3p,
+                                                               const float *__restrict__ b3, const unsigned short *__restrict__ whp,
+                                                               const float *__restrict__ b_cls, int n_cls, const float *__restrict__ b_reg, int n_reg,
+                                                               float *__restrict__ out_cls, float *__restrict__ out_reg)
 {
+    const int b = (int)blockIdx.x;
+    const bool half = b >= first_split;
+    const int tile = half ? first_split + ((b - first_split) >> 1) : b, ysub = half ? 4 * ((b - first_split) & 1) : 0;
     int lvl = 0;
 #pragma unroll
-    for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && (int)blockIdx.x >= L.tile0[l]) ? 1 : 0;
-    if (L.W[lvl] & 1) rpn_conv3x3_head_tile<true>(lvl, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
-    else rpn_conv3x3_head_tile<false>(lvl, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && tile >= L.tile0[l]) ? 1 : 0;
+    const bool odd = (L.W[lvl] & 1) != 0;
+    if (!half) {
+        if (odd) rpn_conv3x3_head_tile<true, 4>(lvl, tile, 0, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+        else rpn_conv3x3_head_tile<false, 4>(lvl, tile, 0, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    } else {
+        if (odd) rpn_conv3x3_head_tile<true, 2>(lvl, tile, ysub, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+        else rpn_conv3x3_head_tile<false, 2>(lvl, tile, ysub, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    }
 }
 
 size_t frcnn_ws_rpn_conv(void) { return (size_t)(16 * 9 * 256 * 16 + 8 * 2 * 32 * 2 * 8) * 2; }
@@ -379,7 +406,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
     unsigned short *w3p = (unsigned short *)workspace, *whp = w3p + 16 * 9 * 256 * 16;
     FRCNN_LAUNCH(KID_RPN_CONV_PACK, rpn_conv_pack_kernel, dim3(16 * 9 * 256 * 16 / 256), dim3(256), 0, s, w3, w_cls, n_cls, w_reg, n_reg, w3p, whp);
     FRCNN_CHECK_LAUNCH("rpn_conv_pack_kernel");
-    const size_t lds = (size_t)(2 * RC3_HP * RC3_PS + 2 * 3 * RC3_C * RC3_PS) * sizeof(unsigned short);
+    const size_t lds = RC3_LDS_BYTES;
     {   // > 64 KB of dynamic LDS is an opt-in per (function, device)
         static std::atomic<unsigned char> done[64];
         int dev = -1;
@@ -403,7 +430,16 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
     L.tile0[FRCNN_MAX_LEVELS] = (int)tiles;
     L.n_levels = n_levels;
     FRCNN_REQUIRE(tiles < ((int64_t)1 << 30), "rpn_conv_head: too many tiles");
-    FRCNN_LAUNCH(KID_RPN_CONV, rpn_conv3x3_head_kernel, dim3((unsigned)tiles), dim3(256), lds, s, L, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    // tiles of the last, at most half-full round of CUs are split into halves (see the kernel)
+    int n_cu = 0;
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const int64_t rem = tiles % n_cu;
+    const int first_split = (int)((rem > 0 && 2 * rem <= n_cu) ? tiles - rem : tiles);
+    const unsigned grid = (unsigned)(first_split + 2 * (tiles - first_split));
+    FRCNN_LAUNCH(KID_RPN_CONV, rpn_conv3x3_head_kernel, dim3(grid), dim3(256), lds, s, L, first_split, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
     FRCNN_CHECK_LAUNCH("rpn_conv3x3_head_kernel");
     return FRCNN_OK;
 }

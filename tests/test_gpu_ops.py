@@ -864,7 +864,8 @@ def test_rpn_head_tail_backward_full_fpn_size_fused_vs_torch(ops, dtype):
     assert (params[0].grad.double() - db3).abs().max() < 1e-3 * float(db3.abs().max())
 
 
-@pytest.mark.parametrize("shapes", [[(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)], [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], [(9, 33)]])
+@pytest.mark.parametrize("shapes", [[(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)], [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], [(9, 33)],
+                                    [(104, 319), (12, 33)]])     # 134 tiles: more than half a round of CUs, so full 8-row tiles of ODD width
 def test_rpn_conv_head_bf16_vs_torch(ops, shapes):
     """The fused bf16 implicit-GEMM RPN head (csrc/rpn_conv.hip; BASELINE configs[4]) against the plain op chain of
     models/new_model.py:109-113 in float64 on the SAME bf16-rounded inputs and weights.  Tolerances: raw is a K = 2304 bf16 dot
