@@ -55,10 +55,10 @@ CONFIGS = {
 }
 
 # what bounds each hand-written kernel
-BOUND = {"nms_resolve_kernel": "latency", "nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
+BOUND = {"nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
          "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency",
          "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
-         "nms_sup_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
+         "nms_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
          "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
          "rpn_conv3x3_head_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
 
@@ -82,8 +82,7 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "proposal_prologue_kernel": 44 * N,                               # reg 16N + cls 8N in, boxes 16N + scores 4N out
         "topk_partition_kernels": 4 * N,                                  # per launch (sample / count / place): scores in
         "topk_bucket_kernel": 8 * N + 16 * K + 28 * K,                    # placed keys + the K gathered boxes in, idx/score/box out
-        "nms_sup_kernel": 16 * K + 8 * K * nblk // 2,                     # boxes in + (at most) the lower-triangle relation out
-        "nms_resolve_kernel": 8 * K + 8 * 2 * nblk,                       # compulsory: one relation word per box + the two bitmaps
+        "nms_kernel": 16 * K + 8 * K * nblk // 2 + 8 * K + 8 * 2 * nblk,  # boxes in + (at most) the lower-triangle relation out; resolver: a word per box + bitmaps
         "nms_emit_kernel": 8 * nblk + 16 * P + 8 * P + 16 * P,            # bitmap + kept boxes in, keep + rois out
         "rpn_colmax_kernel": 16 * (N + G),
         "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
@@ -94,6 +93,17 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "roi_align_fwd_kernel": 4 * R * C * 49 + feat_bytes,              # out + (at most) the four pooled levels in
         "roi_align_bwd_kernel": 4 * R * C * 49 + feat_bytes,              # grad_out in + every gradient pixel written once
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
+    }.get(kernel)
+
+
+MFMA_PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
+
+
+def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
+    """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
+    return {
+        # raw = conv3x3 (C x 9C per position) + both 1x1 heads (6A x C); C = 256 in the FPN head this kernel is built for
+        "rpn_conv3x3_head_kernel": 2 * 256 * (9 * 256 + 6 * A) * P_head,
     }.get(kernel)
 
 
@@ -246,7 +256,7 @@ def main():
         return None
     # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
     # peak (VALU_PEAK_LANE_OPS above): pair IoUs x ~21 VALU ops (counted in the ISA), rank compares x 2
-    valu_ops = {"nms_sup_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
+    valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
     n_sampled = len(range(0, args.steps, args.event_every))          # timed steps whose kernels were bracketed
     per_kernel = {}
     for name, v in samples.items():
@@ -258,14 +268,23 @@ def main():
                             "p90_us": round(p90, 2), "launches": n, "us_per_img": round(sum(v) * 1e3 / n_sampled, 2),
                             "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
                             "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+        af = algorithmic_flops(name, **shape)
+        if af:
+            per_kernel[name]["algorithmic_flops"] = af
+            per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
+            per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / MFMA_PEAK_BF16_TFLOPS, 5)
         if valu_ops.get(name):
             per_kernel[name]["valu_lane_ops"] = valu_ops[name]
             per_kernel[name]["valu_frac_of_78.6T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
-        if name == "nms_sup_kernel":
+        if name == "nms_kernel":
             per_kernel[name]["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (us * 1e-6), 0)
 
     def roofline_of(name):
         d = per_kernel[name]
+        if d["bound"] == "mfma" and d.get("algorithmic_flops"):
+            return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                    "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
         return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
                 "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
@@ -274,7 +293,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
         roofline = roofline_of(dom)
         roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
-        if roofline["bound"] != "hbm":
+        if roofline["bound"] not in ("hbm", "mfma"):
             roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
                                 "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
         hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm"]

@@ -17,8 +17,8 @@ enum FrcnnKernelId {
     KID_PROLOGUE,
     KID_TOPK_RANK,       // topk_sample / topk_count / topk_place kernels (N >= 4096), topk_rank_kernel below
     KID_TOPK_SCATTER,    // topk_bucket_kernel (N >= 4096), topk_scatter_kernel below
-    KID_NMS_MASK,        // nms_sup_kernel
-    KID_NMS_SCAN,        // nms_resolve_kernel
+    KID_NMS_MASK,        // nms_kernel (relation tiles + resolver, one launch)
+    KID_NMS_SCAN,        // (unused since the resolver moved into nms_kernel)
     KID_RPN_COLMAX,
     KID_RPN_LABEL,
     KID_RPN_SAMPLE,

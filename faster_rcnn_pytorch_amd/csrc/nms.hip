@@ -86,20 +86,19 @@ __device__ __forceinline__ unsigned sup_half(float4 a, float area_a, const float
     return word;
 }
 
+__device__ __forceinline__ u64 agent_ld64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_or64(u64 *p, u64 v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_st64(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One wave = one 64 x 64 tile (cb = my block, the lower-scored side; rb <= cb = suppressor block).  The words are published for the
+// resolver waves that run in the SAME launch on other CUs (see nms_kernel): write-through (sc1) stores and agent-scope atomic ORs,
+// the wave's own s_waitcnt vmcnt(0), then the tile's flag done[cb (cb + 1) / 2 + rb] = 1 (sc1 store); row cb is complete when its
+// cb + 1 flags are up.
 template <bool CLS>
-__global__ __launch_bounds__(256) void nms_sup_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev, int K,
-                                                      float thr, int nblk, int nzw, u64 *__restrict__ sup, u64 *__restrict__ nz)
+__device__ __forceinline__ void nms_sup_tile(int cb, int rb, int wave, int lane, float4 (*s_box)[64], float (*s_area)[64], int (*s_cls)[64],
+                                             const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, int n, int K, float thr, int nblk,
+                                             u64 *__restrict__ sup, u64 *__restrict__ nz, int32_t *__restrict__ done)
 {
-    __shared__ float4 s_box[4][64];
-    __shared__ float s_area[4][64];
-    __shared__ int s_cls[4][64];
-    const int n = n_dev ? min(*n_dev, K) : K;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int cb = blockIdx.y;                                  // my block (lower-scored side)
-    const int rb = blockIdx.x * 4 + wave;                       // suppressor block
-    if (rb > cb || cb >= nblk) return;
-    if (cb * 64 >= n) return;                                   // dead boxes: nobody reads their words
     const int me = cb * 64 + lane;
     const float4 a = boxes[min(me, K - 1)];
     const float area_a = (a.z - a.x) * (a.w - a.y);
@@ -131,9 +130,19 @@ __global__ __launch_bounds__(256) void nms_sup_kernel(const float4 *__restrict__
         }
     }
     if (bits != 0ull) {                                         // me < n <= K is implied by a set bit
+#ifdef NMS_PLAIN_STORE
         sup[(size_t)me * nblk + rb] = bits;
-        atomicOr(&nz[(size_t)(rb >> 6) * K + me], 1ull << (rb & 63));   // group-major: the resolver reads it coalesced
+#else
+        agent_st64(&sup[(size_t)me * nblk + rb], bits);
+#endif
+        agent_or64(&nz[(size_t)(rb >> 6) * K + me], 1ull << (rb & 63));   // group-major: the resolver reads it coalesced
     }
+#ifndef NMS_NO_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my stores and ORs have reached the coherence point ...
+#endif
+    // ... before my tile's flag goes up.  One flag WORD per tile, a plain write-through store: a shared per-row counter (cb + 1
+    // agent-scope adds to one address) doubled the kernel's time, 43 -> 83 us.
+    if (lane == 0) __hip_atomic_store(&done[cb * (cb + 1) / 2 + rb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -146,30 +155,37 @@ __global__ __launch_bounds__(256) void nms_sup_kernel(const float4 *__restrict__
 // A box walks its non-zero words in ascending order (= descending suppressor score), EIGHT words and their bitmap words per round
 // trip: the first word holding a kept suppressor -> REMOVED; the first holding an undecided one -> poll that word; none left -> KEPT.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 agent_ld64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void agent_or64(u64 *p, u64 v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 #define NMS_WIDE_BATCH 8
-__global__ __launch_bounds__(256) void nms_resolve_kernel(const int32_t *__restrict__ n_dev, int K, int nblk, int nzw, const u64 *__restrict__ sup,
-                                                          const u64 *__restrict__ nz, u64 *__restrict__ kept, u64 *__restrict__ rem,
-                                                          int32_t *__restrict__ abort_flag)
+#define NMS_ROW_WAIT_SPINS (1 << 21)                                // polls of the row's flags before giving up (each >= 1 us): seconds
+__device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk, int nzw, const u64 *__restrict__ sup, const u64 *__restrict__ nz,
+                                                 u64 *__restrict__ kept, u64 *__restrict__ rem, const int32_t *__restrict__ done,
+                                                 int32_t *__restrict__ abort_flag)
 {
-#ifdef NMS_DEBUG
-    const long long t_start = wall_clock64();
-#endif
-    const int n = n_dev ? min(*n_dev, K) : K;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = wg * 256 + (int)threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int b = i >> 6;                                           // my wave's block = its word of the bitmaps
     if (b * 64 >= n) return;
     const bool live = i < n;
+    {   // wait until the b + 1 tiles of my row have been published (64 flags per load, sc1: served past this CU's L1)
+        const int32_t *fl = done + b * (b + 1) / 2;
+        int spins = 0;
+        for (;;) {
+            bool up = true;
+            for (int k = lane; k <= b; k += 64) up = up && __hip_atomic_load(&fl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__ballot(!up) == 0ull) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > NMS_ROW_WAIT_SPINS) { if (lane == 0) atomicOr(abort_flag, 1); return; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // nothing older than the counter value is served to the loads below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // which 64-word groups of my bitmap are non-empty; cur = the unvisited words of the current group
     unsigned later = 0u;
     u64 cur = 0ull;
     int g = 0;
     if (live) {
         for (int q = nzw - 1; q >= 0; --q) {
-            const u64 a = nz[(size_t)q * K + i];
+            const u64 a = agent_ld64(&nz[(size_t)q * K + i]);
             if (a != 0ull) { later |= 1u << q; cur = a; g = q; }
         }
         later &= later - 1u;                                        // the lowest non-empty group is the current one
@@ -199,7 +215,7 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const int32_t *__restr
                 if (cur == 0ull && later != 0u) {                   // next non-empty group
                     g = __builtin_ctz(later);
                     later &= later - 1u;
-                    cur = nz[(size_t)g * K + i];
+                    cur = agent_ld64(&nz[(size_t)g * K + i]);
                 }
                 if (cur == 0ull) { k_new = true; decided = true; }  // every suppressor is removed
                 else {
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const int32_t *__restr
                         wi[t] = take ? (g << 6) + __builtin_ctzll(cc) : -1;
                         if (take) cc &= cc - 1ull;
                         sv[t] = 0ull; kv[t] = 0ull; rv[t] = 0ull;
-                        if (take) { sv[t] = row[wi[t]]; kv[t] = agent_ld64(&kept[wi[t]]); rv[t] = agent_ld64(&rem[wi[t]]); }
+                        if (take) { sv[t] = agent_ld64(&row[wi[t]]); kv[t] = agent_ld64(&kept[wi[t]]); rv[t] = agent_ld64(&rem[wi[t]]); }
                     }
                     bool settled = false;
 #pragma unroll
@@ -234,13 +250,48 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const int32_t *__restr
         }
         if (!__ballot(progressed)) __builtin_amdgcn_s_sleep(1);      // the whole wave is waiting on other waves' decisions
         if (it > max_iter) { if (lane == 0) atomicOr(abort_flag, 1); break; }
-#ifdef NMS_DEBUG
-        if (lane == 0) { atomicMax(abort_flag + 2, it + 1); atomicAdd(abort_flag + 3, 1); }
-#endif
     }
-#ifdef NMS_DEBUG
-    if (lane == 0) atomicMax(abort_flag + 4, (int)(wall_clock64() - t_start));
+}
+
+// ------------------------------------------------------------------------------------------------
+// nms_kernel: ONE launch for the relation and its resolution.  Workgroups [0, n_res) are the resolver (one thread per box, 256
+// boxes per workgroup: dispatched first, so every resolver wave is resident before any wave it could wait for); the others
+// enumerate the lower-triangular tiles row by row (rows 4g .. 4g + 3 take g + 1 workgroups of 4 tiles each) and never wait for
+// anything, so the launch cannot deadlock.  The resolver wave of block b starts as soon as the b + 1 tiles of its row are flagged, i.e. while the
+// rows below it are still being computed: the relation of the best-scored blocks is ready first, and those are the facts every
+// dependency chain starts from.  As two launches the stage cost sup + resolve = 42 + 60 us on the bench frame; fused, the resolver's
+// chain runs underneath the relation kernel and only the last rows' two or three round trips stick out.
+// ------------------------------------------------------------------------------------------------
+template <bool CLS>
+__global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev,
+                                                  int K, float thr, int nblk, int nzw, int n_res, u64 *__restrict__ sup, u64 *__restrict__ nz,
+                                                  u64 *__restrict__ kept, u64 *__restrict__ rem, int32_t *__restrict__ done,
+                                                  int32_t *__restrict__ abort_flag)
+{
+    __shared__ float4 s_box[4][64];
+    __shared__ float s_area[4][64];
+    __shared__ int s_cls[4][64];
+    const int n = n_dev ? min(*n_dev, K) : K;
+    if ((int)blockIdx.x < n_res) {
+#ifdef NMS_NO_RESOLVE
+        return;
 #endif
+#ifndef NMS_NO_RESOLVE_CODE
+        nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
+#endif
+        return;
+    }
+    const int t = (int)blockIdx.x - n_res;                      // tile workgroup: t = 2 g (g + 1) + (row in group) * (g + 1) + q
+    int g = (int)((sqrtf(1.0f + 2.0f * (float)t) - 1.0f) * 0.5f);
+    while (2 * (g + 1) * (g + 2) <= t) ++g;
+    while (2 * g * (g + 1) > t) --g;
+    const int r = t - 2 * g * (g + 1);
+    const int cb = 4 * g + r / (g + 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = (r % (g + 1)) * 4 + wave;
+    if (rb > cb || cb >= nblk) return;
+    if (cb * 64 >= n) return;                                   // dead boxes: nobody reads their words, no resolver wave waits for them
+    nms_sup_tile<CLS>(cb, rb, wave, (int)(threadIdx.x & 63), s_box, s_area, s_cls, boxes, cls, n, K, thr, nblk, sup, nz, done);
 }
 
 // kept bitmap -> the first post_k kept positions in score order, their boxes / source indices, the count.  One wave per block:
@@ -277,7 +328,7 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float4 *__restrict_
     }
 }
 
-struct NmsWs { u64 *sup, *nz, *kept, *rem; int32_t *flags; int nzw; size_t zero_bytes, total; };
+struct NmsWs { u64 *sup, *nz, *kept, *rem; int32_t *flags, *done; int nzw; size_t zero_bytes, total; };
 static NmsWs carve_nms(void *ws, int64_t K)
 {
     const size_t nblk = (size_t)((K + 63) / 64);
@@ -285,19 +336,20 @@ static NmsWs carve_nms(void *ws, int64_t K)
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
     w.nzw = (int)((nblk + 63) / 64);
     w.sup = (u64 *)take((size_t)K * nblk * 8 + NMS_WS_PAD);
-    // one region to clear before nms_sup_kernel runs: the per-box bitmaps of non-zero words, the kept / removed bitmaps, the flags
+    // one region to clear before nms_kernel runs: the per-box bitmaps of non-zero words, the kept / removed bitmaps, the flags, the row counters
     const size_t z0 = o;
     w.nz = (u64 *)take((size_t)K * w.nzw * 8);
     w.kept = (u64 *)take((nblk + 1) * 8);
     w.rem = (u64 *)take((nblk + 1) * 8);
     w.flags = (int32_t *)take(64);
+    w.done = (int32_t *)take((nblk * (nblk + 1) / 2 + 1) * 4);      // one flag per published tile (the resolver's start condition)
     w.zero_bytes = o - z0;
     w.total = o;
     return w;
 }
 size_t frcnn_ws_nms(int64_t K) { return carve_nms(nullptr, K).total; }
 
-// The region the NMS stage needs cleared before nms_sup_kernel runs.
+// The region the NMS stage needs cleared before nms_kernel runs.
 void frcnn_nms_zero_region(void *ws, int64_t K, int32_t **ptr, int *n_ints)
 {
     const NmsWs w = carve_nms(ws, K);
@@ -315,16 +367,16 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     if (nblk > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
     const NmsWs w = carve_nms(ws, K);
     if (!pre_zeroed && hipMemsetAsync(w.nz, 0, w.zero_bytes, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: memset failed");
+    const int n_res = (int)((K + 255) / 256);
+    const int G = nblk / 4;
+    const unsigned grid = (unsigned)(n_res + 2 * G * (G + 1) + (nblk % 4) * (G + 1));
     if (cls)
-        FRCNN_LAUNCH(KID_NMS_MASK, nms_sup_kernel<true>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
-                     (int)K, thr, nblk, w.nzw, w.sup, w.nz);
+        FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw, n_res,
+                     w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
     else
-        FRCNN_LAUNCH(KID_NMS_MASK, nms_sup_kernel<false>, dim3((nblk + 3) / 4, nblk), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev,
-                     (int)K, thr, nblk, w.nzw, w.sup, w.nz);
-    FRCNN_CHECK_LAUNCH("nms_sup_kernel");
-    FRCNN_LAUNCH(KID_NMS_SCAN, nms_resolve_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, n_boxes_dev, (int)K, nblk, w.nzw, w.sup, w.nz,
-                 w.kept, w.rem, w.flags);
-    FRCNN_CHECK_LAUNCH("nms_resolve_kernel");
+        FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw, n_res,
+                     w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+    FRCNN_CHECK_LAUNCH("nms_kernel");
     FRCNN_LAUNCH(KID_NMS_SCAN_SIMPLE, nms_emit_kernel, dim3((unsigned)((nblk + 1 + 3) / 4)), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, w.kept,
                  w.flags, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
     FRCNN_CHECK_LAUNCH("nms_emit_kernel");

@@ -226,6 +226,35 @@ def test_nms_dense_clusters_near_threshold(ops):
         assert int(cnt.item()) == len(keep_o) and np.array_equal(keep[:len(keep_o)].cpu().numpy(), keep_o)
 
 
+def test_nms_in_kernel_handoff_under_uneven_load(ops):
+    """nms_kernel hands the relation words from its tile waves to its resolver waves INSIDE one launch (write-through stores, a flag
+    word per tile, sc1 polls + an agent acquire; csrc/nms.hip).  A stale word shows up as a different keep list, so: 150 launches
+    with a changing amount of unrelated traffic on a second stream (uneven load, warm L2), every result compared with the oracle's.
+    (With plain instead of write-through stores one launch in ~50 differs by a box on this input.)"""
+    rng = np.random.RandomState(11)
+    K = 12000
+    c = np.stack([rng.rand(K) * 1000, rng.rand(K) * 600], 1).astype(np.float32)
+    sz = np.array([128., 256., 512.], np.float32)[rng.randint(0, 3, K)] * np.exp(rng.randn(K) * 0.1).astype(np.float32)
+    ar = np.array([0.5, 1., 2.], np.float32)[rng.randint(0, 3, K)]
+    wh = np.stack([sz * np.sqrt(ar), sz / np.sqrt(ar)], 1).astype(np.float32)
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    b[:, 0::2] = b[:, 0::2].clip(0, 1000); b[:, 1::2] = b[:, 1::2].clip(0, 600)
+    keep_o = orc.nms(b, 0.7)
+    tb = T(b)
+    side = torch.cuda.Stream()
+    x = torch.randn(2048, 2048, device=DEV)
+    bad = 0
+    for it in range(150):
+        with torch.cuda.stream(side):
+            for _ in range(it % 5):
+                x = torch.tanh(x @ x * 1e-3)
+        keep, _, cnt = ops.nms_sorted(tb, 0.7)
+        n = int(cnt.item())
+        bad += int(n != len(keep_o) or not np.array_equal(keep[:n].cpu().numpy(), keep_o))
+    torch.cuda.synchronize()
+    assert bad == 0, "%d of 150 launches differ from the oracle" % bad
+
+
 # ------------------------------------------------------------------------------------------ whole proposal stage
 @pytest.mark.parametrize("regime,mode", [("init", "train"), ("trained", "train"), ("trained", "test")])
 def test_region_proposal_full_size_bit_exact(ops, regime, mode):
