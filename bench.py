@@ -237,7 +237,10 @@ def main():
     # HBM traffic per launch from the rocprofv3 PMC passes over THIS command (tools/pmc_traffic.sh: separate FETCH_SIZE /
     # WRITE_SIZE runs of bench.py itself, gfx950 fetch correction); measured per round and committed under profiles/
     pmc, pmc_src = {}, None
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.config)))
+    pmc_cfg = "fpn_bf16" if (args.config == "fpn" and args.amp == "bf16") else args.config
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % pmc_cfg)))
+    if not cands:
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.config)))
     if not cands and args.config == "vgg":
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_hotpath_pmc_traffic.json")))
     if cands:
@@ -249,6 +252,8 @@ def main():
             pmc = {}
 
     def pmc_traffic(name):
+        if name in pmc:
+            return pmc[name]["traffic_bytes"]
         stem = name[:-len("_kernel")] if name.endswith("_kernel") else name
         for k, v in pmc.items():
             if k.startswith(stem):

@@ -23,7 +23,8 @@ def main():
     out = sys.argv[1]
     cfg = sys.argv[2] if len(sys.argv) > 2 else "vgg"
     shapes = {"vgg": "config V: N=20646 K=12000 P=2000 R=128 C=512 37x62 (bench.py frames)",
-              "fpn": "config F: N=268569 K=4000 P=1000 R=512 C=256, 4 RoIAlign levels of 800x1344 (bench.py --config fpn frames)"}
+              "fpn": "config F: N=268569 K=4000 P=1000 R=512 C=256, 4 RoIAlign levels of 800x1344 (bench.py --config fpn frames)",
+              "fpn_bf16": "config F under bf16 autocast (bench.py --config fpn --amp bf16 frames): adds the fused RPN conv head kernel"}
     fetch = load(out + "/fetch", "FETCH_SIZE")
     write = load(out + "/write", "WRITE_SIZE")
     res = {}
@@ -37,7 +38,7 @@ def main():
         res[k] = {"launches": max(len(f), len(w)), "fetch_bytes_raw": round(fk * 1024), "fetch_bytes_x2": round(2 * fk * 1024),
                   "write_bytes": round(wk * 1024), "traffic_bytes": round((2 * fk + wk) * 1024)}
     print(json.dumps({"note": "per launch; traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), gfx950 fetch correction applied",
-                      "command": "bench.py --config %s --steps 4 --warmup 1 (all launches of the process, incl. the 3 initialisation steps)" % cfg,
+                      "command": "bench.py %s --steps 4 --warmup 1 (all launches of the process, incl. the 3 initialisation steps)" % ("--config fpn --amp bf16" if cfg == "fpn_bf16" else "--config " + cfg),
                       "shape": shapes.get(cfg, cfg), "kernels": res}, indent=1))
 
 
