@@ -367,9 +367,14 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_head_kernel(ConvLevels L, int
                                                                const float *__restrict__ b_cls, int n_cls, const float *__restrict__ b_reg, int n_reg,
                                                                float *__restrict__ out_cls, float *__restrict__ out_reg)
 {
+    // Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Neighbouring tiles share halo rows and the
+    // 128-byte lines at their left / right edges, so consecutive tile ids are given to blocks b, b + 8, b + 16, ...: one XCD, dispatched
+    // together (PMC: the pixel fetch was 2.4x the input with the identity mapping).
+    auto xcd_order = [](int i, int n) { const int n8 = n & ~7; return i < n8 ? (i & 7) * (n8 >> 3) + (i >> 3) : i; };
     const int b = (int)blockIdx.x;
     const bool half = b >= first_split;
-    const int tile = half ? first_split + ((b - first_split) >> 1) : b, ysub = half ? 4 * ((b - first_split) & 1) : 0;
+    const int hb = half ? xcd_order(b - first_split, (int)gridDim.x - first_split) : 0;
+    const int tile = half ? first_split + (hb >> 1) : xcd_order(b, first_split), ysub = half ? 4 * (hb & 1) : 0;
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && tile >= L.tile0[l]) ? 1 : 0;
