@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
                                                                 const float *__restrict__ g_cls, const float *__restrict__ g_reg,
                                                                 float *__restrict__ part_dw, float *__restrict__ part_db3, float *__restrict__ part_db)
 {
-    __shared__ float s_g[32 * HB_GS];
+    __shared__ float s_gbuf[2][32 * HB_GS];
     __shared__ float s_h[8][32 * HB_HS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lk = lane >> 5;
@@ -272,60 +272,96 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
     }
     float db = 0.0f;                                                // wave 0: lane = output column j
     float *sh = s_h[wave];
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // One workgroup per CU walks ~11 tiles at FPN size; with load -> use inside a tile every tile paid three dependent HBM round trips
+    // (7.5 us per tile, 83 us per launch).  So the loads of tile t + 1 (its g rows and this wave's 16 raw values per channel tile) are
+    // issued before the MFMAs of tile t, g is double-buffered in LDS: one barrier per tile.
+    struct Tile { const TIN *raw; TIN *d_raw; int P, p0; size_t row0; };
+    auto tile_of = [&](int tile) {
         int lvl = 0;
 #pragma unroll
         for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && tile >= L.tile0[l]) ? 1 : 0;
-        const TIN *raw = (const TIN *)L.raw[lvl];
-        TIN *d_raw = (TIN *)L.d_raw[lvl];
-        const int P = L.P[lvl];
-        const int p0 = (tile - L.tile0[lvl]) * 32;
-        const size_t row0 = (size_t)L.pos0[lvl] + p0;               // first row of this tile in the concatenated g tensors
-        __syncthreads();                                            // the previous tile's readers of s_g are done
-        for (int e = threadIdx.x; e < 32 * 64; e += 512) {          // g tile -> LDS, zero-padded (columns >= J, rows >= P)
-            const int p = e >> 6, j = e & 63;
+        Tile t;
+        t.raw = (const TIN *)L.raw[lvl]; t.d_raw = (TIN *)L.d_raw[lvl]; t.P = L.P[lvl];
+        t.p0 = (tile - L.tile0[lvl]) * 32; t.row0 = (size_t)L.pos0[lvl] + t.p0;   // first row of this tile in the concatenated g tensors
+        return t;
+    };
+    float gq[4];                                                    // g elements threadIdx.x + 512 u of the tile (row p = e >> 6, column j = e & 63)
+    float zq[CT][16];                                               // raw values of my position for the 16 channels of each channel tile
+    auto load_tile = [&](const Tile &t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (int)threadIdx.x + 512 * u, p = e >> 6, j = e & 63;
             float v = 0.0f;
-            if (p0 + p < P) {
-                if (j < n_cls) v = g_cls[(row0 + p) * n_cls + j];
-                else if (j < J) v = g_reg[(row0 + p) * n_reg + (j - n_cls)];
+            if (t.p0 + p < t.P) {
+                if (j < n_cls) v = g_cls[(t.row0 + p) * n_cls + j];
+                else if (j < J) v = g_reg[(t.row0 + p) * n_reg + (j - n_cls)];
             }
-            s_g[p * HB_GS + j] = v;
+            gq[u] = v;
         }
-        __syncthreads();
+        const int pos = min(t.p0 + li, t.P - 1);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+#ifdef HB_NO_LOAD
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zq[ct][r] = (float)(pos + r);
+#else
+            for (int r = 0; r < 16; ++r) zq[ct][r] = load_raw(t.raw, (size_t)(cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk) * t.P + pos);
+#endif
+    };
+    int tile = blockIdx.x;
+    Tile cur = tile_of(min(tile, n_tiles - 1));
+    if (tile < n_tiles) load_tile(cur);
+    for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
+        float *s_g = s_gbuf[it & 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 512 * u; s_g[(e >> 6) * HB_GS + (e & 63)] = gq[u]; }
+        float zr[CT][16];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zr[ct][r] = zq[ct][r] + bias[ct][r];
+        __syncthreads();                                            // g of this tile is staged; the other buffer's readers finished a tile ago
+        const Tile me = cur;
+        if (tile + (int)gridDim.x < n_tiles) { cur = tile_of(tile + (int)gridDim.x); load_tile(cur); }   // in flight under the MFMAs below
         if (wave == 0) {
 #pragma unroll 8
             for (int p = 0; p < 32; ++p) db += s_g[p * HB_GS + lane];
         }
-        const int pos = min(p0 + li, P - 1);
-        const bool pv = p0 + li < P;
+        const int P = me.P;
+        const int pos = min(me.p0 + li, P - 1);
+        const bool pv = me.p0 + li < P;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             // ---- dz = W^T g (accumulator: lane = position li, registers = 16 channels)
             f32x16 acc = (f32x16){0};
+#ifndef HB_NO_DZ
 #pragma unroll
             for (int s = 0; s < NJ * 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ct][s], s_g[li * HB_GS + 2 * s + lk], acc, 0, 0, 0);
+#endif
             // ---- ReLU mask, d_raw, db3, h -> LDS
-            float zr[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                zr[r] = load_raw(raw, (size_t)c * P + pos) + bias[ct][r];
-            }
             __builtin_amdgcn_wave_barrier();                        // the previous c-tile's readers of my h tile are done
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float dz = zr[r] > 0.0f ? acc[r] : 0.0f;
-                if (pv) { store_raw(d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
-                sh[cl * HB_HS + li] = zr[r] > 0.0f ? zr[r] : 0.0f;
+                const float dz = zr[ct][r] > 0.0f ? acc[r] : 0.0f;
+#ifdef HB_NO_STORE
+                if (pv) { if (dz == 123.456f) store_raw(me.d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
+#else
+                if (pv) { store_raw(me.d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
+#endif
+                sh[cl * HB_HS + li] = zr[ct][r] > 0.0f ? zr[ct][r] : 0.0f;
             }
             __builtin_amdgcn_wave_barrier();
             // ---- dW += g^T h : A[m = j][k = p] = g[p][j], B[k = p][n = c] = h[c][p], step s covers p = 2 s + lk
 #pragma unroll
             for (int jt = 0; jt < NJ; ++jt) {
 #pragma unroll
-                for (int s = 0; s < 16; ++s)
+                for (int s = 0; s < 16; ++s) {
+#ifndef HB_NO_DW
                     acc_w[jt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_g[(2 * s + lk) * HB_GS + 32 * jt + li], sh[li * HB_HS + 2 * s + lk], acc_w[jt][ct], 0, 0, 0);
+#endif
+                }
             }
         }
     }
@@ -358,23 +394,33 @@ __global__ __launch_bounds__(256) void rpn_head_tail_bwd_finalize_kernel(const f
                                                                          float *__restrict__ dw_reg, float *__restrict__ db_reg, float *__restrict__ db3)
 {
     const int J = n_cls + n_reg;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    // one thread per output, neighbouring threads read neighbouring words of a partial; eight partials in flight per thread
-    // (one load after the other cost 63 us for 256 partials).  The summation order is fixed: bit-reproducible.
+    // 32 outputs per workgroup x 8 groups of partials: thread (g, o) sums partials g, g + 8, g + 16, ... of output o (four loads in
+    // flight, neighbouring threads read neighbouring words), the eight group sums are added in group order through LDS.  The order
+    // is fixed: bit-reproducible.  (One thread per output walking all 256 partials ran on 19 workgroups: 16 us for 17 MB.)
+    __shared__ float s_p[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + o;
     const float *src = nullptr;
     size_t stride = 0;
     if (e < J * C) { src = part_dw + e; stride = (size_t)64 * C; }
     else if (e < J * C + C) { src = part_db3 + (e - J * C); stride = (size_t)C; }
     else if (e < J * C + C + J) { src = part_db + (e - J * C - C); stride = 64; }
-    if (!src) return;
     float v = 0.0f;
-    for (int b0 = 0; b0 < nblk; b0 += 8) {
-        float t[8];
+    if (src) {
+        for (int b0 = g; b0 < nblk; b0 += 32) {
+            float t[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = b0 + u < nblk ? src[(size_t)(b0 + u) * stride] : 0.0f;
+            for (int u = 0; u < 4; ++u) t[u] = b0 + 8 * u < nblk ? src[(size_t)(b0 + 8 * u) * stride] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v += t[u];
+            for (int u = 0; u < 4; ++u) v += t[u];
+        }
     }
+    s_p[g][o] = v;
+    __syncthreads();
+    if (g != 0 || !src) return;
+    v = s_p[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v += s_p[q][o];
     if (e < J * C) {
         const int j = e / C, c = e - j * C;
         if (j < n_cls) dw_cls[(size_t)j * C + c] = v; else dw_reg[(size_t)(j - n_cls) * C + c] = v;
@@ -427,7 +473,7 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, 
 #undef HEAD_BWD_LAUNCH
     FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_kernel");
     const int n_out = (n_cls + n_reg) * C + C + n_cls + n_reg;
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, rpn_head_tail_bwd_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, part_dw, part_db3, part_db,
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, rpn_head_tail_bwd_finalize_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, s, part_dw, part_db3, part_db,
                  nblk, C, n_cls, n_reg, dw_cls, db_cls, dw_reg, db_reg, db3);
     FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_finalize_kernel");
     return FRCNN_OK;
