@@ -236,17 +236,21 @@ __device__ __forceinline__ void store_raw(float *p, size_t i, float v) { p[i] = 
 __device__ __forceinline__ void store_raw(unsigned short *p, size_t i, float v) { p[i] = (unsigned short)to_bf16_rne(v); }
 
 template <typename TIN, int NJ, int CT>
-__global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L, int C, int n_tiles, const float *__restrict__ b3,
+#ifndef HB_NW
+#define HB_NW 8                          // waves per workgroup (32 channels each); 4 (two independent workgroups per CU) measured 5 % slower
+#endif
+#define HB_GQ (2048 / (64 * HB_NW))        // g elements staged per thread
+__global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLevels L, int C, int n_tiles, const float *__restrict__ b3,
                                                                 const float *__restrict__ w_cls, int n_cls, const float *__restrict__ w_reg, int n_reg,
                                                                 const float *__restrict__ g_cls, const float *__restrict__ g_reg,
                                                                 float *__restrict__ part_dw, float *__restrict__ part_db3, float *__restrict__ part_db)
 {
     __shared__ float s_gbuf[2][32 * HB_GS];
-    __shared__ float s_h[8][32 * HB_HS];
+    __shared__ float s_h[HB_NW][32 * HB_HS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int li = lane & 31, lk = lane >> 5;
     const int J = n_cls + n_reg;
-    const int cw = (int)blockIdx.y * 256 * CT + wave * 32 * CT;     // first channel of this wave
+    const int cw = (int)blockIdx.y * 32 * HB_NW * CT + wave * 32 * CT;     // first channel of this wave
     // W^T operand of the first product, resident for the whole kernel: A[m = c][k = j] = W[j][c], step s covers j = 2 s + lk
     float wt[CT][NJ * 16];
     float bias[CT][16];
@@ -285,12 +289,12 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
         t.p0 = (tile - L.tile0[lvl]) * 32; t.row0 = (size_t)L.pos0[lvl] + t.p0;   // first row of this tile in the concatenated g tensors
         return t;
     };
-    float gq[4];                                                    // g elements threadIdx.x + 512 u of the tile (row p = e >> 6, column j = e & 63)
+    float gq[HB_GQ];                                                // g elements threadIdx.x + 64 HB_NW u of the tile (row p = e >> 6, column j = e & 63)
     float zq[CT][16];                                               // raw values of my position for the 16 channels of each channel tile
     auto load_tile = [&](const Tile &t) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int e = (int)threadIdx.x + 512 * u, p = e >> 6, j = e & 63;
+        for (int u = 0; u < HB_GQ; ++u) {
+            const int e = (int)threadIdx.x + 64 * HB_NW * u, p = e >> 6, j = e & 63;
             float v = 0.0f;
             if (t.p0 + p < t.P) {
                 if (j < n_cls) v = g_cls[(t.row0 + p) * n_cls + j];
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(512) void rpn_head_tail_bwd_kernel(HeadBwdLevels L,
     for (int it = 0; tile < n_tiles; tile += gridDim.x, ++it) {
         float *s_g = s_gbuf[it & 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 512 * u; s_g[(e >> 6) * HB_GS + (e & 63)] = gq[u]; }
+        for (int u = 0; u < HB_GQ; ++u) { const int e = (int)threadIdx.x + 64 * HB_NW * u; s_g[(e >> 6) * HB_GS + (e & 63)] = gq[u]; }
         float zr[CT][16];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -466,7 +470,7 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, 
     float *part_db = part_db3 + (size_t)HEAD_BWD_MAX_BLOCKS * C;
     const int nj = n_cls + n_reg <= 32 ? 1 : 2;
 #define HEAD_BWD_LAUNCH(T_, NJ_)                                                                                                            \
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, 1>), dim3((unsigned)nblk, (unsigned)(C / 256)), dim3(512), 0, s, L, C, (int)tiles, \
+    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, 1>), dim3((unsigned)nblk, (unsigned)(C / (32 * HB_NW))), dim3(64 * HB_NW), 0, s, L, C, (int)tiles, \
                  b3, w_cls, n_cls, w_reg, n_reg, g_cls, g_reg, part_dw, part_db3, part_db)
     if (dtype == FRCNN_DTYPE_F32) { if (nj == 1) HEAD_BWD_LAUNCH(float, 1); else HEAD_BWD_LAUNCH(float, 2); }
     else { if (nj == 1) HEAD_BWD_LAUNCH(unsigned short, 1); else HEAD_BWD_LAUNCH(unsigned short, 2); }
