@@ -59,7 +59,7 @@ BOUND = {"nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_tar
          "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency",
          "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
          "nms_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
-         "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm",
+         "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm", "roi_align_bwd_lists_kernel": "latency", "roi_align_bwd_combine_kernel": "hbm",
          "rpn_conv3x3_head_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
 
 

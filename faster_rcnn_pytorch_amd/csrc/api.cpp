@@ -87,7 +87,7 @@ static const char *const g_kernel_names[KID_COUNT] = {
     "anchor_grid_kernel", "box_codec_kernel", "pairwise_iou_kernel", "proposal_prologue_kernel",
     "topk_partition_kernels", "topk_bucket_kernel", "nms_kernel", "nms_resolve_kernel(unused)",
     "rpn_colmax_kernel", "rpn_label_kernel", "rpn_sample_kernel", "head_targets_kernel",
-    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_emit_kernel", "rpn_head_tail_bwd_kernel", "rpn_conv3x3_head_kernel", "rpn_conv_pack_kernel"};
+    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_emit_kernel", "rpn_head_tail_bwd_kernel", "rpn_conv3x3_head_kernel", "rpn_conv_pack_kernel", "roi_align_bwd_lists_kernel", "roi_align_bwd_combine_kernel"};
 
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_prof_mu;

@@ -35,6 +35,8 @@ enum FrcnnKernelId {
     KID_RPN_HEAD_TAIL_BWD,
     KID_RPN_CONV,
     KID_RPN_CONV_PACK,
+    KID_ROI_ALIGN_BWD_LISTS,
+    KID_ROI_ALIGN_BWD_COMBINE,
     KID_COUNT
 };
 

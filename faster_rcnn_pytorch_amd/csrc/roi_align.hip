@@ -12,8 +12,8 @@
 //   backward: tile-owner GATHER: bilinear scatter is separable, dF = Wy^T (fh x 7) . dOut (7x7) . Wx (7 x fw), so a workgroup that
 //             owns a 16 x 8 pixel tile of one level walks the RoIs whose footprint meets the tile IN INDEX ORDER and accumulates
 //             the tile in registers; every gradient pixel is written exactly once: no atomics, no memset, bit-reproducible.
-//             Fine levels: roi_align_bwd_tile_kernel (32 channels per workgroup, one RoI at a time); coarse levels, where a tile's
-//             RoI list is long: roi_align_bwd_coarse_kernel (16 channels, eight RoIs in flight, combined in a fixed order).
+//             The per-tile RoI lists are built once (roi_align_bwd_lists_kernel); long lists are cut into segments whose partial
+//             tiles are added in segment order (roi_align_bwd_combine_kernel).
 // Any other bin/sampling shape takes the generic one-lane-per-output kernels below (memset + fp32 atomics in backward;
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
@@ -284,50 +284,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 }
 
 // ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
-// A workgroup owns a 16 x 8 pixel tile of ONE level for 32 channels (lane = (column, channel), 16 row accumulators in
-// registers) and writes it exactly once.  (Measured 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch
-// 89/178 -- micro-benchmark / FPN step: narrow tiles keep the per-tile RoI chain short.)  It scans the RoI list (level + footprint recomputed from the box: ~150 instructions per RoI,
-// 2 RoIs per lane at R = 512), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot compaction, so the
-// fp32 sum order is fixed: bit-reproducible gradients), and for each of them
-//   A: stores the prefetched dOut[r][32 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
-//      Wy[16][7] and Wx[8][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
-//   B: lane = (channel, column) forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds
-//      sum_ph Wy[y][ph] * T[ph] to its 16 row accumulators (registers) -- one barrier per RoI, LDS tables double-buffered.
+// Three launches:
+//  roi_align_bwd_lists_kernel   one workgroup per 16 x 8 pixel tile of any level: scans the RoIs (level + footprint recomputed
+//      from the box, ~150 instructions per RoI), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot
+//      compaction) as a list in the workspace, with the tile rows each of them reaches.  (Round 1 had every (tile, channel
+//      group) workgroup of the main kernel repeat this scan: 8x the work, and four barriers before the first useful load.)
+//      A tile whose list is longer than RS_SPLIT entries is cut into up to RS_NSEG segments.
+//  roi_align_bwd_tile_kernel    workgroup = (tile, 32 channels, segment): lane = (column, channel) keeps 16 row accumulators in
+//      registers and walks its segment of the list; per RoI
+//        A: stores the prefetched dOut[r][32 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
+//           Wy[16][7] and Wx[8][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
+//        B: forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds sum_ph Wy[y][ph] * T[ph] to the
+//           accumulators of the rows the RoI reaches -- one barrier per RoI, LDS tables double-buffered.
+//      An unsplit tile is written exactly once, straight to the gradient plane; a segment writes its partial tile to the workspace.
+//  roi_align_bwd_combine_kernel adds the partial tiles of a split tile in SEGMENT ORDER and writes the plane.
+// The fp32 sum order is a function of the RoI list alone: bit-reproducible gradients, no atomics, nothing cleared beforehand.
+// Why segments: the time of the gather is the longest chain of RoIs through one workgroup (0.5-0.7 us per RoI).  On the bench's
+// FPN frames the 147 tiles of the stride-8 level meet 30 RoIs on average and up to 71 (tools/dev/roi_stats.py); later in training
+// the coarse levels take over.  Round 2's first answer, a second kernel with eight waves per tile for the COARSE levels, guessed
+// the hot level from the pyramid shape, paid the scan 16 times per tile and took 67-75 us on 400 (tile, RoI) pairs.
+// (Tile shape sweep, micro-benchmark / FPN step: 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch 89/178.)
 #ifndef RT_TH
 #define RT_TH 16
 #endif
 #ifndef RT_TW
 #define RT_TW 8
 #endif
-#define RT_CPS (256 / RT_TW)              // channels per sub-group: lane = (column, channel)
-#ifndef RT_NS
-#define RT_NS 1                          // channel sub-groups of 8 per workgroup (lane = (column, channel within sub-group))
-#endif
-#define RT_CB (RT_CPS * RT_NS)
-#define RT_LIST 256                      // RoIs are scanned in chunks of this many
+#define RT_CPS (256 / RT_TW)              // channels per workgroup: lane = (column, channel)
+#define RT_CB RT_CPS
 #define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
+#define RT_GS 49                         // LDS stride of a channel's 49 dOut values
+#ifndef RS_SPLIT
+#define RS_SPLIT 12                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ...
+#endif
+#ifndef RS_NSEG
+#define RS_NSEG 32                       // ... at most this many
+#endif
+#define RS_CHUNK 64                      // list entries staged in LDS at a time
 
 struct TileLevels { int tile0[FRCNN_MAX_LEVELS + 1]; int tiles_x[FRCNN_MAX_LEVELS]; };
-struct RoiEnt { int r; float sh, sw, bh, bw; };
+struct __attribute__((aligned(8))) RoiEnt { int r; float sh, sw, bh, bw; int rows; };   // rows = first | last << 8 tile row the RoI reaches
 
 template <typename TOUT> __device__ __forceinline__ void store_grad(TOUT *p, float v);
 template <> __device__ __forceinline__ void store_grad<float>(float *p, float v) { *p = v; }
 
-template <typename TOUT>
-__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, int C, const float4 *__restrict__ rois, int R, int aligned,
-                                                                 int k_min, float s0, int k0, const float *__restrict__ grad_out, int n_cg)
+__device__ __forceinline__ int ra_nseg(int n, int split) { return n <= split ? 1 : min(RS_NSEG, (n + split - 1) / split); }
+
+// cnt[tile] = list length; ent[tile * cap + i] = the i-th RoI (index order) whose footprint meets the tile
+__global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, TileLevels TL, const float4 *__restrict__ rois, int R, int aligned,
+                                                                  int k_min, float s0, int k0, int cap, int32_t *__restrict__ cnt,
+                                                                  RoiEnt *__restrict__ ent)
 {
-    __shared__ RoiEnt s_list[RT_LIST];
-    __shared__ int s_n;
     __shared__ int s_woff[5];
-    __shared__ float s_g[2][RT_CB * 49];
-    __shared__ __attribute__((aligned(16))) float s_wy[2][RT_TH * 8];
-    __shared__ float s_wx[2][RT_TW * 8];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // block -> (tile, channel group); groups pinned to XCDs when there are 8 k of them
-    int tile, cg;
-    if ((n_cg & 7) == 0) { const int j = blockIdx.x >> 3; const int q8 = n_cg >> 3; cg = (j % q8) * 8 + (blockIdx.x & 7); tile = j / q8; }
-    else { cg = blockIdx.x % n_cg; tile = blockIdx.x / n_cg; }
+    const int tile = blockIdx.x;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
@@ -335,24 +345,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
     const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
     const int H = L.H[l], W = L.W[l];
     const float scale = L.scale[l];
-    const int cx = t % RT_TW, cc = t / RT_TW;             // phase B: lane -> (column cx, channel cc + RT_CPS s of the group)
-    const int c0 = cg * RT_CB;
-    const int nc = min(RT_CB, C - c0);
-    const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
-
-    float acc[RT_NS][RT_TH];
-#pragma unroll
-    for (int sg = 0; sg < RT_NS; ++sg)
-#pragma unroll
-        for (int y = 0; y < RT_TH; ++y) acc[sg][y] = 0.0f;
-
-    for (int rbase = 0; rbase < R; rbase += RT_LIST) {
-        // ---- scan RT_LIST RoIs: which of them touch this tile?
-        __syncthreads();                                   // the previous chunk's readers of s_list are done
+    RoiEnt *mine = ent + (size_t)tile * cap;
+    int base = 0;
+    for (int rbase = 0; rbase < R; rbase += 256) {
         const int r = rbase + t;
         bool hit = false;
         RoiEnt e;
-        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f;
+        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f; e.rows = 0;
         if (r < R) {
             const float4 b = rois[r];
             const int lr = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
@@ -363,33 +362,123 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
                 const int y0 = min(ya.lo, yb.lo), y1 = max(ya.hi, yb.hi), x0 = min(xa.lo, xb.lo), x1 = max(xa.hi, xb.hi);
                 hit = y0 < ty0 + RT_TH && y1 >= ty0 && x0 < tx0 + RT_TW && x1 >= tx0;
                 e.sh = g.sh; e.sw = g.sw; e.bh = g.bh; e.bw = g.bw;
+                e.rows = max(y0 - ty0, 0) | (min(y1 - ty0, RT_TH - 1) << 8);
             }
         }
         const unsigned long long bm = __ballot(hit);
+        __syncthreads();                                   // the previous chunk's readers of s_woff are done
         if (lane == 0) s_woff[wave + 1] = __builtin_popcountll(bm);
         __syncthreads();
-        if (t == 0) { s_woff[0] = 0; for (int q = 1; q <= 4; ++q) s_woff[q] += s_woff[q - 1]; s_n = s_woff[4]; }
+        if (t == 0) { s_woff[0] = 0; for (int q = 1; q <= 4; ++q) s_woff[q] += s_woff[q - 1]; }
         __syncthreads();
-        if (hit) s_list[s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
+        if (hit) mine[base + s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
+        base += s_woff[4];
+    }
+    if (t == 0) cnt[tile] = base;
+}
+
+// One workgroup: turns the list lengths into work items.  Tile q gets nseg(q) consecutive items from base[q] (an exclusive prefix
+// sum in tile order, so the assignment -- and with it the summation order -- is a function of the lists alone); if the items do not
+// fit the table the split threshold is doubled until they do (every tile keeps at least one item: cap >= tiles).
+__global__ __launch_bounds__(256) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
+                                                                 int32_t *__restrict__ tnseg, int32_t *__restrict__ items, int32_t *__restrict__ n_items)
+{
+    __shared__ int s_scan[256];
+    __shared__ int s_total;
+    const int t = threadIdx.x;
+    const int per = (tiles + 255) / 256, q0 = t * per, q1 = min(q0 + per, tiles);
+    int split = RS_SPLIT;
+    for (;;) {
+        int mine = 0;
+        for (int q = q0; q < q1; ++q) mine += ra_nseg(cnt[q], split);
+        s_scan[t] = mine;
         __syncthreads();
-        const int n = s_n;
-        // ---- the RoIs of this chunk that touch the tile, in index order
+        for (int o = 1; o < 256; o <<= 1) {                // inclusive Hillis-Steele scan over the 256 chunk sums
+            const int v = t >= o ? s_scan[t - o] : 0;
+            __syncthreads();
+            s_scan[t] += v;
+            __syncthreads();
+        }
+        if (t == 255) s_total = s_scan[255];
+        __syncthreads();
+        if (s_total <= cap_items) break;
+        split *= 2;                                        // (terminates: at split >= max(cnt) every tile has one item and tiles <= cap)
+        __syncthreads();
+    }
+    int base = s_scan[t] - 0;
+    {   // exclusive prefix of my chunk
+        int mine = 0;
+        for (int q = q0; q < q1; ++q) mine += ra_nseg(cnt[q], split);
+        base -= mine;
+    }
+    for (int q = q0; q < q1; ++q) {
+        const int ns = ra_nseg(cnt[q], split);
+        tbase[q] = base; tnseg[q] = ns;
+        for (int sgm = 0; sgm < ns; ++sgm) items[base + sgm] = q;
+        base += ns;
+    }
+    if (t == 0) *n_items = s_total;
+}
+
+template <typename TOUT>
+__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, int C, int aligned, const float *__restrict__ grad_out,
+                                                                 int n_cg, int cap, const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
+                                                                 const int32_t *__restrict__ tbase, const int32_t *__restrict__ tnseg,
+                                                                 const int32_t *__restrict__ items, const int32_t *__restrict__ n_items,
+                                                                 float *__restrict__ part)
+{
+    __shared__ __attribute__((aligned(16))) float s_g[2][RT_CB * RT_GS];
+    __shared__ __attribute__((aligned(16))) float s_wy[2][RT_TH * 8];
+    __shared__ float s_wx[2][RT_TW * 8];
+    __shared__ RoiEnt s_list[RS_CHUNK];
+    const int t = threadIdx.x;
+    // block -> (work item, channel group)  (n_cg = 8: blockIdx % 8 = channel group = XCD, so each L2 holds one eighth of dOut)
+    const int cg = blockIdx.x % n_cg, item = blockIdx.x / n_cg;
+    if (item >= *n_items) return;
+    const int tile = items[item];
+    const int n = cnt[tile], nseg = tnseg[tile], seg = item - tbase[tile];
+    const int lo = (int)((long long)n * seg / nseg), hi = (int)((long long)n * (seg + 1) / nseg);
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
+    const int tl = tile - TL.tile0[l];
+    const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
+    const int H = L.H[l], W = L.W[l];
+    const int cx = t % RT_TW, cc = t / RT_TW;             // phase B: lane -> (column cx, channel cc of the group)
+    const int c0 = cg * RT_CB;
+    const int nc = min(RT_CB, C - c0);
+    const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
+    const RoiEnt *mine = ent + (size_t)tile * cap;
+
+    float acc[RT_TH];
+#pragma unroll
+    for (int y = 0; y < RT_TH; ++y) acc[y] = 0.0f;
+    int goff[RT_PF];                                       // LDS position of my staged element t + 256 u (channel stride RT_GS)
+#pragma unroll
+    for (int u = 0; u < RT_PF; ++u) { const int e = t + 256 * u; goff[u] = (e / 49) * RT_GS + e % 49; }
+
+    // the segment's entries go through LDS in chunks (a global load per RoI in the dependent chain cost 1-2 us each)
+    for (int cb = lo; cb < hi; cb += RS_CHUNK) {
+        const int m = min(RS_CHUNK, hi - cb);
+        __syncthreads();                                   // the previous chunk's readers of s_list and of the table buffers are done
+        if (t < m) s_list[t] = mine[cb + t];
+        __syncthreads();
         float pg[RT_PF];                                   // prefetched dOut elements t + 256 u of the next RoI
 #pragma unroll
         for (int u = 0; u < RT_PF; ++u) pg[u] = 0.0f;
-        if (n > 0) {
+        {
             const float *src = grad_out + ((size_t)s_list[0].r * C + c0) * 49;
 #pragma unroll
             for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
         }
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < m; ++i) {
             const int buf = i & 1;
             const RoiEnt en = s_list[i];
             // A: dOut tile -> LDS (zero-padded to RT_CB channels), weight tables of this RoI restricted to the tile
 #pragma unroll
             for (int u = 0; u < RT_PF; ++u)
-                if (t + 256 * u < RT_CB * 49) s_g[buf][t + 256 * u] = t + 256 * u < ne ? pg[u] : 0.0f;
-            if (i + 1 < n) {
+                if (t + 256 * u < RT_CB * 49) s_g[buf][goff[u]] = t + 256 * u < ne ? pg[u] : 0.0f;
+            if (i + 1 < m) {
                 const float *src = grad_out + ((size_t)s_list[i + 1].r * C + c0) * 49;
 #pragma unroll
                 for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
@@ -419,246 +508,81 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
                 }
             }
             __syncthreads();
-            // B: per channel sub-group: T[ph] for (cc + 8 sg, cx), then the tile rows the footprint reaches (uniform bounds)
-            const Lin fa = lin_setup(H, en.sh + 0.5f * en.bh / 2.0f), fb = lin_setup(H, en.sh + 6.0f * en.bh + 1.5f * en.bh / 2.0f);
-            const int ya = __builtin_amdgcn_readfirstlane(max(min(fa.lo, fb.lo) - ty0, 0));
-            const int yb = __builtin_amdgcn_readfirstlane(min(max(fa.hi, fb.hi) - ty0, RT_TH - 1));
+            // B: T[ph] for (cc, cx), then the tile rows the footprint reaches (uniform bounds, from the list entry)
+            const int ya = __builtin_amdgcn_readfirstlane(en.rows & 0xFF), yb = __builtin_amdgcn_readfirstlane(en.rows >> 8);
             float wx[7];
 #pragma unroll
             for (int pw = 0; pw < 7; ++pw) wx[pw] = s_wx[buf][cx * 8 + pw];
+            const float *gch = &s_g[buf][cc * RT_GS];       // (read as 12 ds_read_b128 + 1 the kernel needs 111 instead of 72 registers: 89 vs 81 us)
+            float T[7];
 #pragma unroll
-            for (int sg = 0; sg < RT_NS; ++sg) {
-                if (RT_NS > 1) asm volatile("" ::: "memory");   // re-read the (broadcast) tables per sub-group instead of pinning 300 registers
-                const float *gch = &s_g[buf][(cc + RT_CPS * sg) * 49];
-                float T[7];
+            for (int ph = 0; ph < 7; ++ph) {
+                float a = gch[ph * 7] * wx[0];
 #pragma unroll
-                for (int ph = 0; ph < 7; ++ph) {
-                    float a = gch[ph * 7] * wx[0];
+                for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
+                T[ph] = a;
+            }
 #pragma unroll
-                    for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
-                    T[ph] = a;
-                }
-#pragma unroll
-                for (int y = 0; y < RT_TH; ++y) {
-                    if (y >= ya && y <= yb) {                 // scalar branch
-                        const float4 w0 = *(const float4 *)&s_wy[buf][y * 8], w1 = *(const float4 *)&s_wy[buf][y * 8 + 4];
-                        float a = acc[sg][y];
-                        a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
-                        a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
-                        acc[sg][y] = __builtin_fmaf(w1.z, T[6], a);
-                    }
+            for (int y = 0; y < RT_TH; ++y) {
+                if (y >= ya && y <= yb) {                 // scalar branch
+                    const float4 w0 = *(const float4 *)&s_wy[buf][y * 8], w1 = *(const float4 *)&s_wy[buf][y * 8 + 4];
+                    float a = acc[y];
+                    a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
+                    a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
+                    acc[y] = __builtin_fmaf(w1.z, T[6], a);
                 }
             }
             // no barrier here: the next A writes the OTHER buffers; the one after that is fenced by the next barrier
         }
     }
+    if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
+        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
+#pragma unroll
+        for (int y = 0; y < RT_TH; ++y) dst[y * RT_TW] = acc[y];
+        return;
+    }
     // ---- the tile is complete: one coalesced store per row and channel
-    if (tx0 + cx < W) {
+    if (tx0 + cx < W && cc < nc) {
+        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;
 #pragma unroll
-        for (int sg = 0; sg < RT_NS; ++sg) {
-            const int c = cc + RT_CPS * sg;
-            if (c < nc) {
-                TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + ty0) * W + tx0 + cx;
-#pragma unroll
-                for (int y = 0; y < RT_TH; ++y)
-                    if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[sg][y]);
-            }
-        }
+        for (int y = 0; y < RT_TH; ++y)
+            if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[y]);
     }
 }
 
-// ---- the same gather for the COARSE levels: 8 channels per workgroup, eight RoIs in flight ------------------------
-// (16 channels per workgroup, two sub-groups of 8 per lane.)
-// The coarse levels have few tiles and every large RoI touches all of them: with the kernel above (ONE RoI in flight per
-// workgroup, 32 channels) a coarse tile is a chain of ~200 RoIs x 0.5 us on an untrained frame -- 194 us in the FPN step against
-// 61 us in the micro-benchmark.  Here a workgroup owns a 16 x 8 pixel tile of one level for 16 channels and writes it exactly once.  It scans the RoI list (level +
-// footprint recomputed from the box, 2 RoIs per lane at R = 512), keeps the ones whose footprint meets the tile IN INDEX ORDER
-// (ballot compaction), and its EIGHT WAVES then walk that list concurrently, wave w taking entries w, w + 8, ... with no workgroup
-// barrier in between.  Per RoI a wave
-//   A: stores the prefetched dOut[r][8 ch][7][7] to its private LDS tile and builds the two separable weight tables restricted to the
-//      tile, Wy[16][7] and Wx[8][7] (lane = (row | col, bin): 1-D bilinear set-ups, gathered, no scatter / zero pass),
-//   B: lane = (column, channel) forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds
-//      sum_ph Wy[y][ph] * T[ph] to its 16 row accumulators (registers).
-// At the end the eight private accumulator tiles are added in wave order through LDS: every pixel is written once, the fp32 sum
-// order is fixed (bit-reproducible gradients), nothing is cleared beforehand.
-// (Used for every level it was 6x slower: 24 000 workgroups x 57 KB of LDS, each scanning the whole RoI list.  It only pays where
-// the lists are long.)
-#define RC_TH 16
-#define RC_TW 8
-#define RC_NS 2                          // channel sub-groups of 8 per lane
-#define RC_CB (8 * RC_NS)                // channels per workgroup: lane = (column 0..7, channel 0..7 of each sub-group)
-#define RC_WAVES 8                       // RoIs in flight per workgroup
-#define RC_LIST 512                      // RoIs are scanned in chunks of this many (one per thread)
-#define RC_GE (RC_CB * 49)               // dOut elements of one RoI for this channel group
-#define RC_PF ((RC_GE + 63) / 64)        // ... prefetched per lane
-
-
+// split tiles only: partial tiles added in segment order, plane written once
 template <typename TOUT>
-__global__ __launch_bounds__(64 * RC_WAVES) void roi_align_bwd_coarse_kernel(MsLevels L, TileLevels TL, int C, const float4 *__restrict__ rois, int R, int aligned,
-                                                                          int k_min, float s0, int k0, const float *__restrict__ grad_out, int n_cg)
+__global__ __launch_bounds__(256) void roi_align_bwd_combine_kernel(MsLevels L, TileLevels TL, int C, int n_cg, const int32_t *__restrict__ tbase,
+                                                                    const int32_t *__restrict__ tnseg, const float *__restrict__ part)
 {
-    // the RoI list + the waves' dOut tiles (during the walk) and the waves' accumulator tiles (at the end) share one buffer
-    constexpr int U_WALK = (int)sizeof(RoiEnt) / 4 * RC_LIST + RC_WAVES * (RC_GE + 8), U_ACC = (RC_WAVES - 1) * RC_CB * RC_TH * RC_TW;
-    __shared__ __attribute__((aligned(16))) float s_u[U_WALK > U_ACC ? U_WALK : U_ACC];
-    RoiEnt *s_list = (RoiEnt *)s_u;
-    float (*s_g)[RC_GE + 8] = (float (*)[RC_GE + 8])(s_u + sizeof(RoiEnt) / 4 * RC_LIST);
-    float (*s_acc)[RC_CB * RC_TH * RC_TW] = (float (*)[RC_CB * RC_TH * RC_TW])s_u;
-    __shared__ int s_n;
-    __shared__ int s_woff[RC_WAVES + 1];
-    __shared__ __attribute__((aligned(16))) float s_wy[RC_WAVES][RC_TH * 8];
-    __shared__ float s_wx[RC_WAVES][RC_TW * 8];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // block -> (tile, channel group); groups pinned to XCDs when there are 8 k of them
-    int tile, cg;
-    if ((n_cg & 7) == 0) { const int j = blockIdx.x >> 3; const int q8 = n_cg >> 3; cg = (j % q8) * 8 + (blockIdx.x & 7); tile = j / q8; }
-    else { cg = blockIdx.x % n_cg; tile = blockIdx.x / n_cg; }
+    const int t = threadIdx.x;
+    const int cg = blockIdx.x % n_cg, tile = blockIdx.x / n_cg;
+    const int nseg = tnseg[tile];
+    if (nseg <= 1) return;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
     const int tl = tile - TL.tile0[l];
-    const int ty0 = (tl / TL.tiles_x[l]) * RC_TH, tx0 = (tl % TL.tiles_x[l]) * RC_TW;
+    const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
     const int H = L.H[l], W = L.W[l];
-    const float scale = L.scale[l];
-    const int cx = lane & 7, cc = lane >> 3;              // phase B: lane -> (column cx, channel cc of the group)
-    const int c0 = cg * RC_CB;
-    const int nc = min(RC_CB, C - c0);
-    const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
-    float *my_g = s_g[wave], *my_wy = s_wy[wave], *my_wx = s_wx[wave];
-
-    float acc[RC_NS][RC_TH];
+    const int cx = t % RT_TW, cc = t / RT_TW;
+    const int c0 = cg * RT_CB;
+    const int nc = min(RT_CB, C - c0);
+    const float *src = part + ((size_t)tbase[tile] * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
+    const size_t stride = (size_t)n_cg * (RT_CB * RT_TH * RT_TW);   // from one segment's partial tile to the next
+    float acc[RT_TH];
 #pragma unroll
-    for (int sg = 0; sg < RC_NS; ++sg)
+    for (int y = 0; y < RT_TH; ++y) acc[y] = src[y * RT_TW];
+    for (int sgm = 1; sgm < nseg; ++sgm) {
+        const float *p = src + (size_t)sgm * stride;
 #pragma unroll
-        for (int y = 0; y < RC_TH; ++y) acc[sg][y] = 0.0f;
-
-    for (int rbase = 0; rbase < R; rbase += RC_LIST) {
-        // ---- scan RC_LIST RoIs: which of them touch this tile?
-        __syncthreads();                                   // the previous chunk's readers of s_list are done
-        const int r = rbase + t;
-        bool hit = false;
-        RoiEnt e;
-        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f;
-        if (r < R) {
-            const float4 b = rois[r];
-            const int lr = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
-            if (lr == l) {
-                const AlignGeom g = align_geom(b, scale, 7, 7, 2, aligned != 0);
-                const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
-                const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
-                const int y0 = min(ya.lo, yb.lo), y1 = max(ya.hi, yb.hi), x0 = min(xa.lo, xb.lo), x1 = max(xa.hi, xb.hi);
-                hit = y0 < ty0 + RC_TH && y1 >= ty0 && x0 < tx0 + RC_TW && x1 >= tx0;
-                e.sh = g.sh; e.sw = g.sw; e.bh = g.bh; e.bw = g.bw;
-            }
-        }
-        const unsigned long long bm = __ballot(hit);
-        if (lane == 0) s_woff[wave + 1] = __builtin_popcountll(bm);
-        __syncthreads();
-        if (t == 0) { s_woff[0] = 0; for (int q = 1; q <= RC_WAVES; ++q) s_woff[q] += s_woff[q - 1]; s_n = s_woff[RC_WAVES]; }
-        __syncthreads();
-        if (hit) s_list[s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
-        __syncthreads();
-        const int n = s_n;
-        // ---- my share of the list: entries wave, wave + RC_WAVES, ... (index order inside the share)
-        float pg[RC_PF];                                   // prefetched dOut elements lane + 64 u of my next RoI
-#pragma unroll
-        for (int u = 0; u < RC_PF; ++u) pg[u] = 0.0f;
-        if (wave < n) {
-            const float *src = grad_out + ((size_t)s_list[wave].r * C + c0) * 49;
-#pragma unroll
-            for (int u = 0; u < RC_PF; ++u) if (lane + 64 * u < ne) pg[u] = src[lane + 64 * u];
-        }
-        for (int i = wave; i < n; i += RC_WAVES) {
-            const RoiEnt en = s_list[i];
-            __builtin_amdgcn_wave_barrier();               // my previous RoI's LDS reads are issued (a wave's ds ops run in order)
-            // A: dOut tile -> LDS (zero-padded to RC_CB channels), weight tables of this RoI restricted to the tile
-#pragma unroll
-            for (int u = 0; u < RC_PF; ++u)
-                if (lane + 64 * u < RC_GE) my_g[lane + 64 * u] = lane + 64 * u < ne ? pg[u] : 0.0f;
-            if (i + RC_WAVES < n) {
-                const float *src = grad_out + ((size_t)s_list[i + RC_WAVES].r * C + c0) * 49;
-#pragma unroll
-                for (int u = 0; u < RC_PF; ++u) if (lane + 64 * u < ne) pg[u] = src[lane + 64 * u];
-            }
-            {
-                // lanes 0..55: (col = lane / 7, bin = lane % 7) of Wx and rows 0..7 of Wy; then rows 8..15 of Wy
-                const int bin = lane % 7, rc = lane / 7;
-                if (rc < RC_TW) {
-                    const int x = tx0 + rc;
-                    float wv = 0.0f;
-#pragma unroll
-                    for (int ix = 0; ix < 2; ++ix) {
-                        const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
-                        if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
-                    }
-                    my_wx[rc * 8 + bin] = wv;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        const int yy = rc + 8 * half, y = ty0 + yy;
-                        float wy = 0.0f;
-#pragma unroll
-                        for (int iy = 0; iy < 2; ++iy) {
-                            const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
-                            if (q.ok) wy += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
-                        }
-                        my_wy[yy * 8 + bin] = 0.25f * wy;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // B: T[ph] for (cc, cx), then the tile rows the footprint reaches (uniform bounds)
-            const Lin fa = lin_setup(H, en.sh + 0.5f * en.bh / 2.0f), fb = lin_setup(H, en.sh + 6.0f * en.bh + 1.5f * en.bh / 2.0f);
-            const int ya = __builtin_amdgcn_readfirstlane(max(min(fa.lo, fb.lo) - ty0, 0));
-            const int yb = __builtin_amdgcn_readfirstlane(min(max(fa.hi, fb.hi) - ty0, RC_TH - 1));
-            float wx[7];
-#pragma unroll
-            for (int pw = 0; pw < 7; ++pw) wx[pw] = my_wx[cx * 8 + pw];
-#pragma unroll
-            for (int sg = 0; sg < RC_NS; ++sg) {
-                const float *gch = &my_g[(cc + 8 * sg) * 49];
-                float T[7];
-#pragma unroll
-                for (int ph = 0; ph < 7; ++ph) {
-                    float a = gch[ph * 7] * wx[0];
-#pragma unroll
-                    for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
-                    T[ph] = a;
-                }
-#pragma unroll
-                for (int y = 0; y < RC_TH; ++y) {
-                    if (y >= ya && y <= yb) {             // scalar branch
-                        const float4 w0 = *(const float4 *)&my_wy[y * 8], w1 = *(const float4 *)&my_wy[y * 8 + 4];
-                        float a = acc[sg][y];
-                        a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
-                        a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
-                        acc[sg][y] = __builtin_fmaf(w1.z, T[6], a);
-                    }
-                }
-            }
-        }
+        for (int y = 0; y < RT_TH; ++y) acc[y] += p[y * RT_TW];
     }
-    // ---- add the eight private tiles in wave order, then one coalesced store per row and channel
-    __syncthreads();
-    if (wave > 0) {
+    if (tx0 + cx < W && cc < nc) {
+        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;
 #pragma unroll
-        for (int sg = 0; sg < RC_NS; ++sg)
-#pragma unroll
-            for (int y = 0; y < RC_TH; ++y) s_acc[wave - 1][((cc + 8 * sg) * RC_TH + y) * RC_TW + cx] = acc[sg][y];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int sg = 0; sg < RC_NS; ++sg) {
-        const int c = cc + 8 * sg;
-#pragma unroll
-        for (int w = 0; w < RC_WAVES - 1; ++w)
-#pragma unroll
-            for (int y = 0; y < RC_TH; ++y) acc[sg][y] += s_acc[w][(c * RC_TH + y) * RC_TW + cx];
-        if (tx0 + cx < W && c < nc) {
-            TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + ty0) * W + tx0 + cx;
-#pragma unroll
-            for (int y = 0; y < RC_TH; ++y)
-                if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[sg][y]);
-        }
+        for (int y = 0; y < RT_TH; ++y)
+            if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[y]);
     }
 }
 
@@ -719,9 +643,41 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
     return FRCNN_OK;
 }
 
+// workspace of the 7 x 7 tile gather: list lengths, lists (capacity R per tile), the plan, partial tiles of split tiles
+struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *items, *n_items; RoiEnt *ent; float *part; int cap_items; size_t total; };
+static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
+{
+    RaBwdWs w; char *p = (char *)ws; size_t o = 0;
+    auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
+    // a RoI meets at most ~15 tiles of its level: at most tiles + 15 R / RS_SPLIT items; the plan kernel coarsens the split if not
+    const int64_t cap_items = tiles + 15 * R / RS_SPLIT + 1;
+    w.cap_items = (int)cap_items;
+    w.cnt = (int32_t *)take((size_t)(tiles + 1) * 4);
+    w.tbase = (int32_t *)take((size_t)(tiles + 1) * 4);
+    w.tnseg = (int32_t *)take((size_t)(tiles + 1) * 4);
+    w.items = (int32_t *)take((size_t)(cap_items + RS_NSEG) * 4);
+    w.n_items = (int32_t *)take(4);
+    w.ent = (RoiEnt *)take((size_t)tiles * (size_t)(R > 0 ? R : 1) * sizeof(RoiEnt));
+    w.part = (float *)take((size_t)cap_items * n_cg * (RT_CB * RT_TH * RT_TW) * sizeof(float));
+    w.total = o;
+    return w;
+}
+static int64_t ra_bwd_tiles(const int *H, const int *W, int n_levels)
+{
+    int64_t tiles = 0;
+    for (int l = 0; l < n_levels; ++l) tiles += (int64_t)((W[l] + RT_TW - 1) / RT_TW) * ((H[l] + RT_TH - 1) / RT_TH);
+    return tiles;
+}
+
+FRCNN_EXPORT size_t frcnn_ms_roi_align_bwd_workspace(const int *H, const int *W, int n_levels, int C, int64_t R)
+{
+    if (!H || !W || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || C <= 0 || R < 0) return 0;
+    return carve_ra_bwd(nullptr, ra_bwd_tiles(H, W, n_levels), R, (C + RT_CB - 1) / RT_CB).total;
+}
+
 FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats, const int *H, const int *W, const float *scales,
                                         int n_levels, int C, const float *rois, int64_t R, int PH, int PW, int sampling_ratio, int aligned,
-                                        int k_min, float s0, int k0, void *stream)
+                                        int k_min, float s0, int k0, void *workspace, size_t workspace_bytes, void *stream)
 {
     FRCNN_REQUIRE(C > 0 && PH > 0 && PW > 0 && R >= 0 && sampling_ratio >= 0 && s0 > 0.f, "ms_roi_align_bwd: bad argument");
     FRCNN_REQUIRE((R == 0 || (rois && grad_out)), "ms_roi_align_bwd: NULL pointer");
@@ -731,35 +687,32 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
     const int64_t total = R * C * PH * PW;
     hipStream_t s = (hipStream_t)stream;
     if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24)) {
-        // fine levels: the 32-channel kernel; coarse levels (fewer than a sixth of the finest level's tiles): the 8-channel kernel
-        int real[FRCNN_MAX_LEVELS];
-        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l)
-            real[l] = l < n_levels ? ((L.W[l] + RT_TW - 1) / RT_TW) * ((L.H[l] + RT_TH - 1) / RT_TH) : 0;
-        int first_coarse = n_levels;
-        for (int l = n_levels - 1; l >= 1; --l)
-            if (real[l] * 6 <= real[0]) first_coarse = l; else break;
-        auto fill = [&](TileLevels &T, int lo, int hi) {             // tiles of the levels [lo, hi); the others get none
-            int tiles = 0;
-            for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
-                T.tile0[l] = tiles;
-                T.tiles_x[l] = (L.W[l] + RT_TW - 1) / RT_TW;
-                if (l >= lo && l < hi) tiles += real[l];
-            }
-            T.tile0[FRCNN_MAX_LEVELS] = tiles;
-            return tiles;
-        };
-        static_assert(RT_TH == RC_TH && RT_TW == RC_TW, "both tile kernels use the same tile shape");
-        TileLevels TF, TC;
-        const int tiles_f = fill(TF, 0, first_coarse), tiles_c = fill(TC, first_coarse, n_levels);
-        const int n_quads = (C + RT_CB - 1) / RT_CB, n_oct = (C + RC_CB - 1) / RC_CB;
-        FRCNN_REQUIRE((int64_t)tiles_f * n_quads < ((int64_t)1 << 31) && (int64_t)tiles_c * n_oct < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
-        if (tiles_f > 0)
-            FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(tiles_f * n_quads)), dim3(256), 0, s, L, TF, C,
-                         (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_quads);
-        if (tiles_c > 0)
-            FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_coarse_kernel<float>), dim3((unsigned)(tiles_c * n_oct)), dim3(64 * RC_WAVES), 0, s, L, TC, C,
-                         (const float4 *)rois, (int)R, aligned, k_min, s0, k0, grad_out, n_oct);
+        TileLevels T;
+        int tiles = 0;
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+            T.tile0[l] = tiles;
+            T.tiles_x[l] = (L.W[l] + RT_TW - 1) / RT_TW;
+            if (l < n_levels) tiles += T.tiles_x[l] * ((L.H[l] + RT_TH - 1) / RT_TH);
+        }
+        T.tile0[FRCNN_MAX_LEVELS] = tiles;
+        const int n_cg = (C + RT_CB - 1) / RT_CB;
+        const size_t need = frcnn_ms_roi_align_bwd_workspace(H, W, n_levels, C, R);
+        FRCNN_REQUIRE(workspace != nullptr, "ms_roi_align_bwd: NULL workspace");
+        if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "ms_roi_align_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+        const RaBwdWs w = carve_ra_bwd(workspace, tiles, R, n_cg);
+        FRCNN_REQUIRE((int64_t)w.cap_items * n_cg < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        const int cap = (int)(R > 0 ? R : 1);
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
+                     k_min, s0, k0, cap, w.cnt, w.ent);
+        FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(256), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items, w.n_items);
+        FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(w.cap_items * n_cg)), dim3(256), 0, s, L, T, C, aligned,
+                     grad_out, n_cg, cap, w.cnt, w.ent, w.tbase, w.tnseg, w.items, w.n_items, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_COMBINE, (roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
+                     w.tnseg, w.part);
+        FRCNN_CHECK_LAUNCH("roi_align_bwd_combine_kernel");
         return FRCNN_OK;
     }
     for (int l = 0; l < n_levels; ++l)                  // the scatter kernels accumulate: clear the planes first

@@ -755,9 +755,11 @@ class _MsRoIAlignFn(torch.autograd.Function):
         grads = [torch.empty(s, dtype=torch.float32, device=grad_out.device) for s in shapes]     # overwritten by the library
         ptrs, H, W, sc = _level_tables(grads, scales)
         with torch.cuda.device(grad_out.device):
+            nb = lib.frcnn_ms_roi_align_bwd_workspace(_np_ptr(H), _np_ptr(W), len(grads), shapes[0][1], rois.shape[0])
+            ws = _workspace(grad_out.device, max(nb, 256))
             check(lib.frcnn_ms_roi_align_bwd(_ptr(grad_out), ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(grads), shapes[0][1], _ptr(rois),
-                                             rois.shape[0], PH, PW, sampling_ratio, int(aligned), k_min, float(s0), k0, _stream()),
-                  "ms_roi_align_bwd")
+                                             rois.shape[0], PH, PW, sampling_ratio, int(aligned), k_min, float(s0), k0, _ptr(ws), ws.numel(),
+                                             _stream()), "ms_roi_align_bwd")
         return (None,) * 9 + tuple(grads)
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 2
+#define FRCNN_ABI_VERSION 3
 
 typedef enum {
     FRCNN_OK = 0,
@@ -234,11 +234,14 @@ int frcnn_ms_roi_align_fwd(const float *const *feats_host /*[n_levels] device pt
                            int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0,
                            float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/, void *stream);
 /* grad_feats[l] [C,H_l,W_l] are OVERWRITTEN with the gradient of every level (zero where no RoI reaches); the caller does
- * not clear them.  7x7 / sampling_ratio 2: tile-owner gather, no atomics, bit-reproducible; other shapes: memset + fp32
- * atomics inside the library (sum order not fixed, tolerance 1e-4).                                        */
+ * not clear them.  7x7 / sampling_ratio 2: tile-owner gather (per-tile RoI lists, long lists summed by segments in a fixed
+ * order), no atomics, bit-reproducible; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists + partial tiles).  Other
+ * shapes: memset + fp32 atomics inside the library (sum order not fixed, tolerance 1e-4; no workspace needed).             */
+size_t frcnn_ms_roi_align_bwd_workspace(const int *H_host, const int *W_host, int n_levels, int C, int64_t R);
 int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host, const int *H_host, const int *W_host,
                            const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
-                           int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0, void *stream);
+                           int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0,
+                           void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- detection losses (losses/loss.py:5-85) ------------------------------------------------- */
 /* FRCNNLoss forward AND the un-normalised input gradients in one pass.  out7 (device): total, rpn_cls, rpn_reg,

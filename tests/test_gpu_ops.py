@@ -561,8 +561,10 @@ def test_ms_roi_align_bwd_tile_gather_is_reproducible_and_overwrites(ops):
     def run(fill, R):
         grads = [torch.full(s, fill, dtype=torch.float32, device=DEV) for s in shapes]
         ptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in grads])
+        nb = _lib.lib.frcnn_ms_roi_align_bwd_workspace(H.ctypes.data, W.ctypes.data, 4, 256, R)
+        ws = torch.full((max(nb, 256),), 0x5A, dtype=torch.uint8, device=DEV)     # stale bytes in the workspace must not matter
         _lib.check(_lib.lib.frcnn_ms_roi_align_bwd(T(go).data_ptr(), ptrs, H.ctypes.data, W.ctypes.data, sc.ctypes.data, 4, 256, T(rois).data_ptr(), R,
-                                                   7, 7, 2, 0, 2, 224.0, 4, None), "bwd")
+                                                   7, 7, 2, 0, 2, 224.0, 4, ws.data_ptr(), ws.numel(), None), "bwd")
         torch.cuda.synchronize()
         return [g.cpu().numpy() for g in grads]
     a, b = run(0.0, 300), run(123.0, 300)
