@@ -284,25 +284,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 }
 
 // ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
-// Three launches:
+// Four launches:
 //  roi_align_bwd_lists_kernel   one workgroup per 16 x 8 pixel tile of any level: scans the RoIs (level + footprint recomputed
 //      from the box, ~150 instructions per RoI), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot
 //      compaction) as a list in the workspace, with the tile rows each of them reaches.  (Round 1 had every (tile, channel
 //      group) workgroup of the main kernel repeat this scan: 8x the work, and four barriers before the first useful load.)
-//      A tile whose list is longer than RS_SPLIT entries is cut into up to RS_NSEG segments.
-//  roi_align_bwd_tile_kernel    workgroup = (tile, 32 channels, segment): lane = (column, channel) keeps 16 row accumulators in
+//  roi_align_bwd_plan_kernel    one workgroup: lists -> work items.  A list longer than RS_SPLIT entries is cut into segments.
+//  roi_align_bwd_tile_kernel    item workgroup = (tile, segment, 32 channels): lane = (column, channel) keeps 16 row accumulators in
 //      registers and walks its segment of the list; per RoI
 //        A: stores the prefetched dOut[r][32 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
 //           Wy[16][7] and Wx[8][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
 //        B: forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds sum_ph Wy[y][ph] * T[ph] to the
 //           accumulators of the rows the RoI reaches -- one barrier per RoI, LDS tables double-buffered.
 //      An unsplit tile is written exactly once, straight to the gradient plane; a segment writes its partial tile to the workspace.
+//      Fill workgroups in the same launch zero the pixels of tiles whose list is empty (whole rows: 256-byte stores).
 //  roi_align_bwd_combine_kernel adds the partial tiles of a split tile in SEGMENT ORDER and writes the plane.
 // The fp32 sum order is a function of the RoI list alone: bit-reproducible gradients, no atomics, nothing cleared beforehand.
-// Why segments: the time of the gather is the longest chain of RoIs through one workgroup (0.5-0.7 us per RoI).  On the bench's
-// FPN frames the 147 tiles of the stride-8 level meet 30 RoIs on average and up to 71 (tools/dev/roi_stats.py); later in training
-// the coarse levels take over.  Round 2's first answer, a second kernel with eight waves per tile for the COARSE levels, guessed
-// the hot level from the pyramid shape, paid the scan 16 times per tile and took 67-75 us on 400 (tile, RoI) pairs.
+// Why segments: a workgroup advances one RoI per ~1 us, so the gather takes as long as the longest list.  Which tiles are hot moves
+// with training: on a fresh RPN the 147 tiles of the stride-8 level meet 30 RoIs on average and up to 71; 15 SGD steps later the
+// stride-16 level's 44 tiles meet 53 on average and up to 116 (tools/dev/roi_stats.py).  Round 2's first answer, a second kernel with
+// eight waves per tile for the COARSE levels, guessed the hot level from the pyramid shape, paid the scan 16 times per tile and took
+// 67-75 us; together with the fine kernel 137 us per step, this design 106.
 // (Tile shape sweep, micro-benchmark / FPN step: 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch 89/178.)
 #ifndef RT_TH
 #define RT_TH 16
@@ -313,9 +315,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 #define RT_CPS (256 / RT_TW)              // channels per workgroup: lane = (column, channel)
 #define RT_CB RT_CPS
 #define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
+#ifndef RT_ATTR
+#define RT_ATTR
+#endif
 #define RT_GS 49                         // LDS stride of a channel's 49 dOut values
 #ifndef RS_SPLIT
-#define RS_SPLIT 12                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ...
+#define RS_SPLIT 24                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ... (12 / 16 / 24 / 48: 110 / 110 / 106 / 126 us for the four launches)
 #endif
 #ifndef RS_NSEG
 #define RS_NSEG 32                       // ... at most this many
@@ -377,20 +382,24 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
     if (t == 0) cnt[tile] = base;
 }
 
-// One workgroup: turns the list lengths into work items.  Tile q gets nseg(q) consecutive items from base[q] (an exclusive prefix
-// sum in tile order, so the assignment -- and with it the summation order -- is a function of the lists alone); if the items do not
-// fit the table the split threshold is doubled until they do (every tile keeps at least one item: cap >= tiles).
+// One workgroup: turns the list lengths into work items.  A non-empty tile q gets nseg(q) consecutive items from base[q] (an exclusive
+// prefix sum in tile order, so the assignment -- and with it the summation order -- is a function of the lists alone); an empty
+// tile gets none (its pixels are zero-filled by the fill workgroups of the main launch).  If the items do not fit the table the
+// split threshold is doubled until they do (cap >= tiles).  An item is ONE 16-byte record (tile, first entry, end entry,
+// seg | nseg << 8): a workgroup of the main kernel needs a single load before it can start; unused records carry tile = -1.
+__device__ __forceinline__ int ra_items(int n, int split) { return n == 0 ? 0 : ra_nseg(n, split); }
 __global__ __launch_bounds__(256) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
-                                                                 int32_t *__restrict__ tnseg, int32_t *__restrict__ items, int32_t *__restrict__ n_items)
+                                                                 int32_t *__restrict__ tnseg, int4 *__restrict__ items)
 {
     __shared__ int s_scan[256];
     __shared__ int s_total;
     const int t = threadIdx.x;
     const int per = (tiles + 255) / 256, q0 = t * per, q1 = min(q0 + per, tiles);
     int split = RS_SPLIT;
+    int mine = 0;
     for (;;) {
-        int mine = 0;
-        for (int q = q0; q < q1; ++q) mine += ra_nseg(cnt[q], split);
+        mine = 0;
+        for (int q = q0; q < q1; ++q) mine += ra_items(cnt[q], split);
         s_scan[t] = mine;
         __syncthreads();
         for (int o = 1; o < 256; o <<= 1) {                // inclusive Hillis-Steele scan over the 256 chunk sums
@@ -402,42 +411,64 @@ __global__ __launch_bounds__(256) void roi_align_bwd_plan_kernel(int tiles, int 
         if (t == 255) s_total = s_scan[255];
         __syncthreads();
         if (s_total <= cap_items) break;
-        split *= 2;                                        // (terminates: at split >= max(cnt) every tile has one item and tiles <= cap)
+        split *= 2;                                        // (terminates: at split >= max(cnt) every tile has at most one item and tiles <= cap)
         __syncthreads();
     }
-    int base = s_scan[t] - 0;
-    {   // exclusive prefix of my chunk
-        int mine = 0;
-        for (int q = q0; q < q1; ++q) mine += ra_nseg(cnt[q], split);
-        base -= mine;
-    }
+    int base = s_scan[t] - mine;                           // exclusive prefix of my chunk
     for (int q = q0; q < q1; ++q) {
-        const int ns = ra_nseg(cnt[q], split);
+        const int n = cnt[q], ns = ra_items(n, split);
         tbase[q] = base; tnseg[q] = ns;
-        for (int sgm = 0; sgm < ns; ++sgm) items[base + sgm] = q;
+        for (int sgm = 0; sgm < ns; ++sgm)
+            items[base + sgm] = make_int4(q, (int)((long long)n * sgm / ns), (int)((long long)n * (sgm + 1) / ns), sgm | (ns << 8));
         base += ns;
     }
-    if (t == 0) *n_items = s_total;
+    for (int i = s_total + t; i < cap_items; i += 256) items[i] = make_int4(-1, 0, 0, 0);
 }
 
+#define RF_CH 4                          // channels per fill workgroup
+struct FillLevels { int fill0[FRCNN_MAX_LEVELS + 1]; };   // first fill workgroup of level l: (row blocks of l) x (C / RF_CH) each
+
 template <typename TOUT>
-__global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, int C, int aligned, const float *__restrict__ grad_out,
-                                                                 int n_cg, int cap, const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
-                                                                 const int32_t *__restrict__ tbase, const int32_t *__restrict__ tnseg,
-                                                                 const int32_t *__restrict__ items, const int32_t *__restrict__ n_items,
-                                                                 float *__restrict__ part)
+__global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, FillLevels FL, int C, int aligned,
+                                                                         const float *__restrict__ grad_out, int n_cg, int cap, int n_item_blocks,
+                                                                         const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
+                                                                         const int4 *__restrict__ items, float *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) float s_g[2][RT_CB * RT_GS];
+    __shared__ float s_g[2][RT_CB * RT_GS];
     __shared__ __attribute__((aligned(16))) float s_wy[2][RT_TH * 8];
     __shared__ float s_wx[2][RT_TW * 8];
     __shared__ RoiEnt s_list[RS_CHUNK];
     const int t = threadIdx.x;
-    // block -> (work item, channel group)  (n_cg = 8: blockIdx % 8 = channel group = XCD, so each L2 holds one eighth of dOut)
-    const int cg = blockIdx.x % n_cg, item = blockIdx.x / n_cg;
-    if (item >= *n_items) return;
-    const int tile = items[item];
-    const int n = cnt[tile], nseg = tnseg[tile], seg = item - tbase[tile];
-    const int lo = (int)((long long)n * seg / nseg), hi = (int)((long long)n * (seg + 1) / nseg);
+    if ((int)blockIdx.x >= n_item_blocks) {
+        // ---- fill workgroup: 16 rows x the whole width x RF_CH channels of one level; zero where the owning tile's list is EMPTY
+        // (nobody else writes those pixels).  A wave covers 64 consecutive pixels: 256-byte stores, where a tile's own zero-fill
+        // would write 32-byte pieces (the empty tiles' stores were 40 of the kernel's 80 us).
+        const int f = (int)blockIdx.x - n_item_blocks;
+        int l = 0;
+#pragma unroll
+        for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && f >= FL.fill0[q]) ? 1 : 0;
+        const int ncc = (C + RF_CH - 1) / RF_CH;
+        const int fl = f - FL.fill0[l], rbk = fl / ncc, c0 = (fl % ncc) * RF_CH;
+        const int H = L.H[l], W = L.W[l];
+        const int y0 = rbk * RT_TH, ny = min(RT_TH, H - y0), nch = min(RF_CH, C - c0);
+        for (int x = t; x < W; x += 256) {
+            if (cnt[TL.tile0[l] + rbk * TL.tiles_x[l] + x / RT_TW] != 0) continue;
+            for (int c = 0; c < nch; ++c) {
+                TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + c) * H + y0) * W + x;
+                for (int y = 0; y < ny; ++y) store_grad<TOUT>(out + (size_t)y * W, 0.0f);
+            }
+        }
+        return;
+    }
+    // block -> (work item, channel group)  (n_cg = 8: blockIdx % 8 = channel group = XCD, so each L2 holds one eighth of dOut).
+    // Items are numbered in tile order = fine levels first; they are DISPATCHED in reverse: the coarse levels, whose tiles carry
+    // the long lists once the RPN has learnt to propose large boxes, start first.
+    const int cg = blockIdx.x % n_cg;
+    const int item = n_item_blocks / n_cg - 1 - (int)(blockIdx.x / n_cg);
+    const int4 rec = items[item];
+    const int tile = rec.x;
+    if (tile < 0) return;
+    const int lo = rec.y, hi = rec.z, nseg = rec.w >> 8;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
@@ -513,7 +544,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
             float wx[7];
 #pragma unroll
             for (int pw = 0; pw < 7; ++pw) wx[pw] = s_wx[buf][cx * 8 + pw];
-            const float *gch = &s_g[buf][cc * RT_GS];       // (read as 12 ds_read_b128 + 1 the kernel needs 111 instead of 72 registers: 89 vs 81 us)
+            // (reading the channel's 49 values as ds_read_b128 -- 52-float stride, or rows padded to 8 floats -- did not pay: 89 / 84 us against 80)
+            const float *gch = &s_g[buf][cc * RT_GS];
             float T[7];
 #pragma unroll
             for (int ph = 0; ph < 7; ++ph) {
@@ -522,6 +554,9 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
                 for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
                 T[ph] = a;
             }
+#ifdef RT_NO_B
+            if (T[0] == 123.456f)
+#endif
 #pragma unroll
             for (int y = 0; y < RT_TH; ++y) {
                 if (y >= ya && y <= yb) {                 // scalar branch
@@ -535,12 +570,23 @@ __global__ __launch_bounds__(256) void roi_align_bwd_tile_kernel(MsLevels L, Til
             // no barrier here: the next A writes the OTHER buffers; the one after that is fenced by the next barrier
         }
     }
+#ifdef RT_NO_STORE
+    if (acc[0] != 123.456f) return;
+#endif
     if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
         float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
+#ifdef RT_NO_PART
+        if (acc[0] == 123.456f)
+#endif
+        {
 #pragma unroll
-        for (int y = 0; y < RT_TH; ++y) dst[y * RT_TW] = acc[y];
+            for (int y = 0; y < RT_TH; ++y) dst[y * RT_TW] = acc[y];
+        }
         return;
     }
+#ifdef RT_NO_FINAL
+    if (acc[0] != 123.456f) return;
+#endif
     // ---- the tile is complete: one coalesced store per row and channel
     if (tx0 + cx < W && cc < nc) {
         TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;
@@ -644,7 +690,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
 }
 
 // workspace of the 7 x 7 tile gather: list lengths, lists (capacity R per tile), the plan, partial tiles of split tiles
-struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *items, *n_items; RoiEnt *ent; float *part; int cap_items; size_t total; };
+struct RaBwdWs { int32_t *cnt, *tbase, *tnseg; int4 *items; RoiEnt *ent; float *part; int cap_items; size_t total; };
 static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
 {
     RaBwdWs w; char *p = (char *)ws; size_t o = 0;
@@ -655,8 +701,7 @@ static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
     w.cnt = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.tbase = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.tnseg = (int32_t *)take((size_t)(tiles + 1) * 4);
-    w.items = (int32_t *)take((size_t)(cap_items + RS_NSEG) * 4);
-    w.n_items = (int32_t *)take(4);
+    w.items = (int4 *)take((size_t)(cap_items + RS_NSEG) * sizeof(int4));
     w.ent = (RoiEnt *)take((size_t)tiles * (size_t)(R > 0 ? R : 1) * sizeof(RoiEnt));
     w.part = (float *)take((size_t)cap_items * n_cg * (RT_CB * RT_TH * RT_TW) * sizeof(float));
     w.total = o;
@@ -700,15 +745,23 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         FRCNN_REQUIRE(workspace != nullptr, "ms_roi_align_bwd: NULL workspace");
         if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "ms_roi_align_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         const RaBwdWs w = carve_ra_bwd(workspace, tiles, R, n_cg);
-        FRCNN_REQUIRE((int64_t)w.cap_items * n_cg < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
         const int cap = (int)(R > 0 ? R : 1);
         FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
                      k_min, s0, k0, cap, w.cnt, w.ent);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(256), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items, w.n_items);
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(256), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(w.cap_items * n_cg)), dim3(256), 0, s, L, T, C, aligned,
-                     grad_out, n_cg, cap, w.cnt, w.ent, w.tbase, w.tnseg, w.items, w.n_items, w.part);
+        FillLevels FLv;
+        int64_t fills = 0;
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+            FLv.fill0[l] = (int)fills;
+            if (l < n_levels) fills += (int64_t)((L.H[l] + RT_TH - 1) / RT_TH) * ((C + RF_CH - 1) / RF_CH);
+        }
+        FLv.fill0[FRCNN_MAX_LEVELS] = (int)fills;
+        const int64_t n_item_blocks = (int64_t)w.cap_items * n_cg;
+        FRCNN_REQUIRE(n_item_blocks + fills < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
+                     grad_out, n_cg, cap, (int)n_item_blocks, w.cnt, w.ent, w.items, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
         FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_COMBINE, (roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
                      w.tnseg, w.part);

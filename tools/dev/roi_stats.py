@@ -16,10 +16,18 @@ def spy(feats, boxes, out, sr, scales, *a, **k):
     cap["scales"] = scales; cap["shapes"] = [tuple(f.shape[-2:]) for f in feats]
     return orig(feats, boxes, out, sr, scales, *a, **k)
 ops.ms_roi_align = spy
-for step in range(3):
-    x, bbox, label = bench.synth_frame(cfg, 0, step)
+from faster_rcnn_pytorch_amd.loss import FRCNNLoss
+crit = FRCNNLoss()
+opt = torch.optim.SGD(model.parameters(), lr=2e-3, momentum=0.9, weight_decay=5e-4)
+STEPS = int(os.environ.get("STEPS", "30"))
+for step in range(STEPS):
+    x, bbox, label = bench.synth_frame(cfg, 0, step % 8)
     model.train()
-    out = model(x.to(dev), bbox.to(dev), label.to(dev))
+    pred, target = model(x.to(dev), [bbox.to(dev)], [label.to(dev)])
+    loss = crit(pred, target)[0]
+    opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+    if step not in (0, 5, 15, STEPS - 1):
+        continue
     r = cap["rois"]; sc = cap["scales"]; shp = cap["shapes"]
     w = r[:, 2] - r[:, 0]; h = r[:, 3] - r[:, 1]
     k = np.floor(4 + np.log2(np.sqrt(np.maximum(w * h, 1e-12)) / 224 + 1e-6)).clip(2, 5).astype(int) - 2
