@@ -232,6 +232,13 @@ struct HeadBwdLevels {
     int pos0[FRCNN_MAX_LEVELS];
 };
 
+typedef __bf16 hb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float hb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned hb_cvt_pk_bf16(float lo, float hi)      // one v_cvt_pk_bf16_f32: round to nearest even
+{
+    const hb_bf16x2 r = __builtin_convertvector((hb_f32x2){lo, hi}, hb_bf16x2);
+    return *(const unsigned *)&r;
+}
 __device__ __forceinline__ void store_raw(float *p, size_t i, float v) { p[i] = v; }
 __device__ __forceinline__ void store_raw(unsigned short *p, size_t i, float v) { p[i] = (unsigned short)to_bf16_rne(v); }
 
@@ -245,6 +252,7 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
                                                                 const float *__restrict__ g_cls, const float *__restrict__ g_reg,
                                                                 float *__restrict__ part_dw, float *__restrict__ part_db3, float *__restrict__ part_db)
 {
+    constexpr bool HB_BF16 = sizeof(TIN) == 2;
     __shared__ float s_gbuf[2][32 * HB_GS];
     __shared__ float s_h[HB_NW][32 * HB_HS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -303,15 +311,24 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
             gq[u] = v;
         }
         const int pos = min(t.p0 + li, t.P - 1);
+        if (HB_BF16 && (t.P & 1) == 0) {
+            // bf16 conv output, even plane size: 2-byte loads are slow (68 us against 52 us for the fp32 instance at FPN size), so lanes
+            // (li, li ^ 1) share aligned DWORD loads: the even lane fetches channels r = 0, 2, .. of positions (pos, pos + 1), the odd
+            // lane channels r = 1, 3, .. of (pos - 1, pos); they swap halves when the values are used (zq[ct][k] holds the raw dword)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 2 * k + (li & 1);
+                    const size_t o = (size_t)(cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk) * t.P + (pos & ~1);
+                    zq[ct][k] = __uint_as_float(*(const unsigned *)((const unsigned short *)t.raw + o));
+                }
+            return;
+        }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-#ifdef HB_NO_LOAD
-#pragma unroll
-            for (int r = 0; r < 16; ++r) zq[ct][r] = (float)(pos + r);
-#else
             for (int r = 0; r < 16; ++r) zq[ct][r] = load_raw(t.raw, (size_t)(cw + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * lk) * t.P + pos);
-#endif
     };
     int tile = blockIdx.x;
     Tile cur = tile_of(min(tile, n_tiles - 1));
@@ -321,10 +338,26 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
 #pragma unroll
         for (int u = 0; u < HB_GQ; ++u) { const int e = (int)threadIdx.x + 64 * HB_NW * u; s_g[(e >> 6) * HB_GS + (e & 63)] = gq[u]; }
         float zr[CT][16];
+        const bool paired = HB_BF16 && (cur.P & 1) == 0;            // workgroup-uniform: how load_tile fetched this tile
+        if (paired) {
+            const bool odd = (li & 1) != 0;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+            for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) zr[ct][r] = zq[ct][r] + bias[ct][r];
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned own = __float_as_uint(zq[ct][k]);
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                    const float a = __uint_as_float(odd ? (own & 0xFFFF0000u) : (own << 16));   // my position, channel r = 2 k + odd
+                    const float b = __uint_as_float(odd ? (nb & 0xFFFF0000u) : (nb << 16));     // my position, channel r = 2 k + !odd
+                    zr[ct][2 * k] = (odd ? b : a) + bias[ct][2 * k];
+                    zr[ct][2 * k + 1] = (odd ? a : b) + bias[ct][2 * k + 1];
+                }
+        } else {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zr[ct][r] = zq[ct][r] + bias[ct][r];
+        }
         __syncthreads();                                            // g of this tile is staged; the other buffer's readers finished a tile ago
         const Tile me = cur;
         if (tile + (int)gridDim.x < n_tiles) { cur = tile_of(tile + (int)gridDim.x); load_tile(cur); }   // in flight under the MFMAs below
@@ -345,16 +378,32 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
 #endif
             // ---- ReLU mask, d_raw, db3, h -> LDS
             __builtin_amdgcn_wave_barrier();                        // the previous c-tile's readers of my h tile are done
+            if (paired) {                                           // bf16 d_raw as dwords: the same lane pairing as the loads
+                const bool odd = (li & 1) != 0;
+                const unsigned sel = odd ? 0x03020706u : 0x05040100u;   // v_perm_b32 (a = neighbour, b = own)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float dz = zr[ct][r] > 0.0f ? acc[r] : 0.0f;
-#ifdef HB_NO_STORE
-                if (pv) { if (dz == 123.456f) store_raw(me.d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
-#else
-                if (pv) { store_raw(me.d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
-#endif
-                sh[cl * HB_HS + li] = zr[ct][r] > 0.0f ? zr[ct][r] : 0.0f;
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 2 * k;
+                    const float d0 = zr[ct][r] > 0.0f ? acc[r] : 0.0f, d1 = zr[ct][r + 1] > 0.0f ? acc[r + 1] : 0.0f;
+                    const unsigned own = hb_cvt_pk_bf16(d0, d1);
+                    const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);
+                    const unsigned d = __builtin_amdgcn_perm(nb, own, sel);
+                    const int cl = ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (pv) {
+                        *(unsigned *)((unsigned short *)me.d_raw + (size_t)(cw + 32 * ct + cl) * P + (pos & ~1)) = d;
+                        db3[ct][r] += d0; db3[ct][r + 1] += d1;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sh[((r & 3) + 8 * (r >> 2) + 4 * lk) * HB_HS + li] = zr[ct][r] > 0.0f ? zr[ct][r] : 0.0f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const float dz = zr[ct][r] > 0.0f ? acc[r] : 0.0f;
+                    if (pv) { store_raw(me.d_raw, (size_t)(cw + 32 * ct + cl) * P + pos, dz); db3[ct][r] += dz; }
+                    sh[cl * HB_HS + li] = zr[ct][r] > 0.0f ? zr[ct][r] : 0.0f;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             // ---- dW += g^T h : A[m = j][k = p] = g[p][j], B[k = p][n = c] = h[c][p], step s covers p = 2 s + lk
