@@ -173,6 +173,9 @@ __device__ __forceinline__ void tile_of_block(int b, int R, int n_cg, int *cg, i
 #ifndef RA_FWD_WAVES
 #define RA_FWD_WAVES 3
 #endif
+#ifndef RA_FWD_INFLIGHT
+#define RA_FWD_INFLIGHT 8              // channels' loads in flight per lane and (row, column) slot
+#endif
 #ifndef RA_FWD_LDS
 #define RA_FWD_LDS 8128
 #endif
@@ -238,35 +241,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
         }
         return;
     }
-    // staging: the pass's (channel, row, column) space is flattened so that consecutive lanes read consecutive columns of a
-    // footprint row; 8 independent loads are in flight per lane before the first LDS store.  Divisions by the (uniform)
-    // footprint width / height go through float reciprocals with a one-step correction.
-    const unsigned ufw = (unsigned)fw, ufh = (unsigned)fh;
-    const float rcp_fw = 1.0f / (float)fw, rcp_fh = 1.0f / (float)fh;
+    // staging: lane = (column xi = t % 32, row group rg = t / 32); a wave covers two footprint rows of up to 32 columns, the loops
+    // run over row blocks, column blocks and channels with purely additive addressing, eight channels' loads in flight per lane.
+    // (Round 1 flattened (channel, row, column) into one index and took it apart again per element with reciprocal multiplies and
+    // corrections: ~25 instructions per staged float, 1800 per thread and RoI -- the instruction stream, not the fetch, was the
+    // kernel's time.)
+    const int xi = t & 31, rg = t >> 5;
     const float *lvl = L.feat[l];
     for (int cbase = c0; cbase < c_end; cbase += cb) {
         const int n = min(cb, c_end - cbase);
         __syncthreads();
-        const unsigned total = (unsigned)(n * fh * fw);
-        const unsigned gbase = (unsigned)cbase * (unsigned)plane + (unsigned)(y0 * W + x0);
-        for (unsigned e0 = 0; e0 < total; e0 += 256 * 8) {
-            float v[8]; unsigned lo[8];
+        // 32-bit element offsets from the level's base (a level has < 2^31 elements: checked by the host)
+        const unsigned off0 = (unsigned)cbase * (unsigned)plane + (unsigned)(y0 * W + x0), uplane = (unsigned)plane;
+        for (int yb = rg; yb < fh; yb += 8)
+            for (int xx = xi; xx < fw; xx += 32) {
+                unsigned off = off0 + (unsigned)(yb * W + xx);
+                float *dst = s_f + yb * fwp + xx;
+                for (int c = 0; c < n; c += RA_FWD_INFLIGHT, off += RA_FWD_INFLIGHT * uplane) {
+                    float v[RA_FWD_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned e = e0 + u * 256 + t;
-                unsigned row = (unsigned)((float)e * rcp_fw);             // row = c * fh + y
-                unsigned x = e - row * ufw;
-                if ((int)x < 0) { --row; x += ufw; } else if (x >= ufw) { ++row; x -= ufw; }
-                unsigned c = (unsigned)((float)row * rcp_fh);
-                unsigned y = row - c * ufh;
-                if ((int)y < 0) { --c; y += ufh; } else if (y >= ufh) { ++c; y -= ufh; }
-                lo[u] = e < total ? c * (unsigned)fp + y * (unsigned)fwp + x : 0xFFFFFFFFu;
-                v[u] = e < total ? lvl[gbase + c * (unsigned)plane + y * (unsigned)W + x] : 0.0f;
+                    for (int u = 0; u < RA_FWD_INFLIGHT; ++u) v[u] = c + u < n ? lvl[off + (unsigned)u * uplane] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < RA_FWD_INFLIGHT; ++u) if (c + u < n) dst[(c + u) * fp] = v[u];
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (lo[u] != 0xFFFFFFFFu) s_f[lo[u]] = v[u];
-        }
         __syncthreads();
         if (grp < 5)
             for (int c = grp; c < n; c += 5) {
