@@ -491,6 +491,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     __shared__ unsigned s_key[HT_MAX];
     __shared__ int s_row[HT_ROWS_MAX];
     __shared__ unsigned short s_sel[HT_ROWS_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_pk[HT_ROWS_MAX];   // (philox key << 16 | list position) of the survivors, dense
     __shared__ unsigned s_hist[16 * 256];
     __shared__ unsigned s_pref[4];
     __shared__ int s_nsel;
@@ -570,16 +571,20 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
             }
             __syncthreads();
             const int ns = s_nsel;                                  // == quota
+            // rank of a survivor = number of survivors with a smaller (key, position): the pairs are packed into one 64-bit word
+            // and laid out densely, so the inner loop is two broadcast ds_read_b128 + four compares per four survivors (the first
+            // form chased s_sel[o] -> s_key[..] with two dependent LDS reads per survivor: ~10 of the kernel's 46 us at 512 rows)
+            for (int a = tid; a < ((ns + 3) & ~3); a += 1024)
+                s_pk[a] = a < ns ? ((unsigned long long)s_key[s_sel[a]] << 16) | s_sel[a] : ~0ull;
+            __syncthreads();
             for (int a = tid; a < ns; a += 1024) {
-                const int qa = s_sel[a];
-                const unsigned ka = s_key[qa];
+                const unsigned long long pa = s_pk[a];
                 int rank = 0;
-                for (int o = 0; o < ns; ++o) {
-                    const int qo = s_sel[o];
-                    const unsigned ko = s_key[qo];
-                    rank += (ko < ka) || (ko == ka && qo < qa);
+                for (int o = 0; o < ns; o += 4) {
+                    const ulonglong2 p01 = *(const ulonglong2 *)&s_pk[o], p23 = *(const ulonglong2 *)&s_pk[o + 2];
+                    rank += (p01.x < pa) + (p01.y < pa) + (p23.x < pa) + (p23.y < pa);
                 }
-                s_row[rowbase + rank] = s_list[which][qa];
+                s_row[rowbase + rank] = s_list[which][(int)(pa & 0xFFFFull)];
             }
         }
     }
