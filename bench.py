@@ -18,6 +18,7 @@ frame per GPU.  Frames and boxes are resident in HBM before the timed region.  R
   hot_path     : per-kernel mean / median / p10 / p90 launch time, bytes, GB/s, PMC traffic.
 """
 import argparse
+import gc
 import glob
 import json
 import os
@@ -196,6 +197,10 @@ def main():
     for i in range(3):
         step(i)
     torch.cuda.synchronize()
+    # The FPN step enqueues ~2500 launches from Python; a generation-2 garbage collection in the middle of a step stalls the
+    # enqueue for 70-100 ms (3 of 60 timed steps read 90-115 ms against a 19.4 ms median).  Everything allocated so far is
+    # long-lived: freeze it and keep the collector off while steps are timed (reference counting still frees the step's tensors).
+    gc.collect(); gc.freeze(); gc.disable()
     log("warm-up")
     for i in range(args.warmup):
         step(i)
@@ -204,6 +209,7 @@ def main():
     if not args.no_kernel_events:
         _lib.prof_reset()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the main stream (no sync)
+    ms0 = torch.cuda.memory_stats(device)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -221,6 +227,9 @@ def main():
     dt = parallel.max_over_ranks(dt_local, device)
     per_rank_ms = [round(v / args.steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
     log("timed region: %d steps in %.3f s" % (args.steps, dt))
+    gc.enable()
+    ms1 = torch.cuda.memory_stats(device)
+    allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
     final_loss = float(loss.detach())
     model.check_device_status()                      # sticky device-side error word (aborted scan / short sample): raises if set
     samples = {} if args.no_kernel_events else _lib.prof_samples()
@@ -320,8 +329,10 @@ def main():
         "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},
         "roofline": roofline,
         "cpu_baseline": cpu,
-        "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3),
+        "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
+                    "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
                     "source": "HIP events at the step boundaries on the main stream (rank 0)"},
+        "allocator_in_timed_region": allocator,
         "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
                         "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms)},
         "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * P, 1),
