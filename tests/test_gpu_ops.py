@@ -544,6 +544,35 @@ def test_single_level_roi_align_big_footprints_and_generic_shapes(ops, PH, SR):
     assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=2e-4)
 
 
+def test_ms_roi_align_bwd_plan_coarsens_when_the_item_table_is_too_small(ops):
+    """One level, 512 RoIs that each cover most of a 50 x 84 map: every one of the 44 tiles meets hundreds of RoIs, which asks for
+    far more list segments than the work-item table holds (tiles + 15 R / 24 + 1).  roi_align_bwd_plan_kernel must double the
+    split threshold until the plan fits -- and the gradient must still be the oracle's, bit-reproducibly."""
+    from faster_rcnn_pytorch_amd import _lib
+    import ctypes as C
+    rng = np.random.RandomState(9)
+    Cc, Hh, Ww, R = 64, 50, 84, 512
+    c = rng.rand(R, 2).astype(np.float32) * 0.2 + 0.4
+    wh = rng.rand(R, 2).astype(np.float32) * 0.3 + 0.6
+    rois = (np.concatenate([c - wh / 2, c + wh / 2], 1).clip(0, 1) * np.array([Ww, Hh, Ww, Hh], np.float32) * 16.0).astype(np.float32)
+    go = rng.randn(R, Cc, 7, 7).astype(np.float32)
+    H = np.array([Hh], np.int32); W = np.array([Ww], np.int32); sc = np.array([1.0 / 16.0], np.float32)
+
+    def run():
+        g = torch.full((Cc, Hh, Ww), 3.0, dtype=torch.float32, device=DEV)
+        ptrs = (C.c_void_p * 1)(g.data_ptr())
+        nb = _lib.lib.frcnn_ms_roi_align_bwd_workspace(H.ctypes.data, W.ctypes.data, 1, Cc, R)
+        ws = torch.full((max(nb, 256),), 0xA5, dtype=torch.uint8, device=DEV)
+        _lib.check(_lib.lib.frcnn_ms_roi_align_bwd(T(go).data_ptr(), ptrs, H.ctypes.data, W.ctypes.data, sc.ctypes.data, 1, Cc, T(rois).data_ptr(), R,
+                                                   7, 7, 2, 0, 4, 224.0, 4, ws.data_ptr(), ws.numel(), None), "bwd")
+        torch.cuda.synchronize()
+        return g.cpu().numpy()
+    a, b = run(), run()
+    assert np.array_equal(a, b)
+    ref = orc.roi_align_bwd(go, (Cc, Hh, Ww), rois, 1.0 / 16.0, 2, False)
+    assert np.allclose(a, ref, rtol=2e-4, atol=2e-3), float(np.abs(a - ref).max())
+
+
 def test_ms_roi_align_bwd_tile_gather_is_reproducible_and_overwrites(ops):
     """The 7x7 / sampling-ratio-2 backward owns tiles instead of scattering atomics: two runs give identical bits, stale
     contents of the gradient buffers do not leak (the library overwrites), clustered RoIs (64 on one spot) and R = 0 work."""
