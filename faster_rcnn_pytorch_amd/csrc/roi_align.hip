@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 #define RT_CPS (256 / RT_TW)              // channels per workgroup: lane = (column, channel)
 #define RT_CB RT_CPS
 #define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
+static_assert(128 + RT_TH * 7 <= 256 && 64 + RT_TW * 7 <= 128, "weight-table lanes do not fit the workgroup");
 #ifndef RT_ATTR
 #define RT_ATTR
 #endif
@@ -386,33 +387,33 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
 // split threshold is doubled until they do (cap >= tiles).  An item is ONE 16-byte record (tile, first entry, end entry,
 // seg | nseg << 8): a workgroup of the main kernel needs a single load before it can start; unused records carry tile = -1.
 __device__ __forceinline__ int ra_items(int n, int split) { return n == 0 ? 0 : ra_nseg(n, split); }
-__global__ __launch_bounds__(256) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
-                                                                 int32_t *__restrict__ tnseg, int4 *__restrict__ items)
+__global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
+                                                                  int32_t *__restrict__ tnseg, int4 *__restrict__ items)
 {
-    __shared__ int s_scan[256];
+    // block-wide exclusive scan of the per-thread item counts: wave scans by shuffles, 16 wave totals through LDS (two barriers;
+    // the first version used a 256-thread Hillis-Steele scan with 16 barriers and took 8-10 us)
+    __shared__ int s_wsum[16];
     __shared__ int s_total;
-    const int t = threadIdx.x;
-    const int per = (tiles + 255) / 256, q0 = t * per, q1 = min(q0 + per, tiles);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (tiles + 1023) / 1024, q0 = t * per, q1 = min(q0 + per, tiles);
     int split = RS_SPLIT;
-    int mine = 0;
+    int mine = 0, incl = 0;
     for (;;) {
         mine = 0;
         for (int q = q0; q < q1; ++q) mine += ra_items(cnt[q], split);
-        s_scan[t] = mine;
+        incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        __syncthreads();                                   // the previous round's readers of s_wsum / s_total are done
+        if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {                // inclusive Hillis-Steele scan over the 256 chunk sums
-            const int v = t >= o ? s_scan[t - o] : 0;
-            __syncthreads();
-            s_scan[t] += v;
-            __syncthreads();
-        }
-        if (t == 255) s_total = s_scan[255];
+        if (t == 0) { int a = 0; for (int w = 0; w < 16; ++w) { const int v = s_wsum[w]; s_wsum[w] = a; a += v; } s_total = a; }
         __syncthreads();
         if (s_total <= cap_items) break;
         split *= 2;                                        // (terminates: at split >= max(cnt) every tile has at most one item and tiles <= cap)
-        __syncthreads();
     }
-    int base = s_scan[t] - mine;                           // exclusive prefix of my chunk
+    int base = s_wsum[wave] + incl - mine;                 // exclusive prefix of my chunk
+    const int total = s_total;
     for (int q = q0; q < q1; ++q) {
         const int n = cnt[q], ns = ra_items(n, split);
         tbase[q] = base; tnseg[q] = ns;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_plan_kernel(int tiles, int 
             items[base + sgm] = make_int4(q, (int)((long long)n * sgm / ns), (int)((long long)n * (sgm + 1) / ns), sgm | (ns << 8));
         base += ns;
     }
-    for (int i = s_total + t; i < cap_items; i += 256) items[i] = make_int4(-1, 0, 0, 0);
+    for (int i = total + t; i < cap_items; i += 1024) items[i] = make_int4(-1, 0, 0, 0);
 }
 
 #define RF_CH 4                          // channels per fill workgroup
@@ -513,9 +514,11 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                 for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
             }
             {
-                // lanes 0..223: (col = t / 7, bin = t % 7) of Wx ; lanes 0..111 additionally (row, bin) of Wy
-                const int bin = t % 7, rc = t / 7;
-                if (rc < RT_TW) {
+                // the two tables are spread over three waves (one 1-D bilinear set-up pair per lane): wave 1 builds Wx (lanes 64..119 =
+                // (column, bin)), waves 2 and 3 build Wy (lanes 128..239 = (row, bin)); wave 0 only moves dOut.  (All of it on wave 0 / 1
+                // put ~110 instructions on the critical path of every RoI step.)
+                if (t >= 64 && t < 64 + RT_TW * 7) {
+                    const int q7 = t - 64, bin = q7 % 7, rc = q7 / 7;
                     const int x = tx0 + rc;
                     float wv = 0.0f;
 #pragma unroll
@@ -525,7 +528,8 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                     }
                     s_wx[buf][rc * 8 + bin] = wv;
                 }
-                if (rc < RT_TH) {
+                if (t >= 128 && t < 128 + RT_TH * 7) {
+                    const int q7 = t - 128, bin = q7 % 7, rc = q7 / 7;
                     const int y = ty0 + rc;
                     float wv = 0.0f;
 #pragma unroll
@@ -747,7 +751,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
                      k_min, s0, k0, cap, w.cnt, w.ent);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(256), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
+        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
         FillLevels FLv;
         int64_t fills = 0;
