@@ -121,7 +121,7 @@ class FastRCNNHead(nn.Module):
 
     def forward(self, features, roi):
         f_height, f_width = features.size()[2:]
-        scale = torch.tensor([f_width, f_height, f_width, f_height], dtype=torch.float32, device=roi.device)
+        scale = ops.const_tensor((f_width, f_height, f_width, f_height), roi.device)   # cached: torch.tensor(list, device=cuda) is a blocking copy
         scaled_roi = roi * scale                                               # model.py:107-109
         pool = self.roi_pool(features.float(), [scaled_roi])           # the hot path computes in fp32 (also under autocast)
         x = pool.view(pool.size(0), -1)
@@ -274,7 +274,7 @@ class FRCNN(nn.Module):
         pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.fast_rcnn_head(features, rois)
         pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)                    # model.py:369
         pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4)
-        pred_fast_rcnn_reg = pred_fast_rcnn_reg * torch.tensor([0.1, 0.1, 0.2, 0.2], device=x.device)   # model.py:372
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg * ops.const_tensor((0.1, 0.1, 0.2, 0.2), x.device)   # model.py:372
         rois = rois.reshape(-1, 1, 4).expand_as(pred_fast_rcnn_reg)
         pred_bbox = ops.decode(pred_fast_rcnn_reg.reshape(-1, 4).contiguous(), ops.xy_to_cxcy(rois.reshape(-1, 4).contiguous()))
         pred_bbox = ops.cxcy_to_xy(pred_bbox)

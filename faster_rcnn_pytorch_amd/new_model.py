@@ -248,7 +248,7 @@ class FRCNNHead(nn.Module):
 
     def forward(self, features, roi, img_shape):
         h, w = img_shape
-        scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=roi.device)
+        scale = ops.const_tensor((w, h, w, h), roi.device)                         # cached: torch.tensor(list, device=cuda) is a blocking copy
         scaled_roi = roi * scale                                                   # new_model.py:136-140: image pixels
         pool = self.roi_pool(features, [scaled_roi], [(w, h)])
         x = self.classifier(pool.view(pool.size(0), -1))
@@ -344,7 +344,7 @@ class FRCNN(nn.Module):
         rois = rois[:ops.host_count(n_rois, 'region_proposal')]
         pred_fast_rcnn_cls, pred_fast_rcnn_reg = self.frcnn_head(features, rois, x.shape[2:])
         pred_cls = torch.softmax(pred_fast_rcnn_cls, dim=-1)
-        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4) * torch.tensor([0.1, 0.1, 0.2, 0.2], device=x.device)
+        pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(-1, self.num_classes, 4) * ops.const_tensor((0.1, 0.1, 0.2, 0.2), x.device)
         rois = rois.reshape(-1, 1, 4).expand_as(pred_fast_rcnn_reg)
         pred_bbox = ops.cxcy_to_xy(ops.decode(pred_fast_rcnn_reg.reshape(-1, 4).contiguous(), ops.xy_to_cxcy(rois.reshape(-1, 4).contiguous())))
         pred_bbox = pred_bbox.reshape(-1, self.num_classes * 4).clamp(min=0, max=1)

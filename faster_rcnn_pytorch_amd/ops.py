@@ -55,6 +55,21 @@ def _workspace(device, nbytes):
     return buf
 
 
+_CONST = {}
+
+
+def const_tensor(values, device, dtype=torch.float32):
+    """A small constant on the device, created once per (values, device).  torch.tensor(list, device='cuda') inside a training step
+    is a BLOCKING host-to-device copy: the host waits for everything already enqueued on the stream (the whole backbone) before it
+    can go on enqueueing -- 2.5 ms of lost run-ahead per FPN step."""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.tensor(list(key[0]), dtype=dtype, device=device)
+        _CONST[key] = t
+    return t
+
+
 def _host_i32(v):
     return np.ascontiguousarray(v, dtype=np.int32)
 
