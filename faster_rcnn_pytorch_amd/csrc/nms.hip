@@ -147,16 +147,10 @@ __device__ __forceinline__ void nms_sup_tile(int cb, int rb, int wave, int lane,
         }
     }
     if (bits != 0ull) {                                         // me < n <= K is implied by a set bit
-#ifdef NMS_PLAIN_STORE
-        sup[(size_t)me * nblk + rb] = bits;
-#else
         agent_st64(&sup[(size_t)me * nblk + rb], bits);
-#endif
         agent_or64(&nz[(size_t)(rb >> 6) * K + me], 1ull << (rb & 63));   // group-major: the resolver reads it coalesced
     }
-#ifndef NMS_NO_WAIT
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my stores and ORs have reached the coherence point ...
-#endif
     // ... before my tile's flag goes up.  One flag WORD per tile, a plain write-through store: a shared per-row counter (cb + 1
     // agent-scope adds to one address) doubled the kernel's time, 43 -> 83 us.
     if (lane == 0) __hip_atomic_store(&done[cb * (cb + 1) / 2 + rb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -271,9 +265,7 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
                 }
             }
         }
-#ifndef NMS_NO_SLEEP
         if (!__ballot(progressed)) __builtin_amdgcn_s_sleep(1);
-#endif      // the whole wave is waiting on other waves' decisions
         if (it > max_iter) { if (lane == 0) atomicOr(abort_flag, 1); break; }
     }
 }
@@ -298,12 +290,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     __shared__ int s_cls[4][64];
     const int n = n_dev ? min(*n_dev, K) : K;
     if ((int)blockIdx.x < n_res) {
-#ifdef NMS_NO_RESOLVE
-        return;
-#endif
-#ifndef NMS_NO_RESOLVE_CODE
         nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
-#endif
         return;
     }
     const int t = (int)blockIdx.x - n_res;                      // tile workgroup: t = 2 g (g + 1) + (row in group) * (g + 1) + q

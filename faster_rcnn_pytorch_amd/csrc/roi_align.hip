@@ -556,9 +556,6 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                 for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
                 T[ph] = a;
             }
-#ifdef RT_NO_B
-            if (T[0] == 123.456f)
-#endif
 #pragma unroll
             for (int y = 0; y < RT_TH; ++y) {
                 if (y >= ya && y <= yb) {                 // scalar branch
@@ -572,23 +569,14 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
             // no barrier here: the next A writes the OTHER buffers; the one after that is fenced by the next barrier
         }
     }
-#ifdef RT_NO_STORE
-    if (acc[0] != 123.456f) return;
-#endif
     if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
         float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
-#ifdef RT_NO_PART
-        if (acc[0] == 123.456f)
-#endif
         {
 #pragma unroll
             for (int y = 0; y < RT_TH; ++y) dst[y * RT_TW] = acc[y];
         }
         return;
     }
-#ifdef RT_NO_FINAL
-    if (acc[0] != 123.456f) return;
-#endif
     // ---- the tile is complete: one coalesced store per row and channel
     if (tx0 + cx < W && cc < nc) {
         TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;

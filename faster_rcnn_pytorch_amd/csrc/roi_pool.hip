@@ -307,11 +307,7 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     FRCNN_REQUIRE(total < ((int64_t)1 << 38), "roi_pool_fwd: output too large");
     hipStream_t s = (hipStream_t)stream;
     const size_t plane_bytes = (size_t)4 * H * W * 4;
-#ifdef ROI_FWD_FORCE_DIRECT
-    if (false)
-#else
     if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24))
-#endif
         return roi_pool_fwd_launch<int32_t>(feat, C, H, W, rois, R, PH, PW, spatial_scale, out, argmax, s);
     FRCNN_LAUNCH(KID_ROI_POOL_FWD, roi_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, C, H, W,
                  (const float4 *)rois, total, PH, PW, spatial_scale, out, argmax);

@@ -248,14 +248,12 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         mfma16(P);
         load_frags(P, chunk, ky, 2);
         mfma16(Q);
-#ifndef RC3_NO_STAGE
         store_w((step + 1) & 1, wv);                        // (step 47 stores a clamped reload into the idle buffer: nobody reads it)
         load_w(min(step + 2, 47), wv);
         if (ky == 0) {
             store_x((chunk + 1) & 1, min(chunk + 1, 15), xv);
             load_x(min(chunk + 2, 15), xv);
         }
-#endif
         __syncthreads();
         if (ky == 2) load_frags(Q, chunk + 1, 0, 0); else load_frags(Q, chunk, ky + 1, 0);
         mfma16(P);
@@ -269,20 +267,6 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         do_step(I1{}, I0{}, std::integral_constant<int, 2>{}, chunk + 1);
     }
     __syncthreads();                                        // the stray staging stores of the last step are done before the epilogue reuses LDS
-#ifdef RC3_NO_EPI
-    {   // keep every accumulator alive
-        f32x16 sum = (f32x16){0};
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) sum += acc[ct][pt];
-        float z = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z += sum[r];
-        if (z == 123.456f) L.raw[lvl][0] = 1;
-    }
-    return;
-#endif
 
     // ---- epilogue: raw (bf16), h = relu(raw + b3) as the B operand of the heads' product.
     // Accumulator register r of a lane is channel cb + (r & 3) + 8 (r >> 2) + 4 g at pixel (yy, x0 + li): registers (r, r + 1) are
@@ -310,9 +294,6 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
             for (int k = 0; k < 8; ++k) {
                 const int r = 2 * k, c = cb + (r & 3) + 8 * (r >> 2);          // registers r, r + 1 = channels c, c + 1
                 const unsigned own = cvt_pk_bf16(acc[ct][pt][r], acc[ct][pt][r + 1]);
-#ifdef RC3_NO_RAW
-                if (own == 0x12345678u)
-#endif
                 {
                     if (pair_ok) {
                         const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]

@@ -372,10 +372,8 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
         for (int ct = 0; ct < CT; ++ct) {
             // ---- dz = W^T g (accumulator: lane = position li, registers = 16 channels)
             f32x16 acc = (f32x16){0};
-#ifndef HB_NO_DZ
 #pragma unroll
             for (int s = 0; s < NJ * 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[ct][s], s_g[li * HB_GS + 2 * s + lk], acc, 0, 0, 0);
-#endif
             // ---- ReLU mask, d_raw, db3, h -> LDS
             __builtin_amdgcn_wave_barrier();                        // the previous c-tile's readers of my h tile are done
             if (paired) {                                           // bf16 d_raw as dwords: the same lane pairing as the loads
@@ -411,9 +409,7 @@ __global__ __launch_bounds__(64 * HB_NW) void rpn_head_tail_bwd_kernel(HeadBwdLe
             for (int jt = 0; jt < NJ; ++jt) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-#ifndef HB_NO_DW
                     acc_w[jt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_g[(2 * s + lk) * HB_GS + 32 * jt + li], sh[li * HB_HS + 2 * s + lk], acc_w[jt][ct], 0, 0, 0);
-#endif
                 }
             }
         }
