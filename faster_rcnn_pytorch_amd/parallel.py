@@ -52,7 +52,11 @@ def wrap_ddp(model, device, bucket_cap_mb=100):
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [device.index] if device.type == "cuda" else None
-    return DDP(model, device_ids=ids, find_unused_parameters=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    # broadcast_buffers=False: the only buffers of the two mirrors are the FROZEN batch-norm statistics of the ResNet-50-FPN backbone,
+    # identical on every rank by construction; broadcasting them in every forward costs a collective per step and, being an in-place
+    # copy, would invalidate the cached scale / shift of every FrozenBatchNorm2d (new_model.py) each iteration.
+    return DDP(model, device_ids=ids, find_unused_parameters=False, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
+               broadcast_buffers=False)
 
 
 def max_over_ranks(value, device):
