@@ -89,8 +89,8 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
         "rpn_sample_kernel": 9 * N,
         "head_targets_kernel": 16 * (P + G) + 44 * R,
-        "roi_pool_fwd_kernel": feat_bytes + 16 * R + 8 * R * C * 49,      # features + rois in, out + argmax out
-        "roi_pool_bwd_kernel": 8 * R * C * 49 + feat_bytes,               # grad_out + argmax in, grad_feat out
+        "roi_pool_fwd_kernel": feat_bytes + 16 * R + 6 * R * C * 49,      # features + rois in, out (fp32) + argmax (16-bit, the autograd pair) out
+        "roi_pool_bwd_kernel": 6 * R * C * 49 + feat_bytes,               # grad_out + 16-bit argmax in, grad_feat out
         "roi_align_fwd_kernel": 4 * R * C * 49 + feat_bytes,              # out + (at most) the four pooled levels in
         "roi_align_bwd_kernel": 4 * R * C * 49 + feat_bytes,              # grad_out in + every gradient pixel written once
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
@@ -269,8 +269,8 @@ def main():
                 return v["traffic_bytes"]
         return None
     # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
-    # peak (VALU_PEAK_LANE_OPS above): pair IoUs x ~21 VALU ops (counted in the ISA), rank compares x 2
-    valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 21}
+    # peak (VALU_PEAK_LANE_OPS above): pair IoUs x 16 VALU ops (counted in the ISA of nms.hip's sup_half)
+    valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 16}
     n_sampled = len(range(0, args.steps, args.event_every))          # timed steps whose kernels were bracketed
     per_kernel = {}
     for name, v in samples.items():
@@ -295,6 +295,13 @@ def main():
 
     def roofline_of(name):
         d = per_kernel[name]
+        if d["bound"] == "valu" and d.get("valu_lane_ops"):
+            # priced against the fp32 VALU issue peak: its compulsory HBM bytes are negligible (the GB/s figure is kept beside it)
+            return {"kernel": name, "bound": "valu", "achieved": round(d["valu_lane_ops"] / (d["avg_us"] * 1e-6) * 1e-12, 3),
+                    "peak": round(VALU_PEAK_LANE_OPS * 1e-12, 1), "unit": "T lane-ops/s", "frac": d["valu_frac_of_78.6T"],
+                    "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"], "median_launch_us": d["median_us"],
+                    "valu_lane_ops": d["valu_lane_ops"], "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
+                    "note": "relation tiles (VALU) + a cross-CU dependency chain in one launch: the chain, not the issue rate, is most of the time"}
         if d["bound"] == "mfma" and d.get("algorithmic_flops"):
             return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
@@ -307,7 +314,7 @@ def main():
         dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
         roofline = roofline_of(dom)
         roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
-        if roofline["bound"] not in ("hbm", "mfma"):
+        if roofline["bound"] not in ("hbm", "mfma", "valu"):
             roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
                                 "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
         hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm"]
