@@ -24,15 +24,16 @@ from .model import _Sampler, _unwrap, normal_init
 class FrozenBatchNorm2d(nn.Module):
     """torchvision.ops.misc.FrozenBatchNorm2d: fixed statistics and affine parameters (buffers)."""
 
-    def __init__(self, n, eps=1e-5):
+    def __init__(self, n, eps=1e-5, inner=False):
         super().__init__()
         self.eps = eps
+        self.inner = inner                                   # bn1 / bn2 of a bottleneck: feeds ReLU + the next convolution, not the residual sum
         self.register_buffer("weight", torch.ones(n))
         self.register_buffer("bias", torch.zeros(n))
         self.register_buffer("running_mean", torch.zeros(n))
         self.register_buffer("running_var", torch.ones(n))
 
-        self._affine_key, self._affine = None, None
+        self._affine_key, self._affine, self._affine_bf16 = None, None, None
 
     def affine(self):
         """(scale, bias) of torchvision's forward, computed once per state of the four buffers: they are frozen, and recomputing
@@ -47,7 +48,21 @@ class FrozenBatchNorm2d(nn.Module):
             self._affine_key, self._affine = key, (scale, bias)
         return self._affine
 
+    def affine_bf16(self):
+        scale, bias = self.affine()
+        if self._affine_bf16 is None or self._affine_bf16[0] is not scale:
+            self._affine_bf16 = (scale, scale.bfloat16(), bias.bfloat16())
+        return self._affine_bf16[1], self._affine_bf16[2]
+
     def forward(self, x):
+        if self.inner and x.dtype == torch.bfloat16:
+            # bf16 autocast (configs[4]; the reference has no mixed-precision mode): an INNER norm stays in bf16 -- one addcmul (fp32
+            # arithmetic, one rounding) whose output the next convolution consumes as it is.  x * scale + bias would promote the
+            # activation to fp32 and autocast would cast it back in front of the convolution: two full-tensor kernels more per layer,
+            # forward and backward.  The norms in front of the residual sum (bn3, downsample) keep promoting: the residual stream
+            # stays fp32 (keeping ALL norms in bf16 moved the RPN outputs 13-15 % from the fp32 model instead of < 8 %).
+            scale, bias = self.affine_bf16()
+            return torch.addcmul(bias, x, scale)
         # (One fused F.batch_norm for bf16 activations was tried: it keeps the residual stream in bf16 -- RPN outputs 13-15 % off the fp32
         # model instead of < 8 % on a random-init network -- and its host dispatch costs more than these two ops: 14.6 vs 13.3 ms enqueue.)
         scale, bias = self.affine()
@@ -60,9 +75,9 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
-        self.bn1 = FrozenBatchNorm2d(planes)
+        self.bn1 = FrozenBatchNorm2d(planes, inner=True)
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
-        self.bn2 = FrozenBatchNorm2d(planes)
+        self.bn2 = FrozenBatchNorm2d(planes, inner=True)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = FrozenBatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
