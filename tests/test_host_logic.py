@@ -125,3 +125,37 @@ def test_device_status_names():
     with pytest.raises(_lib.FrcnnError, match="aborted NMS scan"):
         st.check()
     st.check()                                                             # check() cleared the word
+
+
+def test_frozen_batchnorm_cache_follows_its_buffers():
+    """new_model.FrozenBatchNorm2d caches (scale, bias) per state of its four frozen buffers: the cached form must equal
+    torchvision's expression bit for bit, and a load_state_dict / in-place update / .to() must invalidate it."""
+    from faster_rcnn_pytorch_amd.new_model import FrozenBatchNorm2d
+    g = torch.Generator().manual_seed(5)
+    bn = FrozenBatchNorm2d(8)
+
+    def expect(x):
+        scale = (bn.weight * (bn.running_var + bn.eps).rsqrt()).reshape(1, -1, 1, 1)
+        bias = bn.bias.reshape(1, -1, 1, 1) - bn.running_mean.reshape(1, -1, 1, 1) * scale
+        return x * scale + bias
+    x = torch.randn(2, 8, 5, 7, generator=g)
+    assert torch.equal(bn(x), expect(x))
+    key0 = bn._affine_key
+    assert torch.equal(bn(x), expect(x)) and bn._affine_key == key0          # second call: served from the cache
+    sd = {k: torch.rand(8, generator=g) + 0.5 for k in ("weight", "bias", "running_mean", "running_var")}
+    bn.load_state_dict(sd)
+    assert torch.equal(bn(x), expect(x)) and bn._affine_key != key0          # load_state_dict copies in place: version bump
+    key1 = bn._affine_key
+    with torch.no_grad():
+        bn.running_var.mul_(2.0)
+    assert torch.equal(bn(x), expect(x)) and bn._affine_key != key1
+    bn = bn.double()                                                           # new buffer tensors: new data pointers
+    assert torch.equal(bn(x.double()), expect(x.double()))
+
+
+def test_const_tensor_is_cached_per_values_and_device():
+    from faster_rcnn_pytorch_amd import ops
+    a = ops.const_tensor((1, 2, 3, 4), torch.device("cpu"))
+    b = ops.const_tensor([1.0, 2.0, 3.0, 4.0], torch.device("cpu"))
+    c = ops.const_tensor((1, 2, 3, 5), torch.device("cpu"))
+    assert a is b and a is not c and a.tolist() == [1.0, 2.0, 3.0, 4.0] and a.dtype == torch.float32
