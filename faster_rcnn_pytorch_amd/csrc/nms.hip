@@ -381,13 +381,25 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     if (!pre_zeroed && hipMemsetAsync(w.nz, 0, w.zero_bytes, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: memset failed");
     const int n_res = (int)((K + 63) / 64);                         // one resolver wave per workgroup
     const int G = nblk / 4;
-    const unsigned grid = (unsigned)(n_res + 2 * G * (G + 1) + (nblk % 4) * (G + 1));
-    if (cls)
-        FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw, n_res,
-                     w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
-    else
-        FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw, n_res,
-                     w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+    const unsigned n_tile_wg = (unsigned)(2 * G * (G + 1) + (nblk % 4) * (G + 1));
+    // The fused launch needs every resolver workgroup resident NEXT TO free slots for the tile workgroups it waits for: fine for the
+    // proposal stage (188 resolver workgroups at K = 12 000), not guaranteed when the resolver alone could fill the chip.  Above
+    // this many resolver workgroups the same kernel runs as two launches: tiles only, then resolver only (all flags already up).
+    static const int fused_max_res = [] { const char *e = getenv("FRCNN_NMS_FUSED_MAX_RES"); return e ? atoi(e) : 1024; }();
+    auto launch = [&](unsigned grid, int n_res_arg) {
+        if (cls)
+            FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw,
+                         n_res_arg, w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+        else
+            FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw,
+                         n_res_arg, w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+    };
+    if (n_res <= fused_max_res) {
+        launch((unsigned)n_res + n_tile_wg, n_res);
+    } else {
+        launch(n_tile_wg, 0);
+        launch((unsigned)n_res, n_res);
+    }
     FRCNN_CHECK_LAUNCH("nms_kernel");
     FRCNN_LAUNCH(KID_NMS_SCAN_SIMPLE, nms_emit_kernel, dim3((unsigned)((nblk + 1 + 3) / 4)), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, w.kept,
                  w.flags, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);

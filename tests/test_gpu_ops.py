@@ -2,11 +2,16 @@
 on identical seeded inputs.  Integer results must be bit-exact; floating point as stated per test.
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -824,6 +829,27 @@ def test_nms_above_fast_path_limit_uses_generic_scan(ops):
     keep_o = orc.nms(b, 0.6)
     keep, _, cnt = ops.nms_sorted(T(b), 0.6)
     assert int(cnt.item()) == len(keep_o) and np.array_equal(keep[:len(keep_o)].cpu().numpy(), keep_o)
+
+
+def test_nms_two_launch_form_for_very_large_k():
+    """Above FRCNN_NMS_FUSED_MAX_RES resolver workgroups (1024 = K > 65 536) nms_kernel runs as two launches (tiles, then resolver)
+    instead of one.  The limit is read once per process, so a child process runs K = 3000 with the limit at 8."""
+    import subprocess
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from faster_rcnn_pytorch_amd import ops\n"
+        "from oracle import oracle as orc\n"
+        "rng = np.random.RandomState(4); K = 3000\n"
+        "c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15; wh = rng.rand(K, 2).astype(np.float32) * 0.25 + 0.03\n"
+        "b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)\n"
+        "ko = orc.nms(b, 0.5)\n"
+        "keep, _, cnt = ops.nms_sorted(torch.from_numpy(b).cuda(), 0.5)\n"
+        "assert int(cnt.item()) == len(ko) and np.array_equal(keep[:len(ko)].cpu().numpy(), ko)\n"
+        "print('two-launch ok', len(ko))\n") % ROOT
+    env = dict(os.environ, FRCNN_NMS_FUSED_MAX_RES="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "two-launch ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_rpn_targets_single_gt_and_gt_outside_all_anchors(ops):
