@@ -248,11 +248,16 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
                         if (take) { sv[t] = agent_ld64(&row[wi[t]]); kv[t] = agent_ld64(&kept[wi[t]]); rv[t] = agent_ld64(&rem[wi[t]]); }
                     }
                     bool settled = false;
+                    // a kept suppressor ANYWHERE in the batch removes me, also behind a word that still has an undecided one
+                    // (REMOVED needs one kept suppressor, whichever; only KEPT has to wait for every word in turn)
+                    u64 any_kept = 0ull;
+#pragma unroll
+                    for (int t = 0; t < NMS_WIDE_BATCH; ++t) any_kept |= sv[t] & kv[t];
+                    if (any_kept != 0ull) { r_new = true; decided = true; settled = true; }
 #pragma unroll
                     for (int t = 0; t < NMS_WIDE_BATCH; ++t) {
                         if (wi[t] >= 0 && !settled) {
-                            if ((sv[t] & kv[t]) != 0ull) { r_new = true; decided = true; settled = true; }
-                            else if ((sv[t] & ~rv[t]) != 0ull) {      // an undecided suppressor: poll this word
+                            if ((sv[t] & ~rv[t]) != 0ull) {           // an undecided suppressor: poll this word
                                 S = sv[t]; w = wi[t];
                                 cur &= ~((2ull << (wi[t] & 63)) - 1ull);   // the words after it stay unvisited (2 << 63 == 0)
                                 settled = true;
