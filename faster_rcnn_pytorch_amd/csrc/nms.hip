@@ -209,10 +209,7 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
     decided = decided || k_new;
     u64 S = 0ull;
     int w = -1;                                                     // the word I am polling (-1: none)
-#ifndef NMS_BSZ0
-#define NMS_BSZ0 2
-#endif
-    int bsz = NMS_BSZ0;                                             // words per round trip: 2 at first (a removed box needs 1.4 on average), then 8
+    int bsz = 4;                                                    // words per round trip: 4 at first, then 8
     const u64 *row = sup + (size_t)(live ? i : 0) * nblk;
     const int max_iter = 4 * n + 65536;
     for (int it = 0;; ++it) {
