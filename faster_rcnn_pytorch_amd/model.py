@@ -211,7 +211,6 @@ class FRCNN(nn.Module):
         self.rpn_target_maker = RPNTargetMaker(self.sampler)
         self.fast_rcnn_target_maker = FastRcnnTargetMaker(self.sampler)
         self.fast_rcnn_head = FastRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
-        self._streams = {}
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
@@ -223,23 +222,14 @@ class FRCNN(nn.Module):
         sees them even without this call."""
         self.sampler.status.check()
 
-    def _side_stream(self, device):
-        st = self._streams.get(device)
-        if st is None:
-            st = torch.cuda.Stream(device=device)
-            self._streams[device] = st
-        return st
-
     def forward(self, x, bbox, label):
         hw = x.size()[2:]
-        main = torch.cuda.current_stream(x.device)
-        # 5. rpn targets depend only on the anchors and the ground truth (model.py:324), not on the network:
-        #    they run on a second HIP stream underneath the backbone instead of after the proposals
+        # 5. rpn targets depend only on the anchors and the ground truth (model.py:324), not on the network: they are enqueued first.
+        #    (Round 1 ran them on a second HIP stream "underneath" the backbone.  Measured A/B on one box, four runs: the fork / join
+        #    and the single-workgroup sampler competing with MIOpen's kernels cost more than the 48 us they hide: 14.77-14.80 ms per step
+        #    with the side stream, 14.63-14.67 ms without; the same experiment in the FPN mirror: 18.64 vs 18.17 ms.)
         anchor = self.anchor_maker.device_anchors(hw, x.device)           # model.py:310-312: resident in HBM
-        side = self._side_stream(x.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            target_rpn_cls, target_rpn_reg = self.rpn_target_maker(bbox=bbox, anchor=anchor)
+        target_rpn_cls, target_rpn_reg = self.rpn_target_maker(bbox=bbox, anchor=anchor)
         # 1. extract features                                                  model.py:307
         features = self.extractor(x)
         # 3. forward rpn                                                       model.py:315
@@ -255,9 +245,6 @@ class FRCNN(nn.Module):
         # 8. regression row of the target class                                model.py:340-341
         pred_fast_rcnn_reg = pred_fast_rcnn_reg.reshape(128, -1, 4)
         pred_fast_rcnn_reg = pred_fast_rcnn_reg[torch.arange(0, 128, device=x.device), target_fast_rcnn_cls]
-        main.wait_stream(side)
-        target_rpn_cls.record_stream(main)
-        target_rpn_reg.record_stream(main)
         return (pred_rpn_cls, pred_rpn_reg, pred_fast_rcnn_cls, pred_fast_rcnn_reg), \
                (target_rpn_cls, target_rpn_reg, target_fast_rcnn_cls, target_fast_rcnn_reg)
 
