@@ -32,6 +32,16 @@ sys.path.insert(0, ROOT)
 for _k in ("FWD", "BWD", "WRW"):
     os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
 
+# PyTorch TunableOp: the first time a GEMM shape is seen (the initialisation pass below, outside the W / K accounting) every rocBLAS /
+# hipBLASLt solution for it is timed and the fastest is kept for the rest of the process (~8 s for the dozen shapes of a step).  The
+# default heuristic picks a 64x64 macro-tile for the classifier's 128 x 25088 x 4096 GEMMs that streams the 411 MB weight at 1.46 TB/s
+# (282 us, three of them per step); the tuned pick takes 190 us: 14.57 -> 14.29 ms per VGG step.  FRCNN_BENCH_TUNABLEOP=0 turns it off.
+if os.environ.get("FRCNN_BENCH_TUNABLEOP", "1") != "0":
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(os.environ.get("TMPDIR", "/tmp"), "frcnn_bench_tunableop_%d.csv"))
+
 import torch  # noqa: E402
 
 # MI355X_MICROARCH.md:53-54,473: 256 CUs x 4 SIMDs, each SIMD a 32-lane fp32 datapath (a wave64 v_fma_f32 issues in 2 cycles),
@@ -340,6 +350,8 @@ def main():
                     "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
                     "source": "HIP events at the step boundaries on the main stream (rank 0)"},
         "allocator_in_timed_region": allocator,
+        "gemm_selection": ("PyTorch TunableOp: rocBLAS / hipBLASLt solution timed and picked per GEMM shape during the initialisation pass"
+                           if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default heuristics"),
         "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
                         "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms)},
         "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * P, 1),
