@@ -187,6 +187,49 @@ class RefFRCNNFPN(nn.Module):
                (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
 
 
+def ref_suppress(raw_cls_bbox, raw_prob, num_classes, thres):
+    """FRCNN._suppress (models/model.py:382-402, models/new_model.py:445-470) as the reference writes it: a Python loop over the
+    classes 1 .. C-1 (0 = background is skipped), per class the score mask `prob > thres`, torchvision nms(0.3) on the masked
+    boxes (nms visits boxes by descending score; ties by ascending index, the build's definition of torch's unstable sort), and
+    the CLASS-MAJOR concatenation of boxes / (l - 1) labels / scores.  numpy in, numpy out."""
+    boxes = np.ascontiguousarray(raw_cls_bbox, np.float32).reshape(-1, num_classes, 4)
+    prob = np.ascontiguousarray(raw_prob, np.float32)
+    bbox, label, score = [], [], []
+    for l in range(1, num_classes):                                            # model.py:388
+        cls_bbox_l = boxes[:, l, :]
+        prob_l = prob[:, l]
+        mask = prob_l > np.float32(thres)                                      # model.py:391
+        cls_bbox_l = np.ascontiguousarray(cls_bbox_l[mask])
+        prob_l = prob_l[mask]
+        order = np.argsort(-prob_l, kind="stable")
+        keep = orc.nms(cls_bbox_l, 0.3, order) if len(prob_l) else np.zeros((0,), np.int64)   # model.py:394
+        bbox.append(cls_bbox_l[keep])
+        label.append((l - 1) * np.ones((len(keep),)))                          # model.py:396
+        score.append(prob_l[keep])
+    return (np.concatenate(bbox, axis=0).astype(np.float32), np.concatenate(label, axis=0).astype(np.int32),
+            np.concatenate(score, axis=0).astype(np.float32))
+
+
+def ref_predict_post(head_cls, head_reg, rois, num_classes, thres, prob=None):
+    """The post-processing half of FRCNN.predict (models/model.py:368-380, models/new_model.py:431-443) on numpy inputs:
+    softmax over the head's class logits (torch CPU, as the reference's eager op), regression * (0.1, 0.1, 0.2, 0.2)
+    (SURVEY Q10), every class decoded against its RoI (decode / xy_to_cxcy / cxcy_to_xy of utils/util.py), clamp to [0, 1],
+    then _suppress.  `prob` (optional) overrides the softmax output: tests pass the device's own softmax there to separate the
+    last-bit differences of two softmax implementations from the logic under test.
+    Returns (bbox [M,4] f32, label [M] i32, score [M] f32, raw_bbox [R, C*4], prob [R, C])."""
+    head_cls = np.ascontiguousarray(head_cls, np.float32)
+    head_reg = np.ascontiguousarray(head_reg, np.float32).reshape(-1, num_classes, 4)
+    rois = np.ascontiguousarray(rois, np.float32).reshape(-1, 4)
+    if prob is None:
+        prob = torch.softmax(torch.from_numpy(head_cls), dim=-1).numpy()       # model.py:369
+    t = head_reg * np.array([0.1, 0.1, 0.2, 0.2], np.float32)                  # model.py:372
+    r = np.ascontiguousarray(np.broadcast_to(rois.reshape(-1, 1, 4), t.shape)).reshape(-1, 4)   # model.py:373
+    pred = orc.cxcy_to_xy(orc.decode(np.ascontiguousarray(t.reshape(-1, 4)), orc.xy_to_cxcy(r)))   # model.py:374-375
+    pred = np.clip(pred.reshape(-1, num_classes * 4), np.float32(0), np.float32(1))                 # model.py:377-378 (NaN stays NaN)
+    bbox, label, score = ref_suppress(pred, prob, num_classes, thres)
+    return bbox, label, score, pred, prob
+
+
 def ref_loss(pred, target):
     """losses/loss.py:5-85 in torch (CPU), written as the reference writes it (boolean-mask indexing)."""
     import torch.nn.functional as F

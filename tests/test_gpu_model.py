@@ -112,6 +112,58 @@ def test_predict_api(model):
     assert torch.equal(b2, bbox) and torch.equal(l2, label)
 
 
+def _predict_vs_oracle(model, x, thres, num_classes, rpn_mod, head_mod, propose_check):
+    """FRCNN.predict against the oracle's restatement of models/model.py:346-402, stage by stage on identical inputs:
+    proposals (test mode) bit-exact, then the post-processing (softmax -> * std -> per-class decode -> clamp -> per-class
+    nms(0.3) loop -> class-major concatenation): labels and order bit-exact, boxes / scores within 1e-4 (north star)."""
+    cap = {}
+    hooks = [head_mod.register_forward_hook(lambda m, i, o: cap.__setitem__("head", (i, o)))]
+    if rpn_mod is not None:
+        hooks.append(rpn_mod.register_forward_hook(lambda m, i, o: cap.__setitem__("rpn", o)))
+    model.eval()
+    bbox, label, score = model.predict(x.to(DEV), thres)
+    for h in hooks:
+        h.remove()
+    (head_in, head_out) = cap["head"]
+    rois = head_in[1].detach().cpu().numpy()
+    propose_check(cap.get("rpn"), rois)
+    hc, hr = head_out[0].detach().float(), head_out[1].detach().float()
+    prob_dev = torch.softmax(hc, dim=-1).cpu().numpy()
+    # (i) the logic under test with the device's own softmax values: everything bit-exact (decode uses the deterministic exp on both sides)
+    rb, rl, rs, _, _ = model_ref.ref_predict_post(hc.cpu().numpy(), hr.cpu().numpy(), rois, num_classes, thres, prob=prob_dev)
+    assert len(rl) > 0 and len(np.unique(rl)) > 1, "degenerate test frame: nothing above the threshold"
+    assert np.array_equal(label.numpy(), rl)                                      # class-major order, (l - 1) labels
+    assert np.array_equal(score.numpy(), rs)
+    assert np.array_equal(bbox.numpy(), rb)
+    # (ii) end to end with the reference's own eager softmax on the CPU: same labels / order, values within 1e-4
+    cb, cl, cs, _, prob_cpu = model_ref.ref_predict_post(hc.cpu().numpy(), hr.cpu().numpy(), rois, num_classes, thres)
+    assert np.abs(prob_cpu - prob_dev).max() < 1e-6
+    assert np.array_equal(label.numpy(), cl), "a last-bit softmax difference changed the kept set (near-threshold score)"
+    assert np.abs(score.numpy() - cs).max() < 1e-4 and np.abs(bbox.numpy() - cb).max() < 1e-4
+    return len(rl)
+
+
+def test_predict_matches_oracle_at_600x1000(model):
+    """SURVEY A9 at config V test mode (pre 6000 / post 300)."""
+    H, W = 600, 1000
+    x, _, _ = synth(21, H, W, 1)
+    sd = {k: v.clone() for k, v in model.fast_rcnn_head.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():                                   # heads of a random-init net are ~constant: spread the logits and the deltas
+        model.fast_rcnn_head.cls_head.weight.copy_(torch.randn(model.fast_rcnn_head.cls_head.weight.shape, generator=g) * 0.8)
+        model.fast_rcnn_head.reg_head.weight.copy_(torch.randn(model.fast_rcnn_head.reg_head.weight.shape, generator=g) * 0.5)
+
+    def propose_check(rpn_out, rois):
+        cls, reg = rpn_out
+        ro, _ = orc.region_proposal(reg[0].detach().cpu().numpy(), cls[0].detach().cpu().numpy(), orc.anchor_grid(H, W), 1 / 1000, 6000, 0.7, 300)
+        assert rois.shape == ro.shape and np.array_equal(rois, ro)
+    try:
+        n = _predict_vs_oracle(model, x, 0.05, 21, model.rpn, model.fast_rcnn_head, propose_check)
+        assert n > 20
+    finally:
+        model.fast_rcnn_head.load_state_dict(sd)
+
+
 # ------------------------------------------------------------------------------------------------ ResNet-50-FPN (models/new_model.py)
 @pytest.fixture(scope="module")
 def fpn_model():
@@ -160,6 +212,39 @@ def test_fpn_predict_api(fpn_model):
     fpn_model.eval()
     bbox, label, score = fpn_model.predict(x.to(DEV), 0.02)
     assert bbox.dtype == torch.float32 and label.dtype == torch.int32 and bbox.shape[0] == score.shape[0]
+
+
+def test_fpn_predict_matches_oracle_at_800x1344(fpn_model):
+    """SURVEY A9, FPN mirror (models/new_model.py:420-470) at config F test mode (pre 2000 / post 1000)."""
+    H, W = 800, 1344
+    x, _, _ = synth(23, H, W, 1)
+    sd = {k: v.clone() for k, v in fpn_model.frcnn_head.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        fpn_model.frcnn_head.cls_head.weight.copy_(torch.randn(fpn_model.frcnn_head.cls_head.weight.shape, generator=g) * 0.8)
+        fpn_model.frcnn_head.reg_head.weight.copy_(torch.randn(fpn_model.frcnn_head.reg_head.weight.shape, generator=g) * 0.5)
+    cap = {}
+
+    def propose_check(_, rois):
+        # ONE global proposal stage over the five levels (new_model.py:49-86) on the RPN head outputs captured below
+        anchor = orc.tv_anchor_grid(H, W, cap["shapes"], normalise=True)
+        ro, _ = orc.region_proposal(cap["reg"], cap["cls"], anchor, 10 / 1000, 2000, 0.7, 1000)
+        assert rois.shape == ro.shape and np.array_equal(rois, ro)
+    orig = fpn_model.rpn.rpn_head.forward_levels
+
+    def spy(feats):
+        c, r = orig(feats)
+        cap["cls"] = c.detach().float().reshape(-1, 2).cpu().numpy()
+        cap["reg"] = r.detach().float().reshape(-1, 4).cpu().numpy()
+        cap["shapes"] = [tuple(f.shape[-2:]) for f in feats]
+        return c, r
+    fpn_model.rpn.rpn_head.forward_levels = spy
+    try:
+        n = _predict_vs_oracle(fpn_model, x, 0.02, 91, None, fpn_model.frcnn_head, propose_check)
+        assert n > 20
+    finally:
+        fpn_model.rpn.rpn_head.forward_levels = orig
+        fpn_model.frcnn_head.load_state_dict(sd)
 
 
 def test_fpn_bf16_mixed_precision_step_keeps_box_path_fp32(fpn_model):

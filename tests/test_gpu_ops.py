@@ -231,6 +231,50 @@ def test_nms_dense_clusters_near_threshold(ops):
         assert int(cnt.item()) == len(keep_o) and np.array_equal(keep[:len(keep_o)].cpu().numpy(), keep_o)
 
 
+def _with_nonfinite(rng, K):
+    """Boxes as the reference can hand them to nms: SURVEY Q8 -- decode has no clamp on dw / dh, so exp overflows to inf, the centre
+    arithmetic makes inf - inf = NaN, and clamp(0, 1) maps +-inf to 1 / 0 but leaves NaN in place (models/model.py:376-378 -> :394)."""
+    c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15
+    wh = (rng.rand(K, 2).astype(np.float32) * 0.3 + 0.05)
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    bad = rng.choice(K, K // 9, replace=False)
+    for n, i in enumerate(bad):
+        kind = n % 6
+        if kind == 0: b[i, rng.randint(0, 4)] = np.nan               # one NaN coordinate
+        elif kind == 1: b[i] = np.nan                                # all NaN
+        elif kind == 2: b[i, 2] = np.inf                             # infinite width: area inf, IoU 0 with everything finite
+        elif kind == 3: b[i, 0], b[i, 2] = -np.inf, np.inf           # inf - (-inf) = inf
+        elif kind == 4: b[i, 0], b[i, 2] = np.inf, np.inf            # inf - inf = NaN area
+        else: b[i, 2:] = b[i, :2]                                    # zero area
+    return b
+
+
+@pytest.mark.parametrize("K,thr", [(5000, 0.7), (300, 0.3), (64, 0.5)])
+def test_nms_nan_and_inf_boxes_follow_torchvision_semantics(ops, K, thr):
+    """torchvision's nms (CPU and CUDA kernels alike) never tests for NaN: a box with a NaN coordinate has a NaN area, every IoU
+    it takes part in is NaN, `NaN > thr` is false -- it is always KEPT and never suppresses anything; an infinite area gives
+    inter / inf = 0.  The oracle restates exactly that expression; the HIP tiles decide without the division only when
+    inter - thr (1 +- 2^-20) union is ordered, so every NaN pair falls through to the exact IEEE division (csrc/nms.hip)."""
+    rng = np.random.RandomState(K)
+    b = _with_nonfinite(rng, K)
+    keep_o = orc.nms(b, thr)
+    nanrow = np.isnan((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+    assert nanrow.sum() > 0 and set(np.nonzero(nanrow)[0]) <= set(keep_o.tolist())      # NaN-area boxes are all kept
+    keep, rois, cnt = ops.nms_sorted(T(b), thr, want_rois=True)
+    n = int(cnt.item())
+    assert n == len(keep_o) and np.array_equal(keep[:n].cpu().numpy(), keep_o)
+    assert np.array_equal(rois[:n].cpu().numpy(), b[keep_o], equal_nan=True)
+    # the drop-in entry points (sort by score first): scores finite, boxes not
+    sc = rng.rand(K).astype(np.float32)
+    order = np.argsort(-sc, kind="stable")
+    assert np.array_equal(ops.nms(T(b), T(sc), thr).cpu().numpy(), orc.nms(b, thr, order=order))
+    cls = rng.randint(0, 5, K).astype(np.int64)
+    got = ops.batched_nms(T(b), T(sc), T(cls), thr).cpu().numpy()
+    exp = np.concatenate([np.nonzero(cls == c)[0][orc.nms(b[cls == c], thr, order=np.argsort(-sc[cls == c], kind="stable"))] for c in range(5)])
+    exp = exp[np.argsort(-sc[exp], kind="stable")]
+    assert np.array_equal(got, exp)
+
+
 def test_nms_in_kernel_handoff_under_uneven_load(ops):
     """nms_kernel hands the relation words from its tile waves to its resolver waves INSIDE one launch (write-through stores, a flag
     word per tile, sc1 polls + an agent acquire; csrc/nms.hip).  A stale word shows up as a different keep list, so: 150 launches

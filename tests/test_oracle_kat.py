@@ -253,3 +253,45 @@ def test_head_targets_restated_in_numpy():
     e = orc.encode(orc.xy_to_cxcy(gt[am][ki]), orc.xy_to_cxcy(allr[ki])) / np.array([0.1, 0.1, 0.2, 0.2], np.float32)
     assert np.allclose(reg, e, atol=1e-6)
     assert keep[:n_pos].max() >= 0 and (300 in keep or 301 in keep or npc > 32)   # gt rows are candidates too
+
+
+def test_nms_nan_inf_boxes_kat():
+    """torchvision semantics for non-finite boxes: a NaN coordinate -> NaN area -> every IoU NaN -> `> thr` false:
+    the box is kept and suppresses nothing.  Hand case + the numpy brute force above."""
+    nan = np.nan
+    b = np.array([[0, 0, 1, 1], [0, 0, 1, nan], [0.05, 0, 1.05, 1], [nan, nan, nan, nan], [0, 0, 1, np.inf], [0.01, 0, 1.01, 1]], np.float32)
+    # 0 kept; 1 NaN kept; 2 suppressed by 0 (IoU 0.905); 3 NaN kept; 4 area inf: IoU with 0 = 1/inf = 0 -> kept, suppresses nothing; 5 killed by 0
+    assert orc.nms(b, 0.5).tolist() == [0, 1, 3, 4]
+    rng = np.random.RandomState(4)
+    bb = (rng.rand(400, 4) * 0.5).astype(np.float32)
+    bb[:, 2:] += bb[:, :2]
+    bb[rng.choice(400, 60, replace=False), rng.randint(0, 4, 60)] = nan
+    bb[rng.choice(400, 20, replace=False), 2] = np.inf
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(orc.nms(bb, 0.4), brute_nms(bb, 0.4))
+
+
+# ---------------------------------------------------------------- FRCNN.predict post-processing (models/model.py:368-402)
+def test_predict_post_known_answer():
+    """Hand-derived: 3 RoIs, background + 2 classes, threshold 0.05.
+    class 1: RoI 0 (0.60) and RoI 1 (0.70) overlap with IoU 0.82 > 0.3 -> RoI 1 wins; RoI 2 (0.20) is disjoint -> kept after it.
+    class 2: RoI 0 (0.03) is under the threshold; RoI 2 (0.50) then RoI 1 (0.10) are disjoint -> both kept, score order.
+    Output is class-major with labels l - 1."""
+    from oracle import model_ref
+    rois = np.array([[0.10, 0.10, 0.50, 0.50], [0.12, 0.12, 0.52, 0.52], [0.60, 0.60, 0.90, 0.90]], np.float32)
+    raw = np.repeat(rois[:, None, :], 3, axis=1).reshape(3, 12)                 # every class predicts its RoI unchanged
+    prob = np.array([[0.37, 0.60, 0.03], [0.20, 0.70, 0.10], [0.30, 0.20, 0.50]], np.float32)
+    b, l, s = model_ref.ref_suppress(raw, prob, 3, 0.05)
+    assert l.tolist() == [0, 0, 1, 1] and l.dtype == np.int32 and b.dtype == np.float32 and s.dtype == np.float32
+    assert np.array_equal(s, np.array([0.70, 0.20, 0.50, 0.10], np.float32))
+    assert np.array_equal(b, rois[[1, 2, 2, 1]])
+    # zero deltas decode to the RoI itself (up to the rounding of xy -> cxcy -> xy); softmax of equal logits is uniform
+    hb, hl, hs, pred, p = model_ref.ref_predict_post(np.zeros((3, 3), np.float32), np.zeros((3, 12), np.float32), rois, 3, 0.05)
+    assert np.allclose(p, 1 / 3) and np.abs(pred.reshape(3, 3, 4) - rois[:, None, :]).max() < 1e-6
+    assert hl.tolist() == [0, 0, 1, 1] and np.allclose(hs, 1 / 3)               # ties: ascending RoI index, RoI 1 falls to RoI 0
+    assert np.abs(hb - rois[[0, 2, 0, 2]]).max() < 1e-6
+    # a delta of log(2) on w doubles the width around the same centre; x is clamped to [0, 1]
+    reg = np.zeros((1, 12), np.float32)
+    reg[0, 4 + 2] = np.log(2.0) / 0.2                                           # class 1, dw, un-normalised by 0.2 (SURVEY Q10)
+    _, _, _, pred, _ = model_ref.ref_predict_post(np.zeros((1, 3), np.float32), reg, np.array([[0.6, 0.2, 1.0, 0.4]], np.float32), 3, 0.05)
+    assert np.abs(pred.reshape(3, 4)[1] - np.array([0.4, 0.2, 1.0, 0.4], np.float32)).max() < 1e-6
