@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
 OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV = 1, 2, 3, 4, 5, 6, 7, 8
 
@@ -32,13 +32,13 @@ SIGNATURES = {
     "frcnn_argsort_desc": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_nms": (_i, [_vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_nms_classed": (_i, [_vp, _vp, _vp, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "frcnn_region_proposal": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _f, _f, _i64, _f, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_region_proposal": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _f, _f, _f, _i64, _f, _i64, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_head_tail_fwd": (_i, [_vp, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "frcnn_rpn_head_tail_ml_fwd": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "frcnn_rpn_head_tail_ml_bwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
-    "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64,
+    "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "frcnn_roi_pool_fwd": (_i, [_vp, _i, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "frcnn_roi_pool_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),

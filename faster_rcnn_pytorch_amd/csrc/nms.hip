@@ -194,15 +194,15 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // which 64-word groups of my bitmap are non-empty; cur = the unvisited words of the current group
-    unsigned later = 0u;
+    u64 later = 0ull;                                              // one bit per 64-word group: nzw <= NMS_MAX_BLOCKS / 64 = 64 groups
     u64 cur = 0ull;
     int g = 0;
     if (live) {
         for (int q = nzw - 1; q >= 0; --q) {
             const u64 a = agent_ld64(&nz[(size_t)q * K + i]);
-            if (a != 0ull) { later |= 1u << q; cur = a; g = q; }
+            if (a != 0ull) { later |= 1ull << q; cur = a; g = q; }
         }
-        later &= later - 1u;                                        // the lowest non-empty group is the current one
+        later &= later - 1ull;                                      // the lowest non-empty group is the current one
     }
     bool decided = !live;
     bool k_new = live && cur == 0ull, r_new = false;                // no suppressor at all: KEPT
@@ -226,9 +226,9 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
                 else if ((S & ~rw) == 0ull) w = -1;                 // exhausted: walk on below
             }
             if (!decided && w < 0) {
-                if (cur == 0ull && later != 0u) {                   // next non-empty group
-                    g = __builtin_ctz(later);
-                    later &= later - 1u;
+                if (cur == 0ull && later != 0ull) {                 // next non-empty group
+                    g = __builtin_ctzll(later);
+                    later &= later - 1ull;
                     cur = agent_ld64(&nz[(size_t)g * K + i]);
                 }
                 if (cur == 0ull) { k_new = true; decided = true; }  // every suppressor is removed

@@ -331,7 +331,9 @@ FRCNN_EXPORT int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax
     }
     FRCNN_REQUIRE(grad_out && argmax, "roi_pool_bwd: NULL pointer");
     FRCNN_REQUIRE(R * PH * PW < ((int64_t)1 << 31), "roi_pool_bwd: R*bins too large");
-    if (HW * 4 * ROI_BWD_CB <= 64 * 1024) {
+    // the CB-channel LDS kernel maps a thread to (RoI slot, element of the CB * bins run): it needs at least one whole run per pass of
+    // its 512 threads; larger bin grids (e.g. 17 x 17) take the one-channel kernel, which strides over any run length
+    if (HW * 4 * ROI_BWD_CB <= 64 * 1024 && (int64_t)PH * PW * ROI_BWD_CB <= 512) {
         return roi_pool_bwd_launch<int32_t>(grad_out, argmax, R, C, HW, PH * PW, grad_feat, s);
     } else if (HW * 4 <= 64 * 1024) {
         FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_kernel, dim3(C), dim3(256), (size_t)HW * 4, s, grad_out, argmax, (int)R, C, (int)HW,

@@ -46,11 +46,19 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
 
 __global__ __launch_bounds__(256) void rpn_colmax_kernel(int variant, const float4 *__restrict__ anchors, int N,
                                                          const float4 *__restrict__ gt, int G,
-                                                         unsigned long long *__restrict__ colkey, int32_t *__restrict__ counts_zero)
+                                                         unsigned long long *__restrict__ colkey, int32_t *__restrict__ counts_zero,
+                                                         unsigned long long *__restrict__ philox_state, unsigned long long *__restrict__ philox_snap)
 {
     __shared__ unsigned long long s_k[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (counts_zero && blockIdx.x == 0 && threadIdx.x < 4) counts_zero[threadIdx.x] = 0;
+    // device-resident RNG stream: this call consumes ONE offset value.  It is snapshotted for the sampling kernels that follow on
+    // the stream and the counter moves on, so a captured graph draws fresh samples at every replay (no host-side argument changes).
+    if (philox_state && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long sd = philox_state[0], of = philox_state[1];
+        philox_snap[0] = sd; philox_snap[1] = of;
+        philox_state[1] = of + 1ull;
+    }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     bool live = false;
     if (i < N) {
@@ -224,9 +232,11 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
                                                           const int64_t *__restrict__ perm_pos, int n_perm_pos,
                                                           const int64_t *__restrict__ perm_neg, int n_perm_neg,
                                                           unsigned long long seed, unsigned long long offset,
+                                                          const unsigned long long *__restrict__ philox_snap,
                                                           int32_t *__restrict__ list, unsigned *__restrict__ keys,
                                                           int32_t *__restrict__ counts)
 {
+    if (philox_snap) { seed = philox_snap[0]; offset = philox_snap[1]; }
     __shared__ int s_w[17];
     __shared__ unsigned s_hist[16 * 256];
     __shared__ unsigned s_pref[4];
@@ -413,9 +423,10 @@ __device__ __forceinline__ RpnSelState rpn_sel_state(const RpnSelCtl *ctl, const
 
 template <int LEVEL>
 __global__ __launch_bounds__(256) void rpn_samp_hist_kernel(const int8_t *__restrict__ label8, int N, unsigned long long seed,
-                                                            unsigned long long offset, RpnSelCtl *__restrict__ ctl,
-                                                            const int32_t *__restrict__ counts)
+                                                            unsigned long long offset, const unsigned long long *__restrict__ philox_snap,
+                                                            RpnSelCtl *__restrict__ ctl, const int32_t *__restrict__ counts)
 {
+    if (philox_snap) { seed = philox_snap[0]; offset = philox_snap[1]; }
     __shared__ unsigned s_hist[2][RSB];
     __shared__ int s_tmp[8];
     const RpnSelState sn = rpn_sel_state(ctl, counts, 0, LEVEL, s_tmp);
@@ -440,9 +451,11 @@ __global__ __launch_bounds__(256) void rpn_samp_hist_kernel(const int8_t *__rest
 }
 
 __global__ __launch_bounds__(256) void rpn_samp_apply_kernel(const int8_t *__restrict__ label8, int N, unsigned long long seed,
-                                                             unsigned long long offset, const RpnSelCtl *__restrict__ ctl,
+                                                             unsigned long long offset, const unsigned long long *__restrict__ philox_snap,
+                                                             const RpnSelCtl *__restrict__ ctl,
                                                              const int32_t *__restrict__ counts, int64_t *__restrict__ out_cls)
 {
+    if (philox_snap) { seed = philox_snap[0]; offset = philox_snap[1]; }
     __shared__ int s_tmp[8];
     const RpnSelState sn = rpn_sel_state(ctl, counts, 0, 3, s_tmp);      // prefix = exact threshold key T, want = #(key == T) to keep
     const RpnSelState sp = rpn_sel_state(ctl, counts, 1, 3, s_tmp);
@@ -479,10 +492,12 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
                                                             const int64_t *__restrict__ perm_pos, int n_perm_pos,
                                                             const int64_t *__restrict__ perm_neg, int n_perm_neg,
                                                             unsigned long long seed, unsigned long long offset,
+                                                            unsigned long long *__restrict__ philox_state,
                                                             int64_t *__restrict__ out_cls, float4 *__restrict__ out_reg,
                                                             float4 *__restrict__ out_rois, int64_t *__restrict__ out_keep,
                                                             int32_t *__restrict__ counts, int32_t *__restrict__ sticky)
 {
+    if (philox_state) { seed = philox_state[0]; offset = philox_state[1]; }   // every thread reads it here; thread 0 moves it on at the end
     __shared__ int s_w[17];
     __shared__ short s_arg[HT_MAX];
     __shared__ signed char s_flag[HT_MAX];          // 1 pos cand, 0 neg cand, -1 neither
@@ -615,18 +630,20 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
         if (n_pos + n_neg < total) err |= FRCNN_HT_ERR_SHORT;
         counts[0] = npc; counts[1] = nnc; counts[2] = (err & 3) ? 0 : n_pos + n_neg; counts[3] = err;
         if (sticky && err) atomicOr(sticky, err);
+        if (philox_state) philox_state[1] = offset + 1ull;           // one offset value consumed per call (barriers lie between the reads and this)
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-struct RpnWs { unsigned long long *colkey; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
+struct RpnWs { unsigned long long *colkey, *snap; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
 static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
 {
     RpnWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
     w.colkey = (unsigned long long *)take((size_t)G * 8 * 8);
+    w.snap = (unsigned long long *)take(16);
     w.label8 = (int8_t *)take((size_t)N);
     w.list = (int32_t *)take((size_t)N * 4);
     w.keys = (unsigned *)take((size_t)N * 4);
@@ -639,7 +656,7 @@ size_t frcnn_ws_head_targets(int64_t) { return 256; }
 
 FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N, const float *gt, int64_t G,
                                    const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
-                                   uint64_t seed, uint64_t offset, int64_t *out_cls, float *out_reg, int32_t *out_counts,
+                                   uint64_t seed, uint64_t offset, uint64_t *philox_state_dev, int64_t *out_cls, float *out_reg, int32_t *out_counts,
                                    void *workspace, size_t workspace_bytes, void *stream)
 {
     FRCNN_REQUIRE(variant == 0 || variant == 1, "rpn_targets: variant must be 0 (VGG) or 1 (FPN)");
@@ -654,8 +671,9 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     if (hipMemsetAsync(w.colkey, 0, (size_t)G * 8 * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
     FRCNN_LAUNCH(KID_RPN_COLMAX, rpn_colmax_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
-                 (int)G, w.colkey, out_counts);
+                 (int)G, w.colkey, out_counts, (unsigned long long *)philox_state_dev, w.snap);
     FRCNN_CHECK_LAUNCH("rpn_colmax_kernel");
+    const unsigned long long *snap = philox_state_dev ? w.snap : nullptr;
     FRCNN_LAUNCH(KID_RPN_LABEL, rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
                  w.colkey, out_cls, (float4 *)out_reg, w.label8, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_label_kernel");
@@ -663,15 +681,15 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     if (N > RS_LDS_MAX && !perm_pos && !perm_neg && !force_block) {     // chip-wide device-RNG sampler for FPN-sized N
         if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
         const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<0>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<1>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<2>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_apply_kernel, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, w.sel, out_counts, out_cls);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<0>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<1>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<2>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_apply_kernel, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts, out_cls);
         FRCNN_CHECK_LAUNCH("rpn_samp kernels");
         return FRCNN_OK;
     }
     FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_sample_kernel, dim3(1), dim3(1024), 0, s, (int)N, w.label8, out_cls, perm_pos, (int)n_perm_pos, perm_neg,
-                 (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, w.list, w.keys, out_counts);
+                 (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, snap, w.list, w.keys, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_sample_kernel");
     return FRCNN_OK;
 }
@@ -679,7 +697,7 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
 FRCNN_EXPORT int frcnn_head_targets(int variant, const float *rois, const int32_t *n_rois_dev, int64_t P_cap, const float *gt,
                                     const int64_t *gt_label, int64_t G, int64_t label_offset, int64_t max_pos, int64_t total,
                                     const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
-                                    uint64_t seed, uint64_t offset, int64_t *out_cls, float *out_reg, float *out_rois,
+                                    uint64_t seed, uint64_t offset, uint64_t *philox_state_dev, int64_t *out_cls, float *out_reg, float *out_rois,
                                     int64_t *out_keep_index, int32_t *out_counts, int32_t *sticky_status, void *stream)
 {
     FRCNN_REQUIRE(variant == 0 || variant == 1, "head_targets: variant must be 0 (VGG) or 1 (FPN)");
@@ -691,7 +709,7 @@ FRCNN_EXPORT int frcnn_head_targets(int variant, const float *rois, const int32_
     hipStream_t s = (hipStream_t)stream;
     FRCNN_LAUNCH(KID_HEAD_TARGETS, head_targets_kernel, dim3(1), dim3(1024), 0, s, variant, (const float4 *)rois, n_rois_dev, (int)P_cap,
                  (const float4 *)gt, gt_label, (int)G, (int)label_offset, (int)max_pos, (int)total, perm_pos, (int)n_perm_pos, perm_neg,
-                 (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, out_cls, (float4 *)out_reg, (float4 *)out_rois,
+                 (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls, (float4 *)out_reg, (float4 *)out_rois,
                  out_keep_index, out_counts, sticky_status);
     FRCNN_CHECK_LAUNCH("head_targets_kernel");
     return FRCNN_OK;

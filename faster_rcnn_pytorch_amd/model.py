@@ -137,14 +137,28 @@ class _Sampler(object):
             raise ValueError("sampling must be 'device' (Philox on the GPU, no sync) or 'host' (reference RNG stream)")
         self.sampling = sampling
         self.seed = int(seed)
-        self.offset = 0
         # sticky device-side error word: the sync-free ('device') target makers OR their failure bits into it; the training
         # loop reads it where it syncs anyway (FRCNN.check_device_status()).  The same failures also make the loss NaN.
         self.status = ops.DeviceStatus()
+        self._state = {}
 
-    def next_offset(self):
-        self.offset += 1
-        return self.offset
+    def state(self, device):
+        """The device-resident Philox stream (seed, offset) of this model on `device`: each target-maker call uses the pair it
+        finds and leaves offset + 1 behind, ON THE DEVICE -- no host-side counter rides in the launch arguments, so the whole
+        step can be captured in a HIP graph and still draws fresh samples at every replay."""
+        key = str(device)
+        st = self._state.get(key)
+        if st is None:
+            st = ops.philox_state(self.seed, 1, device)
+            self._state[key] = st
+        return st
+
+    def reseed(self, seed=None, offset=1):
+        """Restart the stream (tests; deterministic replays): a device-side copy into the existing state tensors, no sync."""
+        if seed is not None:
+            self.seed = int(seed)
+        for key, st in self._state.items():
+            st.copy_(ops.philox_state(self.seed, offset, st.device))
 
 
 class FastRcnnTargetMaker(nn.Module):
@@ -166,7 +180,7 @@ class FastRcnnTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 128:
                 raise RuntimeError("FastRcnnTargetMaker: fewer than 128 samples (the reference fails here too, model_.py:340)")
         else:
-            cls, reg, srois, _, _ = ops.head_targets(rois, bbox, label, n_rois=n_rois, seed=s.seed, offset=s.next_offset(),
+            cls, reg, srois, _, _ = ops.head_targets(rois, bbox, label, n_rois=n_rois, philox_state=s.state(rois.device),
                                                      status=s.status.word(rois.device))
         return cls, reg, srois
 
@@ -189,7 +203,7 @@ class RPNTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 0:
                 raise RuntimeError("RPNTargetMaker: permutation length mismatch")
         else:
-            cls, reg, _ = ops.rpn_targets(anchor, bbox, seed=s.seed, offset=s.next_offset())
+            cls, reg, _ = ops.rpn_targets(anchor, bbox, philox_state=s.state(anchor.device))
         return cls, reg
 
 

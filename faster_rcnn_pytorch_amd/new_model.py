@@ -222,6 +222,9 @@ class RegionProposalNetwork(nn.Module):
     def __init__(self):
         super().__init__()
         self.min_size = 10
+        # False (default) = ONE class-agnostic NMS over the boxes of all levels: the reference (new_model.py:74-83).
+        # True = the per-FPN-level variant BASELINE.json configs[3] words (torchvision's RPN): boxes only compete inside their level.
+        self.per_level_nms = False
         self.rpn_head = RPNHead()
         self.anchor_generator = ops.AnchorGenerator(sizes=((32,), (64,), (128,), (256,), (512,)),
                                                     aspect_ratios=((0.5, 1.0, 2.0),) * 5)
@@ -240,7 +243,12 @@ class RegionProposalNetwork(nn.Module):
         shapes = [tuple(f.shape[-2:]) for f in feats]
         anchor = self.anchor_generator.grid((h, w), shapes, x.device, normalise=True)   # new_model.py:46-47, cached in HBM
         pre, post = self.top_k(mode)
-        rois, cnt, _ = ops.region_proposal(pred_rpn_reg.detach(), pred_rpn_cls.detach(), anchor, self.min_size / 1000, pre, 0.7, post)
+        lvl = None
+        if self.per_level_nms:
+            A = self.rpn_head.cls_layer.out_channels // 2
+            lvl = np.concatenate([[0], np.cumsum([fh * fw * A for fh, fw in shapes])])
+        rois, cnt, _ = ops.region_proposal(pred_rpn_reg.detach(), pred_rpn_cls.detach(), anchor, self.min_size / 1000, pre, 0.7, post,
+                                           nms_level_offsets=lvl)
         return pred_rpn_cls, pred_rpn_reg, rois, cnt, anchor
 
     def forward(self, x, features, mode):
@@ -289,7 +297,7 @@ class FRCNNTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 512:
                 raise RuntimeError("FRCNNTargetMaker: fewer than 512 samples (assert at new_model.py:183)")
         else:
-            cls, reg, srois, _, _ = ops.head_targets(rois, boxes, labels, seed=s.seed, offset=s.next_offset(),
+            cls, reg, srois, _, _ = ops.head_targets(rois, boxes, labels, philox_state=s.state(rois.device),
                                                      status=s.status.word(rois.device), **kw)
         return cls, reg, srois
 
@@ -312,7 +320,7 @@ class RPNTargetMaker(nn.Module):
             if counts.cpu().tolist()[2] != 0:
                 raise RuntimeError("RPNTargetMaker: permutation length mismatch")
         else:
-            cls, reg, _ = ops.rpn_targets(anchors, boxes, variant=1, seed=s.seed, offset=s.next_offset())
+            cls, reg, _ = ops.rpn_targets(anchors, boxes, variant=1, philox_state=s.state(anchors.device))
         return cls, reg
 
 

@@ -291,9 +291,12 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
     return order[keep[:host_count(cnt)]]
 
 
-def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_threshold, post_nms_top_k, grid=None, want_src=False):
+def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_threshold, post_nms_top_k, grid=None, want_src=False,
+                    nms_level_offsets=None):
     """RegionProposal.forward in one enqueue (no host sync).
     anchors: [N,4] device tensor, or None with grid=(fh, fw, stride, base[A,4] host, div_w, div_h).
+    nms_level_offsets: None = one global class-agnostic NMS (the reference, new_model.py:74-83); a list [0, n_0, n_0 + n_1, ..., N]
+    of per-level anchor offsets = the optional per-FPN-level NMS (boxes only compete inside their level; BASELINE configs[3]).
     Returns (rois [P,4] fixed capacity, count int32[1] device, src_idx [P] | None)."""
     reg = _req(reg, name="reg").reshape(-1, 4)
     cls = _req(cls, name="cls").reshape(-1, 2)
@@ -317,9 +320,15 @@ def region_proposal(reg, cls, anchors, min_size_norm, pre_nms_top_k, iou_thresho
         base = np.ascontiguousarray(base, dtype=np.float32)
         A = base.shape[0]
         base_p = _np_ptr(base)
+    lo_p, n_lv = None, 0
+    if nms_level_offsets is not None:
+        lo = np.ascontiguousarray(nms_level_offsets, dtype=np.int64)
+        if lo.ndim != 1 or len(lo) < 2 or lo[0] != 0 or lo[-1] != N or (np.diff(lo) < 0).any():
+            raise ValueError("region_proposal: nms_level_offsets must be ascending anchor offsets [0, ..., N]")
+        lo_p, n_lv = _np_ptr(lo), len(lo) - 1
     with torch.cuda.device(dev):
         check(lib.frcnn_region_proposal(_ptr(reg), _ptr(cls), _ptr(anchors), N, int(fh), int(fw), int(stride), base_p, int(A),
-                                        float(dw), float(dh), float(min_size_norm), K, float(iou_threshold), P,
+                                        float(dw), float(dh), float(min_size_norm), K, float(iou_threshold), P, lo_p, n_lv,
                                         _ptr(rois), _ptr(cnt), _ptr(src), _ptr(ws), nb, _stream()), "region_proposal")
     return rois, cnt, src
 
@@ -559,8 +568,24 @@ def _perm(p, dev):
     return p, p.numel()
 
 
-def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, offset=0):
-    """RPNTargetMaker.forward.  Returns (cls[N] i64, reg[N,4], counts int32[4] device = n_pos, n_neg, err, -)."""
+def philox_state(seed, offset, device):
+    """Device-resident RNG stream of the target makers: int64[2] = (seed, offset) bit patterns.  Every sampling call that is
+    handed this tensor uses the pair it finds and leaves offset + 1 behind (include/frcnn_hip.h), so a captured HIP graph of
+    the training step draws new samples at each replay."""
+    m = (1 << 64) - 1
+    to_i64 = lambda v: (v & m) - (1 << 64) if (v & m) >= (1 << 63) else (v & m)      # noqa: E731
+    return torch.tensor([to_i64(int(seed)), to_i64(int(offset))], dtype=torch.int64, device=device)
+
+
+def _philox(state):
+    if state is None:
+        return None
+    return _req(state, torch.int64, "philox_state")
+
+
+def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, offset=0, philox_state=None):
+    """RPNTargetMaker.forward.  Returns (cls[N] i64, reg[N,4], counts int32[4] device = n_pos, n_neg, err, -).
+    philox_state (int64[2] on the device, see ops.philox_state) overrides (seed, offset) and is advanced by the call."""
     anchors = _req(anchors, name="anchors").reshape(-1, 4)
     gt = _req(gt, name="gt").reshape(-1, 4)
     N, G = anchors.shape[0], gt.shape[0]
@@ -574,12 +599,12 @@ def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, of
     ws = _workspace(dev, nb)
     with torch.cuda.device(dev):
         check(lib.frcnn_rpn_targets(int(variant), _ptr(anchors), N, _ptr(gt), G, _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
-                                    _ptr(cls), _ptr(reg), _ptr(counts), _ptr(ws), nb, _stream()), "rpn_targets")
+                                    _ptr(_philox(philox_state)), _ptr(cls), _ptr(reg), _ptr(counts), _ptr(ws), nb, _stream()), "rpn_targets")
     return cls, reg, counts
 
 
 def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max_pos=32, total=128,
-                 perm_pos=None, perm_neg=None, seed=0, offset=0, want_keep=False, status=None):
+                 perm_pos=None, perm_neg=None, seed=0, offset=0, want_keep=False, status=None, philox_state=None):
     """FastRcnnTargetMaker.forward.  Returns (cls[total] i64, reg[total,4], sample_rois[total,4], keep|None, counts int32[4]).
     counts[3] holds the _lib.HT_ERR_* bits; they are also OR-ed into `status` (device int32[1], sticky across steps) if given."""
     rois = _req(rois, name="rois").reshape(-1, 4)
@@ -600,7 +625,8 @@ def head_targets(rois, gt, gt_label, n_rois=None, variant=0, label_offset=1, max
     with torch.cuda.device(dev):
         check(lib.frcnn_head_targets(int(variant), _ptr(rois), _ptr(n_rois), rois.shape[0], _ptr(gt), _ptr(gt_label), gt.shape[0],
                                      int(label_offset), int(max_pos), int(total), _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
-                                     _ptr(cls), _ptr(reg), _ptr(srois), _ptr(keep), _ptr(counts), _ptr(status), _stream()), "head_targets")
+                                     _ptr(_philox(philox_state)), _ptr(cls), _ptr(reg), _ptr(srois), _ptr(keep), _ptr(counts), _ptr(status), _stream()),
+              "head_targets")
     return cls, reg, srois, keep, counts
 
 

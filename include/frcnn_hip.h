@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 3
+#define FRCNN_ABI_VERSION 4
 
 typedef enum {
     FRCNN_OK = 0,
@@ -126,11 +126,17 @@ int frcnn_nms_classed(const float *boxes /*[K,4]*/, const int32_t *cls /*[K]*/, 
 
 /* All of RegionProposal.forward in one call (prologue -> top-K -> NMS -> first P), no host sync.
  * anchors may be NULL when the single-level grid description is given (fh,fw,stride,base9x4 on host):
- * the anchors are then regenerated in registers and never read from HBM (anchor.py:34-55 fused away). */
+ * the anchors are then regenerated in registers and never read from HBM (anchor.py:34-55 fused away).
+ * nms_level_offsets_host == NULL (default): ONE class-agnostic NMS over the K boxes of all levels -- what the reference does
+ *   (models/new_model.py:74-83).
+ * nms_level_offsets_host = [n_nms_levels + 1] anchor offsets (level l owns anchors [off[l], off[l+1])): the OPTIONAL per-FPN-level
+ *   variant of BASELINE.json configs[3]: after the same global top-K, box j is suppressed only by a kept box of ITS OWN level
+ *   (torchvision's RPN batched_nms over level ids), then the first P in score order.  n_nms_levels <= 8.                        */
 int frcnn_region_proposal(const float *reg, const float *cls, const float *anchors /*[N,4] or NULL*/, int64_t N,
                           int fh, int fw, int stride, const float *base_host /*[A,4] or NULL*/, int A,
                           float div_w, float div_h,
                           float min_size_norm, int64_t pre_nms_top_k, float iou_threshold, int64_t post_nms_top_k,
+                          const int64_t *nms_level_offsets_host /*[n_nms_levels + 1] or NULL*/, int n_nms_levels,
                           float *out_rois /*[P,4]*/, int32_t *out_count,
                           int64_t *out_src_idx /*[P] anchor index of each roi, or NULL*/,
                           void *workspace, size_t workspace_bytes, void *stream);
@@ -178,11 +184,13 @@ int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *ra
  *   perm_pos / perm_neg != NULL : consume the reference's permutations (parity mode); their lengths must
  *        equal the positive / negative counts (learn them with a first call and out_counts);
  *   else                        : device Philox4x32-10 keyed by (seed, offset): keep the candidates with the
- *        smallest (key, index).
+ *        smallest (key, index).  (seed, offset) come BY VALUE, or -- philox_state_dev != NULL -- from device memory:
+ *        philox_state_dev[0] = seed, [1] = offset; the call uses that pair and leaves offset + 1 behind (ABI v4).  A training
+ *        step captured in a HIP graph therefore draws fresh samples at every replay; by-value arguments would be frozen in it.
  * out_counts (int32[4], device): {n_pos, n_neg before sampling, error flag, reserved}.               */
 int frcnn_rpn_targets(int variant, const float *anchors /*[N,4]*/, int64_t N, const float *gt /*[G,4]*/, int64_t G,
                       const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
-                      uint64_t seed, uint64_t offset,
+                      uint64_t seed, uint64_t offset, uint64_t *philox_state_dev /*[2] device, or NULL*/,
                       int64_t *out_cls /*[N]*/, float *out_reg /*[N,4]*/, int32_t *out_counts /*[4]*/,
                       void *workspace, size_t workspace_bytes, void *stream);
 
@@ -203,7 +211,7 @@ int frcnn_head_targets(int variant, const float *rois, const int32_t *n_rois_dev
                        const float *gt, const int64_t *gt_label, int64_t G,
                        int64_t label_offset, int64_t max_pos, int64_t total,
                        const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
-                       uint64_t seed, uint64_t offset,
+                       uint64_t seed, uint64_t offset, uint64_t *philox_state_dev /*[2] device (see frcnn_rpn_targets), or NULL*/,
                        int64_t *out_cls /*[total]*/, float *out_reg /*[total,4]*/, float *out_rois /*[total,4]*/,
                        int64_t *out_keep_index /*[total] or NULL*/, int32_t *out_counts /*[4]*/,
                        int32_t *sticky_status /* device int32 or NULL */, void *stream);

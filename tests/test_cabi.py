@@ -39,12 +39,12 @@ def test_header_symbols_all_exported_and_bound(L):
 
 
 def test_abi_version_and_error_reporting(L):
-    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 3
+    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 4
     rc = L.lib.frcnn_nms(None, None, 10, 0.5, 10, None, None, None, None, 0, None)      # NULL out_count
     assert rc == -1 and b"nms" in L.lib.frcnn_last_error()
     with pytest.raises(L.FrcnnError):
         L.check(L.lib.frcnn_box_codec(9, None, None, 1, None, None), "box_codec")
-    rc = L.lib.frcnn_rpn_targets(0, None, 10, None, 0, None, 0, None, 0, 0, 0, None, None, None, None, 0, None)
+    rc = L.lib.frcnn_rpn_targets(0, None, 10, None, 0, None, 0, None, 0, 0, 0, None, None, None, None, None, 0, None)
     assert rc == -1 and b"G must be >= 1" in L.lib.frcnn_last_error()                    # the reference crashes on G = 0 too
 
 

@@ -258,7 +258,8 @@ def test_nms_nan_and_inf_boxes_follow_torchvision_semantics(ops, K, thr):
     rng = np.random.RandomState(K)
     b = _with_nonfinite(rng, K)
     keep_o = orc.nms(b, thr)
-    nanrow = np.isnan((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
+    with np.errstate(invalid="ignore"):
+        nanrow = np.isnan((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]))
     assert nanrow.sum() > 0 and set(np.nonzero(nanrow)[0]) <= set(keep_o.tolist())      # NaN-area boxes are all kept
     keep, rois, cnt = ops.nms_sorted(T(b), thr, want_rois=True)
     n = int(cnt.item())
@@ -448,6 +449,64 @@ def test_rpn_targets_device_sampling_fpn_size_chipwide_equals_single_workgroup(o
             assert np.array_equal(a, np.load(os.path.join(d, "out.npy"))), tag
 
 
+def test_philox_state_on_device_equals_by_value_and_advances(ops):
+    """ABI v4: the target makers can take (seed, offset) from a device-resident int64[2]; a call uses the pair it finds and leaves
+    offset + 1 behind.  Same samples as the by-value form for the same (seed, offset); consecutive calls walk the offsets."""
+    rng = np.random.RandomState(21)
+    gt = _gt(rng, 6)
+    lab = rng.randint(0, 20, 6).astype(np.int64)
+    seed = 0x9E3779B97F4A7C15                                   # exercises the high half and the sign bit of the int64 carrier
+    st = ops.philox_state(seed, 40, DEV)
+    rois = rand_boxes(rng, 2000, 0.05, 0.5)
+    rois[:100] = np.clip(gt[rng.randint(0, 6, 100)] + rng.randn(100, 4).astype(np.float32) * 0.01, 0, 1)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    cases = [(orc.anchor_grid(600, 1000), 0), (orc.tv_anchor_grid(800, 1344, shapes, normalise=True), 1)]   # single-workgroup / chip-wide sampler
+    off = 40
+    for anchor, variant in cases:
+        for _ in range(2):
+            a = ops.rpn_targets(T(anchor), T(gt), variant=variant, philox_state=st)[0]
+            b = ops.rpn_targets(T(anchor), T(gt), variant=variant, seed=seed, offset=off)[0]
+            assert torch.equal(a, b)
+            off += 1
+            assert st.cpu().tolist()[1] == off
+    k1 = ops.head_targets(T(rois), T(gt), T(lab), philox_state=st, want_keep=True)[3]
+    k2 = ops.head_targets(T(rois), T(gt), T(lab), seed=seed, offset=off, want_keep=True)[3]
+    k3 = ops.head_targets(T(rois), T(gt), T(lab), philox_state=st, want_keep=True)[3]
+    assert torch.equal(k1, k2) and not torch.equal(k1, k3)
+    assert st.cpu().tolist()[1] == off + 2
+    assert (st.cpu().tolist()[0] & ((1 << 64) - 1)) == seed
+
+
+def test_region_proposal_per_level_nms_option(ops):
+    """Optional per-FPN-level NMS (BASELINE configs[3] wording; the reference itself runs ONE global NMS, new_model.py:74-83):
+    same global top-K, then boxes compete only inside their level.  Oracle = a per-level loop over orc.nms."""
+    rng = np.random.RandomState(8)
+    shapes = [(48, 64), (24, 32), (12, 16), (6, 8), (3, 4)]
+    H, W = 192, 256
+    anchor = orc.tv_anchor_grid(H, W, shapes, normalise=True)
+    N = anchor.shape[0]
+    offs = np.concatenate([[0], np.cumsum([h * w * 3 for h, w in shapes])])
+    assert offs[-1] == N
+    reg, cls = rpn_outputs(rng, N, "trained")
+    reg *= 0.3                                                   # keep neighbours overlapping across levels too
+    K, P = 3000, 500
+    b_o, s_o, _ = orc.proposal_prologue(reg, cls, anchor, 10 / 1000)
+    idx, _ = orc.topk_sorted(s_o, K)
+    sb = b_o[idx]
+    lvl = np.searchsorted(offs, idx, side="right") - 1
+    kept = np.sort(np.concatenate([np.nonzero(lvl == l)[0][orc.nms(sb[lvl == l], 0.7)] for l in range(5)]))[:P]
+    glob = orc.nms(sb, 0.7)[:P]
+    assert not np.array_equal(kept, glob[:len(kept)])            # the option must matter on this input
+    rois, cnt, src = ops.region_proposal(T(reg), T(cls), T(anchor), 10 / 1000, K, 0.7, P, want_src=True, nms_level_offsets=offs)
+    n = int(cnt.item())
+    assert n == len(kept) and np.array_equal(src[:n].cpu().numpy(), idx[kept]) and np.array_equal(rois[:n].cpu().numpy(), sb[kept])
+    rois, cnt, src = ops.region_proposal(T(reg), T(cls), T(anchor), 10 / 1000, K, 0.7, P, want_src=True)      # default: global
+    n = int(cnt.item())
+    assert n == len(glob) and np.array_equal(src[:n].cpu().numpy(), idx[glob])
+    with pytest.raises(ValueError):
+        ops.region_proposal(T(reg), T(cls), T(anchor), 10 / 1000, K, 0.7, P, nms_level_offsets=[0, 5, 3, N])
+
+
 @pytest.mark.parametrize("variant,label_offset,max_pos,total,P", [(0, 1, 32, 128, 2000), (0, 1, 32, 128, 300), (1, 0, 128, 512, 1000)])
 def test_head_targets_host_perm_parity(ops, variant, label_offset, max_pos, total, P):
     rng = np.random.RandomState(P + variant)
@@ -525,6 +584,24 @@ def test_roi_pool_fwd_bwd_vs_oracle(ops, C, H, W, R):
     out.backward(T(go))
     gf_o = orc.roi_pool_bwd(go, arg_o, C, H, W)
     assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-5, atol=1e-5)      # fp32 sum order differs: 1e-5
+
+
+def test_roi_pool_backward_large_bin_grid(ops):
+    """17 x 17 bins: one channel-pair run (2 * 289 elements) is longer than the LDS backward kernel's 512-thread pass; the generic int32
+    entry point must route such shapes to the one-channel kernel instead of writing an all-zero gradient."""
+    rng = np.random.RandomState(17)
+    C, H, W, R, PH = 6, 40, 50, 9, 17
+    feat = rng.randn(C, H, W).astype(np.float32)
+    rois = rand_boxes(rng, R, 0.2, 0.9) * np.array([W, H, W, H], np.float32)
+    out_o, arg_o = orc.roi_pool_fwd(feat, rois, PH, PH, 1.0)
+    out, arg = ops.roi_pool_with_argmax(T(feat[None]), T(rois), (PH, PH), 1.0)
+    assert np.array_equal(out.cpu().numpy(), out_o) and np.array_equal(arg.cpu().numpy(), arg_o)
+    ft = T(feat[None]).requires_grad_(True)
+    o = ops.roi_pool(ft, T(rois), (PH, PH), 1.0)
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    o.backward(T(go))
+    ref = orc.roi_pool_bwd(go, arg_o, C, H, W)
+    assert np.abs(ref).sum() > 0 and np.allclose(ft.grad[0].cpu().numpy(), ref, atol=1e-5)
 
 
 @pytest.mark.parametrize("C,H,W,R", [(512, 37, 62, 128), (6, 9, 11, 5), (3, 70, 70, 9)])
