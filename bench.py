@@ -2,20 +2,26 @@
 """bench.py -- BASELINE.json's metric: training images/sec of Faster R-CNN on synthetic frames, batch 1 per GPU, the
 proposal / RoI-head path on the hand-written HIP kernels.
 
-    python bench.py                          # configs[1]: VGG16, 600x1000, 1 GPU (the headline configuration)
+    python bench.py                          # configs[1]: VGG16, 600x1000, 1 GPU (the headline configuration) + an `also` block
+                                             #   with short driver-timed runs of configs[3] / configs[4] (ResNet-50-FPN fp32 / bf16)
     python bench.py --config fpn             # configs[3]: ResNet-50-FPN, 800x1344 (COCO shape padded to /32), fp32
     python bench.py --config fpn --amp bf16  # configs[4]: bf16 autocast on the torch layers + bf16 MFMA RPN head, fp32 box path
+    python bench.py --config fpn --graph     # the same step captured once per resident frame in a HIP graph and replayed
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One step = forward (backbone -> RPN -> proposals -> targets -> RoIPool / RoIAlign -> head) + loss + backward + SGD on one
 frame per GPU.  Frames and boxes are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
   roofline     : the hand-written kernel with the largest average launch time in the timed region, timed live with HIP events
-                 on its launch stream (libfrcnn_hip's frcnn_prof_* facility); `bound` says what actually bounds it ("latency" for
-                 the single-workgroup sequential kernels, "valu" for the pair-IoU / rank kernels whose compulsory bytes are
-                 negligible, "hbm" for the streaming ones); `hbm_kernel` is the largest HBM-bound kernel beside it.
+                 on its launch stream (libfrcnn_hip's frcnn_prof_* facility; kernels are reported under their own names, the
+                 ones rocprofv3 prints); `bound` says what actually bounds it ("latency" for the single-workgroup sequential
+                 kernels, "valu" for the pair-IoU kernels whose compulsory bytes are negligible, "hbm" for the streaming ones,
+                 "mfma" for the conv head); `hbm_kernel` is the largest HBM-bound kernel beside it.
   cpu_baseline : the oracle's CPU restatement of the same training step (oracle/model_ref.py) on a bounded number of steps.
-  hot_path     : per-kernel mean / median / p10 / p90 launch time, bytes, GB/s, PMC traffic.
+  hot_path     : per-kernel mean / median / p10 / p90 launch time, bytes, GB/s, PMC traffic; proposals/s from the
+                 device-side proposal counts of the timed steps.
+  also         : (default VGG run on one GPU only) the same record for short runs of --config fpn and --config fpn --amp bf16, so
+                 that BASELINE's "RoIAlign + NMS us/img" and configs[3]/[4] are timed by whoever runs this command.
 """
 import argparse
 import gc
@@ -35,12 +41,16 @@ for _k in ("FWD", "BWD", "WRW"):
 # PyTorch TunableOp: the first time a GEMM shape is seen (the initialisation pass below, outside the W / K accounting) every rocBLAS /
 # hipBLASLt solution for it is timed and the fastest is kept for the rest of the process (~8 s for the dozen shapes of a step).  The
 # default heuristic picks a 64x64 macro-tile for the classifier's 128 x 25088 x 4096 GEMMs that streams the 411 MB weight at 1.46 TB/s
-# (282 us, three of them per step); the tuned pick takes 190 us: 14.57 -> 14.29 ms per VGG step.  FRCNN_BENCH_TUNABLEOP=0 turns it off.
-if os.environ.get("FRCNN_BENCH_TUNABLEOP", "1") != "0":
+# (282 us, three of them per step); the tuned pick takes 190 us: 14.57 -> 14.29 ms per VGG step.  --no-tunableop (or
+# FRCNN_BENCH_TUNABLEOP=0) turns it off; the JSON line says which it was and whether the picks were tuned now or read from a file.
+TUNABLEOP = os.environ.get("FRCNN_BENCH_TUNABLEOP", "1") != "0" and "--no-tunableop" not in sys.argv
+TUNABLEOP_FILE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "frcnn_bench_tunableop_%d.csv")
+TUNABLEOP_CACHED = bool(glob.glob(TUNABLEOP_FILE.replace("%d", "*")))
+if TUNABLEOP:
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(os.environ.get("TMPDIR", "/tmp"), "frcnn_bench_tunableop_%d.csv"))
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", TUNABLEOP_FILE)
 
 import torch  # noqa: E402
 
@@ -48,6 +58,7 @@ import torch  # noqa: E402
 # 2.4 GHz -> 256 * 4 * 32 * 2.4e9 = 78.6 T lane-ops/s (= the 157.3 TFLOP/s fp32 vector peak / 2 flops per FMA).
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
 
 CONFIGS = {
     "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
@@ -65,13 +76,12 @@ CONFIGS = {
                          "MultiScaleRoIAlign 7x7 on 256 x {200x336,100x168,50x84,25x42})"),
 }
 
-# what bounds each hand-written kernel
-BOUND = {"nms_emit_kernel": "latency", "rpn_sample_kernel": "latency", "head_targets_kernel": "latency",
-         "rpn_colmax_kernel": "latency", "rpn_label_kernel": "latency", "proposal_prologue_kernel": "latency",
-         "det_loss_kernel": "latency", "rpn_head_tail_kernel": "latency", "rpn_head_tail_bwd_kernel": "latency", "roi_level_map_kernel": "latency",
-         "nms_kernel": "valu", "topk_partition_kernels": "latency", "topk_bucket_kernel": "latency",
-         "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm", "roi_align_fwd_kernel": "hbm", "roi_align_bwd_kernel": "hbm", "roi_align_bwd_lists_kernel": "latency", "roi_align_bwd_combine_kernel": "hbm",
-         "rpn_conv3x3_head_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
+# What bounds each hand-written kernel; keys are the kernels' own names.  Anything not listed: "latency".
+BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
+         "roi_pool_fwd_lds_kernel": "hbm", "roi_pool_bwd_lds_kernel": "hbm", "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm",
+         "roi_align_fwd77_kernel": "hbm", "roi_align_fwd_nhwc_kernel": "hbm", "roi_align_bwd_tile_kernel": "hbm", "roi_align_bwd_nhwc_kernel": "hbm",
+         "roi_align_bwd_combine_kernel": "hbm", "rpn_conv3x3_head_kernel": "mfma", "rpn_conv3x3_bwd_data_kernel": "mfma",
+         "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
 
 
 def synth_frame(cfg, rank, step):
@@ -87,35 +97,34 @@ def synth_frame(cfg, rank, step):
 
 
 def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
-    """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels')."""
+    """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels'); None where the figure would say nothing."""
     nblk = (K + 63) // 64
+    pooled = R * C * 49
     return {
         "proposal_prologue_kernel": 44 * N,                               # reg 16N + cls 8N in, boxes 16N + scores 4N out
-        "topk_partition_kernels": 4 * N,                                  # per launch (sample / count / place): scores in
+        "topk_count_kernel": 4 * N, "topk_place_kernel": 4 * N + 8 * N, "topk_partition_kernel": 8 * N + 8 * N,
         "topk_bucket_kernel": 8 * N + 16 * K + 28 * K,                    # placed keys + the K gathered boxes in, idx/score/box out
-        "nms_kernel": 16 * K + 8 * K * nblk // 2 + 8 * K + 8 * 2 * nblk,  # boxes in + (at most) the lower-triangle relation out; resolver: a word per box + bitmaps
+        "nms_kernel": 16 * K + 8 * K + 8 * 2 * nblk,                      # compulsory: boxes in, a word per box + the two bitmaps (SURVEY 8d: negligible)
+        "nms_filter_kernel": 16 * K + 16 * K,                             # boxes in, compacted survivors out
         "nms_emit_kernel": 8 * nblk + 16 * P + 8 * P + 16 * P,            # bitmap + kept boxes in, keep + rois out
-        "rpn_colmax_kernel": 16 * (N + G),
-        "rpn_label_kernel": 16 * (N + G) + 24 * N,                        # anchors + gt in, cls i64 + reg out
+        "rpn_colmax_kernel": 16 * (N + G), "rpn_label_kernel": 16 * (N + G) + 24 * N, "rpn_match_kernel": 2 * 16 * (N + G) + 24 * N,
         "rpn_sample_kernel": 9 * N,
         "head_targets_kernel": 16 * (P + G) + 44 * R,
-        "roi_pool_fwd_kernel": feat_bytes + 16 * R + 6 * R * C * 49,      # features + rois in, out (fp32) + argmax (16-bit, the autograd pair) out
-        "roi_pool_bwd_kernel": 6 * R * C * 49 + feat_bytes,               # grad_out + 16-bit argmax in, grad_feat out
-        "roi_align_fwd_kernel": 4 * R * C * 49 + feat_bytes,              # SURVEY 8d: out + (at most) the four pooled levels in
-        "roi_align_bwd_kernel": 4 * R * C * 49 + feat_bytes,              # grad_out in + every gradient pixel written once
+        "roi_pool_fwd_lds_kernel": feat_bytes + 16 * R + 6 * pooled,      # features + rois in, out (fp32) + argmax (16-bit, the autograd pair) out
+        "roi_pool_bwd_lds_kernel": 6 * pooled + feat_bytes,               # grad_out + 16-bit argmax in, grad_feat out
+        "roi_align_fwd77_kernel": 4 * pooled + feat_bytes,                # SURVEY 8d: out + (at most) the four pooled levels in
+        "roi_align_fwd_nhwc_kernel": 4 * pooled + feat_bytes,
+        "roi_align_bwd_tile_kernel": 4 * pooled + feat_bytes,             # grad_out in + every gradient pixel written once
+        "roi_align_bwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
     }.get(kernel)
 
 
-MFMA_PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
-
-
 def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
-    return {
-        # raw = conv3x3 (C x 9C per position) + both 1x1 heads (6A x C); C = 256 in the FPN head this kernel is built for
-        "rpn_conv3x3_head_kernel": 2 * 256 * (9 * 256 + 6 * A) * P_head,
-    }.get(kernel)
+    conv = 2 * 256 * 9 * 256 * P_head                                     # C = 256 in the FPN head these kernels are built for
+    return {"rpn_conv3x3_head_kernel": conv + 2 * 256 * 6 * A * P_head,   # raw = conv3x3 + both 1x1 heads
+            "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv}.get(kernel)
 
 
 def percentiles(v):
@@ -130,48 +139,39 @@ def percentiles(v):
 T0 = time.perf_counter()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=12)
-    ap.add_argument("--config", default="vgg", choices=sorted(CONFIGS), help="vgg = BASELINE configs[1]/[2] (headline); fpn = configs[3]/[4]")
-    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident in HBM")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=None)
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket the library kernels of every n-th timed step (live roofline samples)")
-    ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
-    ap.add_argument("--miopen-search", action="store_true", help="torch.backends.cudnn.benchmark=True (exhaustive MIOpen find)")
-    ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
-    ap.add_argument("--no-fused-sgd", action="store_true")
-    ap.add_argument("--amp", default="none", choices=["none", "bf16"],
-                    help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+def load_pmc(config, amp):
+    """HBM traffic per launch from the rocprofv3 PMC passes over THIS command (tools/pmc_traffic.sh: separate FETCH_SIZE /
+    WRITE_SIZE runs of bench.py itself, gfx950 fetch correction); measured per round and committed under profiles/.  Keys are
+    kernel names; lookup is by EXACT name (a kernel the profile does not list has traffic null)."""
+    pmc_cfg = "fpn_bf16" if (config == "fpn" and amp == "bf16") else config
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % pmc_cfg)))
+    if not cands:
+        return {}, None
+    try:
+        with open(cands[-1]) as f:
+            return json.load(f)["kernels"], os.path.relpath(cands[-1], ROOT)
+    except (OSError, ValueError, KeyError):
+        return {}, None
 
+
+def run_config(args, config, amp, steps, warmup, graph, rank, world, device, with_cpu):
+    """One bench record (the JSON object described in the module docstring) for one configuration."""
     from faster_rcnn_pytorch_amd import _lib, parallel
     from faster_rcnn_pytorch_amd.loss import FRCNNLoss
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    rank, local_rank, world, device = parallel.init_for_distributed()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
-    torch.backends.cudnn.benchmark = bool(args.miopen_search)
+    cfg = CONFIGS[config]
 
     def log(msg):
         if rank == 0:
-            print("[bench %7.1fs] %s" % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+            print("[bench %7.1fs] %s%s: %s" % (time.perf_counter() - T0, config, "+" + amp if amp != "none" else "", msg), file=sys.stderr, flush=True)
 
     torch.manual_seed(0)
-    if args.config == "vgg":
+    if config == "vgg":
         from faster_rcnn_pytorch_amd.model import FRCNN
     else:
         from faster_rcnn_pytorch_amd.new_model import FRCNN
     model = FRCNN(num_classes=cfg["num_classes"], sampling="device", seed=1234 + rank).to(device)
     if args.channels_last:
-        bb = "extractor" if args.config == "vgg" else "backbone"
+        bb = "extractor" if config == "vgg" else "backbone"
         setattr(model, bb, getattr(model, bb).to(memory_format=torch.channels_last))
     net = parallel.wrap_ddp(model, device)
     crit = FRCNNLoss(None)
@@ -186,10 +186,11 @@ def main():
             x = x.contiguous(memory_format=torch.channels_last)
         frames.append((x, b.to(device), l.to(device)))
     torch.cuda.synchronize()
+    counts = []                                       # device-side proposal counts of the timed steps (read after the timed region)
 
-    def step(i):
-        x, b, l = frames[i % len(frames)]
-        if args.amp == "bf16":
+    def body(fi):
+        x, b, l = frames[fi]
+        if amp == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred, target = net(x, [b], [l])
             pred = tuple(p.float() for p in pred)
@@ -201,171 +202,271 @@ def main():
         opt.step()
         return loss
 
+    def eager_step(i):
+        loss = body(i % len(frames))
+        counts.append(model.last_proposal_count)
+        return loss
+
     # Initialisation pass, outside the W / K accounting: the first steps of a process select and compile MIOpen kernels, grow the
     # caching allocator and the library workspaces (seconds, not steady state).  The W warm-up steps below then run warm.
-    log("%s model + %d frames resident; initialisation pass" % (args.config, len(frames)))
+    log("model + %d frames resident; initialisation pass" % len(frames))
     for i in range(3):
-        step(i)
+        eager_step(i)
     torch.cuda.synchronize()
+    step = eager_step
+    graphs = None
+    if graph:
+        # One HIP graph per resident frame (the number of ground-truth boxes, a launch argument, differs per frame), all in one
+        # memory pool: forward + loss + backward + SGD captured once, replayed as a single submission.  Nothing on the path syncs
+        # the host; the sampling RNG stream lives in device memory (ops.philox_state), so every replay draws fresh samples.
+        if world > 1:
+            raise SystemExit("--graph is a single-process mode (DDP's bucket hooks are not captured)")
+        log("capturing %d step graphs" % len(frames))
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(len(frames)):
+                body(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs, pool = [], None
+        # the graphs share one memory pool, so a graph's outputs live only until the next graph replays: the two scalars read after
+        # the timed region (loss, proposal count) are copied to persistent tensors INSIDE the captured step
+        keep_loss = torch.zeros((len(frames),), dtype=torch.float32, device=device)
+        keep_cnt = torch.zeros((len(frames),), dtype=torch.int32, device=device)
+        for fi in range(len(frames)):
+            g = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(g, pool=pool):
+                loss = body(fi)
+                keep_loss[fi:fi + 1].copy_(loss.detach().reshape(1))
+                keep_cnt[fi:fi + 1].copy_(model.last_proposal_count)
+            pool = g.pool()
+            graphs.append((g, keep_loss[fi], keep_cnt[fi:fi + 1]))
+
+        def graph_step(i):
+            g, loss, cnt = graphs[i % len(graphs)]
+            g.replay()
+            return loss
+        step = graph_step
     # The FPN step enqueues ~2500 launches from Python; a generation-2 garbage collection in the middle of a step stalls the
     # enqueue for 70-100 ms (3 of 60 timed steps read 90-115 ms against a 19.4 ms median).  Everything allocated so far is
     # long-lived: freeze it and keep the collector off while steps are timed (reference counting still frees the step's tensors).
-    gc.collect(); gc.freeze(); gc.disable()
+    if not args.gc_on:
+        gc.collect(); gc.freeze(); gc.disable()
     log("warm-up")
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
         torch.cuda.synchronize()
-        log("warm-up step %d done" % i)
-    if not args.no_kernel_events:
+    log("warm-up done (%d steps)" % warmup)
+    events = not args.no_kernel_events and not graph
+    if events:
         _lib.prof_reset()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # step boundaries on the main stream (no sync)
+    del counts[:]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # step boundaries on the main stream (no sync)
     ms0 = torch.cuda.memory_stats(device)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         marks[i].record()
-        if not args.no_kernel_events:
+        if events:
             _lib.prof_enable(i % args.event_every == 0)    # the HIP-event brackets cost ~0.2 ms per step: sample every n-th timed step
-        loss = step(args.warmup + i)
-    marks[args.steps].record()
+        loss = step(warmup + i)
+    marks[steps].record()
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0
     _lib.prof_enable(False)
     dt = parallel.max_over_ranks(dt_local, device)
-    per_rank_ms = [round(v / args.steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
-    log("timed region: %d steps in %.3f s" % (args.steps, dt))
+    per_rank_ms = [round(v / steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
+    log("timed region: %d steps in %.3f s" % (steps, dt))
     gc.enable()
     ms1 = torch.cuda.memory_stats(device)
     allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
     final_loss = float(loss.detach())
     model.check_device_status()                      # sticky device-side error word (aborted scan / short sample): raises if set
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    n_sampled = len(range(0, steps, args.event_every))               # timed steps whose kernels were bracketed
+    if graph and not args.no_kernel_events:
+        # a captured graph cannot carry the per-kernel event brackets: the live kernel times of --graph come from a short EAGER pass
+        # of the same steps right after the timed region (same process, same frames, warm)
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        n_sampled = min(8, steps)
+        for i in range(n_sampled):
+            eager_step(i)
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        if graphs:
+            counts[:] = [g[2] for g in graphs]
     samples = {} if args.no_kernel_events else _lib.prof_samples()
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    n_props = [int(c.item()) for c in counts if c is not None]       # device counts, read after the timed region
+    mean_props = sum(n_props) / len(n_props) if n_props else None
     backend = torch.distributed.get_backend() if world > 1 else None
     world_seen = torch.distributed.get_world_size() if world > 1 else 1
+    ddp = parallel.ddp_report(net)
 
-    if rank != 0:
-        parallel.shutdown()
-        return
-    ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
-    shape = cfg["shape"]
-    # HBM traffic per launch from the rocprofv3 PMC passes over THIS command (tools/pmc_traffic.sh: separate FETCH_SIZE /
-    # WRITE_SIZE runs of bench.py itself, gfx950 fetch correction); measured per round and committed under profiles/
-    pmc, pmc_src = {}, None
-    pmc_cfg = "fpn_bf16" if (args.config == "fpn" and args.amp == "bf16") else args.config
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % pmc_cfg)))
-    if not cands:
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % args.config)))
-    if not cands and args.config == "vgg":
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_hotpath_pmc_traffic.json")))
-    if cands:
-        try:
-            with open(cands[-1]) as f:
-                pmc = json.load(f)["kernels"]
-            pmc_src = os.path.relpath(cands[-1], ROOT)
-        except (OSError, ValueError, KeyError):
-            pmc = {}
+    record = None
+    if rank == 0:
+        ms_per_step = dt / steps * 1e3
+        value = world * steps / dt
+        shape = cfg["shape"]
+        pmc, pmc_src = load_pmc(config, amp)
 
-    def pmc_traffic(name):
-        if name in pmc:
-            return pmc[name]["traffic_bytes"]
-        stem = name[:-len("_kernel")] if name.endswith("_kernel") else name
-        for k, v in pmc.items():
-            if k.startswith(stem):
-                return v["traffic_bytes"]
-        return None
-    # the compulsory bytes of NMS / top-k are negligible, so those two are ALSO priced against the fp32 VALU issue
-    # peak (VALU_PEAK_LANE_OPS above): pair IoUs x 16 VALU ops (counted in the ISA of nms.hip's sup_half)
-    valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 16}
-    n_sampled = len(range(0, args.steps, args.event_every))          # timed steps whose kernels were bracketed
-    per_kernel = {}
-    for name, v in samples.items():
-        n = len(v)
-        us = sum(v) / n * 1e3
-        med, p10, p90 = (x * 1e3 for x in percentiles(v))
-        ab = algorithmic_bytes(name, **shape)
-        per_kernel[name] = {"bound": BOUND.get(name, "latency"), "avg_us": round(us, 2), "median_us": round(med, 2), "p10_us": round(p10, 2),
-                            "p90_us": round(p90, 2), "launches": n, "us_per_img": round(sum(v) * 1e3 / n_sampled, 2),
-                            "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
-                            "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
-        af = algorithmic_flops(name, **shape)
-        if af:
-            per_kernel[name]["algorithmic_flops"] = af
-            per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
-            per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / MFMA_PEAK_BF16_TFLOPS, 5)
-        if valu_ops.get(name):
-            per_kernel[name]["valu_lane_ops"] = valu_ops[name]
-            per_kernel[name]["valu_frac_of_78.6T"] = round(valu_ops[name] / (us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
-        if name == "nms_kernel":
-            per_kernel[name]["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (us * 1e-6), 0)
+        def pmc_traffic(name):
+            return pmc[name]["traffic_bytes"] if name in pmc else None
+        # the compulsory bytes of NMS are negligible, so it is ALSO priced against the fp32 VALU issue peak: pair IoUs x 16
+        # VALU ops (counted in the ISA of nms.hip's pair loop).  The pair count is the FULL K (K - 1) / 2 of torchvision's mask
+        # kernel, also where the cascade (nms.hip) evaluates fewer pairs -- `pairs_evaluated` is not known on the host.
+        valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 16}
+        per_kernel = {}
+        for name, v in samples.items():
+            n = len(v)
+            us = sum(v) / n * 1e3
+            med, p10, p90 = (x * 1e3 for x in percentiles(v))
+            ab = algorithmic_bytes(name, **shape)
+            per_kernel[name] = {"bound": BOUND.get(name, "latency"), "avg_us": round(us, 2), "median_us": round(med, 2), "p10_us": round(p10, 2),
+                                "p90_us": round(p90, 2), "launches": n, "launches_per_img": round(n / max(n_sampled, 1), 2),
+                                "us_per_img": round(sum(v) * 1e3 / max(n_sampled, 1), 2),
+                                "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
+                                "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+            af = algorithmic_flops(name, **shape)
+            if af:
+                per_kernel[name]["algorithmic_flops"] = af
+                per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
+                per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / MFMA_PEAK_BF16_TFLOPS, 5)
+        # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
+        nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
+        if "nms_kernel" in per_kernel and nms_us > 0:
+            d = per_kernel["nms_kernel"]
+            d["valu_lane_ops_full_pair_count"] = valu_ops["nms_kernel"]
+            d["nms_stage_us_per_img"] = round(nms_us, 2)
+            d["valu_frac_of_78.6T"] = round(valu_ops["nms_kernel"] / (nms_us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
+            d["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (nms_us * 1e-6), 0)
 
-    def roofline_of(name):
-        d = per_kernel[name]
-        if d["bound"] == "valu" and d.get("valu_lane_ops"):
-            # priced against the fp32 VALU issue peak: its compulsory HBM bytes are negligible (the GB/s figure is kept beside it)
-            return {"kernel": name, "bound": "valu", "achieved": round(d["valu_lane_ops"] / (d["avg_us"] * 1e-6) * 1e-12, 3),
-                    "peak": round(VALU_PEAK_LANE_OPS * 1e-12, 1), "unit": "T lane-ops/s", "frac": d["valu_frac_of_78.6T"],
-                    "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"], "median_launch_us": d["median_us"],
-                    "valu_lane_ops": d["valu_lane_ops"], "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
-                    "note": "relation tiles (VALU) + a cross-CU dependency chain in one launch: the chain, not the issue rate, is most of the time"}
-        if d["bound"] == "mfma" and d.get("algorithmic_flops"):
-            return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
-                    "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
-        return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
-                "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
-    roofline = None
-    if per_kernel:
-        dom = max(per_kernel, key=lambda k: per_kernel[k]["avg_us"])
-        roofline = roofline_of(dom)
-        roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
-        if roofline["bound"] not in ("hbm", "mfma", "valu"):
-            roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
-                                "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
-        hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm"]
-        if hbm:
-            roofline["hbm_kernel"] = roofline_of(max(hbm, key=lambda k: per_kernel[k]["avg_us"]))
-    hot_us = sum(v["us_per_img"] for v in per_kernel.values())
-    smed, sp10, sp90 = percentiles(step_ms)
+        def roofline_of(name):
+            d = per_kernel[name]
+            if d["bound"] == "valu" and d.get("valu_lane_ops_full_pair_count"):
+                # priced against the fp32 VALU issue peak: its compulsory HBM bytes are negligible (the GB/s figure is kept beside it)
+                return {"kernel": name, "bound": "valu", "achieved": round(d["valu_lane_ops_full_pair_count"] / (d["nms_stage_us_per_img"] * 1e-6) * 1e-12, 3),
+                        "peak": round(VALU_PEAK_LANE_OPS * 1e-12, 1), "unit": "T lane-ops/s", "frac": d["valu_frac_of_78.6T"],
+                        "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"], "median_launch_us": d["median_us"],
+                        "nms_stage_us_per_img": d["nms_stage_us_per_img"], "valu_lane_ops": d["valu_lane_ops_full_pair_count"],
+                        "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
+                        "note": "all NMS launches of one image over the full K(K-1)/2 pair count x 16 VALU; the cascade evaluates fewer pairs than that"}
+            if d["bound"] == "mfma" and d.get("algorithmic_flops"):
+                return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                        "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
+            return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                    "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
+        roofline = None
+        if per_kernel:
+            dom = max(per_kernel, key=lambda k: per_kernel[k]["us_per_img"])
+            roofline = roofline_of(dom)
+            roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
+            if roofline["bound"] not in ("hbm", "mfma", "valu"):
+                roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
+                                    "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
+            hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm" and per_kernel[k]["algorithmic_bytes"]]
+            if hbm:
+                roofline["hbm_kernel"] = roofline_of(max(hbm, key=lambda k: per_kernel[k]["us_per_img"]))
+            if graph:
+                roofline["measured_in"] = "an eager pass of %d steps after the timed graph replays (a captured graph cannot carry the event brackets)" % n_sampled
+        hot_us = sum(v["us_per_img"] for v in per_kernel.values())
+        smed, sp10, sp90 = percentiles(step_ms)
+        cpu = cpu_baseline(config, cfg, args.cpu_steps, args.lr) if with_cpu else None
+        st = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("proposal_prologue", "topk_", "nms_", "level_ids")))
+        record = {
+            "metric": cfg["metric"], "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
+            "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox",
+                       "submission": "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
+                        "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
+                        "source": "HIP events at the step boundaries on the main stream (rank 0)"},
+            "allocator_in_timed_region": allocator,
+            "conditions": {
+                "gemm_selection": ("PyTorch TunableOp: rocBLAS / hipBLASLt solution timed and picked per GEMM shape during the initialisation pass"
+                                   if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default heuristics"),
+                "tunableop_results": (("read from a results file of an earlier run + tuned now for new shapes" if TUNABLEOP_CACHED else "tuned in this process")
+                                      if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else None),
+                "python_gc": "on" if args.gc_on else "frozen after initialisation, off while the timed steps run (--gc-on to leave it on)",
+                "off_switches": "--no-tunableop --gc-on give the untuned, collector-on figure"},
+            "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
+                            "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms), "ddp": ddp},
+            "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1),
+                         "launches_per_img": round(sum(v["launches_per_img"] for v in per_kernel.values()), 1),
+                         # proposals actually produced: mean of the device-side counts of the timed steps (capacity P is an upper bound)
+                         "mean_proposals_per_img": round(mean_props, 1) if mean_props is not None else None,
+                         "proposals_per_s": round(value * mean_props, 1) if mean_props is not None else None,
+                         # BASELINE.json's second figure: NMS + RoI pooling forward/backward, HIP-event us per image
+                         "nms_plus_roi_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
+                         # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
+                         "proposal_stage_us_per_img": round(st, 1),
+                         "proposal_stage_proposals_per_s": round(mean_props / (st * 1e-6), 0) if (st and mean_props is not None) else None,
+                         "kernels": per_kernel},
+            "final_loss": round(final_loss, 4), "device_status": 0,
+        }
+    return record
 
-    cpu = None
-    if not args.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline(args.config, cfg, args.cpu_steps, args.lr)
 
-    P = shape["P"]
-    out = {
-        "metric": cfg["metric"], "value": round(value, 3), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
-        "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox"},
-        "roofline": roofline,
-        "cpu_baseline": cpu,
-        "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
-                    "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
-                    "source": "HIP events at the step boundaries on the main stream (rank 0)"},
-        "allocator_in_timed_region": allocator,
-        "gemm_selection": ("PyTorch TunableOp: rocBLAS / hipBLASLt solution timed and picked per GEMM shape during the initialisation pass"
-                           if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default heuristics"),
-        "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
-                        "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms)},
-        "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1), "proposals_per_s": round(value * P, 1),
-                     # BASELINE.json's second figure: NMS (mask + scan) + RoI pooling forward/backward, HIP-event us per image
-                     "nms_plus_roi_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
-                     # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
-                     "proposal_stage_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items()
-                                                            if k.startswith(("proposal_prologue", "topk_", "nms_"))), 1),
-                     "kernels": per_kernel},
-        "final_loss": round(final_loss, 4), "device_status": 0,
-    }
-    st = out["hot_path"]["proposal_stage_us_per_img"]
-    out["hot_path"]["proposal_stage_proposals_per_s"] = round(P / (st * 1e-6), 0) if st else None
-    print(json.dumps(out), flush=True)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--config", default="vgg", choices=sorted(CONFIGS), help="vgg = BASELINE configs[1]/[2] (headline); fpn = configs[3]/[4]")
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
+    ap.add_argument("--event-every", type=int, default=4, help="bracket the library kernels of every n-th timed step (live roofline samples)")
+    ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
+    ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
+    ap.add_argument("--no-fused-sgd", action="store_true")
+    ap.add_argument("--no-tunableop", action="store_true", help="library default GEMM heuristics instead of PyTorch TunableOp")
+    ap.add_argument("--gc-on", action="store_true", help="leave Python's cyclic garbage collector on during the timed region")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (one HIP graph per resident frame) and time replays")
+    ap.add_argument("--no-also", action="store_true", help="headline run only: skip the short FPN fp32 / bf16 runs of the `also` block")
+    ap.add_argument("--also-steps", type=int, default=20)
+    ap.add_argument("--amp", default="none", choices=["none", "bf16"],
+                    help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
+    args = ap.parse_args()
+
+    from faster_rcnn_pytorch_amd import parallel
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    rank, local_rank, world, device = parallel.init_for_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+    torch.backends.cudnn.benchmark = False
+
+    def release():                                    # the finished configuration's model / optimizer / graphs, before the next one is built
+        gc.unfreeze()
+        gc.collect()
+        torch.cuda.empty_cache()
+    out = run_config(args, args.config, args.amp, args.steps, args.warmup, args.graph, rank, world, device,
+                     with_cpu=(not args.no_cpu_baseline and world == 1))
+    release()
+    if rank == 0 and world == 1 and not args.no_also and args.config == "vgg" and args.amp == "none" and not args.graph:
+        # BASELINE.json configs[3] / configs[4] and its "RoIAlign + NMS us/img" figure, timed by the same command (short runs)
+        also = []
+        for amp in ("none", "bf16"):
+            rec = run_config(args, "fpn", amp, args.also_steps, 5, False, rank, world, device, with_cpu=False)
+            rec["config"]["note"] = "short run inside the headline command: %d timed steps, 5 warm-up" % args.also_steps
+            also.append(rec)
+            release()
+        out["also"] = also
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     parallel.shutdown()
 
 

@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cctype>
 #include <mutex>
+#include <string>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -83,12 +85,7 @@ FRCNN_EXPORT int frcnn_tv_base_anchors_host(float size, const float *ratios, int
 }
 
 // ---- per-kernel timing with HIP events on the launch stream ----
-static const char *const g_kernel_names[KID_COUNT] = {
-    "anchor_grid_kernel", "box_codec_kernel", "pairwise_iou_kernel", "proposal_prologue_kernel",
-    "topk_partition_kernels", "topk_bucket_kernel", "nms_kernel", "nms_resolve_kernel(unused)",
-    "rpn_colmax_kernel", "rpn_label_kernel", "rpn_sample_kernel", "head_targets_kernel",
-    "roi_pool_fwd_kernel", "roi_pool_bwd_kernel", "roi_level_map_kernel", "roi_align_fwd_kernel", "roi_align_bwd_kernel", "rpn_head_tail_kernel", "det_loss_kernel", "preprocess_kernel", "nms_emit_kernel", "rpn_head_tail_bwd_kernel", "rpn_conv3x3_head_kernel", "rpn_conv_pack_kernel", "roi_align_bwd_lists_kernel", "roi_align_bwd_combine_kernel"};
-
+#define KID_COUNT FRCNN_PROF_MAX_KERNELS
 struct ProfRec { int kid; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_enabled = false;
@@ -97,6 +94,25 @@ static std::vector<hipEvent_t> g_prof_free;
 static double g_prof_ms[KID_COUNT];
 static int64_t g_prof_n[KID_COUNT];
 static std::vector<float> g_prof_samples[KID_COUNT];      // per-launch durations (ms): median / percentiles for bench.py
+static std::string g_kernel_names[KID_COUNT];
+static int g_n_kernels = 0;
+
+// "(roi_pool_fwd_lds_kernel<7, 7, AT>)" -> "roi_pool_fwd_lds_kernel": the name rocprofv3 prints without its template arguments
+int frcnn_prof_register(const char *expr)
+{
+    std::string n(expr ? expr : "");
+    size_t b = 0;
+    while (b < n.size() && (n[b] == '(' || n[b] == ' ')) ++b;
+    size_t e = b;
+    while (e < n.size() && (isalnum((unsigned char)n[e]) || n[e] == '_')) ++e;
+    n = n.substr(b, e - b);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < g_n_kernels; ++i)
+        if (g_kernel_names[i] == n) return i;
+    if (g_n_kernels >= KID_COUNT) return KID_COUNT - 1;
+    g_kernel_names[g_n_kernels] = n;
+    return g_n_kernels++;
+}
 
 bool frcnn_prof_on() { return g_prof_enabled; }
 
@@ -155,8 +171,8 @@ FRCNN_EXPORT int frcnn_prof_reset(void)
     return FRCNN_OK;
 }
 
-FRCNN_EXPORT int frcnn_prof_num_kernels(void) { return KID_COUNT; }
-FRCNN_EXPORT const char *frcnn_prof_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? g_kernel_names[kid] : ""; }
+FRCNN_EXPORT int frcnn_prof_num_kernels(void) { std::lock_guard<std::mutex> lk(g_prof_mu); return g_n_kernels; }
+FRCNN_EXPORT const char *frcnn_prof_kernel_name(int kid) { return (kid >= 0 && kid < KID_COUNT) ? g_kernel_names[kid].c_str() : ""; }
 FRCNN_EXPORT int frcnn_prof_get(int kid, double *total_ms, int64_t *launches)
 {
     FRCNN_REQUIRE(kid >= 0 && kid < KID_COUNT && total_ms && launches, "prof_get: bad argument");

@@ -68,7 +68,7 @@ FRCNN_EXPORT int frcnn_anchor_grid(int n_levels, const int *fh, const int *fw, c
     FRCNN_REQUIRE(out, "anchor grid: NULL output");
     FRCNN_REQUIRE(n == N, "anchor grid: level table describes %lld anchors, caller passed N=%lld", (long long)n, (long long)N);
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(KID_ANCHOR_GRID, anchor_grid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d, (float4 *)out, N);
+    FRCNN_LAUNCH(anchor_grid_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d, (float4 *)out, N);
     FRCNN_CHECK_LAUNCH("anchor_grid_kernel");
     return FRCNN_OK;
 }
@@ -99,7 +99,7 @@ FRCNN_EXPORT int frcnn_box_codec(int op, const float *a, const float *b, int64_t
     FRCNN_REQUIRE(op < 2 || n == 0 || b, "box_codec: op %d needs a second operand", op);
     if (n == 0) return FRCNN_OK;
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(KID_BOX_CODEC, box_codec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, (const float4 *)a,
+    FRCNN_LAUNCH(box_codec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, op, (const float4 *)a,
                  (const float4 *)b, n, (float4 *)out);
     FRCNN_CHECK_LAUNCH("box_codec_kernel");
     return FRCNN_OK;
@@ -128,7 +128,7 @@ FRCNN_EXPORT int frcnn_pairwise_iou(const float *set1, int64_t n1, const float *
     FRCNN_REQUIRE(n1 * n2 < ((int64_t)1 << 40), "pairwise_iou: output too large");
     hipStream_t s = (hipStream_t)stream;
     const int64_t tot = n1 * n2;
-    FRCNN_LAUNCH(KID_PAIRWISE_IOU, pairwise_iou_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float4 *)set1, n1,
+    FRCNN_LAUNCH(pairwise_iou_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const float4 *)set1, n1,
                  (const float4 *)set2, n2, eps, eps != 0.f ? 1 : 0, out);
     FRCNN_CHECK_LAUNCH("pairwise_iou_kernel");
     return FRCNN_OK;
@@ -176,10 +176,10 @@ int frcnn_launch_prologue(const float *reg, const float *cls, const float *ancho
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
     if (anchors) {
         AnchorDesc dummy = {};
-        FRCNN_LAUNCH(KID_PROLOGUE, proposal_prologue_kernel<true>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
+        FRCNN_LAUNCH(proposal_prologue_kernel<true>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
                      (const float4 *)anchors, dummy, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
     } else {
-        FRCNN_LAUNCH(KID_PROLOGUE, proposal_prologue_kernel<false>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
+        FRCNN_LAUNCH(proposal_prologue_kernel<false>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
                      (const float4 *)nullptr, *d, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
     }
     FRCNN_CHECK_LAUNCH("proposal_prologue_kernel");

@@ -10,35 +10,10 @@
 // ---------------------------------------------------------------------------------------------
 // host side: error reporting + per-kernel event timing
 // ---------------------------------------------------------------------------------------------
-enum FrcnnKernelId {
-    KID_ANCHOR_GRID = 0,
-    KID_BOX_CODEC,
-    KID_PAIRWISE_IOU,
-    KID_PROLOGUE,
-    KID_TOPK_RANK,       // topk_sample / topk_count / topk_place kernels (N >= 4096), topk_rank_kernel below
-    KID_TOPK_SCATTER,    // topk_bucket_kernel (N >= 4096), topk_scatter_kernel below
-    KID_NMS_MASK,        // nms_kernel (relation tiles + resolver, one launch)
-    KID_NMS_SCAN,        // (unused since the resolver moved into nms_kernel)
-    KID_RPN_COLMAX,
-    KID_RPN_LABEL,
-    KID_RPN_SAMPLE,
-    KID_HEAD_TARGETS,
-    KID_ROI_POOL_FWD,
-    KID_ROI_POOL_BWD,
-    KID_ROI_LEVEL_MAP,
-    KID_ROI_ALIGN_FWD,
-    KID_ROI_ALIGN_BWD,
-    KID_RPN_HEAD_TAIL,
-    KID_DET_LOSS,
-    KID_PREPROCESS,
-    KID_NMS_SCAN_SIMPLE, // nms_emit_kernel
-    KID_RPN_HEAD_TAIL_BWD,
-    KID_RPN_CONV,
-    KID_RPN_CONV_PACK,
-    KID_ROI_ALIGN_BWD_LISTS,
-    KID_ROI_ALIGN_BWD_COMBINE,
-    KID_COUNT
-};
+// Per-kernel HIP-event timing: every launch site registers its kernel under the kernel's OWN name (template arguments stripped), so
+// the names frcnn_prof_kernel_name() reports are exactly the names rocprofv3 and the PMC passes print -- no hand-kept id table.
+#define FRCNN_PROF_MAX_KERNELS 128
+int frcnn_prof_register(const char *kernel_expr);
 
 int frcnn_set_error(int code, const char *fmt, ...);
 void frcnn_prof_begin(int kid, hipStream_t s);
@@ -51,9 +26,10 @@ struct FrcnnProfScope {
     ~FrcnnProfScope() { if (on) frcnn_prof_end(kid, s); }
 };
 
-#define FRCNN_LAUNCH(kid, kernel, grid, block, shmem, stream, ...)                         \
+#define FRCNN_LAUNCH(kernel, grid, block, shmem, stream, ...)                              \
     do {                                                                                   \
-        FrcnnProfScope _prof((kid), (stream));                                             \
+        static const int _kid = frcnn_prof_register(#kernel);                              \
+        FrcnnProfScope _prof(_kid, (stream));                                              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
     } while (0)
 

@@ -143,11 +143,11 @@ FRCNN_EXPORT int frcnn_detection_loss(const float *rpn_cls, const float *rpn_reg
     if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "detection_loss: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     LossAcc *slots = (LossAcc *)workspace;
-    FRCNN_LAUNCH(KID_DET_LOSS, det_loss_kernel, dim3((unsigned)(nb_rpn + nb_head)), dim3(256), 0, s, (const float2 *)rpn_cls, (const float4 *)rpn_reg,
+    FRCNN_LAUNCH(det_loss_kernel, dim3((unsigned)(nb_rpn + nb_head)), dim3(256), 0, s, (const float2 *)rpn_cls, (const float4 *)rpn_reg,
                  t_rpn_cls, (const float4 *)t_rpn_reg, (int)N, head_cls, (const float4 *)head_reg, t_cls, (const float4 *)t_reg, (int)R, NC,
                  (float2 *)g_rpn_cls, (float4 *)g_rpn_reg, g_head_cls, (float4 *)g_head_reg, slots, nb_rpn);
     FRCNN_CHECK_LAUNCH("det_loss_kernel");
-    FRCNN_LAUNCH(KID_DET_LOSS, det_loss_finalize_kernel, dim3(1), dim3(64), 0, s, slots, nb_rpn + nb_head, (int)R, out7);
+    FRCNN_LAUNCH(det_loss_finalize_kernel, dim3(1), dim3(64), 0, s, slots, nb_rpn + nb_head, (int)R, out7);
     FRCNN_CHECK_LAUNCH("det_loss_finalize_kernel");
     return FRCNN_OK;
 }

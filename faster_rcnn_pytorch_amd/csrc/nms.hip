@@ -1,37 +1,31 @@
-// nms.hip -- torchvision.ops.nms as the reference calls it (models/model.py:53,394), gfx950.
+// nms.hip -- torchvision.ops.nms as the reference calls it (models/model.py:53,394), gfx950.  No host round trip (torchvision
+// copies an 18 MB mask to the host and scans there); counts stay on the device.
 //
-// Two kernels, no host round trip (torchvision copies the 18 MB mask to the host and scans there):
+// Greedy NMS = the lexicographically-first maximal independent set of the conflict graph (IoU > thr) in score order.  Two facts
+// shape the kernels:
+//  (1) it can be RESOLVED CHAOTICALLY: box i is REMOVED as soon as one of its suppressors (higher score, IoU > thr) is known KEPT,
+//      and KEPT as soon as all of its suppressors are known REMOVED.  Both rules consume only final facts, so all boxes may iterate
+//      at once against two bitmaps that only ever gain bits; by induction over the score rank the result is the sequential one.
+//  (2) it can be CASCADED: let S0 = the kept boxes among the T best-scored ones (final: they depend on nothing below them).  A box
+//      below the top T that a member of S0 suppresses is removed -- final -- and removed boxes never suppress anybody.  What is left
+//      ("survivors") is suppressed by no member of S0, so its fate depends on the survivors alone: an independent NMS problem over a
+//      fraction of the boxes.  On the 600x1000 training frame (12 000 boxes, ~90 % suppressed) the pair count drops from 72 M to
+//      ~2 M (top 2048) + ~3-10 M (rest x S0) + ~1-8 M (survivors); results are identical by construction.
 //
-//  nms_sup_kernel : chip-wide.  Lower-triangular 64x64 tiles of the suppression relation in PULL orientation: one wave per
-//      tile (row block rb <= column block cb), lane = box i of the column block (the LOWER-scored side), and the wave walks the 64
-//      boxes j of the row block (staged in LDS with one coalesced load, read back as wave-uniform broadcast ds_read_b128).  Each lane
-//      builds the word "which boxes j of block rb suppress me": bit j = (j < i) and IoU(j, i) > thr.
-//      inter/(a_i+a_j-inter) > thr is decided WITHOUT the IEEE division on the fast path: if inter is outside a 2^-20 relative
-//      band around thr*union the comparison is already decided; only inside the band is the exact division evaluated, so results
-//      are bit-identical to the oracle.  Boxes must be NaN-free (v_max/v_min drop NaNs where std::max would keep one).
-//      Only NON-ZERO words are stored (sup[i][rb]); which words of a box are non-zero is kept in a per-box bitmap nz[i]
-//      (one atomicOr per non-zero word).
-//
-//  nms_resolve_kernel : chip-wide, ONE THREAD PER BOX.  Greedy NMS is the lexicographically-first maximal independent set of the
-//      conflict graph in score order:
-//          box i is REMOVED as soon as one of its suppressors (higher score, IoU > thr) is known KEPT,
-//          box i is KEPT    as soon as all of its suppressors are known REMOVED.
-//      Both rules consume only FINAL facts, so they may be applied in any order, by all boxes at once, without barriers, against
-//      two bitmaps that only ever gain bits (chaotic iteration of a monotone system).  By induction over the score rank the result
-//      is exactly the sequential one.  A box walks its non-zero words in ASCENDING word order = descending suppressor score: a
-//      removed box typically meets its kept suppressor in its first or second word (measured on the 600x1000 regimes: 1.4 words
-//      per removed box, 15 k words read in total of the 150-180 k non-zero ones; longest dependency chain 9-10 boxes), a kept box
-//      has few suppressors by construction.  See the comment in front of the kernel for the memory protocol.
-//      Time = (longest dependency chain) x (one cross-CU hop) instead of (K / 64 blocks) x (one sequential resolver step): the
-//      round-1 forward-mask scans (a barrier-free dataflow over 64-row blocks inside one workgroup, 0.4 us per block: 78 us at
-//      K = 12 000 on an untrained RPN) are gone.  Single-workgroup forms of the same pull resolver were tried first and dropped: one
-//      CU cannot fetch 12 000 scattered relation words in less than ~15 us, and every advance of a waiting box costs the polling
-//      wave an L2 round trip (93 / 58 / 130 us for three variants; numbers in profiles/README.md).
-//      Progress is guaranteed (the best-scored undecided box can always be decided; all waves are co-resident) and the iteration
-//      counter is bounded anyway: on overflow the abort flag is raised and the count comes out as -1.  Worst case (an adversarial
-//      chain in which box i is suppressed only by box i-1, K deep) degrades to one cross-CU hop per box.
-//
-//  nms_emit_kernel : kept bitmap -> the first post_k kept positions (score order), their boxes, source indices, the count.
+//  nms_kernel<CLS>   : one LEVEL (relation + resolution in one launch).  Tile workgroups enumerate the lower-triangular 64 x 64
+//      tiles of the suppression relation in PULL orientation (one wave per tile; lane = the lower-scored box; the 64 candidate
+//      suppressors staged in LDS and read back as wave-uniform broadcast ds_read_b128; 16 VALU per pair, no division: see sup_half).
+//      Only NON-ZERO words are stored (sup[i][rb]) + a per-box bitmap of which words are non-zero (nz).  Resolver workgroups (one
+//      64-box wave each, dispatched first) wait for their row's tile flags and then apply (1): a box walks its non-zero words in
+//      ascending order, several words per round trip.  Boxes may carry NaN / inf coordinates: such a pair is never decided by the
+//      division-free test (every compare with NaN is false), falls through to the exact IEEE division, and comes out as
+//      torchvision's `NaN > thr` = false (tests/test_gpu_ops.py: test_nms_nan_and_inf_boxes_follow_torchvision_semantics).
+//  nms_filter_kernel<CLS> : the cascade step (2): every box below the top T against S0 (compacted into LDS by each workgroup from the
+//      level-0 kept bitmap); survivors are compacted IN ORDER into a second box array by a ticketed decoupled look-back over the
+//      workgroups' survivor counts (workgroups take their logical block from an atomic ticket, so a block only ever waits for
+//      blocks that are already running).
+//  nms_emit_kernel   : kept bitmaps of the level(s) -> the first post_k kept positions (score order), boxes, source indices, count.
+// K <= NMS_CASCADE_MIN boxes (the FPN stage's 4000, predict's per-image lists) run one level directly.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include <cstdlib>
@@ -290,7 +284,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     __shared__ float4 s_box[4][64];
     __shared__ float s_area[4][64];
     __shared__ int s_cls[4][64];
-    const int n = n_dev ? min(*n_dev, K) : K;
+    const int n = n_dev ? min(max(*n_dev, 0), K) : K;
     if ((int)blockIdx.x < n_res) {
         nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
         return;
@@ -308,33 +302,186 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     nms_sup_tile<CLS>(cb, rb, wave, (int)(threadIdx.x & 63), s_box, s_area, s_cls, boxes, cls, n, K, thr, nblk, sup, nz, done);
 }
 
-// kept bitmap -> the first post_k kept positions in score order, their boxes / source indices, the count.  One wave per block:
-// its base position = the popcount of all earlier words (<= 1024 words: 16 per lane).
-__global__ __launch_bounds__(256) void nms_emit_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K, const u64 *__restrict__ kept,
-                                                       const int32_t *__restrict__ abort_flag, int post_k, int64_t *__restrict__ out_keep,
-                                                       float4 *__restrict__ out_rois, const int64_t *__restrict__ src_map,
-                                                       int64_t *__restrict__ out_src, int32_t *__restrict__ out_count)
+// ------------------------------------------------------------------------------------------------
+// nms_filter_kernel: the cascade step.  Workgroup = one 64-box block of the boxes BELOW the top T; its NW waves split S0 (the kept
+// boxes of the top T, compacted into LDS from the level-0 kept bitmap) into 32-candidate chunks, lane = box.  The pair test is the
+// division-free one of sup_half (15 VALU: the yes-masks are OR-ed as scalars); lanes with an undecided pair and no sure suppressor
+// redo their chunk with the exact IEEE division.  Survivors (suppressed by no member of S0) are written IN ORDER to cbox / cidx /
+// ccls: the workgroup's base = the sum of the survivor counts of all earlier blocks, obtained by a decoupled look-back over
+// look[b] = (count << 1) | 1.  Logical blocks are handed out by an atomic ticket, so block b only waits for blocks that have
+// already started (the look-back of rocPRIM's single-pass scan); the spin is bounded anyway (abort flag -> count -1).
+// ------------------------------------------------------------------------------------------------
+#define NMS_T_MAX 2048
+#define NMS_FILTER_WAVES 8
+#define NMS_LOOK_SPINS (1 << 22)
+template <bool CLS>
+__global__ __launch_bounds__(64 * NMS_FILTER_WAVES) void nms_filter_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls,
+                                                                           const int32_t *__restrict__ n_dev, int K, int T, float thr,
+                                                                           const u64 *__restrict__ kept0, float4 *__restrict__ cbox,
+                                                                           int32_t *__restrict__ cidx, int32_t *__restrict__ ccls,
+                                                                           int32_t *__restrict__ look, int32_t *__restrict__ ctl)
 {
-    const int n = n_dev ? min(*n_dev, K) : K;
-    const int nb = (n + 63) >> 6;
+    constexpr int NW = NMS_FILTER_WAVES;
+    __shared__ float4 s_box[NMS_T_MAX + 32];
+    __shared__ float s_area[NMS_T_MAX + 32];
+    __shared__ int s_cls[CLS ? NMS_T_MAX + 32 : 1];
+    __shared__ u64 s_kw[NMS_T_MAX / 64];
+    __shared__ int s_pref[NMS_T_MAX / 64 + 1];
+    __shared__ u64 s_any[NW];
+    __shared__ int s_ticket, s_notpos;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = n_dev ? min(max(*n_dev, 0), K) : K;
+    const int n0 = min(n, T);
+    const int nrest = (max(n - T, 0) + 63) >> 6;                     // logical blocks that exist
+    if (tid == 0) { s_ticket = atomicAdd(&ctl[1], 1); s_notpos = 0; }
+    // the kept words of the top T and their exclusive popcount prefix
+    const int nw0 = (n0 + 63) >> 6;
+    if (tid < 64) {
+        const u64 w = tid < nw0 ? kept0[tid] : 0ull;
+        int inc = __builtin_popcountll(w);
+        const int mine = inc;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (tid < NMS_T_MAX / 64) { s_kw[tid] = w; s_pref[tid] = inc - mine; }
+        if (tid == NMS_T_MAX / 64 - 1) s_pref[NMS_T_MAX / 64] = inc;
+    }
+    __syncthreads();
+    const int b = s_ticket;
+    if (b >= nrest) {
+        if (b == 0 && tid == 0) ctl[2] = 0;                          // nothing below the top T: no survivors (nrest == 0)
+        return;
+    }
+    const int m0 = s_pref[NMS_T_MAX / 64];
+    // S0 -> LDS, compacted in score order; padded to a multiple of 32 with boxes that suppress nothing
+    bool notpos = false;
+    for (int p = tid; p < n0; p += 64 * NW) {
+        const u64 w = s_kw[p >> 6];
+        if ((w >> (p & 63)) & 1ull) {
+            const int slot = s_pref[p >> 6] + __builtin_popcountll(w & ((1ull << (p & 63)) - 1ull));
+            const float4 bx = boxes[p];
+            const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+            s_box[slot] = bx; s_area[slot] = ar;
+            if (CLS) s_cls[slot] = cls[p];
+            notpos |= !(ar > 0.0f);
+        }
+    }
+    const int m0p = (m0 + 31) & ~31;
+    if (tid < m0p - m0) {
+        s_box[m0 + tid] = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f);   // zero area, intersects nothing finite
+        s_area[m0 + tid] = 0.0f;
+        if (CLS) s_cls[m0 + tid] = -1;
+    }
+    const int me = T + b * 64 + lane;
+    const bool live = me < n;
+    const float4 a = boxes[min(me, K - 1)];
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    const int my_cls = CLS ? cls[min(me, K - 1)] : 0;
+    notpos |= !(area_a > 0.0f);
+    if (__ballot(notpos) != 0ull && lane == 0) s_notpos = 1;         // benign race: every writer stores 1
+    __syncthreads();
+    const bool pos = s_notpos == 0;                                  // all areas positive: union > 0 needs no test
+    const float n_hi = -(thr * (1.0f + 9.5367431640625e-07f)), n_lo = -(thr * (1.0f - 9.5367431640625e-07f));
+    u64 any = 0ull;
+    const u64 live_mask = __ballot(live);
+    for (int c = wave; c * 32 < m0; c += NW) {
+        const float4 *sb = s_box + c * 32;
+        const float *sa = s_area + c * 32;
+        u64 uns = 0ull, yes = 0ull;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float4 bj = sb[j];                                 // wave-uniform address: LDS broadcast
+            const float w = vmaxf(vminf(a.z, bj.z) - vmaxf(a.x, bj.x), 0.0f);
+            const float h = vmaxf(vminf(a.w, bj.w) - vmaxf(a.y, bj.y), 0.0f);
+            const float inter = w * h;
+            const float uni = area_a + sa[j] - inter;
+            const float t_hi = __builtin_fmaf(n_hi, uni, inter), t_lo = __builtin_fmaf(n_lo, uni, inter);
+            u64 m_yes = __builtin_amdgcn_ballot_w64(t_hi > 0.0f);
+            u64 m_sure = m_yes | __builtin_amdgcn_ballot_w64(t_lo < 0.0f);
+            if (!pos) m_sure &= __builtin_amdgcn_ballot_w64(uni > 0.0f);
+            if (CLS) {
+                const u64 same = __builtin_amdgcn_ballot_w64(s_cls[c * 32 + j] == my_cls);
+                m_yes &= same;
+                m_sure |= ~same;                                     // another class: never a suppressor, whatever the overlap
+            }
+            uns |= ~m_sure;
+            yes |= m_yes & m_sure;
+        }
+        any |= yes;
+        uns &= live_mask & ~any;
+        if (uns != 0ull) {                                           // rare: the exact division for the undecided lanes of this chunk
+            bool hit = false;
+            if ((uns >> lane) & 1ull)
+                for (int j = 0; j < 32; ++j)
+                    hit = hit || (nms_suppress_exact(sb[j], sa[j], a, area_a, thr) && (!CLS || s_cls[c * 32 + j] == my_cls));
+            any |= __ballot(hit);
+        }
+        if ((live_mask & ~any) == 0ull) break;                       // every box of the block already has a kept suppressor
+    }
+    if (lane == 0) s_any[wave] = any;
+    __syncthreads();
+    if (wave != 0) return;
+    u64 sup_any = 0ull;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) sup_any |= s_any[q];
+    const u64 alive = live_mask & ~sup_any;
+    const int cnt = __builtin_popcountll(alive);
+    if (lane == 0) __hip_atomic_store(&look[b], (cnt << 1) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look back over the earlier blocks (<= NMS_MAX_BLOCKS of them: a few per lane)
+    int base = 0;
+    for (int k = lane; k < b; k += 64) {
+        int v, spins = 0;
+        while (((v = __hip_atomic_load(&look[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1) == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > NMS_LOOK_SPINS) { atomicOr(&ctl[0], 1); v = 1; break; }
+        }
+        base += v >> 1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) base += __shfl_xor(base, o);
+    if ((alive >> lane) & 1ull) {
+        const int r = base + __builtin_popcountll(alive & ((1ull << lane) - 1ull));
+        cbox[r] = a;
+        cidx[r] = me;
+        if (CLS) ccls[r] = my_cls;
+    }
+    if (b == nrest - 1 && lane == 0) ctl[2] = base + cnt;            // the number of survivors = the live count of level 1
+}
+
+// kept bitmap(s) -> the first post_k kept positions in score order, their boxes / source indices, the count.  One wave per 64-box
+// block of level 0 (the first n0 = min(n, T) boxes; T = K without a cascade) and of level 1 (the n1 survivors; position = cidx[rank]);
+// a wave's base = the popcount of all earlier kept words (<= a few thousand words: tens per lane).
+__global__ __launch_bounds__(256) void nms_emit_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ n_dev, int K, int T,
+                                                       const u64 *__restrict__ kept0, const u64 *__restrict__ kept1,
+                                                       const int32_t *__restrict__ cidx, const int32_t *__restrict__ ctl, int post_k,
+                                                       int64_t *__restrict__ out_keep, float4 *__restrict__ out_rois,
+                                                       const int64_t *__restrict__ src_map, int64_t *__restrict__ out_src,
+                                                       int32_t *__restrict__ out_count)
+{
+    const int n = n_dev ? min(max(*n_dev, 0), K) : K;
+    const int n0 = min(n, T);
+    const int n1 = kept1 ? ctl[2] : 0;
+    const int nb0 = (n0 + 63) >> 6, nb1 = (n1 + 63) >> 6;
+    const int nb = nb0 + nb1;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const bool aborted = *abort_flag != 0;
+    const bool aborted = ctl[0] != 0;
     if (b > nb) return;                                              // wave nb only writes the count
     int part = 0;
-    for (int w = lane; w < min(b, nb); w += 64) part += __builtin_popcountll(kept[w]);
+    for (int w = lane; w < min(b, nb); w += 64) part += __builtin_popcountll(w < nb0 ? kept0[w] : kept1[w - nb0]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (b == nb) {
         if (lane == 0) *out_count = aborted ? -1 : (part < post_k ? part : post_k);
         return;
     }
-    if (aborted) return;
-    const u64 kw = kept[b];
-    const int i = b * 64 + lane;
-    if (((kw >> lane) & 1ull) && i < n) {
+    if (aborted || part >= post_k) return;
+    const bool lvl1 = b >= nb0;
+    const u64 kw = lvl1 ? kept1[b - nb0] : kept0[b];
+    const int r = (lvl1 ? b - nb0 : b) * 64 + lane;
+    if (((kw >> lane) & 1ull) && r < (lvl1 ? n1 : n0)) {
         const int pos = part + __builtin_popcountll(kw & ((1ull << lane) - 1ull));
         if (pos < post_k) {
+            const int i = lvl1 ? cidx[r] : r;
             out_keep[pos] = (int64_t)i;
             if (out_rois) out_rois[pos] = boxes[i];
             if (out_src) out_src[pos] = src_map ? src_map[i] : (int64_t)i;
@@ -342,59 +489,88 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float4 *__restrict_
     }
 }
 
-struct NmsWs { u64 *sup, *nz, *kept, *rem; int32_t *flags, *done; int nzw; size_t zero_bytes, total; };
+// ---- workspace: two levels (level 1 only with the cascade) + the cascade's compacted survivors ----
+#define NMS_CASCADE_MIN 16384          // K above this: cascade with T = NMS_T_MAX
+struct NmsLevelWs { u64 *sup, *nz, *kept, *rem; int32_t *done; int nblk, nzw; };
+struct NmsWs {
+    NmsLevelWs L[2];
+    int T;                             // level-0 size (= K without a cascade)
+    float4 *cbox; int32_t *cidx, *ccls, *look, *ctl;
+    char *zero_begin; size_t zero_bytes, total;
+};
+static bool nms_use_cascade(int64_t K)
+{
+    static const int mode = [] { const char *e = getenv("FRCNN_NMS_CASCADE"); return e ? atoi(e) : 1; }();
+    return mode != 0 && K > NMS_CASCADE_MIN;
+}
 static NmsWs carve_nms(void *ws, int64_t K)
 {
-    const size_t nblk = (size_t)((K + 63) / 64);
     NmsWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
-    w.nzw = (int)((nblk + 63) / 64);
-    w.sup = (u64 *)take((size_t)K * nblk * 8 + NMS_WS_PAD);
-    // one region to clear before nms_kernel runs: the per-box bitmaps of non-zero words, the kept / removed bitmaps, the flags, the row counters
+    const bool casc = nms_use_cascade(K);
+    w.T = casc ? NMS_T_MAX : (int)K;
+    const int64_t Kl[2] = {w.T, casc ? K - w.T : 0};
+    for (int l = 0; l < 2; ++l) {
+        w.L[l].nblk = (int)((Kl[l] + 63) / 64);
+        w.L[l].nzw = (w.L[l].nblk + 63) / 64;
+        w.L[l].sup = Kl[l] ? (u64 *)take((size_t)Kl[l] * w.L[l].nblk * 8 + NMS_WS_PAD) : nullptr;
+    }
+    w.cbox = casc ? (float4 *)take((size_t)Kl[1] * 16) : nullptr;
+    w.cidx = casc ? (int32_t *)take((size_t)Kl[1] * 4) : nullptr;
+    w.ccls = casc ? (int32_t *)take((size_t)Kl[1] * 4) : nullptr;
+    // ONE region to clear before the stage runs: the per-box bitmaps of non-zero words, the kept / removed bitmaps and the tile flags of
+    // both levels, the look-back words, the control block (abort flag, ticket, survivor count)
     const size_t z0 = o;
-    w.nz = (u64 *)take((size_t)K * w.nzw * 8);
-    w.kept = (u64 *)take((nblk + 1) * 8);
-    w.rem = (u64 *)take((nblk + 1) * 8);
-    w.flags = (int32_t *)take(64);
-    w.done = (int32_t *)take((nblk * (nblk + 1) / 2 + 1) * 4);      // one flag per published tile (the resolver's start condition)
+    w.zero_begin = p ? p + o : nullptr;
+    for (int l = 0; l < 2; ++l) {
+        const size_t nb = (size_t)w.L[l].nblk;
+        w.L[l].nz = Kl[l] ? (u64 *)take((size_t)Kl[l] * w.L[l].nzw * 8) : nullptr;
+        w.L[l].kept = Kl[l] ? (u64 *)take((nb + 1) * 8) : nullptr;
+        w.L[l].rem = Kl[l] ? (u64 *)take((nb + 1) * 8) : nullptr;
+        w.L[l].done = Kl[l] ? (int32_t *)take((nb * (nb + 1) / 2 + 1) * 4) : nullptr;   // one flag per published tile (the resolver's start condition)
+    }
+    w.look = casc ? (int32_t *)take(((size_t)w.L[1].nblk + 1) * 4) : nullptr;
+    w.ctl = (int32_t *)take(64);
     w.zero_bytes = o - z0;
     w.total = o;
     return w;
 }
 size_t frcnn_ws_nms(int64_t K) { return carve_nms(nullptr, K).total; }
 
-// The region the NMS stage needs cleared before nms_kernel runs.
+// The region the NMS stage needs cleared before it runs.
 void frcnn_nms_zero_region(void *ws, int64_t K, int32_t **ptr, int *n_ints)
 {
     const NmsWs w = carve_nms(ws, K);
-    *ptr = (int32_t *)w.nz;
+    *ptr = (int32_t *)w.zero_begin;
     *n_ints = (int)(w.zero_bytes / 4);
 }
 
-int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
-                     int64_t *out_keep, float *out_rois, const int64_t *src_map, int64_t *out_src, int32_t *out_count,
-                     void *ws, size_t ws_bytes, bool pre_zeroed, hipStream_t s)
+// one level: relation tiles + resolver, as one launch (or two above fused_max_res resolver workgroups)
+static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *n_dev, int Kl, float thr, const NmsLevelWs &L, int32_t *abort_flag, hipStream_t s)
 {
-    if (ws_bytes < frcnn_ws_nms(K))
-        return frcnn_set_error(FRCNN_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_nms(K));
-    const int nblk = (int)((K + 63) / 64);
-    if (nblk > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
-    const NmsWs w = carve_nms(ws, K);
-    if (!pre_zeroed && hipMemsetAsync(w.nz, 0, w.zero_bytes, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: memset failed");
-    const int n_res = (int)((K + 63) / 64);                         // one resolver wave per workgroup
+    const int nblk = L.nblk;
+    const int n_res = nblk;                                         // one resolver wave per workgroup
     const int G = nblk / 4;
     const unsigned n_tile_wg = (unsigned)(2 * G * (G + 1) + (nblk % 4) * (G + 1));
-    // The fused launch needs every resolver workgroup resident NEXT TO free slots for the tile workgroups it waits for: fine for the
-    // proposal stage (188 resolver workgroups at K = 12 000), not guaranteed when the resolver alone could fill the chip.  Above
-    // this many resolver workgroups the same kernel runs as two launches: tiles only, then resolver only (all flags already up).
-    static const int fused_max_res = [] { const char *e = getenv("FRCNN_NMS_FUSED_MAX_RES"); return e ? atoi(e) : 1024; }();
+    // The fused launch needs every resolver workgroup resident NEXT TO free slots for the tile workgroups it waits for.  Workgroups are
+    // dispatched in index order (resolvers first) and a resolver workgroup keeps ONE wave: up to four per CU (of eight workgroup slots)
+    // leave most of the chip's wave slots to the tile workgroups.  Above that the same kernel runs as two launches: tiles only, then
+    // resolver only (all flags already up).  HIP does not promise in-order dispatch; if the assumption ever failed the resolver's
+    // bounded wait runs out, the abort flag goes up, the count comes out as -1 and the step's loss is NaN (never a silent wrong result).
+    static const int fused_max_res = [] {
+        const char *e = getenv("FRCNN_NMS_FUSED_MAX_RES");
+        if (e) return atoi(e);
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 4;
+    }();
     auto launch = [&](unsigned grid, int n_res_arg) {
         if (cls)
-            FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<true>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw,
-                         n_res_arg, w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+            FRCNN_LAUNCH(nms_kernel<true>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
+                         L.done, abort_flag);
         else
-            FRCNN_LAUNCH(KID_NMS_MASK, nms_kernel<false>, dim3(grid), dim3(256), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, thr, nblk, w.nzw,
-                         n_res_arg, w.sup, w.nz, w.kept, w.rem, w.done, w.flags);
+            FRCNN_LAUNCH(nms_kernel<false>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
+                         L.done, abort_flag);
     };
     if (n_res <= fused_max_res) {
         launch((unsigned)n_res + n_tile_wg, n_res);
@@ -403,8 +579,38 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
         launch((unsigned)n_res, n_res);
     }
     FRCNN_CHECK_LAUNCH("nms_kernel");
-    FRCNN_LAUNCH(KID_NMS_SCAN_SIMPLE, nms_emit_kernel, dim3((unsigned)((nblk + 1 + 3) / 4)), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, w.kept,
-                 w.flags, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
+    return FRCNN_OK;
+}
+
+int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_boxes_dev, int64_t K, float thr, int64_t post_k,
+                     int64_t *out_keep, float *out_rois, const int64_t *src_map, int64_t *out_src, int32_t *out_count,
+                     void *ws, size_t ws_bytes, bool pre_zeroed, hipStream_t s)
+{
+    if (ws_bytes < frcnn_ws_nms(K))
+        return frcnn_set_error(FRCNN_ERR_WORKSPACE, "nms: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_nms(K));
+    if ((K + 63) / 64 > NMS_MAX_BLOCKS) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "nms: K=%lld above limit %d", (long long)K, NMS_MAX_BLOCKS * 64);
+    const NmsWs w = carve_nms(ws, K);
+    if (!pre_zeroed && hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: memset failed");
+    const bool casc = w.L[1].nblk > 0;
+    // level 0: the T best-scored boxes (all K without a cascade)
+    int rc = launch_level((const float4 *)boxes, cls, n_boxes_dev, w.T, thr, w.L[0], w.ctl, s);
+    if (rc) return rc;
+    if (casc) {
+        const unsigned nrest = (unsigned)w.L[1].nblk;
+        if (cls)
+            FRCNN_LAUNCH(nms_filter_kernel<true>, dim3(nrest), dim3(64 * NMS_FILTER_WAVES), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, w.T, thr,
+                         w.L[0].kept, w.cbox, w.cidx, w.ccls, w.look, w.ctl);
+        else
+            FRCNN_LAUNCH(nms_filter_kernel<false>, dim3(nrest), dim3(64 * NMS_FILTER_WAVES), 0, s, (const float4 *)boxes, cls, n_boxes_dev, (int)K, w.T, thr,
+                         w.L[0].kept, w.cbox, w.cidx, w.ccls, w.look, w.ctl);
+        FRCNN_CHECK_LAUNCH("nms_filter_kernel");
+        // level 1: the survivors among themselves (live count = ctl[2], written by the filter)
+        rc = launch_level(w.cbox, cls ? w.ccls : nullptr, w.ctl + 2, (int)(K - w.T), thr, w.L[1], w.ctl, s);
+        if (rc) return rc;
+    }
+    const int nb_tot = w.L[0].nblk + w.L[1].nblk;
+    FRCNN_LAUNCH(nms_emit_kernel, dim3((unsigned)((nb_tot + 1 + 3) / 4)), dim3(256), 0, s, (const float4 *)boxes, n_boxes_dev, (int)K, w.T, w.L[0].kept,
+                 casc ? w.L[1].kept : nullptr, w.cidx, w.ctl, (int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count);
     FRCNN_CHECK_LAUNCH("nms_emit_kernel");
     return FRCNN_OK;
 }

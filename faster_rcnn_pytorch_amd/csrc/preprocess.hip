@@ -171,11 +171,11 @@ FRCNN_EXPORT int frcnn_preprocess_image(const uint8_t *src_hwc, int h, int w, in
     hipStream_t s = (hipStream_t)stream;
     NormConst nc;
     for (int c = 0; c < 3; ++c) { nc.mean[c] = mean_host[c]; nc.std[c] = std_host[c]; }
-    FRCNN_LAUNCH(KID_PREPROCESS, resample_coeffs_kernel, dim3((unsigned)((ow + oh + 255) / 256)), dim3(256), 0, s, w, ow, p.ksx, p.bx, p.kx, h, oh,
+    FRCNN_LAUNCH(resample_coeffs_kernel, dim3((unsigned)((ow + oh + 255) / 256)), dim3(256), 0, s, w, ow, p.ksx, p.bx, p.kx, h, oh,
                  p.ksy, p.by, p.ky);
-    FRCNN_LAUNCH(KID_PREPROCESS, resample_h_kernel, dim3((unsigned)((ow + 255) / 256), (unsigned)h), dim3(256), 0, s, src_hwc, h, w, flip ? 1 : 0, ow,
+    FRCNN_LAUNCH(resample_h_kernel, dim3((unsigned)((ow + 255) / 256), (unsigned)h), dim3(256), 0, s, src_hwc, h, w, flip ? 1 : 0, ow,
                  p.ksx, p.bx, p.kx, p.tmp);
-    FRCNN_LAUNCH(KID_PREPROCESS, resample_v_norm_kernel, dim3((unsigned)((pad_w + 255) / 256), (unsigned)(out_chw ? pad_h : oh)), dim3(256), 0, s,
+    FRCNN_LAUNCH(resample_v_norm_kernel, dim3((unsigned)((pad_w + 255) / 256), (unsigned)(out_chw ? pad_h : oh)), dim3(256), 0, s,
                  p.tmp, oh, ow, pad_h, pad_w, p.ksy, p.by, p.ky, nc, out_chw, out_u8);
     FRCNN_CHECK_LAUNCH("preprocess kernels");
     return FRCNN_OK;
@@ -187,7 +187,7 @@ FRCNN_EXPORT int frcnn_preprocess_boxes(const float *boxes, int64_t n, int w, in
     if (n == 0) return FRCNN_OK;
     FRCNN_REQUIRE(boxes && out, "preprocess_boxes: NULL pointer");
     const float rw = (float)((double)ow / (double)w), rh = (float)((double)oh / (double)h);
-    FRCNN_LAUNCH(KID_PREPROCESS, preprocess_boxes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes, n,
+    FRCNN_LAUNCH(preprocess_boxes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)boxes, n,
                  (float)w, flip ? 1 : 0, rw, rh, (float)ow, (float)oh, (float4 *)out);
     FRCNN_CHECK_LAUNCH("preprocess_boxes_kernel");
     return FRCNN_OK;

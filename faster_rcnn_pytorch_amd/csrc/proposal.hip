@@ -87,7 +87,7 @@ FRCNN_EXPORT int frcnn_region_proposal(const float *reg, const float *cls, const
         LevelOffsets lo;
         lo.n = n_nms_levels;
         for (int l = 0; l <= n_nms_levels; ++l) lo.off[l] = nms_level_offsets_host[l];
-        FRCNN_LAUNCH(KID_ROI_LEVEL_MAP, level_ids_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, w.sidx, (int)K, lo, w.lvl);
+        FRCNN_LAUNCH(level_ids_kernel, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, w.sidx, (int)K, lo, w.lvl);
         FRCNN_CHECK_LAUNCH("level_ids_kernel");
         lvl = w.lvl;
     }

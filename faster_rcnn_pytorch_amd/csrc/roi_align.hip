@@ -629,7 +629,7 @@ FRCNN_EXPORT int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, in
     if (R == 0) return FRCNN_OK;
     FRCNN_REQUIRE(rois && out_level, "roi_level_map: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(KID_ROI_LEVEL_MAP, roi_level_map_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const float4 *)rois, R, k_min,
+    FRCNN_LAUNCH(roi_level_map_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, (const float4 *)rois, R, k_min,
                  k_max, s0, k0, eps, out_level);
     FRCNN_CHECK_LAUNCH("roi_level_map_kernel");
     return FRCNN_OK;
@@ -668,12 +668,12 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
     for (int l = 0; l < n_levels; ++l) small_planes = small_planes && (int64_t)C * H[l] * W[l] < ((int64_t)1 << 30);
     if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24) && small_planes) {
         const int n_cg = (C + RA_FWD_CG - 1) / RA_FWD_CG;
-        FRCNN_LAUNCH(KID_ROI_ALIGN_FWD, roi_align_fwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,
+        FRCNN_LAUNCH(roi_align_fwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,
                      aligned, k_min, s0, k0, out, out_level, n_cg);
         FRCNN_CHECK_LAUNCH("roi_align_fwd77_kernel");
         return FRCNN_OK;
     }
-    FRCNN_LAUNCH(KID_ROI_ALIGN_FWD, roi_align_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, C, (const float4 *)rois,
+    FRCNN_LAUNCH(roi_align_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, C, (const float4 *)rois,
                  total, PH, PW, sampling_ratio, aligned, k_min, s0, k0, out, out_level);
     FRCNN_CHECK_LAUNCH("roi_align_fwd_kernel");
     return FRCNN_OK;
@@ -736,10 +736,10 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "ms_roi_align_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         const RaBwdWs w = carve_ra_bwd(workspace, tiles, R, n_cg);
         const int cap = (int)(R > 0 ? R : 1);
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
+        FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
                      k_min, s0, k0, cap, w.cnt, w.ent);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_LISTS, roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
+        FRCNN_LAUNCH(roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
         FillLevels FLv;
         int64_t fills = 0;
@@ -750,10 +750,10 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         FLv.fill0[FRCNN_MAX_LEVELS] = (int)fills;
         const int64_t n_item_blocks = (int64_t)w.cap_items * n_cg;
         FRCNN_REQUIRE(n_item_blocks + fills < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, (roi_align_bwd_tile_kernel<float>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
+        FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
                      grad_out, n_cg, cap, (int)n_item_blocks, w.cnt, w.ent, w.items, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
-        FRCNN_LAUNCH(KID_ROI_ALIGN_BWD_COMBINE, (roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
+        FRCNN_LAUNCH((roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
                      w.tnseg, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_combine_kernel");
         return FRCNN_OK;
@@ -762,7 +762,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         if (hipMemsetAsync(L.grad[l], 0, (size_t)C * L.H[l] * L.W[l] * sizeof(float), s) != hipSuccess)
             return frcnn_set_error(FRCNN_ERR_LAUNCH, "ms_roi_align_bwd: memset failed");
     if (R == 0) return FRCNN_OK;
-    FRCNN_LAUNCH(KID_ROI_ALIGN_BWD, roi_align_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, C, (const float4 *)rois,
+    FRCNN_LAUNCH(roi_align_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, L, C, (const float4 *)rois,
                  total, PH, PW, sampling_ratio, aligned, k_min, s0, k0, grad_out);
     FRCNN_CHECK_LAUNCH("roi_align_bwd_kernel");
     return FRCNN_OK;

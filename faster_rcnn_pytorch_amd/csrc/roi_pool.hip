@@ -255,7 +255,7 @@ static int roi_pool_fwd_launch(const float *feat, int C, int H, int W, const flo
 {
     const int RB = ROI_FWD_RB;
     const size_t shmem = (size_t)4 * H * W * 4 + (size_t)RB * (7 + 7) * 4;
-    FRCNN_LAUNCH(KID_ROI_POOL_FWD, (roi_pool_fwd_lds_kernel<7, 7, AT>), dim3((C + 3) / 4, (unsigned)((R + RB - 1) / RB)), dim3(ROI_FWD_BS),
+    FRCNN_LAUNCH((roi_pool_fwd_lds_kernel<7, 7, AT>), dim3((C + 3) / 4, (unsigned)((R + RB - 1) / RB)), dim3(ROI_FWD_BS),
                  shmem, s, feat, C, H, W, (const float4 *)rois, (int)R, RB, spatial_scale, out, argmax);
     FRCNN_CHECK_LAUNCH("roi_pool_fwd_lds_kernel");
     return FRCNN_OK;
@@ -264,7 +264,7 @@ static int roi_pool_fwd_launch(const float *feat, int C, int H, int W, const flo
 template <typename AT>
 static int roi_pool_bwd_launch(const float *grad_out, const AT *argmax, int64_t R, int C, int64_t HW, int bins, float *grad_feat, hipStream_t s)
 {
-    FRCNN_LAUNCH(KID_ROI_POOL_BWD, (roi_pool_bwd_lds_kernel<ROI_BWD_CB, AT>), dim3((C + ROI_BWD_CB - 1) / ROI_BWD_CB), dim3(512), (size_t)HW * 4 * ROI_BWD_CB, s,
+    FRCNN_LAUNCH((roi_pool_bwd_lds_kernel<ROI_BWD_CB, AT>), dim3((C + ROI_BWD_CB - 1) / ROI_BWD_CB), dim3(512), (size_t)HW * 4 * ROI_BWD_CB, s,
                  grad_out, argmax, (int)R, C, (int)HW, bins, grad_feat);
     FRCNN_CHECK_LAUNCH("roi_pool_bwd_lds_kernel");
     return FRCNN_OK;
@@ -312,7 +312,7 @@ FRCNN_EXPORT int frcnn_roi_pool_fwd(const float *feat, int C, int H, int W, cons
     const size_t plane_bytes = (size_t)4 * H * W * 4;
     if (PH == 7 && PW == 7 && plane_bytes <= 48 * 1024 && R < (1 << 24))
         return roi_pool_fwd_launch<int32_t>(feat, C, H, W, rois, R, PH, PW, spatial_scale, out, argmax, s);
-    FRCNN_LAUNCH(KID_ROI_POOL_FWD, roi_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, C, H, W,
+    FRCNN_LAUNCH(roi_pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, feat, C, H, W,
                  (const float4 *)rois, total, PH, PW, spatial_scale, out, argmax);
     FRCNN_CHECK_LAUNCH("roi_pool_fwd_kernel");
     return FRCNN_OK;
@@ -336,13 +336,13 @@ FRCNN_EXPORT int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax
     if (HW * 4 * ROI_BWD_CB <= 64 * 1024 && (int64_t)PH * PW * ROI_BWD_CB <= 512) {
         return roi_pool_bwd_launch<int32_t>(grad_out, argmax, R, C, HW, PH * PW, grad_feat, s);
     } else if (HW * 4 <= 64 * 1024) {
-        FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_kernel, dim3(C), dim3(256), (size_t)HW * 4, s, grad_out, argmax, (int)R, C, (int)HW,
+        FRCNN_LAUNCH(roi_pool_bwd_kernel, dim3(C), dim3(256), (size_t)HW * 4, s, grad_out, argmax, (int)R, C, (int)HW,
                      PH * PW, grad_feat);
         FRCNN_CHECK_LAUNCH("roi_pool_bwd_kernel");
     } else {
         if (hipMemsetAsync(grad_feat, 0, (size_t)C * HW * 4, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "roi_pool_bwd: memset failed");
         const int64_t total = R * C * PH * PW;
-        FRCNN_LAUNCH(KID_ROI_POOL_BWD, roi_pool_bwd_atomic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, grad_out, argmax,
+        FRCNN_LAUNCH(roi_pool_bwd_atomic_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, grad_out, argmax,
                      total, C, (int)HW, PH * PW, grad_feat);
         FRCNN_CHECK_LAUNCH("roi_pool_bwd_atomic_kernel");
     }

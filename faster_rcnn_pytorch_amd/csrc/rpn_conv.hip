@@ -390,7 +390,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
     FRCNN_REQUIRE(pos0[n_levels] < ((int64_t)1 << 31), "rpn_conv_head: too many positions");
     hipStream_t s = (hipStream_t)stream;
     unsigned short *w3p = (unsigned short *)workspace, *whp = w3p + 16 * 9 * 256 * 16;
-    FRCNN_LAUNCH(KID_RPN_CONV_PACK, rpn_conv_pack_kernel, dim3(16 * 9 * 256 * 16 / 256), dim3(256), 0, s, w3, w_cls, n_cls, w_reg, n_reg, w3p, whp);
+    FRCNN_LAUNCH(rpn_conv_pack_kernel, dim3(16 * 9 * 256 * 16 / 256), dim3(256), 0, s, w3, w_cls, n_cls, w_reg, n_reg, w3p, whp);
     FRCNN_CHECK_LAUNCH("rpn_conv_pack_kernel");
     const size_t lds = RC3_LDS_BYTES;
     {   // > 64 KB of dynamic LDS is an opt-in per (function, device)
@@ -425,7 +425,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
     const int64_t rem = tiles % n_cu;
     const int first_split = (int)((rem > 0 && 2 * rem <= n_cu) ? tiles - rem : tiles);
     const unsigned grid = (unsigned)(first_split + 2 * (tiles - first_split));
-    FRCNN_LAUNCH(KID_RPN_CONV, rpn_conv3x3_head_kernel, dim3(grid), dim3(256), lds, s, L, first_split, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
+    FRCNN_LAUNCH(rpn_conv3x3_head_kernel, dim3(grid), dim3(256), lds, s, L, first_split, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
     FRCNN_CHECK_LAUNCH("rpn_conv3x3_head_kernel");
     return FRCNN_OK;
 }

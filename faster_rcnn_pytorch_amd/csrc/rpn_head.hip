@@ -157,7 +157,7 @@ static void launch_head(int nt, const HeadLevels &L, int tiles, int C, const flo
 {
     // 8 waves per 32-position tile when the K slice stays a multiple of 16 (C % 128 == 0): half the dependent load rounds
 #define HEAD_LAUNCH(NT_, W_)                                                                                                            \
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL, (rpn_head_tail_kernel<TIN, NT_, BF16MM, W_>), dim3((unsigned)tiles), dim3(64 * W_), 0, s, L, C, b3, w_cls, \
+    FRCNN_LAUNCH((rpn_head_tail_kernel<TIN, NT_, BF16MM, W_>), dim3((unsigned)tiles), dim3(64 * W_), 0, s, L, C, b3, w_cls, \
                  b_cls, n_cls, w_reg, b_reg, n_reg, out_cls, out_reg)
     const bool w8 = (C % 128) == 0;
     if (nt == 1) { if (w8) HEAD_LAUNCH(1, 8); else HEAD_LAUNCH(1, 4); }
@@ -515,14 +515,14 @@ FRCNN_EXPORT int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, 
     float *part_db = part_db3 + (size_t)HEAD_BWD_MAX_BLOCKS * C;
     const int nj = n_cls + n_reg <= 32 ? 1 : 2;
 #define HEAD_BWD_LAUNCH(T_, NJ_)                                                                                                            \
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, (rpn_head_tail_bwd_kernel<T_, NJ_, 1>), dim3((unsigned)nblk, (unsigned)(C / (32 * HB_NW))), dim3(64 * HB_NW), 0, s, L, C, (int)tiles, \
+    FRCNN_LAUNCH((rpn_head_tail_bwd_kernel<T_, NJ_, 1>), dim3((unsigned)nblk, (unsigned)(C / (32 * HB_NW))), dim3(64 * HB_NW), 0, s, L, C, (int)tiles, \
                  b3, w_cls, n_cls, w_reg, n_reg, g_cls, g_reg, part_dw, part_db3, part_db)
     if (dtype == FRCNN_DTYPE_F32) { if (nj == 1) HEAD_BWD_LAUNCH(float, 1); else HEAD_BWD_LAUNCH(float, 2); }
     else { if (nj == 1) HEAD_BWD_LAUNCH(unsigned short, 1); else HEAD_BWD_LAUNCH(unsigned short, 2); }
 #undef HEAD_BWD_LAUNCH
     FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_kernel");
     const int n_out = (n_cls + n_reg) * C + C + n_cls + n_reg;
-    FRCNN_LAUNCH(KID_RPN_HEAD_TAIL_BWD, rpn_head_tail_bwd_finalize_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, s, part_dw, part_db3, part_db,
+    FRCNN_LAUNCH(rpn_head_tail_bwd_finalize_kernel, dim3((unsigned)((n_out + 31) / 32)), dim3(256), 0, s, part_dw, part_db3, part_db,
                  nblk, C, n_cls, n_reg, dw_cls, db_cls, dw_reg, db_reg, db3);
     FRCNN_CHECK_LAUNCH("rpn_head_tail_bwd_finalize_kernel");
     return FRCNN_OK;

@@ -670,25 +670,25 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(w.colkey, 0, (size_t)G * 8 * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
-    FRCNN_LAUNCH(KID_RPN_COLMAX, rpn_colmax_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
+    FRCNN_LAUNCH(rpn_colmax_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
                  (int)G, w.colkey, out_counts, (unsigned long long *)philox_state_dev, w.snap);
     FRCNN_CHECK_LAUNCH("rpn_colmax_kernel");
     const unsigned long long *snap = philox_state_dev ? w.snap : nullptr;
-    FRCNN_LAUNCH(KID_RPN_LABEL, rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
+    FRCNN_LAUNCH(rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
                  w.colkey, out_cls, (float4 *)out_reg, w.label8, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_label_kernel");
     static const bool force_block = [] { const char *e = getenv("FRCNN_RPN_SAMPLE"); return e && !strcmp(e, "block"); }();   // tests: old path
     if (N > RS_LDS_MAX && !perm_pos && !perm_neg && !force_block) {     // chip-wide device-RNG sampler for FPN-sized N
         if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
         const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<0>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<1>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_hist_kernel<2>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
-        FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_samp_apply_kernel, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts, out_cls);
+        FRCNN_LAUNCH(rpn_samp_hist_kernel<0>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(rpn_samp_hist_kernel<1>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(rpn_samp_hist_kernel<2>, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts);
+        FRCNN_LAUNCH(rpn_samp_apply_kernel, dim3(gb), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snap, w.sel, out_counts, out_cls);
         FRCNN_CHECK_LAUNCH("rpn_samp kernels");
         return FRCNN_OK;
     }
-    FRCNN_LAUNCH(KID_RPN_SAMPLE, rpn_sample_kernel, dim3(1), dim3(1024), 0, s, (int)N, w.label8, out_cls, perm_pos, (int)n_perm_pos, perm_neg,
+    FRCNN_LAUNCH(rpn_sample_kernel, dim3(1), dim3(1024), 0, s, (int)N, w.label8, out_cls, perm_pos, (int)n_perm_pos, perm_neg,
                  (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, snap, w.list, w.keys, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_sample_kernel");
     return FRCNN_OK;
@@ -707,7 +707,7 @@ FRCNN_EXPORT int frcnn_head_targets(int variant, const float *rois, const int32_
     FRCNN_REQUIRE((P_cap == 0 || rois) && gt && gt_label && out_cls && out_reg && out_rois && out_counts, "head_targets: NULL pointer");
     FRCNN_REQUIRE(n_perm_pos >= 0 && n_perm_neg >= 0, "head_targets: bad perm length");
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(KID_HEAD_TARGETS, head_targets_kernel, dim3(1), dim3(1024), 0, s, variant, (const float4 *)rois, n_rois_dev, (int)P_cap,
+    FRCNN_LAUNCH(head_targets_kernel, dim3(1), dim3(1024), 0, s, variant, (const float4 *)rois, n_rois_dev, (int)P_cap,
                  (const float4 *)gt, gt_label, (int)G, (int)label_offset, (int)max_pos, (int)total, perm_pos, (int)n_perm_pos, perm_neg,
                  (int)n_perm_neg, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls, (float4 *)out_reg, (float4 *)out_rois,
                  out_keep_index, out_counts, sticky_status);

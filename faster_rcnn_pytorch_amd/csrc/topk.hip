@@ -346,14 +346,14 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
         const int full = S / SS_BUCKETS;                                        // stride that spreads 255 splitters over all S samples
         int stride = (int)((3 * K * S + 2 * (SS_BUCKETS - 1) * N - 1) / (2 * (SS_BUCKETS - 1) * N));     // ceil(1.5 K S / (255 N))
         stride = stride < 1 ? 1 : (stride > full ? full : stride);
-        if (S == 512) FRCNN_LAUNCH(KID_TOPK_RANK, topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
-        else FRCNN_LAUNCH(KID_TOPK_RANK, topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+        if (S == 512) FRCNN_LAUNCH(topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+        else FRCNN_LAUNCH(topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
         FRCNN_CHECK_LAUNCH("topk_sample_kernel");
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);
+        FRCNN_LAUNCH(topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);
         FRCNN_CHECK_LAUNCH("topk_count_kernel");
-        FRCNN_LAUNCH(KID_TOPK_RANK, topk_place_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, ctl, sorted);
+        FRCNN_LAUNCH(topk_place_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, ctl, sorted);
         FRCNN_CHECK_LAUNCH("topk_place_kernel");
-        FRCNN_LAUNCH(KID_TOPK_SCATTER, topk_bucket_kernel, dim3(SS_BUCKETS, N < 65536 ? 4 : 8), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, ctl,
+        FRCNN_LAUNCH(topk_bucket_kernel, dim3(SS_BUCKETS, N < 65536 ? 4 : 8), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, ctl,
                      sorted, out_idx, out_scores, (float4 *)out_boxes, out_count);
         FRCNN_CHECK_LAUNCH("topk_bucket_kernel");
         return FRCNN_OK;
@@ -361,9 +361,9 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
     const int nseg = (int)((N + TOPK_SEG - 1) / TOPK_SEG);
     const int nrow = (int)((N + TOPK_ROWS - 1) / TOPK_ROWS);
     int32_t *partial = (int32_t *)ws;
-    FRCNN_LAUNCH(KID_TOPK_RANK, topk_rank_kernel, dim3(nrow, nseg), dim3(TOPK_ROWS), 0, s, scores, (int)N, partial, out_count);
+    FRCNN_LAUNCH(topk_rank_kernel, dim3(nrow, nseg), dim3(TOPK_ROWS), 0, s, scores, (int)N, partial, out_count);
     FRCNN_CHECK_LAUNCH("topk_rank_kernel");
-    FRCNN_LAUNCH(KID_TOPK_SCATTER, topk_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, scores,
+    FRCNN_LAUNCH(topk_scatter_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, scores,
                  (const float4 *)boxes_in, partial, (int)N, nseg, (int)K, proposal_mode, out_idx, out_scores, (float4 *)out_boxes,
                  out_count);
     FRCNN_CHECK_LAUNCH("topk_scatter_kernel");

@@ -225,6 +225,7 @@ class FRCNN(nn.Module):
         self.rpn_target_maker = RPNTargetMaker(self.sampler)
         self.fast_rcnn_target_maker = FastRcnnTargetMaker(self.sampler)
         self.fast_rcnn_head = FastRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
+        self.last_proposal_count = None
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
@@ -251,6 +252,7 @@ class FRCNN(nn.Module):
         # 4. propose regions -> fixed-capacity rois + device count (anchors regenerated in registers)   model.py:318
         rois, n_rois, _ = self.rp.propose(pred_rpn_cls.squeeze(0), pred_rpn_reg.squeeze(0), None, "train",
                                           grid=self.anchor_maker.grid_desc(hw))
+        self.last_proposal_count = n_rois                                     # device int32[1]: how many proposals survived NMS (<= 2000)
         # 6. fast rcnn targets                                                 model.py:328
         target_fast_rcnn_cls, target_fast_rcnn_reg, sample_rois = self.fast_rcnn_target_maker(bbox=bbox, label=label, rois=rois,
                                                                                               n_rois=n_rois)

@@ -338,6 +338,7 @@ class FRCNN(nn.Module):
         self.rpn_target_maker = RPNTargetMaker(self.sampler)
         self.frcnn_target_maker = FRCNNTargetMaker(self.sampler)
         self.frcnn_head = FRCNNHead(num_classes=num_classes, roi_size=7, classifier=self.classifier)
+        self.last_proposal_count = None
 
     def count_parameters(self):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
@@ -350,6 +351,7 @@ class FRCNN(nn.Module):
     def forward(self, x, boxes, labels):
         features = self.backbone(x)                                                # new_model.py:394
         pred_rpn_cls, pred_rpn_reg, rois, n_rois, anchors = self.rpn.propose(x, features, "train")
+        self.last_proposal_count = n_rois                                          # device int32[1]: proposals that survived NMS (<= 1000)
         target_rpn_cls, target_rpn_reg = self.rpn_target_maker(boxes=boxes, anchors=anchors)
         target_fast_rcnn_cls, target_fast_rcnn_reg, sample_rois = self.frcnn_target_maker(boxes=boxes, labels=labels, rois=rois,
                                                                                           n_rois=n_rois)

@@ -59,6 +59,28 @@ def wrap_ddp(model, device, bucket_cap_mb=100):
                broadcast_buffers=False)
 
 
+def ddp_report(net):
+    """What DDP's reducer was built over, from its own logging record: the number of parameter tensors it hooked (each
+    parameter ONCE -- the VGG mirror registers `classifier` twice, as FRCNN.classifier and fast_rcnn_head.classifier, like the
+    reference, models/model.py:282,298), their bytes, the bucket cap and the bucket sizes (initial assignment; DDP re-buckets
+    in gradient-ready order after the first backward and reports that as rebuilt_bucket_sizes).  None for an unwrapped model."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    if not isinstance(net, DDP):
+        return None
+    d = net._get_ddp_logging_data()
+
+    def sizes(key):
+        v = d.get(key)
+        return [int(x) for x in str(v).replace(",", " ").split()] if v not in (None, "") else None
+    unique = {id(p): p for p in net.module.parameters() if p.requires_grad}
+    return {"num_parameter_tensors": int(d.get("num_parameter_tensors", -1)), "total_parameter_size_bytes": int(d.get("total_parameter_size_bytes", -1)),
+            "unique_trainable_parameters": len(unique), "unique_trainable_bytes": int(sum(p.numel() * p.element_size() for p in unique.values())),
+            "registered_names_with_aliases": len(list(net.module.named_parameters(remove_duplicate=False))),
+            "bucket_cap_bytes": int(d.get("bucket_cap_bytes", -1)), "bucket_sizes": sizes("bucket_sizes"),
+            "rebuilt_bucket_sizes": sizes("rebuilt_bucket_sizes"), "gradient_as_bucket_view": bool(d.get("gradient_as_bucket_view", 0)),
+            "find_unused_parameters": bool(d.get("find_unused_parameters", 0))}
+
+
 def max_over_ranks(value, device):
     """MAX of a python float over all ranks (bench.py's timing rule)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

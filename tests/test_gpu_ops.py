@@ -216,6 +216,55 @@ def test_nms_bit_exact_vs_oracle(ops, K, thr):
     assert int(cnt.item()) == len(ko) and np.array_equal(keep[:len(ko)].cpu().numpy(), ko)
 
 
+@pytest.mark.parametrize("live", [1, 64, 1500, 2047, 2048, 2049, 2111, 2112, 4097, 11999])
+def test_nms_cascade_live_count_around_the_level_boundary(ops, live):
+    """K = 12 000 takes the cascade (top 2048 -> filter -> survivors); the device-side live count may fall anywhere relative to the
+    level boundary, including an empty second level."""
+    rng = np.random.RandomState(5)
+    K = 12000
+    c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15
+    wh = (rng.rand(K, 2).astype(np.float32) * 0.3 + 0.05)
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    ko = orc.nms(b[:live], 0.7)
+    keep, rois, cnt = ops.nms_sorted(T(b), 0.7, n_boxes=T(np.array([live], np.int32)), want_rois=True)
+    n = int(cnt.item())
+    assert n == len(ko) and np.array_equal(keep[:n].cpu().numpy(), ko) and np.array_equal(rois[:n].cpu().numpy(), b[ko])
+    post = max(1, len(ko) // 2)                                   # post_k cuts inside level 0 or level 1
+    keep, _, cnt = ops.nms_sorted(T(b), 0.7, post_k=post, n_boxes=T(np.array([live], np.int32)))
+    assert int(cnt.item()) == post and np.array_equal(keep[:post].cpu().numpy(), ko[:post])
+
+
+@pytest.mark.parametrize("regime", ["heavy", "sparse", "chain"])
+def test_nms_cascade_regimes(ops, regime):
+    """The cascade's three stages under different survivor fractions: 'heavy' = piles of near-duplicates (almost everything dies in
+    the filter), 'sparse' = almost nothing overlaps (everything survives into level 1), 'chain' = a long suppression chain that
+    crosses the level boundary (box i overlaps box i + 1 only: kept / removed alternate, decided one from the other)."""
+    rng = np.random.RandomState(9)
+    K = 9000
+    if regime == "heavy":
+        centers = rng.rand(40, 2).astype(np.float32) * 0.6 + 0.2
+        c = centers[rng.randint(0, 40, K)] + rng.randn(K, 2).astype(np.float32) * 0.004
+        wh = np.float32(0.15) + rng.randn(K, 2).astype(np.float32) * 0.004
+    elif regime == "sparse":
+        c = rng.rand(K, 2).astype(np.float32) * 0.9 + 0.05
+        wh = np.full((K, 2), 0.004, np.float32)
+    else:
+        t = np.arange(K, dtype=np.float32) / K
+        c = np.stack([0.1 + 0.8 * t, np.full(K, 0.5, np.float32)], 1).astype(np.float32)
+        wh = np.stack([np.full(K, 0.8 / K * 4, np.float32), np.full(K, 0.2, np.float32)], 1)       # IoU(i, i+1) = 3/5 > 0.5, IoU(i, i+2) = 1/3
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    thr = 0.5
+    ko = orc.nms(b, thr)
+    keep, _, cnt = ops.nms_sorted(T(b), thr)
+    n = int(cnt.item())
+    assert n == len(ko) and np.array_equal(keep[:n].cpu().numpy(), ko)
+    cls = rng.randint(0, 7, K).astype(np.int64)                    # the class-aware instantiation through the same cascade
+    sc = np.linspace(1.0, 0.0, K).astype(np.float32)
+    got = ops.batched_nms(T(b), T(sc), T(cls), thr).cpu().numpy()
+    exp = np.sort(np.concatenate([np.nonzero(cls == q)[0][orc.nms(b[cls == q], thr)] for q in range(7)]))
+    assert np.array_equal(got, exp)
+
+
 def test_nms_dense_clusters_near_threshold(ops):
     # many boxes piled on few objects with IoUs straddling the threshold: stresses the exact-division band
     rng = np.random.RandomState(3)

@@ -91,6 +91,51 @@ def test_ddp_gloo_world2_gradient_average_and_timing_rule():
     assert np.allclose(res[0][1], ((gs[0] + gs[1]) / 2).numpy(), atol=1e-6)
 
 
+def _ddp_struct_worker(r, world, port, q):
+    os.environ.update(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from faster_rcnn_pytorch_amd import parallel
+    from faster_rcnn_pytorch_amd.model import FRCNN
+    _, _, w, dev = parallel.init_for_distributed(backend="gloo")
+    torch.manual_seed(0)
+    model = FRCNN(num_classes=21)                      # module construction needs no GPU (only forward does)
+    net = parallel.wrap_ddp(model, dev)
+    rep = parallel.ddp_report(net)
+    # a gradient for every parameter, produced through autograd so that DDP's per-parameter hooks fire: rank-dependent values
+    net.require_backward_grad_sync = True
+    net.reducer.prepare_for_backward([])
+    loss = sum((p * float(1 + r + i % 3)).sum() for i, p in enumerate(model.parameters()))
+    loss.backward()
+    g = [float(p.grad.flatten()[0]) for p in model.parameters()]
+    q.put((r, rep, g, parallel.ddp_report(net)))
+    parallel.shutdown()
+
+
+def test_ddp_wraps_every_parameter_once_with_the_aliased_classifier():
+    """the VGG mirror registers `classifier` under two names (models/model.py:282,298).  DDP must hook each of the
+    40 parameter tensors exactly once (44 names), reduce 548 MB per step, and average the per-parameter gradients across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 7) % 2000
+    procs = [ctx.Process(target=_ddp_struct_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r, rep, g, rep2 in res:
+        assert rep["num_parameter_tensors"] == rep["unique_trainable_parameters"] == 40
+        assert rep["registered_names_with_aliases"] == 44                       # classifier.{0,2}.{weight,bias} twice
+        assert rep["total_parameter_size_bytes"] == rep["unique_trainable_bytes"] == 548312956
+        assert rep["bucket_cap_bytes"] == 100 * 1024 * 1024 and rep["gradient_as_bucket_view"] and not rep["find_unused_parameters"]
+        assert sum(rep["bucket_sizes"]) == 548312956
+    # every parameter's gradient was all-reduced exactly once: mean over ranks of (1 + r + i % 3)
+    for i in range(40):
+        exp = ((1 + 0 + i % 3) + (1 + 1 + i % 3)) / 2
+        assert res[0][2][i] == res[1][2][i] == exp
+
+
 def test_torchvision_scale_inference_with_the_references_swapped_shapes():
     """models/new_model.py:143 passes image_shapes=[(w, h)] where torchvision's pooler reads (h, w): under
     torchvision the FEATURE HEIGHT is divided by the IMAGE WIDTH.  ops.MultiScaleRoIAlign(scales='reference') reproduces that."""
