@@ -1,4 +1,4 @@
-// loss.hip -- FRCNNLoss (losses/loss.py:5-85) as one streaming kernel + a one-thread finalize.
+// loss.hip -- FRCNNLoss (losses/loss.py:5-85) as ONE streaming kernel whose last workgroup adds up the partial sums.
 //   RPN : CE(ignore -1) over [N,2] + SmoothL1(beta 1/9) over the positives, both / #(label >= 0)     (loss.py:20-40)
 //   head: CE over [R,C]            + SmoothL1(beta 1)   over the positives, both / R                   (loss.py:43-61)
 // A head class outside [0, C) (the failure mark of frcnn_head_targets) makes the head CE, hence the total, NaN.
@@ -6,8 +6,10 @@
 // many per backward.  Here one pass over the predictions produces the four sums AND the un-normalised gradients
 // (softmax - onehot, SmoothL1'), so backward is four scalar multiplies.  RPN rows: one lane per anchor, grid-stride over at
 // most 256 workgroups; head rows: one WAVE per RoI (lanes over the classes, coalesced row reads, shuffle max / sum).  Every
-// workgroup writes its partial sums to its own slot and the finalize kernel adds the slots in index order: no atomics
-// (1051 same-line atomics x 5 cost 50 us at FPN size) and a loss that is bit-reproducible run to run.
+// workgroup writes its partial sums to its own slot; the workgroup that finishes LAST (an agent-scope ticket, acq_rel) adds the slots in
+// index order: no float atomics (1051 same-line atomics x 5 cost 50 us at FPN size), a loss that is bit-reproducible run to run, and no
+// second launch (round 2 ran the sum as its own one-wave kernel: a launch at the ~5 us floor for 2 KB of data).  The ticket word is the
+// first int32 of the workspace: it must be ZERO before the first call and the last workgroup leaves it zero (frcnn_hip.h).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 
@@ -42,10 +44,12 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float2 *__restrict_
                                                        const int64_t *__restrict__ t_cls, const float4 *__restrict__ t_reg, int R, int NC,
                                                        float2 *__restrict__ g_rpn_cls, float4 *__restrict__ g_rpn_reg,
                                                        float *__restrict__ g_head_cls, float4 *__restrict__ g_head_reg,
-                                                       LossAcc *__restrict__ slots, int nb_rpn)
+                                                       LossAcc *__restrict__ slots, int nb_rpn, int32_t *__restrict__ ticket,
+                                                       float *__restrict__ out)
 {
     __shared__ float s_part[4][4];
     __shared__ int s_cnt[4];
+    __shared__ int s_last;
     float ce = 0.f, sl = 0.f, hce = 0.f, hsl = 0.f;
     int valid = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -102,18 +106,26 @@ __global__ __launch_bounds__(256) void det_loss_kernel(const float2 *__restrict_
     for (int o = 32; o > 0; o >>= 1) vc += __shfl_xor(vc, o);
     if (lane == 0) { s_part[w][0] = ce; s_part[w][1] = sl; s_part[w][2] = hce; s_part[w][3] = hsl; s_cnt[w] = vc; }
     __syncthreads();
-    if (threadIdx.x < 4) (&slots[blockIdx.x].rpn_ce)[threadIdx.x] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-    if (threadIdx.x == 4) slots[blockIdx.x].rpn_valid = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-}
-
-// out[0..4] = total, rpn_cls, rpn_reg, head_cls, head_reg ; out[5] = 1/n_valid, out[6] = 1/R (gradient scales)
-__global__ __launch_bounds__(64) void det_loss_finalize_kernel(const LossAcc *__restrict__ slots, int n_slots, int R, float *__restrict__ out)
-{
+    // my slot: write-through stores (the adder may sit on another XCD), then the ticket
+    if (threadIdx.x < 4)
+        __hip_atomic_store(&(&slots[blockIdx.x].rpn_ce)[threadIdx.x], s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 4) __hip_atomic_store(&slots[blockIdx.x].rpn_valid, s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                                   // (the stores of threads 0-4 are ordered before thread 0's ticket by the barrier + release)
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return;
+    // ---- the last workgroup: out[0..4] = total, rpn_cls, rpn_reg, head_cls, head_reg ; out[5] = 1/n_valid, out[6] = 1/R (gradient scales)
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+    const int n_slots = (int)gridDim.x;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     int nvi = 0;
     for (int b = threadIdx.x; b < n_slots; b += 64) {                  // fixed assignment + fixed shuffle tree: deterministic
-        a[0] += slots[b].rpn_ce; a[1] += slots[b].rpn_sl1; a[2] += slots[b].head_ce; a[3] += slots[b].head_sl1;
-        nvi += slots[b].rpn_valid;
+        a[0] += __hip_atomic_load(&slots[b].rpn_ce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a[1] += __hip_atomic_load(&slots[b].rpn_sl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a[2] += __hip_atomic_load(&slots[b].head_ce, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a[3] += __hip_atomic_load(&slots[b].head_sl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nvi += __hip_atomic_load(&slots[b].rpn_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) a[q] = wave_sum(a[q]);
@@ -139,15 +151,14 @@ FRCNN_EXPORT int frcnn_detection_loss(const float *rpn_cls, const float *rpn_reg
                   "detection_loss: NULL pointer");
     const int nb_rpn = (int)((N + 255) / 256 < LOSS_MAX_BLOCKS ? (N + 255) / 256 : LOSS_MAX_BLOCKS);
     const int nb_head = (int)((R + 3) / 4 < LOSS_MAX_BLOCKS ? (R + 3) / 4 : LOSS_MAX_BLOCKS);
-    const size_t need = (size_t)(nb_rpn + nb_head) * sizeof(LossAcc);
+    const size_t need = 64 + (size_t)(nb_rpn + nb_head) * sizeof(LossAcc);
     if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "detection_loss: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
-    LossAcc *slots = (LossAcc *)workspace;
+    int32_t *ticket = (int32_t *)workspace;                            // zero between calls (see the file header)
+    LossAcc *slots = (LossAcc *)((char *)workspace + 64);
     FRCNN_LAUNCH(det_loss_kernel, dim3((unsigned)(nb_rpn + nb_head)), dim3(256), 0, s, (const float2 *)rpn_cls, (const float4 *)rpn_reg,
                  t_rpn_cls, (const float4 *)t_rpn_reg, (int)N, head_cls, (const float4 *)head_reg, t_cls, (const float4 *)t_reg, (int)R, NC,
-                 (float2 *)g_rpn_cls, (float4 *)g_rpn_reg, g_head_cls, (float4 *)g_head_reg, slots, nb_rpn);
+                 (float2 *)g_rpn_cls, (float4 *)g_rpn_reg, g_head_cls, (float4 *)g_head_reg, slots, nb_rpn, ticket, out7);
     FRCNN_CHECK_LAUNCH("det_loss_kernel");
-    FRCNN_LAUNCH(det_loss_finalize_kernel, dim3(1), dim3(64), 0, s, slots, nb_rpn + nb_head, (int)R, out7);
-    FRCNN_CHECK_LAUNCH("det_loss_finalize_kernel");
     return FRCNN_OK;
 }

@@ -14,6 +14,7 @@
 #include "frcnn_common.h"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "frcnn_internal.h"
 
 #define EPS_JACCARD 1e-5f
@@ -228,20 +229,16 @@ __device__ void block_radix_select(int n, int keep, KeyFn key_of, FlagFn is_cand
 //   if n_pos > 128: label[pos_indices[perm[128:]]] = -1
 //   if n_neg > 256 - n_pos: label[neg_indices[perm[(256 - min(n_pos,128)):]]] = -1
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restrict__ label8, int64_t *__restrict__ out_cls,
-                                                          const int64_t *__restrict__ perm_pos, int n_perm_pos,
-                                                          const int64_t *__restrict__ perm_neg, int n_perm_neg,
-                                                          unsigned long long seed, unsigned long long offset,
-                                                          const unsigned long long *__restrict__ philox_snap,
-                                                          int32_t *__restrict__ list, unsigned *__restrict__ keys,
-                                                          int32_t *__restrict__ counts)
+struct RpnSampleLds { int s_w[17]; unsigned s_hist[16 * 256]; unsigned s_pref[4]; int s_cnt; unsigned s_keys[RS_LDS_MAX]; };
+
+__device__ __forceinline__ void rpn_sample_body(RpnSampleLds &L, int N, int8_t *__restrict__ label8, int64_t *__restrict__ out_cls,
+                                                const int64_t *__restrict__ perm_pos, int n_perm_pos,
+                                                const int64_t *__restrict__ perm_neg, int n_perm_neg,
+                                                unsigned long long seed, unsigned long long offset,
+                                                int32_t *__restrict__ list, unsigned *__restrict__ keys,
+                                                int32_t *__restrict__ counts)
 {
-    if (philox_snap) { seed = philox_snap[0]; offset = philox_snap[1]; }
-    __shared__ int s_w[17];
-    __shared__ unsigned s_hist[16 * 256];
-    __shared__ unsigned s_pref[4];
-    __shared__ int s_cnt;
-    __shared__ unsigned s_keys[RS_LDS_MAX];
+    int *s_w = L.s_w; unsigned *s_hist = L.s_hist; unsigned *s_pref = L.s_pref; int &s_cnt = L.s_cnt; unsigned *s_keys = L.s_keys;
     const int n_pos = counts[0], n_neg = counts[1];
     const int np_eff = min(n_pos, 128);
     const bool drop_pos = n_pos > 128;
@@ -353,6 +350,145 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
             }
             __syncthreads();
         }
+    }
+}
+
+__global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restrict__ label8, int64_t *__restrict__ out_cls,
+                                                          const int64_t *__restrict__ perm_pos, int n_perm_pos,
+                                                          const int64_t *__restrict__ perm_neg, int n_perm_neg,
+                                                          unsigned long long seed, unsigned long long offset,
+                                                          const unsigned long long *__restrict__ philox_snap,
+                                                          int32_t *__restrict__ list, unsigned *__restrict__ keys,
+                                                          int32_t *__restrict__ counts)
+{
+    __shared__ RpnSampleLds L;
+    if (philox_snap) { seed = philox_snap[0]; offset = philox_snap[1]; }
+    rpn_sample_body(L, N, label8, out_cls, perm_pos, n_perm_pos, perm_neg, n_perm_neg, seed, offset, list, keys, counts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rpn_match_kernel<SAMPLE>: RPNTargetMaker.forward in ONE launch (device-RNG mode).  1024 anchors per workgroup, all workgroups
+// co-resident (the launcher checks the count against the chip), three phases:
+//   (1) per-GT best anchor: wave shuffles -> LDS -> one atomicMax per workgroup and GT box (colkey, a 64-byte line per box);
+//   (2) after a GRID BARRIER (an agent-scope arrival counter every workgroup bumps and then polls) every anchor takes its label
+//       from its own IoU row and the now final column maxima, encodes its regression target, counts positives / negatives;
+//   (3) SAMPLE (N <= 24 576): the workgroup that finishes phase 2 LAST (a second ticket, acq_rel) runs the sampler on the labels all
+//       workgroups have written -- round 2 had three launches here (rpn_colmax -> rpn_label -> rpn_sample), each at the ~5 us floor.
+// The control block {barrier, ticket, philox snapshot} and colkey live in a workspace that is ZERO before the first call; the last
+// workgroup leaves barrier, ticket and colkey zero for the next call (no memset node in the pipeline, HIP-graph friendly).
+// A wait that runs out of spins (a workgroup that was never scheduled: cannot happen while the grid fits the chip) raises counts[2].
+// ------------------------------------------------------------------------------------------------
+struct RpnCtl { int32_t bar, ticket, n_pos, n_neg; unsigned long long snap[2]; };
+#define RPN_BAR_SPINS (1 << 22)
+#define RPN_MAX_G 4096
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const float4 *__restrict__ anchors, int N, const float4 *__restrict__ gt, int G,
+                                                         unsigned long long *__restrict__ colkey, RpnCtl *__restrict__ ctl,
+                                                         unsigned long long seed, unsigned long long offset, unsigned long long *__restrict__ philox_state,
+                                                         int64_t *__restrict__ out_cls, float4 *__restrict__ out_reg, int8_t *__restrict__ label8,
+                                                         int32_t *__restrict__ list, unsigned *__restrict__ keys, int32_t *__restrict__ counts)
+{
+    __shared__ unsigned long long s_k[16];
+    __shared__ int s_cnt2[2][16];
+    __shared__ int s_flag;
+    __shared__ typename std::conditional<SAMPLE, RpnSampleLds, int>::type Ls_store;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    const int nb = (int)gridDim.x;
+    if (philox_state && blockIdx.x == 0 && tid == 0) {              // this call's (seed, offset); the stream moves on (frcnn_hip.h)
+        const unsigned long long sd = philox_state[0], of = philox_state[1];
+        ctl->snap[0] = sd; ctl->snap[1] = of;
+        philox_state[1] = of + 1ull;
+    }
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool live = false;
+    if (i < N) { a = anchors[i]; live = variant == 1 || anchor_inside(a); }
+    // ---- (1) column maxima
+    const bool any_live = __syncthreads_or(live) != 0;
+    if (any_live) {
+        for (int g = 0; g < G; ++g) {
+            unsigned long long key = 0ull;
+            if (live) {
+                const float v = iou_variant(variant, a, gt[g]);
+                if (v >= 0.0f) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);   // NaN never wins
+            }
+            key = wave_max_u64(key);
+            if (lane == 0) s_k[wave] = key;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long m = s_k[0];
+#pragma unroll
+                for (int q = 1; q < 16; ++q) m = s_k[q] > m ? s_k[q] : m;
+                if (m != 0ull && m > __hip_atomic_load(&colkey[(size_t)g * CK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    atomicMax(&colkey[(size_t)g * CK_STRIDE], m);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- grid barrier
+    if (tid == 0) {
+        __hip_atomic_fetch_add(&ctl->bar, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, ok = 1;
+        while (__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nb) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > RPN_BAR_SPINS) { ok = 0; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_flag = ok;
+    }
+    __syncthreads();
+    if (!s_flag) { if (tid == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 4; counts[3] = 0; } return; }   // (control words stay dirty; the caller sees the error flag)
+    // ---- (2) labels
+    int lab = -1;
+    if (i < N) {
+        float4 reg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            float best = -__builtin_inff();
+            int arg = 0;
+            bool match = false;
+            for (int g = 0; g < G; ++g) {
+                const float v = iou_variant(variant, a, gt[g]);
+                if (v > best) { best = v; arg = g; }
+                const unsigned long long ck = __hip_atomic_load(&colkey[(size_t)g * CK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (variant == 1) match |= (v == __uint_as_float((unsigned)(ck >> 32))) && ck != 0ull;
+                else match |= (0xFFFFFFFFu - (unsigned)ck) == (unsigned)i && ck != 0ull;
+            }
+            if (best < 0.3f) lab = 0;
+            if (match) lab = 1;
+            if (best >= 0.7f) lab = 1;
+            reg = encode4(xy_to_cxcy4(gt[arg]), xy_to_cxcy4(a));
+        }
+        out_cls[i] = lab;
+        out_reg[i] = reg;
+        label8[i] = (int8_t)lab;
+    }
+    const unsigned long long bp = __ballot(lab == 1), bn = __ballot(lab == 0);
+    if (lane == 0) { s_cnt2[0][wave] = __builtin_popcountll(bp); s_cnt2[1][wave] = __builtin_popcountll(bn); }
+    __syncthreads();
+    if (tid < 2) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c += s_cnt2[tid][q];
+        if (c) atomicAdd(tid == 0 ? &ctl->n_pos : &ctl->n_neg, c);  // (summed in the zero-kept control block: no ordering against a clearing store)
+    }
+    // ---- (3) the last workgroup hands out the counts, resets the control words and (SAMPLE) draws the samples
+    __syncthreads();
+    if (tid == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    __syncthreads();
+    if (!s_flag) return;
+    for (int g = tid; g < G; g += 1024) colkey[(size_t)g * CK_STRIDE] = 0ull;
+    if (tid == 0) {
+        counts[0] = __hip_atomic_load(&ctl->n_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        counts[1] = __hip_atomic_load(&ctl->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        counts[2] = 0; counts[3] = 0;
+        __hip_atomic_store(&ctl->n_pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->n_neg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();                                                // the sampler reads counts[0..1]
+    if constexpr (SAMPLE) {
+        if (philox_state) { seed = ctl->snap[0]; offset = ctl->snap[1]; }
+        rpn_sample_body(*(RpnSampleLds *)&Ls_store, N, label8, out_cls, nullptr, 0, nullptr, 0, seed, offset, list, keys, counts);
     }
 }
 
@@ -637,13 +773,18 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-struct RpnWs { unsigned long long *colkey, *snap; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
+struct RpnWs { unsigned long long *colkey, *colkey2, *snap; RpnCtl *ctl; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
 static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
 {
     RpnWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
-    w.colkey = (unsigned long long *)take((size_t)G * 8 * 8);
+    // FIXED prefix (independent of N and G, so that a workspace reused at another size finds its control words where it left them,
+    // zero): the control block, then one 64-byte line per GT box for the largest G the entry point accepts
+    w.ctl = (RpnCtl *)take(sizeof(RpnCtl));
     w.snap = (unsigned long long *)take(16);
+    w.colkey = (unsigned long long *)take((size_t)RPN_MAX_G * 8 * 8);
+    w.colkey2 = (unsigned long long *)take((size_t)G * 8 * 8);      // the staged (three-launch) path's own maxima: cleared per call, so that
+                                                                    // the fused kernel's colkey keeps its "zero between calls" invariant
     w.label8 = (int8_t *)take((size_t)N);
     w.list = (int32_t *)take((size_t)N * 4);
     w.keys = (unsigned *)take((size_t)N * 4);
@@ -662,22 +803,56 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     FRCNN_REQUIRE(variant == 0 || variant == 1, "rpn_targets: variant must be 0 (VGG) or 1 (FPN)");
     FRCNN_REQUIRE(N > 0 && N < ((int64_t)1 << 31), "rpn_targets: bad N");
     FRCNN_REQUIRE(G > 0, "rpn_targets: G must be >= 1 (the reference fails on an image without boxes)");
-    FRCNN_REQUIRE(G <= 4096, "rpn_targets: G=%lld above limit 4096", (long long)G);
+    FRCNN_REQUIRE(G <= RPN_MAX_G, "rpn_targets: G=%lld above limit %d", (long long)G, RPN_MAX_G);
     FRCNN_REQUIRE(anchors && gt && out_cls && out_reg && out_counts && workspace, "rpn_targets: NULL pointer");
     FRCNN_REQUIRE(n_perm_pos >= 0 && n_perm_neg >= 0 && n_perm_pos < ((int64_t)1 << 31) && n_perm_neg < ((int64_t)1 << 31), "rpn_targets: bad perm length");
     RpnWs w = carve_rpn(workspace, N, G);
     if (workspace_bytes < w.total) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_targets: workspace %zu < %zu bytes", workspace_bytes, w.total);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(w.colkey, 0, (size_t)G * 8 * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
+    static const bool force_block = [] { const char *e = getenv("FRCNN_RPN_SAMPLE"); return e && !strcmp(e, "block"); }();   // tests: old path
+    static const int n_cus = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus;
+    }();
+    static const bool no_fuse = [] { const char *e = getenv("FRCNN_RPN_FUSED"); return e && !strcmp(e, "0"); }();
+    const int64_t nb1024 = (N + 1023) / 1024;
+    if (!perm_pos && !perm_neg && !no_fuse && !force_block) {
+        // device-RNG mode: ONE launch for column maxima, labels and (N <= 24 576) sampling; every workgroup must be resident for the
+        // in-kernel barrier: one 1024-thread workgroup per CU with the sampler's 112 KB of LDS, two without
+        const bool sample = N <= RS_LDS_MAX;
+        if (nb1024 <= (sample ? n_cus : 2 * n_cus)) {
+            if (sample)
+                FRCNN_LAUNCH(rpn_match_kernel<true>, dim3((unsigned)nb1024), dim3(1024), 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
+                             w.colkey, w.ctl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
+                             (float4 *)out_reg, w.label8, w.list, w.keys, out_counts);
+            else
+                FRCNN_LAUNCH(rpn_match_kernel<false>, dim3((unsigned)nb1024), dim3(1024), 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
+                             w.colkey, w.ctl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
+                             (float4 *)out_reg, w.label8, w.list, w.keys, out_counts);
+            FRCNN_CHECK_LAUNCH("rpn_match_kernel");
+            if (sample) return FRCNN_OK;
+            // chip-wide radix sampler for FPN-sized N (the snapshot of the device RNG stream sits in the control block)
+            const unsigned long long *snapf = philox_state_dev ? w.ctl->snap : nullptr;
+            if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
+            const int gbf = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
+            FRCNN_LAUNCH(rpn_samp_hist_kernel<0>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
+            FRCNN_LAUNCH(rpn_samp_hist_kernel<1>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
+            FRCNN_LAUNCH(rpn_samp_hist_kernel<2>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
+            FRCNN_LAUNCH(rpn_samp_apply_kernel, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts, out_cls);
+            FRCNN_CHECK_LAUNCH("rpn_samp kernels");
+            return FRCNN_OK;
+        }
+    }
+    if (hipMemsetAsync(w.colkey2, 0, (size_t)G * 8 * 8, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
     const dim3 grid((unsigned)((N + 255) / 256)), block(256);
     FRCNN_LAUNCH(rpn_colmax_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt,
-                 (int)G, w.colkey, out_counts, (unsigned long long *)philox_state_dev, w.snap);
+                 (int)G, w.colkey2, out_counts, (unsigned long long *)philox_state_dev, w.snap);
     FRCNN_CHECK_LAUNCH("rpn_colmax_kernel");
     const unsigned long long *snap = philox_state_dev ? w.snap : nullptr;
     FRCNN_LAUNCH(rpn_label_kernel, grid, block, 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
-                 w.colkey, out_cls, (float4 *)out_reg, w.label8, out_counts);
+                 w.colkey2, out_cls, (float4 *)out_reg, w.label8, out_counts);
     FRCNN_CHECK_LAUNCH("rpn_label_kernel");
-    static const bool force_block = [] { const char *e = getenv("FRCNN_RPN_SAMPLE"); return e && !strcmp(e, "block"); }();   // tests: old path
     if (N > RS_LDS_MAX && !perm_pos && !perm_neg && !force_block) {     // chip-wide device-RNG sampler for FPN-sized N
         if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
         const int gb = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;

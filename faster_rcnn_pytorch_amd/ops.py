@@ -55,6 +55,22 @@ def _workspace(device, nbytes):
     return buf
 
 
+_CTRL = {}
+
+
+def _ctrl_workspace(device, tag, nbytes):
+    """A persistent, ZERO-INITIALISED workspace per (op, device) for the ops whose kernels keep a control word between calls (a
+    last-workgroup ticket that the kernel itself resets: include/frcnn_hip.h).  Never shared with the scratch of other ops; one per
+    device, not per stream (calls of one op on one device are stream-ordered in the training step), so that a HIP-graph capture on its
+    own capture stream finds the buffer the warm-up created instead of allocating -- and zero-filling -- a new one inside the graph."""
+    key = (tag, device.index)
+    buf = _CTRL.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        _CTRL[key] = buf
+    return buf
+
+
 _CONST = {}
 
 
@@ -596,10 +612,10 @@ def rpn_targets(anchors, gt, variant=0, perm_pos=None, perm_neg=None, seed=0, of
     pp, npp = _perm(perm_pos, dev)
     pn, npn = _perm(perm_neg, dev)
     nb = _lib.workspace_bytes(_lib.OP_RPN_TARGETS, N, G)
-    ws = _workspace(dev, nb)
+    ws = _ctrl_workspace(dev, "rpn_targets", nb)          # holds the fused kernel's barrier / ticket words: zero on first use, left zero by every call
     with torch.cuda.device(dev):
         check(lib.frcnn_rpn_targets(int(variant), _ptr(anchors), N, _ptr(gt), G, _ptr(pp), npp, _ptr(pn), npn, int(seed), int(offset),
-                                    _ptr(_philox(philox_state)), _ptr(cls), _ptr(reg), _ptr(counts), _ptr(ws), nb, _stream()), "rpn_targets")
+                                    _ptr(_philox(philox_state)), _ptr(cls), _ptr(reg), _ptr(counts), _ptr(ws), ws.numel(), _stream()), "rpn_targets")
     return cls, reg, counts
 
 
@@ -651,10 +667,10 @@ class _DetLossFn(torch.autograd.Function):
         dev = rc.device
         out = torch.empty((7,), dtype=torch.float32, device=dev)
         g = [torch.empty_like(t) for t in (rc, rr, hc, hr)]
-        ws = _workspace(dev, 16384)
+        ws = _ctrl_workspace(dev, "det_loss", 32768)        # zero on first use; the kernel's last workgroup leaves its ticket zero
         with torch.cuda.device(dev):
             check(lib.frcnn_detection_loss(_ptr(rc), _ptr(rr), _ptr(trc), _ptr(trr), N, _ptr(hc), _ptr(hr), _ptr(tc), _ptr(tr), R, NC,
-                                           _ptr(out), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(ws), 16384, _stream()), "detection_loss")
+                                           _ptr(out), _ptr(g[0]), _ptr(g[1]), _ptr(g[2]), _ptr(g[3]), _ptr(ws), ws.numel(), _stream()), "detection_loss")
         ctx.save_for_backward(out, *g)
         ctx.shapes = shapes
         return out[0], out[1], out[2], out[3], out[4]

@@ -187,7 +187,10 @@ int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *ra
  *        smallest (key, index).  (seed, offset) come BY VALUE, or -- philox_state_dev != NULL -- from device memory:
  *        philox_state_dev[0] = seed, [1] = offset; the call uses that pair and leaves offset + 1 behind (ABI v4).  A training
  *        step captured in a HIP graph therefore draws fresh samples at every replay; by-value arguments would be frozen in it.
- * out_counts (int32[4], device): {n_pos, n_neg before sampling, error flag, reserved}.               */
+ * out_counts (int32[4], device): {n_pos, n_neg before sampling, error flag, reserved}.
+ * workspace: DEDICATED to this entry point and ZERO before the first call.  In device-RNG mode column maxima, labels and (N <= 24 576)
+ * sampling run as ONE launch whose workgroups meet at an in-kernel barrier; its arrival counter, last-workgroup ticket and the
+ * per-GT maxima live in the workspace and are left zero by every call (no memset node; HIP-graph replays need no clearing).          */
 int frcnn_rpn_targets(int variant, const float *anchors /*[N,4]*/, int64_t N, const float *gt /*[G,4]*/, int64_t G,
                       const int64_t *perm_pos, int64_t n_perm_pos, const int64_t *perm_neg, int64_t n_perm_neg,
                       uint64_t seed, uint64_t offset, uint64_t *philox_state_dev /*[2] device, or NULL*/,
@@ -254,7 +257,9 @@ int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host,
 /* ---- detection losses (losses/loss.py:5-85) ------------------------------------------------- */
 /* FRCNNLoss forward AND the un-normalised input gradients in one pass.  out7 (device): total, rpn_cls, rpn_reg,
  * head_cls, head_reg losses, then 1/#(rpn label >= 0) and 1/R (the scales backward multiplies the gradients by).
- * g_* have the shapes of the predictions.  workspace >= 16 KiB.                                                    */
+ * g_* have the shapes of the predictions.  workspace >= 32 KiB, DEDICATED to this entry point and ZERO before the first call:
+ * its first word is the ticket by which the last workgroup to finish adds up the partial sums (one launch, no finalize kernel);
+ * that workgroup leaves the ticket zero, so consecutive calls (and HIP-graph replays) need no clearing in between.            */
 int frcnn_detection_loss(const float *rpn_cls /*[N,2]*/, const float *rpn_reg /*[N,4]*/, const int64_t *t_rpn_cls /*[N]*/,
                          const float *t_rpn_reg /*[N,4]*/, int64_t N,
                          const float *head_cls /*[R,NC]*/, const float *head_reg /*[R,4]*/, const int64_t *t_cls /*[R]*/,
