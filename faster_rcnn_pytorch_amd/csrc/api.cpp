@@ -32,6 +32,7 @@ size_t frcnn_ws_region_proposal(int64_t N, int64_t K, int64_t P);
 size_t frcnn_ws_preprocess(int64_t in_hw, int64_t out_hw);
 size_t frcnn_ws_head_bwd(int64_t C);
 size_t frcnn_ws_rpn_conv(void);
+size_t frcnn_ws_rpn_conv_wgrad(void);
 
 FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
 {
@@ -45,6 +46,7 @@ FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
     case FRCNN_OP_PREPROCESS: return frcnn_ws_preprocess(n1, n2);
     case FRCNN_OP_HEAD_BWD: return frcnn_ws_head_bwd(n1);
     case FRCNN_OP_RPN_CONV: return frcnn_ws_rpn_conv();
+    case FRCNN_OP_RPN_CONV_WGRAD: return frcnn_ws_rpn_conv_wgrad();
     default: return 0;
     }
 }

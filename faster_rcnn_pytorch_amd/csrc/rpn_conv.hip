@@ -87,8 +87,21 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_kernel(const float *__restr
     }
 }
 
+// Backward-data of the same convolution IS the same convolution: d_x[ci](y, x) = sum_{co, ky, kx} W3[co][ci][ky][kx] d_raw[co](y + 1 - ky, x + 1 - kx),
+// i.e. a 3x3 / pad 1 convolution of d_raw with the weights transposed (in <-> out) and flipped (tap -> 8 - tap):
+// W3 [256 out][256 in][3][3] fp32 -> W3p'[chunk 16 of co][tap 9][m = ci 256][16 co] bf16
+__global__ __launch_bounds__(256) void rpn_conv_pack_bwd_kernel(const float *__restrict__ w3, unsigned short *__restrict__ w3p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 16 * 9 * 256 * 16) {
+        const int k = i & 15, m = (i >> 4) & 255, tap = (i >> 12) % 9, chunk = (i >> 12) / 9;
+        w3p[i] = f2bf(w3[((size_t)(chunk * 16 + k) * RC3_C + m) * 9 + (8 - tap)]);
+    }
+}
+
 // NPT = position tiles (image rows) per wave: 4 = the full 8-row tile, 2 = a 4-row half tile (ysub = 0 / 4 inside the full tile)
-template <bool ODDW, int NPT>
+// HEAD = true: the fused RPN head (raw + bias + ReLU + both 1x1 heads); false: the plain convolution, output stored as bf16 (backward-data)
+template <bool ODDW, int NPT, bool HEAD = true>
 __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysub, const ConvLevels &L, const unsigned short *__restrict__ w3p, const float *__restrict__ b3,
                                                                const unsigned short *__restrict__ whp, const float *__restrict__ b_cls, int n_cls,
                                                                const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
@@ -226,7 +239,7 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
     u32x4 wv[6];
     load_x(0, xv);
     load_w(0, wv);
-    {
+    if (HEAD) {
         u32x4 hv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) hv[k] = ((const u32x4 *)whp)[t + 256 * k];
@@ -279,6 +292,32 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
     const bool odd_lane = (li & 1) != 0;
     constexpr bool pair_ok = !ODDW;
     const unsigned sel = odd_lane ? 0x03020706u : 0x05040100u;                 // v_perm_b32 (a = neighbour, b = own): bytes of {a, b} = 7..4, 3..0
+    if (!HEAD) {                                              // plain convolution: the accumulators, rounded to bf16, are the output
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int yy = y0 + NPT * wp + pt, xx = x0 + li;
+            const bool in = yy < H && xx < W;
+            const unsigned pix = (unsigned)yy * (unsigned)W + (unsigned)xx;
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const int cb = 128 * wc + 32 * ct + 4 * g;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 2 * k, c = cb + (r & 3) + 8 * (r >> 2);
+                    const unsigned own = cvt_pk_bf16(acc[ct][pt][r], acc[ct][pt][r + 1]);
+                    if (pair_ok) {
+                        const unsigned nb = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+                        const unsigned d = __builtin_amdgcn_perm(nb, own, sel);
+                        if (in) *(unsigned *)(rawp + (unsigned)(c + (odd_lane ? 1 : 0)) * (unsigned)plane + (pix & ~1u)) = d;
+                    } else if (in) {
+                        rawp[(size_t)c * plane + pix] = (unsigned short)own;
+                        rawp[(size_t)(c + 1) * plane + pix] = (unsigned short)(own >> 16);
+                    }
+                }
+            }
+        }
+        return;
+    }
     float *s_part = (float *)s_all;                           // [wc 2][wp 2][pt 4][r 16][lane 64] floats = 64 KB of the 106 KB
 #pragma unroll
     for (int pt = 0; pt < NPT; ++pt) {
@@ -369,7 +408,101 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_head_kernel(ConvLevels L, int
     }
 }
 
+// backward-data launch: the same tiling and XCD order as the forward, plain-convolution epilogue
+__global__ __launch_bounds__(256) void rpn_conv3x3_bwd_data_kernel(ConvLevels L, int first_split, const unsigned short *__restrict__ w3p)
+{
+    auto xcd_order = [](int i, int n) { const int n8 = n & ~7; return i < n8 ? (i & 7) * (n8 >> 3) + (i >> 3) : i; };
+    const int b = (int)blockIdx.x;
+    const bool half = b >= first_split;
+    const int hb = half ? xcd_order(b - first_split, (int)gridDim.x - first_split) : 0;
+    const int tile = half ? first_split + (hb >> 1) : xcd_order(b, first_split), ysub = half ? 4 * (hb & 1) : 0;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && tile >= L.tile0[l]) ? 1 : 0;
+    const bool odd = (L.W[lvl] & 1) != 0;
+    if (!half) {
+        if (odd) rpn_conv3x3_head_tile<true, 4, false>(lvl, tile, 0, L, w3p, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr);
+        else rpn_conv3x3_head_tile<false, 4, false>(lvl, tile, 0, L, w3p, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr);
+    } else {
+        if (odd) rpn_conv3x3_head_tile<true, 2, false>(lvl, tile, ysub, L, w3p, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr);
+        else rpn_conv3x3_head_tile<false, 2, false>(lvl, tile, ysub, L, w3p, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr);
+    }
+}
+
 size_t frcnn_ws_rpn_conv(void) { return (size_t)(16 * 9 * 256 * 16 + 8 * 2 * 32 * 2 * 8) * 2; }
+
+// levels -> ConvLevels + launch geometry shared by the forward and the backward-data launch
+static int rpn_conv_levels(const char *who, const void *const *in_levels, void *const *out_levels, const int *H, const int *W, int n_levels,
+                           ConvLevels *Lp, int *first_split, unsigned *grid)
+{
+    int64_t pos0[FRCNN_MAX_LEVELS + 1] = {0};
+    for (int k = 0; k < n_levels; ++k) {
+        FRCNN_REQUIRE(in_levels[k] && out_levels[k] && H[k] > 0 && W[k] > 0 && (int64_t)H[k] * W[k] * RC3_C < ((int64_t)1 << 31), "%s: bad level %d", who, k);
+        FRCNN_REQUIRE((((uintptr_t)in_levels[k] | (uintptr_t)out_levels[k]) & 3) == 0, "%s: level %d is not 4-byte aligned", who, k);
+        pos0[k + 1] = pos0[k] + (int64_t)H[k] * W[k];
+    }
+    FRCNN_REQUIRE(pos0[n_levels] < ((int64_t)1 << 31), "%s: too many positions", who);
+    ConvLevels &L = *Lp;
+    int64_t tiles = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {              // unused slots repeat level 0 and start past the last tile
+        const int k = l < n_levels ? l : 0;
+        L.x[l] = (const unsigned short *)in_levels[k]; L.raw[l] = (unsigned short *)out_levels[k];
+        L.H[l] = H[k]; L.W[l] = W[k];
+        L.tiles_x[l] = (W[k] + RC3_TW - 1) / RC3_TW;
+        L.tile0[l] = (int)tiles; L.pos0[l] = (int)pos0[k];
+        if (l < n_levels) tiles += (int64_t)L.tiles_x[l] * ((H[k] + RC3_TH - 1) / RC3_TH);
+    }
+    L.tile0[FRCNN_MAX_LEVELS] = (int)tiles;
+    L.n_levels = n_levels;
+    FRCNN_REQUIRE(tiles < ((int64_t)1 << 30), "%s: too many tiles", who);
+    // tiles of the last, at most half-full round of CUs are split into halves (see the kernel)
+    int n_cu = 0;
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    const int64_t rem = tiles % n_cu;
+    *first_split = (int)((rem > 0 && 2 * rem <= n_cu) ? tiles - rem : tiles);
+    *grid = (unsigned)(*first_split + 2 * (tiles - *first_split));
+    return FRCNN_OK;
+}
+
+template <typename K>
+static int rpn_conv_reserve_lds(K kernel, const char *who, std::atomic<unsigned char> *done)
+{   // > 64 KB of dynamic LDS is an opt-in per (function, device)
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return frcnn_set_error(FRCNN_ERR_LAUNCH, "%s: no current device", who);
+    if (dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+        const hipError_t rc = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC3_LDS_BYTES);
+        if (rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, (size_t)RC3_LDS_BYTES, hipGetErrorString(rc));
+        if (dev < 64) done[dev].store(1, std::memory_order_release);
+    }
+    return FRCNN_OK;
+}
+
+FRCNN_EXPORT int frcnn_rpn_conv_bwd_data(const void *const *d_raw_levels_bf16, void *const *d_feat_levels_bf16, const int *H, const int *W, int n_levels,
+                                         int C, const float *w3, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FRCNN_REQUIRE(C == RC3_C, "rpn_conv_bwd_data: C=%d (this kernel is built for the FPN head: 256 channels)", C);
+    FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS && d_raw_levels_bf16 && d_feat_levels_bf16 && H && W, "rpn_conv_bwd_data: bad level table");
+    FRCNN_REQUIRE(w3 && workspace, "rpn_conv_bwd_data: NULL pointer");
+    if (workspace_bytes < frcnn_ws_rpn_conv()) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_conv_bwd_data: workspace %zu < %zu bytes", workspace_bytes, frcnn_ws_rpn_conv());
+    ConvLevels L;
+    int first_split = 0;
+    unsigned grid = 0;
+    int rc = rpn_conv_levels("rpn_conv_bwd_data", d_raw_levels_bf16, d_feat_levels_bf16, H, W, n_levels, &L, &first_split, &grid);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short *w3p = (unsigned short *)workspace;
+    FRCNN_LAUNCH(rpn_conv_pack_bwd_kernel, dim3(16 * 9 * 256 * 16 / 256), dim3(256), 0, s, w3, w3p);
+    FRCNN_CHECK_LAUNCH("rpn_conv_pack_bwd_kernel");
+    static std::atomic<unsigned char> done[64];
+    rc = rpn_conv_reserve_lds(rpn_conv3x3_bwd_data_kernel, "rpn_conv_bwd_data", done);
+    if (rc) return rc;
+    FRCNN_LAUNCH(rpn_conv3x3_bwd_data_kernel, dim3(grid), dim3(256), RC3_LDS_BYTES, s, L, first_split, w3p);
+    FRCNN_CHECK_LAUNCH("rpn_conv3x3_bwd_data_kernel");
+    return FRCNN_OK;
+}
 
 FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *raw_levels_bf16, const int *H, const int *W, int n_levels, int C,
                                          const float *w3, const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
@@ -427,5 +560,315 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
     const unsigned grid = (unsigned)(first_split + 2 * (tiles - first_split));
     FRCNN_LAUNCH(rpn_conv3x3_head_kernel, dim3(grid), dim3(256), lds, s, L, first_split, w3p, b3, whp, b_cls, n_cls, b_reg, n_reg, out_cls, out_reg);
     FRCNN_CHECK_LAUNCH("rpn_conv3x3_head_kernel");
+    return FRCNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convolution on the bf16 matrix cores (what autograd derives for `inter_layer.weight`,
+// models/new_model.py:96,109):   dW[co][ci][ky][kx] = sum over levels, y, x of  d_raw[co](y, x) * x[ci](y + ky - 1, x + kx - 1).
+// GEMM view: M = co, N = ci (one 32 x 32 product per tap), K = positions, 16 consecutive columns of one image row per
+// v_mfma_f32_32x32x16_bf16 -- in NCHW both operands of a K step are "8 consecutive pixels of one channel row", the A / B register
+// layout of that instruction as the tensors lie in memory.
+//   workgroup = 4 waves = (128 output channels) x (32 input channels) x 9 taps, wave w owns output channels [32 w, +32): 9 accumulators;
+//   it walks a K range: row segments of 64 pixels, down the rows of one 64-pixel column strip, strip after strip, level after level;
+//   per row segment the d_raw tile [128][64] and ONE new feature row [32][66] are staged through LDS (double buffer / ring of 4 rows); the
+//   feature rows are kept in THREE copies shifted by -1 / 0 / +1 pixel (built with v_alignbit at staging time), so that every tap is an
+//   aligned ds_read_b128 of "8 pixels of my channel"; the kernel row is the ring slot.  9 MFMAs per K step and wave against 1 + 9 reads.
+//   grid = (splits of the K range) x (8 input-channel chunks x 2 output-channel halves); every workgroup leaves its partial
+//   [128][32][9] in the workspace and rpn_conv_wgrad_finalize_kernel adds the splits in order (bit-reproducible, no atomics).
+// MIOpen needs 689 us for the five levels at 800 x 1344 (igemm_wrw + transposes for the large levels, ~41 us of launch skeleton for
+// each of the small ones).
+// ------------------------------------------------------------------------------------------------------------------------------
+#define WG_SEG 64                        // pixels per row segment (4 K steps)
+#define WG_AS 72                         // LDS row stride in bf16 elements (144 bytes: 9 x 16, conflict-free ds_read_b128 down a column of rows)
+#define WG_CO 128
+#define WG_CI 32
+#define WG_MAX_SPLITS 32
+struct WgradLevels {
+    int n_levels;
+    const unsigned short *x[FRCNN_MAX_LEVELS];     // features  [256, H, W] bf16
+    const unsigned short *d[FRCNN_MAX_LEVELS];     // d_raw     [256, H, W] bf16
+    int H[FRCNN_MAX_LEVELS], W[FRCNN_MAX_LEVELS];
+    int seg0[FRCNN_MAX_LEVELS + 1];                // first row segment of level l in the global order (level, strip, row)
+    int split0[WG_MAX_SPLITS + 1];                 // first row segment of split s
+};
+#define WG_SLOW_COST 3                   // cost of a generically staged row segment relative to a 16-byte staged one (host-side balancing)
+#define WG_LDS_BYTES ((2 * WG_CO * WG_AS + 3 * 4 * WG_CI * WG_AS) * 2)     // 36 864 + 55 296 = 92 160 bytes
+
+// one run = consecutive rows [y_first, y_first + n_rows) of one 64-pixel column strip of one level.
+// FAST: W % 8 == 0 and 16-byte aligned planes (the two large levels: 94 % of the positions): 16-byte loads / LDS stores, 7 load
+// instructions per thread and row instead of 28 dword loads.  Loads run TWO rows ahead of the MFMAs in two alternating register sets
+// (one row of MFMAs, ~0.5 us, does not cover an L2 / Infinity-Cache round trip under load: with one row of cover the kernel ran at 14 %
+// of the matrix peak, the waves waiting ~80 % of the time for the next row's operands).
+template <bool FAST>
+__device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__ xin, const unsigned short *__restrict__ din, int H, int W, int x0,
+                                              int y_first, int n_rows, int ci0, int co0, unsigned short (*s_a)[WG_CO * WG_AS],
+                                              unsigned short (*s_f)[4][WG_CI * WG_AS], f32x16 (&acc)[9])
+{
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const size_t plane = (size_t)H * W;
+    const bool odd_w = (W & 1) != 0;
+    constexpr int NA = FAST ? 4 : 16;                                  // A registers per row: 4 x 16 bytes / 16 dwords
+    constexpr int NF = FAST ? 6 : 12;                                  // F registers per row: 16 bytes + 2 edge dwords / 4 items x 3 dwords
+    struct Set { unsigned a[16]; unsigned f[12]; };
+    // ---- feature row yy of my 32 channels
+    auto load_f = [&](int yy, Set &S) {
+        if (FAST) {                                                    // item t: channel t >> 3, 8-pixel piece t & 7
+            const int ch = t >> 3, xe = x0 + 8 * (t & 7);
+            const unsigned short *row = xin + (size_t)(ci0 + ch) * plane + (size_t)yy * W;
+            const bool rin = yy >= 0 && yy < H;
+            u32x4 mid = (u32x4){0u, 0u, 0u, 0u};
+            unsigned left = 0u, right = 0u;
+            if (rin && xe < W) mid = *(const u32x4 *)(row + xe);
+            if (rin && xe >= 2 && xe - 2 < W) left = *(const unsigned *)(row + xe - 2);
+            if (rin && xe + 8 < W) right = *(const unsigned *)(row + xe + 8);
+            S.f[0] = mid[0]; S.f[1] = mid[1]; S.f[2] = mid[2]; S.f[3] = mid[3]; S.f[4] = left; S.f[5] = right;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t + 256 * u, ch = c >> 5, j = c & 31;
+                const unsigned short *row = xin + (size_t)(ci0 + ch) * plane + (size_t)yy * W;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int xe = x0 - 2 + 2 * (j + q);               // even pixel of dword j + q
+                    unsigned v = 0u;
+                    if (yy >= 0 && yy < H) {
+                        if (!odd_w) { if (xe >= 0 && xe < W) v = *(const unsigned *)(row + xe); }      // W even: xe + 1 < W as well, dword aligned
+                        else {
+                            const unsigned lo = (xe >= 0 && xe < W) ? row[xe] : 0u, hi = (xe + 1 >= 0 && xe + 1 < W) ? row[xe + 1] : 0u;
+                            v = lo | (hi << 16);
+                        }
+                    }
+                    S.f[3 * u + q] = v;
+                }
+            }
+        }
+    };
+    // copy kx holds pixel x0 + p + kx - 1 at position p (three aligned reads instead of misaligned ones)
+    auto store_f = [&](int yy, const Set &S) {
+        const int slot = (yy + 1) & 3;
+        if (FAST) {
+            const int e = (t >> 3) * WG_AS + 8 * (t & 7);
+            const unsigned m0 = S.f[0], m1 = S.f[1], m2 = S.f[2], m3 = S.f[3], lf = S.f[4], rt = S.f[5];
+            *(u32x4 *)(&s_f[0][slot][e]) = (u32x4){__builtin_amdgcn_alignbit(m0, lf, 16), __builtin_amdgcn_alignbit(m1, m0, 16),
+                                                  __builtin_amdgcn_alignbit(m2, m1, 16), __builtin_amdgcn_alignbit(m3, m2, 16)};
+            *(u32x4 *)(&s_f[1][slot][e]) = (u32x4){m0, m1, m2, m3};
+            *(u32x4 *)(&s_f[2][slot][e]) = (u32x4){__builtin_amdgcn_alignbit(m1, m0, 16), __builtin_amdgcn_alignbit(m2, m1, 16),
+                                                  __builtin_amdgcn_alignbit(m3, m2, 16), __builtin_amdgcn_alignbit(rt, m3, 16)};
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t + 256 * u, ch = c >> 5, j = c & 31;
+                const int e = ch * WG_AS + 2 * j;                      // element index of pair j in the row (even: dword aligned)
+                *(unsigned *)(&s_f[0][slot][e]) = __builtin_amdgcn_alignbit(S.f[3 * u + 1], S.f[3 * u], 16);       // (x0 + 2j - 1, x0 + 2j)
+                *(unsigned *)(&s_f[1][slot][e]) = S.f[3 * u + 1];                                                  // (x0 + 2j,     x0 + 2j + 1)
+                *(unsigned *)(&s_f[2][slot][e]) = __builtin_amdgcn_alignbit(S.f[3 * u + 2], S.f[3 * u + 1], 16);   // (x0 + 2j + 1, x0 + 2j + 2)
+            }
+        }
+    };
+    auto load_a = [&](int yy, Set &S) {
+        if (FAST) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t + 256 * u, r = c >> 3, xe = x0 + 8 * (c & 7);
+                u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+                if (yy < H && xe < W) v = *(const u32x4 *)(din + (size_t)(co0 + r) * plane + (size_t)yy * W + xe);
+                S.a[4 * u] = v[0]; S.a[4 * u + 1] = v[1]; S.a[4 * u + 2] = v[2]; S.a[4 * u + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = t + 256 * u, r = c >> 5, xe = x0 + 2 * (c & 31);
+                const unsigned short *row = din + (size_t)(co0 + r) * plane + (size_t)yy * W;
+                unsigned v = 0u;
+                if (yy < H) {
+                    if (!odd_w) { if (xe < W) v = *(const unsigned *)(row + xe); }
+                    else {
+                        const unsigned lo = xe < W ? row[xe] : 0u, hi = xe + 1 < W ? row[xe + 1] : 0u;
+                        v = lo | (hi << 16);
+                    }
+                }
+                S.a[u] = v;
+            }
+        }
+    };
+    auto store_a = [&](int buf, const Set &S) {
+        if (FAST) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = t + 256 * u;
+                *(u32x4 *)(&s_a[buf][(c >> 3) * WG_AS + 8 * (c & 7)]) = (u32x4){S.a[4 * u], S.a[4 * u + 1], S.a[4 * u + 2], S.a[4 * u + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int c = t + 256 * u;
+                *(unsigned *)(&s_a[buf][(c >> 5) * WG_AS + 2 * (c & 31)]) = S.a[u];
+            }
+        }
+    };
+    (void)NA; (void)NF;
+    auto compute = [&](int y, int buf) {
+        const unsigned short *sa = s_a[buf] + (32 * wave + li) * WG_AS + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < WG_SEG / 16; ++ks) {
+            const bf16x8 fa = *(const bf16x8 *)(sa + 16 * ks);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int slot = (y + ky) & 3;                          // row y + ky - 1 lives in slot (y + ky - 1 + 1) & 3
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16x8 fb = *(const bf16x8 *)(&s_f[kx][slot][li * WG_AS + 16 * ks + 8 * g]);
+                    acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[3 * ky + kx], 0, 0, 0);
+                }
+            }
+        }
+    };
+    // ---- prime: feature rows y_first - 1 .. y_first + 1 and the d_raw row y_first go straight to LDS; the two register sets take
+    //      (d_raw y_first + 1, features y_first + 2) and (d_raw y_first + 2, features y_first + 3)
+    Set S0, S1;
+    {   // all of the window's loads in flight together: ONE exposed round trip per run (a load -> store pair at a time cost three)
+        Set S2;
+        load_f(y_first - 1, S0); load_f(y_first, S1); load_f(y_first + 1, S2); load_a(y_first, S2);
+        __syncthreads();                                                // the previous run's readers are done with LDS
+        store_f(y_first - 1, S0); store_f(y_first, S1); store_f(y_first + 1, S2); store_a(0, S2);
+    }
+    load_a(y_first + 1, S0); load_f(y_first + 2, S0);
+    load_a(y_first + 2, S1); load_f(y_first + 3, S1);
+    for (int i = 0; i < n_rows; i += 2) {
+        {   // even row of the pair: set S0 carries (d_raw y + 1, features y + 2)
+            const int y = y_first + i;
+            __syncthreads();
+            compute(y, i & 1);
+            store_a((i + 1) & 1, S0); store_f(y + 2, S0);
+            load_a(y + 3, S0); load_f(y + 4, S0);
+        }
+        if (i + 1 < n_rows) {
+            const int y = y_first + i + 1;
+            __syncthreads();
+            compute(y, (i + 1) & 1);
+            store_a(i & 1, S1); store_f(y + 2, S1);
+            load_a(y + 3, S1); load_f(y + 4, S1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, float *__restrict__ part)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_wg[];
+    unsigned short (*s_a)[WG_CO * WG_AS] = (unsigned short (*)[WG_CO * WG_AS])s_wg;                              // [2][128 x 72]
+    unsigned short (*s_f)[4][WG_CI * WG_AS] = (unsigned short (*)[4][WG_CI * WG_AS])(s_wg + 2 * WG_CO * WG_AS);    // [kx 3][slot 4][32 x 72]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, g = lane >> 5;
+    const int split = blockIdx.x, ci0 = ((int)blockIdx.y >> 1) * WG_CI, co0 = ((int)blockIdx.y & 1) * WG_CO;
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = (f32x16){0};
+    // K range of this split: segments [L.split0[split], L.split0[split + 1]) of the global order (level, 64-pixel column strip, row).
+    // The host cuts the order into ranges of equal COST: a row segment of a level that takes the generic staging path counts
+    // WG_SLOW_COST times (equal COUNTS left all the narrow levels to the last split, whose workgroups then set the kernel's time),
+    // and ranges stay contiguous because every new run (strip) costs a window of exposed loads.
+    int seg = L.split0[split];
+    const int seg_end = L.split0[split + 1];
+    while (seg < seg_end) {
+        int lvl = 0;
+#pragma unroll
+        for (int l = 1; l < FRCNN_MAX_LEVELS; ++l) lvl += (l < L.n_levels && seg >= L.seg0[l]) ? 1 : 0;
+        const int H = L.H[lvl], W = L.W[lvl];
+        const int rel = seg - L.seg0[lvl];
+        const int strip = rel / H, y_first = rel - strip * H;
+        const int n_rows = min(H - y_first, seg_end - seg);
+        const bool fast = (W & 7) == 0 && ((((uintptr_t)L.x[lvl]) | ((uintptr_t)L.d[lvl])) & 15) == 0;
+        if (fast) rpn_wgrad_run<true>(L.x[lvl], L.d[lvl], H, W, strip * WG_SEG, y_first, n_rows, ci0, co0, s_a, s_f, acc);
+        else rpn_wgrad_run<false>(L.x[lvl], L.d[lvl], H, W, strip * WG_SEG, y_first, n_rows, ci0, co0, s_a, s_f, acc);
+        seg += n_rows;
+    }
+    // ---- my partial [128][32][9]: register r of acc[tap] is (co = co0 + 32 wave + (r & 3) + 8 (r >> 2) + 4 g, ci = ci0 + li)
+    float *dst = part + (size_t)split * RC3_C * RC3_C * 9;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * g;
+            dst[((size_t)co * RC3_C + ci0 + li) * 9 + tap] = acc[tap][r];
+        }
+}
+
+// dW = sum of the split partials, in split order (fixed: bit-reproducible)
+__global__ __launch_bounds__(256) void rpn_conv_wgrad_finalize_kernel(const float *__restrict__ part, int n_splits, float *__restrict__ dw)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= RC3_C * RC3_C * 9) return;
+    float v = 0.0f;
+    for (int s0 = 0; s0 < n_splits; s0 += 8) {
+        float tv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tv[u] = s0 + u < n_splits ? part[(size_t)(s0 + u) * RC3_C * RC3_C * 9 + i] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += tv[u];
+    }
+    dw[i] = v;
+}
+
+size_t frcnn_ws_rpn_conv_wgrad(void) { return (size_t)WG_MAX_SPLITS * RC3_C * RC3_C * 9 * sizeof(float); }
+
+FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const void *const *d_raw_levels_bf16, const int *H, const int *W, int n_levels,
+                                      int C, float *dw3, void *workspace, size_t workspace_bytes, void *stream)
+{
+    FRCNN_REQUIRE(C == RC3_C, "rpn_conv_wgrad: C=%d (this kernel is built for the FPN head: 256 channels)", C);
+    FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS && feat_levels_bf16 && d_raw_levels_bf16 && H && W && dw3 && workspace, "rpn_conv_wgrad: bad argument");
+    if (workspace_bytes < frcnn_ws_rpn_conv_wgrad()) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "rpn_conv_wgrad: workspace %zu < %zu bytes", workspace_bytes, frcnn_ws_rpn_conv_wgrad());
+    WgradLevels L;
+    int64_t segs = 0, cost = 0;
+    int lvl_cost[FRCNN_MAX_LEVELS] = {0};
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        const int k = l < n_levels ? l : 0;
+        FRCNN_REQUIRE(feat_levels_bf16[k] && d_raw_levels_bf16[k] && H[k] > 0 && W[k] > 0 && (int64_t)H[k] * W[k] * RC3_C < ((int64_t)1 << 31), "rpn_conv_wgrad: bad level %d", k);
+        FRCNN_REQUIRE((((uintptr_t)feat_levels_bf16[k] | (uintptr_t)d_raw_levels_bf16[k]) & 3) == 0, "rpn_conv_wgrad: level %d is not 4-byte aligned", k);
+        L.x[l] = (const unsigned short *)feat_levels_bf16[k]; L.d[l] = (const unsigned short *)d_raw_levels_bf16[k];
+        L.H[l] = H[k]; L.W[l] = W[k];
+        L.seg0[l] = (int)segs;
+        const bool fast = (W[k] & 7) == 0 && ((((uintptr_t)feat_levels_bf16[k]) | ((uintptr_t)d_raw_levels_bf16[k])) & 15) == 0;
+        lvl_cost[l] = fast ? 1 : WG_SLOW_COST;
+        if (l < n_levels) { const int64_t n = (int64_t)H[k] * ((W[k] + WG_SEG - 1) / WG_SEG); segs += n; cost += n * lvl_cost[l]; }
+    }
+    for (int l = n_levels; l <= FRCNN_MAX_LEVELS; ++l) L.seg0[l] = (int)segs;
+    L.n_levels = n_levels;
+    FRCNN_REQUIRE(segs < ((int64_t)1 << 30), "rpn_conv_wgrad: too many positions");
+    // K splits: 16 column groups (8 input-channel chunks x 2 output-channel halves) x splits workgroups = one round of the chip
+    int n_cu = 256;
+    { int dev = -1; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+    int splits = n_cu / 16;
+    if (splits < 1) splits = 1;
+    if (splits > WG_MAX_SPLITS) splits = WG_MAX_SPLITS;
+    if ((int64_t)splits > segs) splits = (int)segs;
+    {   // boundaries of equal cumulative cost
+        int s_i = 1, lvl = 0;
+        int64_t acc_cost = 0;
+        L.split0[0] = 0;
+        for (int64_t sg = 0; sg < segs && s_i < splits; ++sg) {
+            while (lvl + 1 < n_levels && sg >= L.seg0[lvl + 1]) ++lvl;
+            acc_cost += lvl_cost[lvl];
+            if (acc_cost * splits >= cost * s_i) L.split0[s_i++] = (int)(sg + 1);
+        }
+        for (; s_i <= WG_MAX_SPLITS; ++s_i) L.split0[s_i] = (int)segs;
+        L.split0[splits] = (int)segs;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    static std::atomic<unsigned char> done[64];
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_conv_wgrad: no current device");
+        if (dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
+            const hipError_t rc = hipFuncSetAttribute((const void *)rpn_conv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG_LDS_BYTES);
+            if (rc != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_conv_wgrad: cannot reserve %d bytes of LDS: %s", (int)WG_LDS_BYTES, hipGetErrorString(rc));
+            if (dev < 64) done[dev].store(1, std::memory_order_release);
+        }
+    }
+    FRCNN_LAUNCH(rpn_conv3x3_wgrad_kernel, dim3((unsigned)splits, 16), dim3(256), WG_LDS_BYTES, s, L, (float *)workspace);
+    FRCNN_CHECK_LAUNCH("rpn_conv3x3_wgrad_kernel");
+    FRCNN_LAUNCH(rpn_conv_wgrad_finalize_kernel, dim3(RC3_C * RC3_C * 9 / 256), dim3(256), 0, s, (const float *)workspace, splits, dw3);
+    FRCNN_CHECK_LAUNCH("rpn_conv_wgrad_finalize_kernel");
     return FRCNN_OK;
 }

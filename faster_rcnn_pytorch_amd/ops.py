@@ -13,6 +13,7 @@ PyTorch is plumbing here (device memory, streams, autograd glue).  Every op requ
 fp32 tensors on a HIP device and raises otherwise: there is no CPU path in the product.
 """
 import ctypes as C
+import os as _os
 
 import numpy as np
 import torch
@@ -447,7 +448,8 @@ class _RPNHeadTailFn(torch.autograd.Function):
 class _RPNConvHeadFn(torch.autograd.Function):
     """The whole FPN RPN head in the bf16 mixed-precision configuration (csrc/rpn_conv.hip): 3x3 conv + bias + ReLU + both 1x1
     heads for all levels in one MFMA implicit-GEMM launch.  args: (w3, b3, w_cls, b_cls, w_reg, b_reg, *feats bf16 [1,256,h,w]).
-    Backward: the fused tail backward (d_raw, head gradients) + the convolution's own backward through aten (MIOpen)."""
+    Backward: the fused tail backward (d_raw, head gradients), then the convolution's data gradient (the forward kernel on transposed,
+    flipped weights) and weight gradient (split-K MFMA kernel) -- no MIOpen kernel is left in the head."""
 
     @staticmethod
     def forward(ctx, w3, b3, w_cls, b_cls, w_reg, b_reg, *feats):
@@ -503,15 +505,64 @@ class _RPNConvHeadFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             check(lib.frcnn_rpn_head_tail_ml_bwd(ptrs, dptrs, 1, Cc, pl, len(raws), _ptr(b3), _ptr(wc), n_cls, _ptr(wr), n_reg, _ptr(g_cls), _ptr(g_reg),
                                                  _ptr(dwc), _ptr(dbc), _ptr(dwr), _ptr(dbr), _ptr(db3), _ptr(ws), nb, _stream()), "rpn_head_tail_ml_bwd")
-        # the 3x3 convolution's backward stays on MIOpen (aten): data gradient per level, weight gradient accumulated in fp32
-        w3b = w3.to(torch.bfloat16)
-        dw3 = torch.zeros_like(w3)
-        d_feats = []
-        for f, d in zip(feats, d_raws):
-            gi, gw, _ = torch.ops.aten.convolution_backward(d, f, w3b, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [ctx.needs_input_grad[6], True, False])
-            d_feats.append(gi)
-            dw3 += gw.float()
+        # data gradient of the 3x3 convolution: the same implicit-GEMM kernel on the transposed, flipped weights, all levels in one launch
+        d_feats = [None] * len(feats)
+        use_aten = _os.environ.get("FRCNN_CONV_BWD") == "aten"          # developer A/B switch: MIOpen for the data gradient too
+        if any(ctx.needs_input_grad[6:]) and not use_aten:
+            d_feats = [torch.empty_like(f) for f in feats]
+            H = _host_i32([f.shape[2] for f in feats])
+            W = _host_i32([f.shape[3] for f in feats])
+            fptrs = (C.c_void_p * len(feats))(*[t.data_ptr() for t in d_feats])
+            nbc = _lib.workspace_bytes(_lib.OP_RPN_CONV, 0)
+            wsc = _workspace(dev, nbc)
+            with torch.cuda.device(dev):
+                check(lib.frcnn_rpn_conv_bwd_data(dptrs, fptrs, _np_ptr(H), _np_ptr(W), len(feats), Cc, _ptr(w3), _ptr(wsc), nbc, _stream()), "rpn_conv_bwd_data")
+        # weight gradient: the hand-written split-K MFMA kernel, all levels in one launch + a fixed-order finalize
+        if not use_aten:
+            dw3 = rpn_conv_wgrad(feats, d_raws)
+        else:                                                           # (A/B: MIOpen per level, accumulated in fp32)
+            w3b = w3.to(torch.bfloat16)
+            dw3 = torch.zeros_like(w3)
+            for k, (f, d) in enumerate(zip(feats, d_raws)):
+                gi, gw, _ = torch.ops.aten.convolution_backward(d, f, w3b, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
+                dw3 += gw.float()
+                d_feats[k] = gi
         return (dw3, db3, dwc.reshape(ctx.w_shapes[0]), dbc, dwr.reshape(ctx.w_shapes[1]), dbr, *d_feats)
+
+
+def rpn_conv_bwd_data(d_raws, w3):
+    """Data gradient of the shared 3x3 RPN convolution (models/new_model.py:96) for all levels in one launch: d_raws = bf16
+    [1,256,h,w] gradients of the bias-free conv output, w3 = the fp32 weight [256,256,3,3]; returns bf16 gradients of the inputs."""
+    d_raws = [_req(d, torch.bfloat16, "d_raw") for d in d_raws]
+    w3 = _req(w3, name="w3")
+    dev = d_raws[0].device
+    outs = [torch.empty_like(d) for d in d_raws]
+    H = _host_i32([d.shape[2] for d in d_raws])
+    W = _host_i32([d.shape[3] for d in d_raws])
+    ip = (C.c_void_p * len(d_raws))(*[d.data_ptr() for d in d_raws])
+    op = (C.c_void_p * len(d_raws))(*[o.data_ptr() for o in outs])
+    nb = _lib.workspace_bytes(_lib.OP_RPN_CONV, 0)
+    ws = _workspace(dev, nb)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_rpn_conv_bwd_data(ip, op, _np_ptr(H), _np_ptr(W), len(d_raws), d_raws[0].shape[1], _ptr(w3), _ptr(ws), nb, _stream()), "rpn_conv_bwd_data")
+    return outs
+
+
+def rpn_conv_wgrad(feats, d_raws):
+    """Weight gradient of the shared 3x3 RPN convolution summed over the levels: feats / d_raws = bf16 [1,256,h,w]; returns fp32 [256,256,3,3]."""
+    feats = [_req(f, torch.bfloat16, "feature map") for f in feats]
+    d_raws = [_req(d, torch.bfloat16, "d_raw") for d in d_raws]
+    dev = feats[0].device
+    dw = torch.empty((256, 256, 3, 3), dtype=torch.float32, device=dev)
+    H = _host_i32([f.shape[2] for f in feats])
+    W = _host_i32([f.shape[3] for f in feats])
+    fp = (C.c_void_p * len(feats))(*[f.data_ptr() for f in feats])
+    dp = (C.c_void_p * len(feats))(*[d.data_ptr() for d in d_raws])
+    nb = _lib.workspace_bytes(_lib.OP_RPN_CONV_WGRAD, 0)
+    ws = _workspace(dev, nb)
+    with torch.cuda.device(dev):
+        check(lib.frcnn_rpn_conv_wgrad(fp, dp, _np_ptr(H), _np_ptr(W), len(feats), feats[0].shape[1], _ptr(dw), _ptr(ws), nb, _stream()), "rpn_conv_wgrad")
+    return dw
 
 
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):

@@ -55,7 +55,8 @@ typedef enum {
     FRCNN_OP_HEAD_TARGETS = 5,    /* n1 = P + G candidates */
     FRCNN_OP_PREPROCESS = 6,      /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
     FRCNN_OP_HEAD_BWD = 7,        /* n1 = C (frcnn_rpn_head_tail_ml_bwd) */
-    FRCNN_OP_RPN_CONV = 8         /* frcnn_rpn_conv_head_fwd (packed bf16 weights) */
+    FRCNN_OP_RPN_CONV = 8,        /* frcnn_rpn_conv_head_fwd / frcnn_rpn_conv_bwd_data (packed bf16 weights) */
+    FRCNN_OP_RPN_CONV_WGRAD = 9   /* frcnn_rpn_conv_wgrad (per-split partial gradients) */
 } frcnn_op;
 
 int frcnn_abi_version(void);
@@ -177,6 +178,18 @@ int frcnn_rpn_head_tail_ml_bwd(const void *const *conv_raw_levels, void *const *
 int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, void *const *raw_levels_bf16, const int *H_host, const int *W_host, int n_levels,
                             int C, const float *w3, const float *b3, const float *w_cls, const float *b_cls, int n_cls, const float *w_reg,
                             const float *b_reg, int n_reg, float *out_cls, float *out_reg, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Backward-data of that 3x3 convolution (what autograd derives for `inter_layer`, models/new_model.py:96,109) on the same implicit-GEMM
+ * kernel: d_feat[ci] = conv3x3(d_raw, W3 transposed and flipped), bf16 operands, fp32 accumulate, bf16 output.  d_raw_levels /
+ * d_feat_levels: [256, H_l, W_l] bf16 NCHW.  workspace >= frcnn_workspace_bytes(FRCNN_OP_RPN_CONV, 0, 0).                         */
+int frcnn_rpn_conv_bwd_data(const void *const *d_raw_levels_bf16, void *const *d_feat_levels_bf16, const int *H_host, const int *W_host, int n_levels,
+                            int C, const float *w3, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Weight gradient of that convolution: dw3 [256,256,3,3] fp32 (fully overwritten) = sum over levels and positions of
+ * d_raw[co](y, x) * feat[ci](y + ky - 1, x + kx - 1), bf16 operands, fp32 accumulate, split over the positions with a fixed-order
+ * finalize (bit-reproducible).  workspace >= frcnn_workspace_bytes(FRCNN_OP_RPN_CONV_WGRAD, 0, 0).                                */
+int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const void *const *d_raw_levels_bf16, const int *H_host, const int *W_host, int n_levels,
+                         int C, float *dw3, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

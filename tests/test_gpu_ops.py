@@ -1170,3 +1170,37 @@ def test_rpn_conv_head_bf16_vs_torch(ops, shapes):
     ((c2 * gc).sum() + (r2 * gr).sum()).backward()
     assert (params[0].grad - p2[0].grad).abs().max() < 4e-2 * float(p2[0].grad.abs().max())       # a few bf16 ulps of the largest entry (MIOpen returns bf16)
     assert (cls.detach() - c2.detach()).abs().max() < 1e-2 and (reg.detach() - r2.detach()).abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("shapes", [[(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], [(9, 33)], [(104, 319), (12, 33)]])
+def test_rpn_conv_bwd_data_bf16_vs_torch(ops, shapes):
+    """Backward-data of the 3x3 RPN convolution on the forward's implicit-GEMM kernel (transposed, flipped weights) against
+    conv_transpose2d in float64 on the SAME bf16-rounded operands.  A K = 2304 bf16 dot product accumulated in fp32 and rounded to
+    bf16: 2^-8 relative to the value (values ~0.5: 4e-3 absolute), odd widths and half tiles included."""
+    g = torch.Generator().manual_seed(33)
+    d_raws = [torch.randn(1, 256, h, w, generator=g).bfloat16().to(DEV) for h, w in shapes]
+    w3 = (torch.randn(256, 256, 3, 3, generator=g) * 0.01).to(DEV)
+    got = ops.rpn_conv_bwd_data(d_raws, w3)
+    for d, o in zip(d_raws, got):
+        ref = torch.nn.functional.conv_transpose2d(d.double(), w3.bfloat16().double(), padding=1)
+        assert o.dtype == torch.bfloat16 and o.shape == d.shape
+        err = (o.double() - ref).abs().max().item()
+        assert err < 6e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("shapes", [[(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], [(9, 33)], [(104, 319), (12, 33)], [(3, 4)], [(70, 130), (5, 64)]])
+def test_rpn_conv_wgrad_bf16_vs_torch(ops, shapes):
+    """Weight gradient of the 3x3 RPN convolution (hand-written MFMA kernel, K split + fixed-order finalize) against float64 autograd on
+    the SAME bf16-rounded operands.  Sums of up to 89 523 products of bf16 values accumulated in fp32: 1e-3 of the largest entry;
+    reproducible bit for bit from run to run."""
+    g = torch.Generator().manual_seed(44)
+    feats = [torch.randn(1, 256, h, w, generator=g).bfloat16().to(DEV) for h, w in shapes]
+    d_raws = [(torch.randn(1, 256, h, w, generator=g) * 0.1).bfloat16().to(DEV) for h, w in shapes]
+    got = ops.rpn_conv_wgrad(feats, d_raws)
+    w = torch.zeros(256, 256, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    tot = sum((torch.nn.functional.conv2d(f.double(), w, None, padding=1) * d.double()).sum() for f, d in zip(feats, d_raws))
+    tot.backward()
+    ref = w.grad
+    err = (got.double() - ref).abs().max().item()
+    assert err < 1e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
+    assert torch.equal(got, ops.rpn_conv_wgrad(feats, d_raws))
