@@ -416,33 +416,8 @@ class _RPNHeadTailFn(torch.autograd.Function):
                                                      n_cls, _ptr(wr), n_reg, _ptr(g_cls), _ptr(g_reg), _ptr(dwc), _ptr(dbc), _ptr(dwr), _ptr(dbr),
                                                      _ptr(db3), _ptr(ws), nb, _stream()), "rpn_head_tail_ml_bwd")
             return (None, db3, dwc.reshape(ctx.w_shapes[0]), dbc, dwr.reshape(ctx.w_shapes[1]), dbr, *d_raws)
-        return _RPNHeadTailFn._backward_torch(ctx, g_cls, g_reg)
-
-    @staticmethod
-    def _backward_torch(ctx, g_cls, g_reg):
-        """The same gradients as plain torch ops (other channel counts; also the fp32 reference of the fused kernel's test)."""
-        b3, wc, wr = ctx.saved_tensors[:3]
-        raws = ctx.saved_tensors[3:]
-        n_cls, n_reg = wc.shape[0], wr.shape[0]
-        Cc = wc.shape[1]
-        w_all = torch.cat([wc, wr], dim=0)
-        dW = torch.zeros((n_cls + n_reg, Cc), dtype=torch.float32, device=wc.device)
-        db = torch.zeros((n_cls + n_reg,), dtype=torch.float32, device=wc.device)
-        db3 = torch.zeros((Cc,), dtype=torch.float32, device=wc.device)
-        g_cls, g_reg = g_cls.reshape(-1, n_cls), g_reg.reshape(-1, n_reg)
-        d_raws, p0 = [], 0
-        for raw in raws:
-            P = raw.shape[2] * raw.shape[3]
-            g = torch.cat([g_cls[p0:p0 + P], g_reg[p0:p0 + P]], dim=1)                       # [P, n_cls + n_reg]
-            z = raw.reshape(Cc, P).float() + b3[:, None]
-            h = torch.relu(z)                                                               # recomputed, never stored in forward
-            dW += g.t() @ h.t()
-            db += g.sum(0)
-            dz = (w_all.t() @ g.t()) * (z > 0).to(torch.float32)                            # [C, P]
-            db3 += dz.sum(1)
-            d_raws.append(dz.reshape(raw.shape).to(raw.dtype))
-            p0 += P
-        return (None, db3, dW[:n_cls].reshape(ctx.w_shapes[0]), db[:n_cls], dW[n_cls:].reshape(ctx.w_shapes[1]), db[n_cls:], *d_raws)
+        raise _lib.FrcnnError("rpn_head_tail backward: the fused kernel is built for the reference's head widths C = 256 (FPN) and 512 (VGG), "
+                              "got C = %d (forward-only use is fine)" % Cc)
 
 
 class _RPNConvHeadFn(torch.autograd.Function):

@@ -14,7 +14,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BCFG=$CFG; EXTRA=""
 if [ "$CFG" = "fpn_bf16" ]; then BCFG=fpn; EXTRA="--amp bf16"; fi
-ARGS="--config $BCFG $EXTRA --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events $*"
+ARGS="--config $BCFG $EXTRA --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events --no-also $*"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$ROOT/$OUT/fetch" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$ROOT/$OUT/write" -- python3 "$ROOT/bench.py" $ARGS > "$ROOT/$OUT/write.log" 2>&1
 cd "$ROOT"

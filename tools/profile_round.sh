@@ -9,10 +9,11 @@ R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 prof() {   # name, bench args...
     local name=$1; shift
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_prof_$name" -- python3 "$R/bench.py" "$@" --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-events > "$R/gpurun_out/${TAG}_prof_$name.log" 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/${TAG}_prof_$name" -- python3 "$R/bench.py" "$@" --steps 12 --warmup 3 --no-cpu-baseline --no-kernel-events --no-also > "$R/gpurun_out/${TAG}_prof_$name.log" 2>&1
     python3 "$R/tools/profile_summary.py" $(ls "$R"/gpurun_out/${TAG}_prof_$name/*/*_kernel_trace.csv | head -1) --steps 10 > "$R/gpurun_out/${TAG}_${name}_kernel_summary.csv"
     cp $(ls "$R"/gpurun_out/${TAG}_prof_$name/*/*_kernel_stats.csv | head -1) "$R/gpurun_out/${TAG}_${name}_rocprofv3_kernel_stats.csv"
     grep '^{"metric"' "$R/gpurun_out/${TAG}_prof_$name.log" | tail -1 > "$R/gpurun_out/${TAG}_${name}_bench_under_rocprof.json"
+    rm -rf "$R/gpurun_out/${TAG}_prof_$name"          # the raw trace (tens of MB) stays on the box: gpurun copies back at most 64 MiB
     echo "$name done"
 }
 prof vgg
@@ -22,12 +23,12 @@ cd "$R"
 bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_vgg vgg > /dev/null
 bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_fpn fpn > /dev/null
 bash tools/pmc_traffic.sh gpurun_out/${TAG}_pmc_fpn_bf16 fpn_bf16 > /dev/null
-for c in vgg fpn fpn_bf16; do cp gpurun_out/${TAG}_pmc_$c/traffic.json gpurun_out/${TAG}_pmc_traffic_$c.json; done
+for c in vgg fpn fpn_bf16; do cp gpurun_out/${TAG}_pmc_$c/traffic.json gpurun_out/${TAG}_pmc_traffic_$c.json; rm -rf gpurun_out/${TAG}_pmc_$c; done
 echo "pmc done"
 # the plain bench lines of the same session (live HIP-event roofline + CPU baseline), reading this session's PMC traffic
 mkdir -p profiles
 for c in vgg fpn fpn_bf16; do cp gpurun_out/${TAG}_pmc_traffic_$c.json profiles/${TAG}_pmc_traffic_$c.json; done
-python3 bench.py > gpurun_out/${TAG}_bench_vgg.json 2> gpurun_out/${TAG}_bench_vgg.err
+python3 bench.py --no-also > gpurun_out/${TAG}_bench_vgg.json 2> gpurun_out/${TAG}_bench_vgg.err
 python3 bench.py --config fpn > gpurun_out/${TAG}_bench_fpn.json 2> gpurun_out/${TAG}_bench_fpn.err
 python3 bench.py --config fpn --amp bf16 > gpurun_out/${TAG}_bench_fpn_bf16.json 2> gpurun_out/${TAG}_bench_fpn_bf16.err
 echo "bench done"
