@@ -581,7 +581,8 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
 // ------------------------------------------------------------------------------------------------------------------------------
 #define WG_SEG 64                        // pixels per row segment (4 K steps)
 #define WG_AS 72                         // LDS row stride in bf16 elements (144 bytes: 9 x 16, conflict-free ds_read_b128 down a column of rows)
-#define WG_CO 128
+#define WG_NCT 1                         // output-channel tiles (32 channels) per wave (2: 288 accumulators, spills: 740 scratch stores)
+#define WG_CO (128 * WG_NCT)
 #define WG_CI 32
 #define WG_MAX_SPLITS 32
 struct WgradLevels {
@@ -593,7 +594,8 @@ struct WgradLevels {
     int split0[WG_MAX_SPLITS + 1];                 // first row segment of split s
 };
 #define WG_SLOW_COST 3                   // cost of a generically staged row segment relative to a 16-byte staged one (host-side balancing)
-#define WG_LDS_BYTES ((2 * WG_CO * WG_AS + 3 * 4 * WG_CI * WG_AS) * 2)     // 36 864 + 55 296 = 92 160 bytes
+#define WG_RUN_COST 0                    // cost of starting a column strip (two exposed round trips), in fast row segments
+#define WG_LDS_BYTES ((2 * WG_CO * WG_AS + 3 * 4 * WG_CI * WG_AS) * 2)     // 73 728 + 55 296 = 129 024 bytes of the CU's 160 KB
 
 // one run = consecutive rows [y_first, y_first + n_rows) of one 64-pixel column strip of one level.
 // FAST: W % 8 == 0 and 16-byte aligned planes (the two large levels: 94 % of the positions): 16-byte loads / LDS stores, 7 load
@@ -603,54 +605,60 @@ struct WgradLevels {
 template <bool FAST>
 __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__ xin, const unsigned short *__restrict__ din, int H, int W, int x0,
                                               int y_first, int n_rows, int ci0, int co0, unsigned short (*s_a)[WG_CO * WG_AS],
-                                              unsigned short (*s_f)[4][WG_CI * WG_AS], f32x16 (&acc)[9])
+                                              unsigned short (*s_f)[4][WG_CI * WG_AS], f32x16 (&acc)[WG_NCT][9])
 {
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, g = lane >> 5;
     const size_t plane = (size_t)H * W;
     const bool odd_w = (W & 1) != 0;
-    constexpr int NA = FAST ? 4 : 16;                                  // A registers per row: 4 x 16 bytes / 16 dwords
-    constexpr int NF = FAST ? 6 : 12;                                  // F registers per row: 16 bytes + 2 edge dwords / 4 items x 3 dwords
-    struct Set { unsigned a[16]; unsigned f[12]; };
+    constexpr int NA16 = WG_CO * 8 / 256;                              // 16-byte pieces of the d_raw tile per thread (fast path)
+    constexpr int NA4 = WG_CO * 32 / 256;                              // dwords per thread (generic path)
+    // All loads are UNCONDITIONAL: an item outside the image reads element 0 of its plane and is zeroed at the LDS store (mask bits kept
+    // beside the data).  A load under a lane-dependent branch makes the compiler's s_waitcnt bookkeeping give up: it then waits for
+    // vmcnt(0) before every LDS store, i.e. for the OTHER register set's just-issued loads too, and the two-rows-ahead prefetch
+    // degenerates to one row (the generic path even waited after every single load).
+    struct Set { unsigned a[NA4]; unsigned f[12]; unsigned ma, mf; };
     // ---- feature row yy of my 32 channels
     auto load_f = [&](int yy, Set &S) {
+        const bool rin = yy >= 0 && yy < H;
+        unsigned m = 0u;
         if (FAST) {                                                    // item t: channel t >> 3, 8-pixel piece t & 7
             const int ch = t >> 3, xe = x0 + 8 * (t & 7);
-            const unsigned short *row = xin + (size_t)(ci0 + ch) * plane + (size_t)yy * W;
-            const bool rin = yy >= 0 && yy < H;
-            u32x4 mid = (u32x4){0u, 0u, 0u, 0u};
-            unsigned left = 0u, right = 0u;
-            if (rin && xe < W) mid = *(const u32x4 *)(row + xe);
-            if (rin && xe >= 2 && xe - 2 < W) left = *(const unsigned *)(row + xe - 2);
-            if (rin && xe + 8 < W) right = *(const unsigned *)(row + xe + 8);
+            const unsigned short *pl = xin + (size_t)(ci0 + ch) * plane;
+            const size_t ro = (size_t)(rin ? yy : 0) * W;
+            const bool in_m = rin && xe < W, in_l = rin && xe >= 2 && xe - 2 < W, in_r = rin && xe + 8 < W;
+            const u32x4 mid = *(const u32x4 *)(pl + (in_m ? ro + xe : 0));
+            const unsigned left = *(const unsigned *)(pl + (in_l ? ro + xe - 2 : 0)), right = *(const unsigned *)(pl + (in_r ? ro + xe + 8 : 0));
             S.f[0] = mid[0]; S.f[1] = mid[1]; S.f[2] = mid[2]; S.f[3] = mid[3]; S.f[4] = left; S.f[5] = right;
+            m = (in_m ? 1u : 0u) | (in_l ? 2u : 0u) | (in_r ? 4u : 0u);
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = t + 256 * u, ch = c >> 5, j = c & 31;
-                const unsigned short *row = xin + (size_t)(ci0 + ch) * plane + (size_t)yy * W;
+                const unsigned short *pl = xin + (size_t)(ci0 + ch) * plane;
+                const size_t ro = (size_t)(rin ? yy : 0) * W;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int xe = x0 - 2 + 2 * (j + q);               // even pixel of dword j + q
-                    unsigned v = 0u;
-                    if (yy >= 0 && yy < H) {
-                        if (!odd_w) { if (xe >= 0 && xe < W) v = *(const unsigned *)(row + xe); }      // W even: xe + 1 < W as well, dword aligned
-                        else {
-                            const unsigned lo = (xe >= 0 && xe < W) ? row[xe] : 0u, hi = (xe + 1 >= 0 && xe + 1 < W) ? row[xe + 1] : 0u;
-                            v = lo | (hi << 16);
-                        }
-                    }
+                    const bool i0 = rin && xe >= 0 && xe < W, i1 = rin && xe + 1 >= 0 && xe + 1 < W;
+                    unsigned v;
+                    if (!odd_w) v = *(const unsigned *)(pl + (i0 ? ro + xe : 0));      // W even: both pixels in or out together, dword aligned
+                    else v = (unsigned)pl[i0 ? ro + xe : 0] | ((unsigned)pl[i1 ? ro + xe + 1 : 0] << 16);
                     S.f[3 * u + q] = v;
+                    m |= (i0 ? 1u : 0u) << (2 * (3 * u + q)) | (i1 ? 2u : 0u) << (2 * (3 * u + q));
                 }
             }
         }
+        S.mf = m;
     };
     // copy kx holds pixel x0 + p + kx - 1 at position p (three aligned reads instead of misaligned ones)
     auto store_f = [&](int yy, const Set &S) {
         const int slot = (yy + 1) & 3;
         if (FAST) {
             const int e = (t >> 3) * WG_AS + 8 * (t & 7);
-            const unsigned m0 = S.f[0], m1 = S.f[1], m2 = S.f[2], m3 = S.f[3], lf = S.f[4], rt = S.f[5];
+            const bool km = (S.mf & 1u) != 0u;
+            const unsigned m0 = km ? S.f[0] : 0u, m1 = km ? S.f[1] : 0u, m2 = km ? S.f[2] : 0u, m3 = km ? S.f[3] : 0u;
+            const unsigned lf = (S.mf & 2u) ? S.f[4] : 0u, rt = (S.mf & 4u) ? S.f[5] : 0u;
             *(u32x4 *)(&s_f[0][slot][e]) = (u32x4){__builtin_amdgcn_alignbit(m0, lf, 16), __builtin_amdgcn_alignbit(m1, m0, 16),
                                                   __builtin_amdgcn_alignbit(m2, m1, 16), __builtin_amdgcn_alignbit(m3, m2, 16)};
             *(u32x4 *)(&s_f[1][slot][e]) = (u32x4){m0, m1, m2, m3};
@@ -661,68 +669,91 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
             for (int u = 0; u < 4; ++u) {
                 const int c = t + 256 * u, ch = c >> 5, j = c & 31;
                 const int e = ch * WG_AS + 2 * j;                      // element index of pair j in the row (even: dword aligned)
-                *(unsigned *)(&s_f[0][slot][e]) = __builtin_amdgcn_alignbit(S.f[3 * u + 1], S.f[3 * u], 16);       // (x0 + 2j - 1, x0 + 2j)
-                *(unsigned *)(&s_f[1][slot][e]) = S.f[3 * u + 1];                                                  // (x0 + 2j,     x0 + 2j + 1)
-                *(unsigned *)(&s_f[2][slot][e]) = __builtin_amdgcn_alignbit(S.f[3 * u + 2], S.f[3 * u + 1], 16);   // (x0 + 2j + 1, x0 + 2j + 2)
+                unsigned d[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned mm = (S.mf >> (2 * (3 * u + q))) & 3u;
+                    d[q] = S.f[3 * u + q] & ((mm & 1u ? 0x0000FFFFu : 0u) | (mm & 2u ? 0xFFFF0000u : 0u));
+                }
+                *(unsigned *)(&s_f[0][slot][e]) = __builtin_amdgcn_alignbit(d[1], d[0], 16);       // (x0 + 2j - 1, x0 + 2j)
+                *(unsigned *)(&s_f[1][slot][e]) = d[1];                                            // (x0 + 2j,     x0 + 2j + 1)
+                *(unsigned *)(&s_f[2][slot][e]) = __builtin_amdgcn_alignbit(d[2], d[1], 16);       // (x0 + 2j + 1, x0 + 2j + 2)
             }
         }
     };
     auto load_a = [&](int yy, Set &S) {
+        const bool rin = yy < H;
+        const size_t ro = (size_t)(rin ? yy : 0) * W;
+        unsigned m = 0u;
         if (FAST) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NA16; ++u) {
                 const int c = t + 256 * u, r = c >> 3, xe = x0 + 8 * (c & 7);
-                u32x4 v = (u32x4){0u, 0u, 0u, 0u};
-                if (yy < H && xe < W) v = *(const u32x4 *)(din + (size_t)(co0 + r) * plane + (size_t)yy * W + xe);
+                const bool in = rin && xe < W;
+                const u32x4 v = *(const u32x4 *)(din + (size_t)(co0 + r) * plane + (in ? ro + xe : 0));
                 S.a[4 * u] = v[0]; S.a[4 * u + 1] = v[1]; S.a[4 * u + 2] = v[2]; S.a[4 * u + 3] = v[3];
+                m |= (in ? 1u : 0u) << u;
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < NA4; ++u) {
                 const int c = t + 256 * u, r = c >> 5, xe = x0 + 2 * (c & 31);
-                const unsigned short *row = din + (size_t)(co0 + r) * plane + (size_t)yy * W;
-                unsigned v = 0u;
-                if (yy < H) {
-                    if (!odd_w) { if (xe < W) v = *(const unsigned *)(row + xe); }
-                    else {
-                        const unsigned lo = xe < W ? row[xe] : 0u, hi = xe + 1 < W ? row[xe + 1] : 0u;
-                        v = lo | (hi << 16);
-                    }
-                }
+                const unsigned short *pl = din + (size_t)(co0 + r) * plane;
+                const bool i0 = rin && xe < W, i1 = rin && xe + 1 < W;
+                unsigned v;
+                if (!odd_w) v = *(const unsigned *)(pl + (i0 ? ro + xe : 0));
+                else v = (unsigned)pl[i0 ? ro + xe : 0] | ((unsigned)pl[i1 ? ro + xe + 1 : 0] << 16);
+                if (odd_w && !i1) v &= 0x0000FFFFu;
                 S.a[u] = v;
+                m |= (i0 ? 1u : 0u) << u;
             }
         }
+        S.ma = m;
     };
     auto store_a = [&](int buf, const Set &S) {
         if (FAST) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NA16; ++u) {
                 const int c = t + 256 * u;
-                *(u32x4 *)(&s_a[buf][(c >> 3) * WG_AS + 8 * (c & 7)]) = (u32x4){S.a[4 * u], S.a[4 * u + 1], S.a[4 * u + 2], S.a[4 * u + 3]};
+                const bool in = (S.ma >> u) & 1u;
+                *(u32x4 *)(&s_a[buf][(c >> 3) * WG_AS + 8 * (c & 7)]) =
+                    (u32x4){in ? S.a[4 * u] : 0u, in ? S.a[4 * u + 1] : 0u, in ? S.a[4 * u + 2] : 0u, in ? S.a[4 * u + 3] : 0u};
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < NA4; ++u) {
                 const int c = t + 256 * u;
-                *(unsigned *)(&s_a[buf][(c >> 5) * WG_AS + 2 * (c & 31)]) = S.a[u];
+                *(unsigned *)(&s_a[buf][(c >> 5) * WG_AS + 2 * (c & 31)]) = ((S.ma >> u) & 1u) ? S.a[u] : 0u;
             }
         }
     };
-    (void)NA; (void)NF;
+    // wave w owns the output-channel tiles WG_NCT w .. WG_NCT w + WG_NCT - 1: a feature fragment read from LDS feeds WG_NCT MFMAs (all four
+    // waves read the SAME nine feature fragments per K step; with one tile per wave the LDS read volume, 160 KB per row segment and CU,
+    // took as long as the MFMAs themselves)
     auto compute = [&](int y, int buf) {
-        const unsigned short *sa = s_a[buf] + (32 * wave + li) * WG_AS + 8 * g;
+        const unsigned short *sa = s_a[buf] + (32 * WG_NCT * wave + li) * WG_AS + 8 * g;
+        // one wave per SIMD: nothing overlaps the LDS fragment reads with the MFMAs unless the code does.  The fragments of K step
+        // ks + 1 are read into the other register set while the MFMAs of step ks run (two sets x (1 + 9) fragments = 80 registers).
+        bf16x8 fa[2][WG_NCT], fb[2][9];
+        auto frags = [&](int p, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < WG_SEG / 16; ++ks) {
-            const bf16x8 fa = *(const bf16x8 *)(sa + 16 * ks);
+            for (int ct = 0; ct < WG_NCT; ++ct) fa[p][ct] = *(const bf16x8 *)(sa + ct * 32 * WG_AS + 16 * ks);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int slot = (y + ky) & 3;                          // row y + ky - 1 lives in slot (y + ky - 1 + 1) & 3
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const bf16x8 fb = *(const bf16x8 *)(&s_f[kx][slot][li * WG_AS + 16 * ks + 8 * g]);
-                    acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[3 * ky + kx], 0, 0, 0);
-                }
+                for (int kx = 0; kx < 3; ++kx) fb[p][3 * ky + kx] = *(const bf16x8 *)(&s_f[kx][slot][li * WG_AS + 16 * ks + 8 * g]);
             }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < WG_SEG / 16; ++ks) {
+            if (ks + 1 < WG_SEG / 16) frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int ct = 0; ct < WG_NCT; ++ct)
+                    acc[ct][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][ct], fb[ks & 1][k], acc[ct][k], 0, 0, 0);
         }
     };
     // ---- prime: feature rows y_first - 1 .. y_first + 1 and the d_raw row y_first go straight to LDS; the two register sets take
@@ -761,10 +792,12 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
     unsigned short (*s_f)[4][WG_CI * WG_AS] = (unsigned short (*)[4][WG_CI * WG_AS])(s_wg + 2 * WG_CO * WG_AS);    // [kx 3][slot 4][32 x 72]
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, g = lane >> 5;
-    const int split = blockIdx.x, ci0 = ((int)blockIdx.y >> 1) * WG_CI, co0 = ((int)blockIdx.y & 1) * WG_CO;
-    f32x16 acc[9];
+    const int split = blockIdx.x, ci0 = ((int)blockIdx.y / (RC3_C / WG_CO)) * WG_CI, co0 = ((int)blockIdx.y % (RC3_C / WG_CO)) * WG_CO;
+    f32x16 acc[WG_NCT][9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = (f32x16){0};
+    for (int ct = 0; ct < WG_NCT; ++ct)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[ct][k] = (f32x16){0};
     // K range of this split: segments [L.split0[split], L.split0[split + 1]) of the global order (level, 64-pixel column strip, row).
     // The host cuts the order into ranges of equal COST: a row segment of a level that takes the generic staging path counts
     // WG_SLOW_COST times (equal COUNTS left all the narrow levels to the last split, whose workgroups then set the kernel's time),
@@ -784,21 +817,25 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
         else rpn_wgrad_run<false>(L.x[lvl], L.d[lvl], H, W, strip * WG_SEG, y_first, n_rows, ci0, co0, s_a, s_f, acc);
         seg += n_rows;
     }
-    // ---- my partial [128][32][9]: register r of acc[tap] is (co = co0 + 32 wave + (r & 3) + 8 (r >> 2) + 4 g, ci = ci0 + li)
+    // ---- my partial, laid out [split][co][tap][ci]: register r of acc[ct][tap] is (co = co0 + 32 (WG_NCT wave + ct) + (r & 3) + 8 (r >> 2) + 4 g,
+    //      ci = ci0 + li), so the 32 lanes of a half-wave store 128 contiguous bytes (the weight's own [co][ci][tap] order made every
+    //      store instruction touch ~18 cache lines: ~30 us of the kernel for 38 MB of partials)
     float *dst = part + (size_t)split * RC3_C * RC3_C * 9;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int ct = 0; ct < WG_NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * g;
-            dst[((size_t)co * RC3_C + ci0 + li) * 9 + tap] = acc[tap][r];
-        }
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + 32 * (WG_NCT * wave + ct) + (r & 3) + 8 * (r >> 2) + 4 * g;
+                dst[((size_t)co * 9 + tap) * RC3_C + ci0 + li] = acc[ct][tap][r];
+            }
 }
 
-// dW = sum of the split partials, in split order (fixed: bit-reproducible)
+// dW = sum of the split partials, in split order (fixed: bit-reproducible); partials are [co][tap][ci], the weight is [co][ci][tap]
 __global__ __launch_bounds__(256) void rpn_conv_wgrad_finalize_kernel(const float *__restrict__ part, int n_splits, float *__restrict__ dw)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;                  // index in the partial layout: (co * 9 + tap) * 256 + ci
     if (i >= RC3_C * RC3_C * 9) return;
     float v = 0.0f;
     for (int s0 = 0; s0 < n_splits; s0 += 8) {
@@ -808,7 +845,8 @@ __global__ __launch_bounds__(256) void rpn_conv_wgrad_finalize_kernel(const floa
 #pragma unroll
         for (int u = 0; u < 8; ++u) v += tv[u];
     }
-    dw[i] = v;
+    const int ci = i & (RC3_C - 1), ct = i >> 8, tap = ct % 9, co = ct / 9;
+    dw[((size_t)co * RC3_C + ci) * 9 + tap] = v;
 }
 
 size_t frcnn_ws_rpn_conv_wgrad(void) { return (size_t)WG_MAX_SPLITS * RC3_C * RC3_C * 9 * sizeof(float); }
@@ -831,7 +869,10 @@ FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const
         L.seg0[l] = (int)segs;
         const bool fast = (W[k] & 7) == 0 && ((((uintptr_t)feat_levels_bf16[k]) | ((uintptr_t)d_raw_levels_bf16[k])) & 15) == 0;
         lvl_cost[l] = fast ? 1 : WG_SLOW_COST;
-        if (l < n_levels) { const int64_t n = (int64_t)H[k] * ((W[k] + WG_SEG - 1) / WG_SEG); segs += n; cost += n * lvl_cost[l]; }
+        if (l < n_levels) {                                         // + WG_RUN_COST per column strip: its window of exposed loads
+            const int64_t strips = (W[k] + WG_SEG - 1) / WG_SEG, n = (int64_t)H[k] * strips;
+            segs += n; cost += n * lvl_cost[l] + strips * WG_RUN_COST;
+        }
     }
     for (int l = n_levels; l <= FRCNN_MAX_LEVELS; ++l) L.seg0[l] = (int)segs;
     L.n_levels = n_levels;
@@ -839,7 +880,8 @@ FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const
     // K splits: 16 column groups (8 input-channel chunks x 2 output-channel halves) x splits workgroups = one round of the chip
     int n_cu = 256;
     { int dev = -1; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
-    int splits = n_cu / 16;
+    const int groups = (RC3_C / WG_CI) * (RC3_C / WG_CO);           // workgroups per split: input-channel chunks x output-channel parts
+    int splits = n_cu / groups;
     if (splits < 1) splits = 1;
     if (splits > WG_MAX_SPLITS) splits = WG_MAX_SPLITS;
     if ((int64_t)splits > segs) splits = (int)segs;
@@ -849,7 +891,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const
         L.split0[0] = 0;
         for (int64_t sg = 0; sg < segs && s_i < splits; ++sg) {
             while (lvl + 1 < n_levels && sg >= L.seg0[lvl + 1]) ++lvl;
-            acc_cost += lvl_cost[lvl];
+            acc_cost += lvl_cost[lvl] + ((sg - L.seg0[lvl]) % L.H[lvl] == 0 ? WG_RUN_COST : 0);
             if (acc_cost * splits >= cost * s_i) L.split0[s_i++] = (int)(sg + 1);
         }
         for (; s_i <= WG_MAX_SPLITS; ++s_i) L.split0[s_i] = (int)segs;
@@ -866,7 +908,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const
             if (dev < 64) done[dev].store(1, std::memory_order_release);
         }
     }
-    FRCNN_LAUNCH(rpn_conv3x3_wgrad_kernel, dim3((unsigned)splits, 16), dim3(256), WG_LDS_BYTES, s, L, (float *)workspace);
+    FRCNN_LAUNCH(rpn_conv3x3_wgrad_kernel, dim3((unsigned)splits, (unsigned)groups), dim3(256), WG_LDS_BYTES, s, L, (float *)workspace);
     FRCNN_CHECK_LAUNCH("rpn_conv3x3_wgrad_kernel");
     FRCNN_LAUNCH(rpn_conv_wgrad_finalize_kernel, dim3(RC3_C * RC3_C * 9 / 256), dim3(256), 0, s, (const float *)workspace, splits, dw3);
     FRCNN_CHECK_LAUNCH("rpn_conv_wgrad_finalize_kernel");
