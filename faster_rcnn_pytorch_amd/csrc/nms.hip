@@ -36,6 +36,21 @@
 
 typedef unsigned long long u64;
 
+#ifdef NMS_TRACE                       // developer build only (tools/dev/nms_trace.py): per-wave timeline in a device-global table
+__device__ u64 g_nms_trace[8192][8];
+__device__ u64 g_nms_sweep[4096][16];
+#define NMS_T(idx, slot) do { if ((threadIdx.x & 63) == 0) g_nms_trace[idx][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define NMS_TV(idx, slot, v) do { if ((threadIdx.x & 63) == 0) g_nms_trace[idx][slot] = (u64)(v); } while (0)
+#define NMS_TSWEEP(idx, k) do { if ((threadIdx.x & 63) == 0 && (k) < 16) g_nms_sweep[idx][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" __attribute__((visibility("default"))) void frcnn_nms_trace_clear() { static u64 z[8192 * 8]; hipMemcpyToSymbol(HIP_SYMBOL(g_nms_trace), z, sizeof(g_nms_trace)); hipMemcpyToSymbol(HIP_SYMBOL(g_nms_sweep), z, sizeof(g_nms_sweep)); }
+extern "C" __attribute__((visibility("default"))) void frcnn_nms_trace_read(void *dst) { hipDeviceSynchronize(); hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_nms_trace), sizeof(g_nms_trace)); }
+extern "C" __attribute__((visibility("default"))) void frcnn_nms_sweep_read(void *dst) { hipDeviceSynchronize(); hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_nms_sweep), sizeof(g_nms_sweep)); }
+#else
+#define NMS_T(idx, slot) do {} while (0)
+#define NMS_TV(idx, slot, v) do {} while (0)
+#define NMS_TSWEEP(idx, k) do {} while (0)
+#endif
+
 // v_max_f32 / v_min_f32 without LLVM's sNaN-canonicalising v_max(x,x) in front of every operand
 __device__ __forceinline__ float vmaxf(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vminf(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -62,6 +77,13 @@ __device__ __forceinline__ unsigned shift_in(unsigned word, u64 mask)
     u64 carry_out;
     asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(word), "=s"(carry_out) : "v"(word), "s"(mask));
     return word;
+}
+// acc & x as an instruction of its own: the compiler otherwise re-associates the 32 ANDs into a tree "for parallelism", keeps all the
+// masks alive to the end of the unrolled loop and spills them into VGPR lanes (3 v_writelane per step)
+__device__ __forceinline__ u64 and_now(u64 acc, u64 x)
+{
+    asm("s_and_b64 %0, %0, %1" : "+s"(acc) : "s"(x) : "scc");
+    return acc;
 }
 template <bool CHECK, bool CLS, bool POS>
 __device__ __forceinline__ unsigned sup_half(float4 a, float area_a, const float4 *__restrict__ sb, const float *__restrict__ sa,
@@ -92,62 +114,123 @@ __device__ __forceinline__ unsigned sup_half(float4 a, float area_a, const float
     return word;
 }
 
+// The common case (no index checks, every area positive), TWO candidates per step on packed fp32 (v_pk_add / v_pk_mul / v_pk_fma_f32):
+//   inter / (aa + ab - inter) > thr  <=>  inter (1 + thr) > thr aa + thr ab =: q        (the union is positive)
+// with w clamped at 0 and h left as it is (h < 0 gives inter <= 0 < q: a sure no, which is the right answer), q from the two
+// pre-multiplied areas, and the guard band on the (1 + thr) factor: inter c_lo - q > 0 is a sure yes, inter c_hi - q < 0 a sure no
+// (c = (1 + thr)(1 -+ 2^-20): 16x the roundings of q's three operations and the FMA).  Per pair of candidates: 8 min / max, 2 packed
+// subtractions, 2 clamps, 1 packed product, 1 packed sum, 2 packed FMAs, 4 compares, 2 carry-shifts = 22 VALU, 11 per pair.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool CLS>
+__device__ __forceinline__ unsigned sup_half_pos(float4 a, float ta, const float4 *__restrict__ sb, const float *__restrict__ stb, float thr,
+                                                 u64 *unsure, int my_cls, const int *__restrict__ sc)
+{
+    unsigned word = 0u;
+    u64 sure = ~0ull;
+    const float c_lo = (1.0f + thr) * (1.0f - 9.5367431640625e-07f), c_hi = (1.0f + thr) * (1.0f + 9.5367431640625e-07f);
+    const f32x2 clo2 = {c_lo, c_lo}, chi2 = {c_hi, c_hi}, ta2 = {ta, ta};
+    // the LDS reads of step k + 1 are issued before step k's arithmetic (the scheduler, left alone, sinks them to their first use and
+    // every step then waits out the LDS latency)
+    float4 b0 = sb[31], b1 = sb[30];
+    f32x2 tb = {stb[31], stb[30]};
+#pragma unroll
+    for (int jj = 0; jj < 32; jj += 2) {
+        const int j = 31 - jj;                                   // candidates j (element 0) and j - 1 (element 1)
+        float4 nb0 = b0, nb1 = b1;
+        f32x2 ntb = tb;
+        if (jj + 2 < 32) { nb0 = sb[j - 2]; nb1 = sb[j - 3]; ntb = f32x2{stb[j - 2], stb[j - 3]}; }
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x2 xlo = {vmaxf(a.x, b0.x), vmaxf(a.x, b1.x)}, xhi = {vminf(a.z, b0.z), vminf(a.z, b1.z)};
+        const f32x2 ylo = {vmaxf(a.y, b0.y), vmaxf(a.y, b1.y)}, yhi = {vminf(a.w, b0.w), vminf(a.w, b1.w)};
+        f32x2 w = xhi - xlo;
+        const f32x2 h = yhi - ylo;
+        w = f32x2{vmaxf(w.x, 0.0f), vmaxf(w.y, 0.0f)};
+        const f32x2 inter = w * h;
+        const f32x2 q = ta2 + tb;
+        const f32x2 t_yes = __builtin_elementwise_fma(inter, clo2, -q), t_no = __builtin_elementwise_fma(inter, chi2, -q);
+        u64 y0 = __builtin_amdgcn_ballot_w64(t_yes.x > 0.0f), y1 = __builtin_amdgcn_ballot_w64(t_yes.y > 0.0f);
+        const u64 s0 = y0 | __builtin_amdgcn_ballot_w64(t_no.x < 0.0f), s1 = y1 | __builtin_amdgcn_ballot_w64(t_no.y < 0.0f);
+        sure = and_now(sure, s0 & s1);
+        if (CLS) { y0 &= __builtin_amdgcn_ballot_w64(sc[j] == my_cls); y1 &= __builtin_amdgcn_ballot_w64(sc[j - 1] == my_cls); }
+        word = shift_in(word, y0);
+        word = shift_in(word, y1);
+        b0 = nb0; b1 = nb1; tb = ntb;
+    }
+    *unsure |= ~sure;
+    return word;
+}
+
 __device__ __forceinline__ u64 agent_ld64(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_or64(u64 *p, u64 v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void agent_st64(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// One wave = one 64 x 64 tile (cb = my block, the lower-scored side; rb <= cb = suppressor block).  The words are published for the
-// resolver waves that run in the SAME launch on other CUs (see nms_kernel): write-through (sc1) stores and agent-scope atomic ORs,
-// the wave's own s_waitcnt vmcnt(0), then the tile's flag done[cb (cb + 1) / 2 + rb] = 1 (sc1 store); row cb is complete when its
-// cb + 1 flags are up.
+// One wave = one 64 x 64 tile (cb = my block, the lower-scored side; rb <= cb = suppressor block, staged in LDS).  The words are
+// published for the resolver workgroups that run in the SAME launch on other CUs (see nms_kernel): write-through (sc1) stores (and
+// agent-scope atomic ORs on the generic path), the wave's own s_waitcnt vmcnt(0), then the tile's flag
+// done[cb (cb + 1) / 2 + rb] = 1 (empty) or 2 (sc1 store); row cb is complete when its cb + 1 flags are up.
+// What bounds the relation (profiles/README.md, round 3): ~24 us of VALU-bound bulk at 12 000 boxes (72 M pairs x 11 instructions)
+// on top of a ~16 us fill / drain floor -- one wave's life is a load round trip, ~3.5 us of single-wave issue and a write-through
+// acknowledgement.  Variants that did NOT move it: two rows per lane (half the LDS broadcasts), several tiles per wave with the next
+// tile's loads and the previous tile's acknowledgement under the compute (fewer, longer waves: 47 / 58 / 87 us for 2 / 4 / 8 tiles),
+// candidate boxes through scalar loads (45 us), 3 to 8 waves per SIMD (46 .. 42 us).
 template <bool CLS>
-__device__ __forceinline__ void nms_sup_tile(int cb, int rb, int wave, int lane, float4 (*s_box)[64], float (*s_area)[64], int (*s_cls)[64],
-                                             const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, int n, int K, float thr, int nblk,
+__device__ __forceinline__ void nms_sup_tile(int cb, int rb, int wave, int lane, float4 (*s_box)[64], float (*s_area)[64], float (*s_tarea)[64], int (*s_cls)[64],
+                                             const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, int n, int K, float thr, int nblk, bool dense,
                                              u64 *__restrict__ sup, u64 *__restrict__ nz, int32_t *__restrict__ done)
 {
     const int me = cb * 64 + lane;
+#ifdef NMS_TRACE
+    if (lane == 0) { const u64 t = __builtin_amdgcn_s_memrealtime(); if (atomicCAS(&g_nms_trace[4096 + cb][0], 0ull, t) != 0ull) atomicMin(&g_nms_trace[4096 + cb][0], t); }
+#endif
     const float4 a = boxes[min(me, K - 1)];
     const float area_a = (a.z - a.x) * (a.w - a.y);
     const int my_cls = CLS ? cls[min(me, K - 1)] : 0;
     const int j0 = rb * 64;
     const float4 rbx = boxes[min(j0 + lane, K - 1)];            // coalesced 1 KB
     if (CLS) s_cls[wave][lane] = cls[min(j0 + lane, K - 1)];
+    const float area_r = (rbx.z - rbx.x) * (rbx.w - rbx.y);
     s_box[wave][lane] = rbx;
-    s_area[wave][lane] = (rbx.z - rbx.x) * (rbx.w - rbx.y);
+    s_area[wave][lane] = area_r;
+    s_tarea[wave][lane] = thr * area_r;
     __builtin_amdgcn_wave_barrier();                            // same-wave LDS RAW: ds ops of one wave complete in order
     u64 unsure = 0ull;
     unsigned lo, hi;
     // all 128 areas positive (always, for clipped proposals): the union test leaves the inner loop
-    const bool pos = __ballot(!(area_a > 0.0f) || !(s_area[wave][lane] > 0.0f)) == 0ull;
+    const bool pos = __ballot(!(area_a > 0.0f) || !(area_r > 0.0f)) == 0ull;
     if (cb == rb || cb * 64 + 64 > n) {                         // diagonal / tail tile
         lo = sup_half<true, CLS, false>(a, area_a, s_box[wave], s_area[wave], thr, j0, me, n, &unsure, my_cls, s_cls[wave]);
         hi = sup_half<true, CLS, false>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, j0 + 32, me, n, &unsure, my_cls, s_cls[wave] + 32);
     } else if (pos) {
-        lo = sup_half<false, CLS, true>(a, area_a, s_box[wave], s_area[wave], thr, j0, me, n, &unsure, my_cls, s_cls[wave]);
-        hi = sup_half<false, CLS, true>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, j0 + 32, me, n, &unsure, my_cls, s_cls[wave] + 32);
+        lo = sup_half_pos<CLS>(a, thr * area_a, s_box[wave], s_tarea[wave], thr, &unsure, my_cls, s_cls[wave]);
+        hi = sup_half_pos<CLS>(a, thr * area_a, s_box[wave] + 32, s_tarea[wave] + 32, thr, &unsure, my_cls, s_cls[wave] + 32);
     } else {
         lo = sup_half<false, CLS, false>(a, area_a, s_box[wave], s_area[wave], thr, j0, me, n, &unsure, my_cls, s_cls[wave]);
         hi = sup_half<false, CLS, false>(a, area_a, s_box[wave] + 32, s_area[wave] + 32, thr, j0 + 32, me, n, &unsure, my_cls, s_cls[wave] + 32);
     }
     u64 bits = ((u64)hi << 32) | lo;
-    if (unsure != 0ull) {                                       // rare: redo the affected lanes with the IEEE division
-        if ((unsure >> lane) & 1ull) {
-            bits = 0ull;
-            for (int j = 0; j < 64; ++j) {
-                const bool s = nms_suppress_exact(s_box[wave][j], s_area[wave][j], a, area_a, thr) && (j0 + j < me) && (me < n) &&
-                               (!CLS || s_cls[wave][j] == my_cls);
-                bits |= s ? (1ull << j) : 0ull;
-            }
+    if (unsure != 0ull && ((unsure >> lane) & 1ull)) {          // rare: redo the affected lanes with the IEEE division
+        bits = 0ull;
+        for (int j = 0; j < 64; ++j) {
+            const bool sp = nms_suppress_exact(s_box[wave][j], s_area[wave][j], a, area_a, thr) && (j0 + j < me) && (me < n) &&
+                            (!CLS || s_cls[wave][j] == my_cls);
+            bits |= sp ? (1ull << j) : 0ull;
         }
     }
-    if (bits != 0ull) {                                         // me < n <= K is implied by a set bit
+    const int tile = cb * (cb + 1) / 2 + rb;
+    int flag = 1;
+    if (dense) {                                                // one coalesced 512 B store per non-empty tile (see nms_resolve_block_dense)
+        if (__ballot(bits != 0ull) != 0ull) { agent_st64(&sup[(size_t)tile * 64 + lane], bits); flag = 2; }
+    } else if (bits != 0ull) {                                  // me < n <= K is implied by a set bit
         agent_st64(&sup[(size_t)me * nblk + rb], bits);
         agent_or64(&nz[(size_t)(rb >> 6) * K + me], 1ull << (rb & 63));   // group-major: the resolver reads it coalesced
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // my stores and ORs have reached the coherence point ...
     // ... before my tile's flag goes up.  One flag WORD per tile, a plain write-through store: a shared per-row counter (cb + 1
     // agent-scope adds to one address) doubled the kernel's time, 43 -> 83 us.
-    if (lane == 0) __hip_atomic_store(&done[cb * (cb + 1) / 2 + rb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&done[tile], flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef NMS_TRACE
+    if (lane == 0) atomicMax(&g_nms_trace[4096 + cb][1], (u64)__builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -267,6 +350,118 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
 }
 
 // ------------------------------------------------------------------------------------------------
+// nms_resolve_block_dense: the resolver for nblk <= NMS_DENSE_MAX_BLOCKS (K <= 16384: every proposal stage and predict list of the
+// two configurations).  Same two rules; what changes is the memory behaviour.  The relation is stored DENSE PER TILE
+// (supd[cb (cb + 1) / 2 + rb][lane]: one coalesced 512 B store per non-empty tile, none for an empty one -- the tile's flag says
+// which: 1 = empty, 2 = stored), so the row of block b is (b + 1) x 512 contiguous bytes and every access of the resolver is one
+// coalesced load.  (The per-box layout of the generic path costs one partial-line write-through store and one atomic OR PER BOX AND
+// TILE -- about a million of each at K = 12 000 -- and the resolver gathers 64 different lines per load; with the memory system busy
+// with those a round trip took 4-5 us, profiles/README.md.)
+// The four waves of the workgroup share the 64 boxes of block b (lane = box) and split its tiles (wave v: rb = 4 k + v).  A SWEEP:
+// each wave loads its ACTIVE tiles (NMS_DENSE_BATCH per round trip, unconditional clamped loads) while the 256 threads take one
+// coalesced snapshot of the kept / removed bitmaps into LDS; per tile hit |= w & kept[rb], und |= w & ~removed[rb] (bitmap words as
+// LDS broadcasts); a tile none of whose undecided boxes has an undecided suppressor left is dropped from the wave's active mask
+// for good (both bitmaps only gain bits).  The per-wave hit / und lane masks are OR-ed through LDS; every wave then runs the same
+// scalar fixpoint over the DIAGONAL tile (held in registers by all four waves), so chains inside the block cost no memory round
+// trip, and wave 0 publishes the block's two bitmap words with plain write-through stores (one writer per word).
+// ------------------------------------------------------------------------------------------------
+#define NMS_DENSE_MAX_BLOCKS 256
+#ifndef NMS_DENSE_BATCH
+#define NMS_DENSE_BATCH 24
+#endif
+struct NmsResLds {
+    u64 stk[NMS_DENSE_MAX_BLOCKS], str[NMS_DENSE_MAX_BLOCKS];
+    u64 hitm[4], undm[4];
+    int abort;
+};
+__device__ __forceinline__ void nms_resolve_block_dense(int b, int n, int nblk, const u64 *__restrict__ supd, u64 *__restrict__ kept,
+                                                        u64 *__restrict__ rem, const int32_t *__restrict__ done, int32_t *__restrict__ abort_flag,
+                                                        NmsResLds *__restrict__ L)
+{
+    if (b * 64 >= n) return;                                        // the whole workgroup
+    const int lane = threadIdx.x & 63;
+    const int v = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 live_m = n - b * 64 >= 64 ? ~0ull : (1ull << (n - b * 64)) - 1ull;
+    const size_t row0 = (size_t)b * (b + 1) / 2;
+    const int32_t *fl = done + row0;
+    const u64 *rowp = supd + row0 * 64 + lane;
+    NMS_T(b * 4 + v, 0);
+    // my wave's tiles: lane k <-> rb = 4 k + v (< b; the diagonal tile is everybody's); wait for their flags
+    u64 act;
+    int fd;
+    {
+        const int my_rb = 4 * lane + v;
+        const bool mine = my_rb < b;
+        int spins = 0, f;
+        for (;;) {
+            f = __hip_atomic_load(&fl[mine ? my_rb : b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(f == 0) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > NMS_ROW_WAIT_SPINS) { if (lane == 0) atomicOr(abort_flag, 1); break; }   // the sweep loop sees the flag and ends
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        act = __ballot(mine && f == 2);
+        fd = __hip_atomic_load(&fl[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    NMS_T(b * 4 + v, 1);
+    const u64 wdiag = fd == 2 ? agent_ld64(rowp + (size_t)b * 64) : 0ull;
+    u64 dec = ~live_m, acc_k = 0ull, acc_r = 0ull;
+    const int max_iter = 4 * n + 65536;
+    for (int it = 0;; ++it) {
+        NMS_TSWEEP(b, it);
+        const int tc = min((int)threadIdx.x, nblk - 1);
+        const u64 sk = agent_ld64(&kept[tc]), sr = agent_ld64(&rem[tc]);
+        const int ab = threadIdx.x == 0 ? __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        u64 hit = 0ull, und = 0ull, rest = act;
+        bool first = true;
+        do {
+            int rbs[NMS_DENSE_BATCH];
+            u64 w[NMS_DENSE_BATCH];
+#pragma unroll
+            for (int t = 0; t < NMS_DENSE_BATCH; ++t) {
+                rbs[t] = rest != 0ull ? 4 * (int)__builtin_ctzll(rest) + v : -1;
+                rest &= rest - 1ull;                                // 0 stays 0
+                w[t] = agent_ld64(rowp + (size_t)max(rbs[t], 0) * 64);
+            }
+            if (first) {
+                L->stk[tc] = sk; L->str[tc] = sr;
+                if (threadIdx.x == 0) L->abort = ab;
+                __syncthreads();
+                first = false;
+            }
+#pragma unroll
+            for (int t = 0; t < NMS_DENSE_BATCH; ++t) {
+                if (rbs[t] >= 0) {                                  // wave-uniform
+                    const u64 u = w[t] & ~L->str[rbs[t]];
+                    hit |= w[t] & L->stk[rbs[t]];
+                    und |= u;
+                    if ((__ballot(u != 0ull) & ~dec) == 0ull) act &= ~(1ull << (rbs[t] >> 2));
+                }
+            }
+        } while (rest != 0ull);
+        const u64 hm = __ballot(hit != 0ull), um = __ballot(und != 0ull);
+        if (lane == 0) { L->hitm[v] = hm; L->undm[v] = um; }
+        __syncthreads();
+        const u64 hit_o = L->hitm[0] | L->hitm[1] | L->hitm[2] | L->hitm[3];
+        const u64 und_o = L->undm[0] | L->undm[1] | L->undm[2] | L->undm[3];
+        const bool aborted = L->abort != 0;
+        const u64 dec0 = dec;
+        for (;;) {                                                  // chains inside the block: scalar, identical in the four waves
+            const u64 hd = __ballot((wdiag & acc_k) != 0ull), ud = __ballot((wdiag & ~acc_r) != 0ull);
+            const u64 nr = ~dec & (hit_o | hd), nk = ~dec & ~(hit_o | hd) & ~(und_o | ud);
+            if ((nr | nk) == 0ull) break;
+            acc_k |= nk; acc_r |= nr; dec |= nk | nr;
+        }
+        if (threadIdx.x == 0 && dec != dec0) { agent_st64(&kept[b], acc_k); agent_st64(&rem[b], acc_r); }
+        if (dec == ~0ull) { NMS_T(b * 4 + v, 3); NMS_TV(b * 4 + v, 4, it + 1); break; }
+        if (aborted) break;
+        if (dec == dec0) __builtin_amdgcn_s_sleep(1);
+        if (it > max_iter) { if (threadIdx.x == 0) atomicOr(abort_flag, 1); break; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // nms_kernel: ONE launch for the relation and its resolution.  Workgroups [0, n_res) are the resolver (one thread per box, one
 // 64-box wave per workgroup: dispatched first, so every resolver wave is resident before any wave it could wait for); the others
 // enumerate the lower-triangular tiles row by row (rows 4g .. 4g + 3 take g + 1 workgroups of 4 tiles each) and never wait for
@@ -281,14 +476,21 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
                                                   u64 *__restrict__ kept, u64 *__restrict__ rem, int32_t *__restrict__ done,
                                                   int32_t *__restrict__ abort_flag)
 {
-    __shared__ float4 s_box[4][64];
-    __shared__ float s_area[4][64];
-    __shared__ int s_cls[4][64];
+    struct TileLds { float4 box[4][64]; float area[4][64]; float tarea[4][64]; int cls[4][64]; };
+    constexpr size_t LDS_BYTES = sizeof(NmsResLds) > sizeof(TileLds) ? sizeof(NmsResLds) : sizeof(TileLds);
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_BYTES];
     const int n = n_dev ? min(max(*n_dev, 0), K) : K;
+    const bool dense = nblk <= NMS_DENSE_MAX_BLOCKS;
     if ((int)blockIdx.x < n_res) {
-        nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
+        if (dense) nms_resolve_block_dense((int)blockIdx.x, n, nblk, sup, kept, rem, done, abort_flag, (NmsResLds *)s_raw);
+        else nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
         return;
     }
+    TileLds *tl = (TileLds *)s_raw;
+    float4 (*s_box)[64] = tl->box;
+    float (*s_area)[64] = tl->area;
+    float (*s_tarea)[64] = tl->tarea;
+    int (*s_cls)[64] = tl->cls;
     const int t = (int)blockIdx.x - n_res;                      // tile workgroup: t = 2 g (g + 1) + (row in group) * (g + 1) + q
     int g = (int)((sqrtf(1.0f + 2.0f * (float)t) - 1.0f) * 0.5f);
     while (2 * (g + 1) * (g + 2) <= t) ++g;
@@ -299,7 +501,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     const int rb = (r % (g + 1)) * 4 + wave;
     if (rb > cb || cb >= nblk) return;
     if (cb * 64 >= n) return;                                   // dead boxes: nobody reads their words, no resolver wave waits for them
-    nms_sup_tile<CLS>(cb, rb, wave, (int)(threadIdx.x & 63), s_box, s_area, s_cls, boxes, cls, n, K, thr, nblk, sup, nz, done);
+    nms_sup_tile<CLS>(cb, rb, wave, (int)(threadIdx.x & 63), s_box, s_area, s_tarea, s_cls, boxes, cls, n, K, thr, nblk, dense, sup, nz, done);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,7 +703,8 @@ struct NmsWs {
 static bool nms_use_cascade(int64_t K)
 {
     static const int mode = [] { const char *e = getenv("FRCNN_NMS_CASCADE"); return e ? atoi(e) : 1; }();
-    return mode != 0 && K > NMS_CASCADE_MIN;
+    static const int kmin = [] { const char *e = getenv("FRCNN_NMS_CASCADE_MIN"); return e ? atoi(e) : NMS_CASCADE_MIN; }();
+    return mode != 0 && K > kmin;
 }
 static NmsWs carve_nms(void *ws, int64_t K)
 {
@@ -572,6 +775,9 @@ static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *
             FRCNN_LAUNCH(nms_kernel<false>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
                          L.done, abort_flag);
     };
+#ifdef NMS_TILES_ONLY                  // developer timing build: the relation alone (results are meaningless)
+    if (true) { launch(n_tile_wg, 0); } else
+#endif
     if (n_res <= fused_max_res) {
         launch((unsigned)n_res + n_tile_wg, n_res);
     } else {

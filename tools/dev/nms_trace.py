@@ -17,14 +17,14 @@ torch.cuda.synchronize()
 buf = np.zeros((8192, 8), np.uint64)
 L.frcnn_nms_trace_read(buf.ctypes.data_as(C.c_void_p))
 nblk = (K + 63) // 64
-res = buf[:nblk].astype(np.int64); tiles = buf[4096:4096 + nblk].astype(np.int64)
+res = buf[0:4 * nblk:4].astype(np.int64); tiles = buf[4096:4096 + nblk].astype(np.int64)
 t0 = min(res[:, 0].min(), tiles[:, 0].min())
 us = lambda v: (v - t0) / 100.0
 print("kept", int(cnt.item()), "nblk", nblk)
-print("blk | entry row_ready state decided | sweeps batches gpoll_sweeps || tile row: first_start last_end")
+print("blk | entry row_ready first_fill decided | sweeps fills || tile row: first_start last_end")
 for bl in list(range(0, nblk, max(1, nblk // 24))) + [nblk - 1]:
     r = res[bl]; t = tiles[bl]
-    print("%3d | %6.2f %6.2f %6.2f %6.2f | %5d %4d(adv sweeps %d) %5d || %6.2f %6.2f | poll us total %.2f, adv-section us total %.2f" % (bl, us(r[0]), us(r[1]), us(r[2]), us(r[3]), r[4], r[5] % 100, r[5] // 100, r[6], us(t[0]), us(t[1]), (int(r[7]) >> 32) / 100.0, (int(r[7]) & 0xffffffff) / 100.0))
+    print("%3d | %6.2f %6.2f %6.2f %6.2f | %5d %4d || %6.2f %6.2f" % (bl, us(r[0]), us(r[1]), us(r[2]), us(r[3]), r[4], r[5], us(t[0]), us(t[1])))
 sw = np.zeros((4096, 16), np.uint64)
 L.frcnn_nms_sweep_read(sw.ctypes.data_as(C.c_void_p))
 for bl in (0, 7, 49, 105, 126, 187):
