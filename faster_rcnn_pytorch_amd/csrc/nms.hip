@@ -366,6 +366,13 @@ __device__ __forceinline__ void nms_resolve_wave(int wg, int n, int K, int nblk,
 // trip, and wave 0 publishes the block's two bitmap words with plain write-through stores (one writer per word).
 // ------------------------------------------------------------------------------------------------
 #define NMS_DENSE_MAX_BLOCKS 256
+// the outputs of the stage, for the resolver workgroup that finishes last (nms_kernel folds nms_emit_kernel's job in when the level is
+// the only one and runs the dense resolver: out_count == nullptr switches it off)
+struct NmsEmitArgs {
+    int post_k;
+    int64_t *out_keep; float4 *out_rois; const int64_t *src_map; int64_t *out_src; int32_t *out_count;
+    int32_t *ticket;                   // zero before the launch
+};
 #ifndef NMS_DENSE_BATCH
 #define NMS_DENSE_BATCH 24
 #endif
@@ -376,7 +383,7 @@ struct NmsResLds {
 };
 __device__ __forceinline__ void nms_resolve_block_dense(int b, int n, int nblk, const u64 *__restrict__ supd, u64 *__restrict__ kept,
                                                         u64 *__restrict__ rem, const int32_t *__restrict__ done, int32_t *__restrict__ abort_flag,
-                                                        NmsResLds *__restrict__ L)
+                                                        NmsResLds *__restrict__ L, const float4 *__restrict__ boxes, const NmsEmitArgs &ea)
 {
     if (b * 64 >= n) return;                                        // the whole workgroup
     const int lane = threadIdx.x & 63;
@@ -459,6 +466,86 @@ __device__ __forceinline__ void nms_resolve_block_dense(int b, int n, int nblk, 
         if (dec == dec0) __builtin_amdgcn_s_sleep(1);
         if (it > max_iter) { if (threadIdx.x == 0) atomicOr(abort_flag, 1); break; }
     }
+    if (!ea.out_count) return;
+    // The workgroup that finishes LAST writes the stage's outputs (what nms_emit_kernel does as a launch of its own): the first post_k
+    // kept positions in score order, their boxes and source indices, and the count.  Every live block takes one ticket after its
+    // last bitmap store has been acknowledged (write-through stores + s_waitcnt vmcnt(0), the hand-off used for the tile flags: no
+    // L2 write-back / invalidate as an agent-scope release / acquire pair would cost); the holder of the last ticket reads the bitmap
+    // with sc1 loads.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        L->abort = __hip_atomic_fetch_add(ea.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int nb = (n + 63) >> 6;
+    if (L->abort != nb - 1) return;
+    NMS_T(8100, 0);
+    __syncthreads();
+    const int tc = min((int)threadIdx.x, nb - 1);
+    u64 kw = agent_ld64(&kept[tc]);
+    if ((int)threadIdx.x >= nb) kw = 0ull;
+    if ((int)threadIdx.x == nb - 1 && (n & 63)) kw &= (1ull << (n & 63)) - 1ull;
+    const bool aborted = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    // exclusive scan of the blocks' kept counts over the 256 threads
+    int inc = __builtin_popcountll(kw);
+    const int own = inc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    int *s_w = (int *)L->hitm;
+    if (lane == 63) s_w[v] = inc;
+    __syncthreads();
+    int base = inc - own;
+    for (int q = 0; q < v; ++q) base += s_w[q];
+    NMS_T(8100, 1);
+    int *s_total = (int *)L->undm;
+    if (threadIdx.x == 255) { *ea.out_count = aborted ? -1 : min(base + own, ea.post_k); *s_total = min(base + own, ea.post_k); }
+    // output position -> (block, bit): a binary search over the blocks' exclusive prefix sums (the LAST block whose prefix is <= pos:
+    // empty blocks share their successor's prefix) and a 6-step select of the r-th set bit; every thread then gathers and stores
+    // independently (coalesced in pos)
+    __syncthreads();                                                // (kw is in registers: the bitmap snapshots in stk / str are dead)
+    L->stk[threadIdx.x] = kw;
+    int *pre = (int *)L->str;
+    pre[threadIdx.x] = base;
+    __syncthreads();
+    const int cnt = aborted ? 0 : *s_total;
+    NMS_T(8100, 2);
+    for (int p0 = threadIdx.x; p0 < cnt; p0 += 4 * 256) {           // four positions per thread and round: the gathers overlap
+        int idx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pos = min(p0 + e * 256, cnt - 1);
+            int blk = 0;
+#pragma unroll
+            for (int step = NMS_DENSE_MAX_BLOCKS / 2; step > 0; step >>= 1)
+                if (pre[blk + step] <= pos) blk += step;
+            const u64 w = L->stk[blk];
+            int r = pos - pre[blk], bit = 0;
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const int c = __builtin_popcountll(w & ((((u64)1 << sft) - 1ull) << bit));
+                if (r >= c) { r -= c; bit += sft; }
+            }
+            idx[e] = blk * 64 + bit;
+        }
+        float4 bx[4];
+        int64_t sm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bx[e] = boxes[idx[e]]; sm[e] = ea.src_map ? ea.src_map[idx[e]] : (int64_t)idx[e]; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int pos = p0 + e * 256;
+            if (pos < cnt) {
+                ea.out_keep[pos] = (int64_t)idx[e];
+                if (ea.out_rois) ea.out_rois[pos] = bx[e];
+                if (ea.out_src) ea.out_src[pos] = sm[e];
+            }
+        }
+    }
+#ifdef NMS_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    NMS_T(8100, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,7 +561,7 @@ template <bool CLS>
 __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev,
                                                   int K, float thr, int nblk, int nzw, int n_res, u64 *__restrict__ sup, u64 *__restrict__ nz,
                                                   u64 *__restrict__ kept, u64 *__restrict__ rem, int32_t *__restrict__ done,
-                                                  int32_t *__restrict__ abort_flag)
+                                                  int32_t *__restrict__ abort_flag, NmsEmitArgs ea)
 {
     struct TileLds { float4 box[4][64]; float area[4][64]; float tarea[4][64]; int cls[4][64]; };
     constexpr size_t LDS_BYTES = sizeof(NmsResLds) > sizeof(TileLds) ? sizeof(NmsResLds) : sizeof(TileLds);
@@ -482,7 +569,8 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     const int n = n_dev ? min(max(*n_dev, 0), K) : K;
     const bool dense = nblk <= NMS_DENSE_MAX_BLOCKS;
     if ((int)blockIdx.x < n_res) {
-        if (dense) nms_resolve_block_dense((int)blockIdx.x, n, nblk, sup, kept, rem, done, abort_flag, (NmsResLds *)s_raw);
+        if (n == 0 && ea.out_count && blockIdx.x == 0 && threadIdx.x == 0) *ea.out_count = 0;   // no live block takes a ticket
+        if (dense) nms_resolve_block_dense((int)blockIdx.x, n, nblk, sup, kept, rem, done, abort_flag, (NmsResLds *)s_raw, boxes, ea);
         else nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
         return;
     }
@@ -749,7 +837,8 @@ void frcnn_nms_zero_region(void *ws, int64_t K, int32_t **ptr, int *n_ints)
 }
 
 // one level: relation tiles + resolver, as one launch (or two above fused_max_res resolver workgroups)
-static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *n_dev, int Kl, float thr, const NmsLevelWs &L, int32_t *abort_flag, hipStream_t s)
+static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *n_dev, int Kl, float thr, const NmsLevelWs &L, int32_t *abort_flag,
+                        const NmsEmitArgs &ea, hipStream_t s)
 {
     const int nblk = L.nblk;
     const int n_res = nblk;                                         // one resolver wave per workgroup
@@ -770,10 +859,10 @@ static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *
     auto launch = [&](unsigned grid, int n_res_arg) {
         if (cls)
             FRCNN_LAUNCH(nms_kernel<true>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
-                         L.done, abort_flag);
+                         L.done, abort_flag, ea);
         else
             FRCNN_LAUNCH(nms_kernel<false>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
-                         L.done, abort_flag);
+                         L.done, abort_flag, ea);
     };
 #ifdef NMS_TILES_ONLY                  // developer timing build: the relation alone (results are meaningless)
     if (true) { launch(n_tile_wg, 0); } else
@@ -799,8 +888,14 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     if (!pre_zeroed && hipMemsetAsync(w.zero_begin, 0, w.zero_bytes, s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "nms: memset failed");
     const bool casc = w.L[1].nblk > 0;
     // level 0: the T best-scored boxes (all K without a cascade)
-    int rc = launch_level((const float4 *)boxes, cls, n_boxes_dev, w.T, thr, w.L[0], w.ctl, s);
+    // a single level on the dense resolver writes the outputs itself (the last resolver workgroup); otherwise nms_emit_kernel does
+    static const bool fold_ok = [] { const char *e = getenv("FRCNN_NMS_FOLD_EMIT"); return !e || atoi(e) != 0; }();
+    const bool fold_emit = fold_ok && !casc && w.L[0].nblk <= NMS_DENSE_MAX_BLOCKS;
+    const NmsEmitArgs no_emit = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const NmsEmitArgs ea = {(int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count, w.ctl + 4};
+    int rc = launch_level((const float4 *)boxes, cls, n_boxes_dev, w.T, thr, w.L[0], w.ctl, fold_emit ? ea : no_emit, s);
     if (rc) return rc;
+    if (fold_emit) return FRCNN_OK;
     if (casc) {
         const unsigned nrest = (unsigned)w.L[1].nblk;
         if (cls)
@@ -811,7 +906,7 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
                          w.L[0].kept, w.cbox, w.cidx, w.ccls, w.look, w.ctl);
         FRCNN_CHECK_LAUNCH("nms_filter_kernel");
         // level 1: the survivors among themselves (live count = ctl[2], written by the filter)
-        rc = launch_level(w.cbox, cls ? w.ccls : nullptr, w.ctl + 2, (int)(K - w.T), thr, w.L[1], w.ctl, s);
+        rc = launch_level(w.cbox, cls ? w.ccls : nullptr, w.ctl + 2, (int)(K - w.T), thr, w.L[1], w.ctl, no_emit, s);
         if (rc) return rc;
     }
     const int nb_tot = w.L[0].nblk + w.L[1].nblk;

@@ -19,8 +19,14 @@ if BENCH:                                  # real bench-frame boxes (tools/dev/d
     bb = np.load(BENCH)[int(os.environ.get("FRAME", "0"))]
     b = torch.from_numpy(bb).to(DEV); K = b.shape[0]
     s = torch.linspace(1, 0, K).to(DEV)
-for _ in range(20): keep = ops.nms(b, s, 0.7)
+POST = os.environ.get("POST_K")             # POST_K=2000: the proposal stage's call (boxes already sorted, outputs written by the NMS kernel itself)
+def run():
+    if POST:
+        k, r, c = ops.nms_sorted(b, 0.7, post_k=int(POST), want_rois=True)
+        return k[:int(c.item())] if False else k
+    return ops.nms(b, s, 0.7)
+for _ in range(20): keep = run()
 torch.cuda.synchronize(); _lib.prof_reset(); _lib.prof_enable(True)
-for _ in range(50): keep = ops.nms(b, s, 0.7)
+for _ in range(50): keep = run()
 torch.cuda.synchronize(); _lib.prof_enable(False)
 print(os.environ.get("FRCNN_HIP_LIB", "default"), "kept", int(keep.numel()), {k: round(ms / n * 1e3, 1) for k, (ms, n) in _lib.prof_report().items()})

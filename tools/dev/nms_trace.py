@@ -12,7 +12,7 @@ for _ in range(5): ops.nms_sorted(b, 0.7)
 torch.cuda.synchronize()
 L = _lib.lib
 L.frcnn_nms_trace_clear()
-keep, _, cnt = ops.nms_sorted(b, 0.7)
+keep, _, cnt = ops.nms_sorted(b, 0.7, post_k=int(os.environ['POST_K']) if 'POST_K' in os.environ else None, want_rois=True)
 torch.cuda.synchronize()
 buf = np.zeros((8192, 8), np.uint64)
 L.frcnn_nms_trace_read(buf.ctypes.data_as(C.c_void_p))
@@ -25,6 +25,8 @@ print("blk | entry row_ready first_fill decided | sweeps fills || tile row: firs
 for bl in list(range(0, nblk, max(1, nblk // 24))) + [nblk - 1]:
     r = res[bl]; t = tiles[bl]
     print("%3d | %6.2f %6.2f %6.2f %6.2f | %5d %4d || %6.2f %6.2f" % (bl, us(r[0]), us(r[1]), us(r[2]), us(r[3]), r[4], r[5], us(t[0]), us(t[1])))
+e = buf[8100].astype(np.int64)
+if e[0]: print("emit by the last workgroup: ticket %.2f | bitmap loaded + scanned %.2f, list built %.2f, outputs stored %.2f (us)" % (us(e[0]), us(e[1]), us(e[2]), us(e[3])))
 sw = np.zeros((4096, 16), np.uint64)
 L.frcnn_nms_sweep_read(sw.ctypes.data_as(C.c_void_p))
 for bl in (0, 7, 49, 105, 126, 187):
