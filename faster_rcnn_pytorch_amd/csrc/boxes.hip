@@ -4,6 +4,7 @@
 // (float4) coalesced loads and stores, nothing staged in LDS because nothing is reused.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "topk_dev.h"
 
 // ------------------------------------------------------------------------------------------
 // anchor of flat index i from the level table (anchor.py:34-55; models/new_model.py:46-47)
@@ -142,18 +143,12 @@ FRCNN_EXPORT int frcnn_pairwise_iou(const float *set1, int64_t n1, const float *
 // Algorithmic bytes per anchor: 16 (reg) + 8 (cls) [+16 anchors] in, 16 (box) + 4 (score) out.
 // The first lanes also clear the pipeline's control words (topk count, nms count) and the NMS stage's pull counters.
 // ------------------------------------------------------------------------------------------
+// SS = 512 / 2048: the last SS / 64 workgroups of the grid draw the top-k stage's splitters instead (topk_dev.h): the score of a
+// sampled anchor comes from the same per-anchor function, so it is bit-identical to the one the prologue workgroups store.
 template <bool HAS_ANCHORS>
-__global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__restrict__ reg, const float2 *__restrict__ cls,
-                                                                const float4 *__restrict__ anchors, AnchorDesc d, int64_t N,
-                                                                float min_size, float4 *__restrict__ out_boxes,
-                                                                float *__restrict__ out_scores, int32_t *__restrict__ ctrl_zero,
-                                                                int n_ctrl, int32_t *__restrict__ zero2, int n_zero2)
+__device__ __forceinline__ float prologue_one(const float4 *__restrict__ reg, const float2 *__restrict__ cls, const float4 *__restrict__ anchors,
+                                              const AnchorDesc &d, int64_t i, float min_size, float4 *box)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (ctrl_zero && i < n_ctrl) ctrl_zero[i] = 0;
-    if (zero2)                                                  // second region: the NMS stage's per-box pull counters + flags
-        for (int64_t j = i; j < n_zero2; j += (int64_t)gridDim.x * 256) zero2[j] = 0;
-    if (i >= N) return;
     const float4 t = reg[i];
     const float2 c = cls[i];
     const float4 an = HAS_ANCHORS ? anchors[i] : anchor_at(d, i);
@@ -165,23 +160,60 @@ __global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__
     const float e0 = det_expf(c.x - m), e1 = det_expf(c.y - m);
     float sc = e1 / (e0 + e1);
     if (!keep || !(sc >= 0.0f)) sc = -1.0f;
+    *box = b;
+    return sc;
+}
+template <bool HAS_ANCHORS, int SS>
+__global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__restrict__ reg, const float2 *__restrict__ cls,
+                                                                const float4 *__restrict__ anchors, AnchorDesc d, int64_t N,
+                                                                float min_size, float4 *__restrict__ out_boxes,
+                                                                float *__restrict__ out_scores, int32_t *__restrict__ ctrl_zero,
+                                                                int n_ctrl, int32_t *__restrict__ zero2, int n_zero2,
+                                                                SsCtl *__restrict__ ss_ctl, int ss_stride)
+{
+    if constexpr (SS > 0) {
+        const int n_pro = (int)gridDim.x - SS / 64;
+        if ((int)blockIdx.x >= n_pro) {
+            __shared__ uint4 s_k4[SS / 4];
+            __shared__ int s_part[4][64];
+            ss_sample_body<SS>([&](int i) { float4 b; return prologue_one<HAS_ANCHORS>(reg, cls, anchors, d, i, min_size, &b); }, (int)N, ss_stride, ss_ctl,
+                               (int)blockIdx.x - n_pro, s_k4, s_part);
+            return;
+        }
+    }
+    const int n_wg = (int)gridDim.x - SS / 64;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ctrl_zero && i < n_ctrl) ctrl_zero[i] = 0;
+    if (zero2)                                                  // second region: the NMS stage's per-box pull counters + flags
+        for (int64_t j = i; j < n_zero2; j += (int64_t)n_wg * 256) zero2[j] = 0;
+    if (i >= N) return;
+    float4 b;
+    const float sc = prologue_one<HAS_ANCHORS>(reg, cls, anchors, d, i, min_size, &b);
     out_boxes[i] = b;
     out_scores[i] = sc;
 }
 
 int frcnn_launch_prologue(const float *reg, const float *cls, const float *anchors, const AnchorDesc *d, int64_t N,
                           float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, int32_t *zero2, int n_zero2,
-                          hipStream_t s)
+                          void *sample_ctl, int64_t pre_k, hipStream_t s)
 {
-    const dim3 grid((unsigned)((N + 255) / 256)), block(256);
+    int S = 0, stride = 0;
+    if (sample_ctl) ss_plan(N, pre_k, &S, &stride);
+    const dim3 grid((unsigned)((N + 255) / 256) + (unsigned)(S / 64)), block(256);
+    AnchorDesc dummy = {};
+    const AnchorDesc &dd = anchors ? dummy : *d;
+    const float4 *an = (const float4 *)anchors;
+#define PRO_ARGS (const float4 *)reg, (const float2 *)cls, an, dd, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2, (SsCtl *)sample_ctl, stride
     if (anchors) {
-        AnchorDesc dummy = {};
-        FRCNN_LAUNCH(proposal_prologue_kernel<true>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
-                     (const float4 *)anchors, dummy, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
+        if (S == 0) FRCNN_LAUNCH((proposal_prologue_kernel<true, 0>), grid, block, 0, s, PRO_ARGS);
+        else if (S == 512) FRCNN_LAUNCH((proposal_prologue_kernel<true, 512>), grid, block, 0, s, PRO_ARGS);
+        else FRCNN_LAUNCH((proposal_prologue_kernel<true, 2048>), grid, block, 0, s, PRO_ARGS);
     } else {
-        FRCNN_LAUNCH(proposal_prologue_kernel<false>, grid, block, 0, s, (const float4 *)reg, (const float2 *)cls,
-                     (const float4 *)nullptr, *d, N, min_size, (float4 *)out_boxes, out_scores, ctrl_zero, n_ctrl, zero2, n_zero2);
+        if (S == 0) FRCNN_LAUNCH((proposal_prologue_kernel<false, 0>), grid, block, 0, s, PRO_ARGS);
+        else if (S == 512) FRCNN_LAUNCH((proposal_prologue_kernel<false, 512>), grid, block, 0, s, PRO_ARGS);
+        else FRCNN_LAUNCH((proposal_prologue_kernel<false, 2048>), grid, block, 0, s, PRO_ARGS);
     }
+#undef PRO_ARGS
     FRCNN_CHECK_LAUNCH("proposal_prologue_kernel");
     return FRCNN_OK;
 }
@@ -193,5 +225,5 @@ FRCNN_EXPORT int frcnn_proposal_prologue(const float *reg, const float *cls, con
     if (N == 0) return FRCNN_OK;
     FRCNN_REQUIRE(reg && cls && anchors && out_boxes && out_scores, "prologue: NULL pointer");
     FRCNN_REQUIRE(N < ((int64_t)1 << 31), "prologue: N too large");
-    return frcnn_launch_prologue(reg, cls, anchors, nullptr, N, min_size_norm, out_boxes, out_scores, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+    return frcnn_launch_prologue(reg, cls, anchors, nullptr, N, min_size_norm, out_boxes, out_scores, nullptr, 0, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }

@@ -17,15 +17,18 @@ struct AnchorDesc {
 int frcnn_fill_anchor_desc(AnchorDesc *d, int n_levels, const int *fh, const int *fw, const int *sh, const int *sw,
                            const float *base, int A, float div_w, float div_h, int64_t *n_total);
 
+// sample_ctl != nullptr: S / 64 extra workgroups of the same launch sample the top-k stage's splitters (topk_dev.h) for pre_k
 int frcnn_launch_prologue(const float *reg, const float *cls, const float *anchors, const AnchorDesc *d, int64_t N,
                           float min_size, float *out_boxes, float *out_scores, int32_t *ctrl_zero, int n_ctrl, int32_t *zero2, int n_zero2,
-                          hipStream_t s);
+                          void *sample_ctl, int64_t pre_k, hipStream_t s);
 
 // top-K: count must be zero before topk_scatter runs; zero_count = true lets the rank kernel clear it.
 size_t frcnn_ws_topk(int64_t N);
+// sampled: the splitters are already in the workspace's control block (frcnn_topk_sample_ctl(ws, N); nullptr below the sample sort's size)
+void *frcnn_topk_sample_ctl(void *ws, int64_t N);
 int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int64_t K, int proposal_mode,
                       int64_t *out_idx, float *out_scores, float *out_boxes, int32_t *out_count,
-                      void *ws, size_t ws_bytes, hipStream_t s);
+                      void *ws, size_t ws_bytes, bool sampled, hipStream_t s);
 
 size_t frcnn_ws_nms(int64_t K);
 // pre_zeroed: the caller has already cleared the region frcnn_nms_zero_region() describes (e.g. inside an earlier kernel of the

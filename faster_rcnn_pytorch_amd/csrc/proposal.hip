@@ -78,9 +78,10 @@ FRCNN_EXPORT int frcnn_region_proposal(const float *reg, const float *cls, const
     int32_t *nz_ptr = nullptr;
     int nz_n = 0;
     frcnn_nms_zero_region(w.nms_ws, K, &nz_ptr, &nz_n);            // cleared by the prologue kernel: no memset node in the pipeline
-    int rc = frcnn_launch_prologue(reg, cls, anchors, &d, N, min_size_norm, w.boxes, w.scores, w.ctrl, 8, nz_ptr, nz_n, s);
+    void *sample_ctl = frcnn_topk_sample_ctl(w.topk_ws, N);        // the sample sort's splitters are drawn inside the prologue launch
+    int rc = frcnn_launch_prologue(reg, cls, anchors, &d, N, min_size_norm, w.boxes, w.scores, w.ctrl, 8, nz_ptr, nz_n, sample_ctl, K, s);
     if (rc) return rc;
-    rc = frcnn_launch_topk(w.scores, w.boxes, N, K, 1, w.sidx, w.sscores, w.sboxes, w.ctrl, w.topk_ws, w.topk_bytes, s);
+    rc = frcnn_launch_topk(w.scores, w.boxes, N, K, 1, w.sidx, w.sscores, w.sboxes, w.ctrl, w.topk_ws, w.topk_bytes, sample_ctl != nullptr, s);
     if (rc) return rc;
     const int32_t *lvl = nullptr;
     if (nms_level_offsets_host) {                                  // optional per-level NMS (not the reference's behaviour)

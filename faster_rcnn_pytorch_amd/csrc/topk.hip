@@ -15,16 +15,11 @@
 // Work: N^2 pair compares -- used for N < 4096 only; larger N take the sample sort further down.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "topk_dev.h"
+#include <cstdlib>
 
 #define TOPK_ROWS 256
 #define TOPK_SEG 1024
-
-// order-preserving map float -> uint32 (total order; -0 < +0)
-__device__ __forceinline__ uint32_t f2key(float f)
-{
-    const uint32_t b = __float_as_uint(f);
-    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
 
 __global__ __launch_bounds__(TOPK_ROWS) void topk_rank_kernel(const float *__restrict__ scores, int N, int32_t *__restrict__ partial,
                                                               int32_t *__restrict__ count_zero)
@@ -121,65 +116,18 @@ __global__ __launch_bounds__(256) void topk_scatter_kernel(const float *__restri
 // Work N * (8 + N / 256) compares instead of N^2: the chip-wide rank sort above took 34 us + 11 us (scatter) at N = 20 646 and
 // the radix-select pre-filter of round 1 57 us + 6 us at N = 268 569 (four histogram / compaction launches before its rank sort).
 // ------------------------------------------------------------------------------------------------
-#define SS_BUCKETS 256
-#define SS_MIN_N 4096
 #define SS_PER_THREAD 4                                            // keys per thread of the placing kernel
 
 typedef unsigned long long u64;
-struct SsCtl { u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; };
 
-__device__ __forceinline__ u64 ss_key(float sc, int idx) { return ((u64)f2key(sc) << 32) | (u64)(uint32_t)(~idx); }
-
-// S evenly spaced samples, rank-sorted by S threads (32-bit keys; the sample position breaks ties exactly like the index would:
-// positions grow with the index).  Splitter q (1..255) = the sample of rank q * stride: stride 4 (S = 1024) / 2 (S = 512) covers the
-// whole distribution; a smaller stride concentrates the 255 splitters on the best-scored part when K << N (buckets past rank K are
-// never ranked), keeping the buckets that matter at ~N / S * stride keys.
+// the splitter sampling as a launch of its own (the generic top-k / argsort entry points; the proposal stage runs ss_sample_body
+// inside its prologue launch, see topk_dev.h and boxes.hip)
 template <int S>
 __global__ __launch_bounds__(256) void topk_sample_kernel(const float *__restrict__ scores, int N, int stride, SsCtl *__restrict__ ctl)
 {
-    // S / 64 workgroups; each ranks 64 samples against ALL S sample keys (staged in LDS), its four waves taking every fourth
-    // 64-key chunk.  (All samples in one workgroup: 9 us at S = 512, 21 us at S = 1024 -- one CU's VALU; one lone wave per 64
-    // samples: 9 / 15 us -- a lone wave issues one instruction every 4-8 cycles.)
     __shared__ uint4 s_k4[S / 4];
     __shared__ int s_part[4][64];
-    uint32_t *s_k = (uint32_t *)s_k4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rb = blockIdx.x;                                       // my 64 samples = chunk rb
-    const int t = rb * 64 + lane;
-    for (int tq = threadIdx.x; tq < S; tq += 256) s_k[tq] = f2key(scores[(int)(((long long)tq * N) / S)]);
-    const int idx = (int)(((long long)t * N) / S);
-    const float sc = scores[idx];
-    const uint32_t k = f2key(sc);
-    if (blockIdx.x == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->split[0] = ~0ull; } }
-    __syncthreads();
-    // rank among the samples, (key desc, position asc): whole 64-sample chunks before / after my own chunk need no tie-break
-    // (>= / >), only the own chunk evaluates it per lane (same scheme as topk_rank_kernel)
-    int rank = 0;
-    for (int c = wave; c < S / 64; c += 4) {
-        const uint4 *p = s_k4 + c * 16;
-        if (c < rb) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { const uint4 v = p[q]; rank += (v.x >= k) + (v.y >= k) + (v.z >= k) + (v.w >= k); }
-        } else if (c > rb) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) { const uint4 v = p[q]; rank += (v.x > k) + (v.y > k) + (v.z > k) + (v.w > k); }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const uint4 v = p[q];
-                rank += (v.x > k) || (v.x == k && 4 * q + 0 < lane);
-                rank += (v.y > k) || (v.y == k && 4 * q + 1 < lane);
-                rank += (v.z > k) || (v.z == k && 4 * q + 2 < lane);
-                rank += (v.w > k) || (v.w == k && 4 * q + 3 < lane);
-            }
-        }
-    }
-    s_part[wave][lane] = rank;
-    __syncthreads();
-    if (wave != 0) return;
-    rank = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
-    // bucket b holds the keys x with split[b] > x >= split[b + 1] (split[0] = +inf, split[256] = -inf): descending ranges
-    if (rank > 0 && rank % stride == 0 && rank / stride < SS_BUCKETS) ctl->split[rank / stride] = ss_key(sc, idx);
+    ss_sample_body<S>([&](int i) { return scores[i]; }, N, stride, ctl, (int)blockIdx.x, s_k4, s_part);
 }
 
 // number of splitters 1..255 that are > k  =  the bucket of k
@@ -263,6 +211,64 @@ __global__ __launch_bounds__(256) void topk_place_kernel(const float *__restrict
         if (bk[e] >= 0) sorted[s_base[bk[e]] + slot[e]] = k[e];
 }
 
+// topk_count_kernel + topk_place_kernel as ONE launch for grids that are certainly co-resident (<= SS_PART_MAX_WG workgroups of 256
+// threads and ~4 KB of LDS): every key's bucket is searched once, the block's histogram goes to the global counts, and a grid barrier
+// (arrival counter in the control block, zeroed by the sampling workgroup of the launch before; sc1 polls, bounded) separates that
+// from the scan + placement.  Between the phases a thread keeps its four keys, buckets and slots in registers.
+#define SS_PART_MAX_WG 1024
+#define SS_BARRIER_SPINS (1 << 22)
+__global__ __launch_bounds__(256) void topk_partition_kernel(const float *__restrict__ scores, int N, int proposal_mode, SsCtl *__restrict__ ctl,
+                                                             u64 *__restrict__ sorted)
+{
+    __shared__ u64 s_split[SS_BUCKETS];
+    __shared__ int s_base[SS_BUCKETS], s_cnt[SS_BUCKETS];
+    __shared__ int s_w[4];
+    __shared__ int s_valid;
+    s_split[threadIdx.x] = ctl->split[threadIdx.x];
+    s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    u64 k[SS_PER_THREAD];
+    int bk[SS_PER_THREAD], slot[SS_PER_THREAD];
+    int valid = 0;
+#pragma unroll
+    for (int e = 0; e < SS_PER_THREAD; ++e) {
+        const int i = (blockIdx.x * SS_PER_THREAD + e) * 256 + threadIdx.x;
+        bk[e] = -1;
+        if (i < N) {
+            const float sc = scores[i];
+            valid += (!proposal_mode || sc >= 0.0f) ? 1 : 0;
+            k[e] = ss_key(sc, i);
+            bk[e] = ss_bucket(s_split, k[e]);
+            slot[e] = atomicAdd(&s_cnt[bk[e]], 1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_xor(valid, o);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    const int c = s_cnt[threadIdx.x];
+    if (c) atomicAdd(&ctl->cnt[threadIdx.x], c);
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl->n_valid, s_valid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my adds have been performed before my workgroup arrives
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&ctl->pad[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&ctl->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < SS_BARRIER_SPINS)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    const int total = __hip_atomic_load(&ctl->cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_base[threadIdx.x] = ss_scan256(total, s_w);
+    __syncthreads();
+    if (c) s_base[threadIdx.x] += atomicAdd(&ctl->cursor[threadIdx.x], c);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < SS_PER_THREAD; ++e)
+        if (bk[e] >= 0) sorted[s_base[bk[e]] + slot[e]] = k[e];
+}
+
 __global__ __launch_bounds__(256) void topk_bucket_kernel(const float *__restrict__ scores, const float4 *__restrict__ boxes_in, int N, int K,
                                                           const SsCtl *__restrict__ ctl, const u64 *__restrict__ sorted,
                                                           int64_t *__restrict__ out_idx, float *__restrict__ out_scores,
@@ -330,9 +336,11 @@ size_t frcnn_ws_topk(int64_t N)
     return align_up((size_t)(nseg > 0 ? nseg : 1) * (size_t)N * sizeof(int32_t), 256);
 }
 
+void *frcnn_topk_sample_ctl(void *ws, int64_t N) { return N >= SS_MIN_N ? ws : nullptr; }
+
 int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int64_t K, int proposal_mode,
                       int64_t *out_idx, float *out_scores, float *out_boxes, int32_t *out_count,
-                      void *ws, size_t ws_bytes, hipStream_t s)
+                      void *ws, size_t ws_bytes, bool sampled, hipStream_t s)
 {
     if (ws_bytes < frcnn_ws_topk(N))
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "topk: workspace %zu < %zu bytes", ws_bytes, frcnn_ws_topk(N));
@@ -340,19 +348,23 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
         SsCtl *ctl = (SsCtl *)ws;
         u64 *sorted = (u64 *)((char *)ws + align_up(sizeof(SsCtl), 256));
         const int gb = (int)((N + 256 * SS_PER_THREAD - 1) / (256 * SS_PER_THREAD));
-        // 512 samples for the sizes of one feature map, 2048 above; the splitter stride covers ranks up to ~1.5 K (at least), the
-        // whole distribution at most
-        const int S = N < 65536 ? 512 : 2048;
-        const int full = S / SS_BUCKETS;                                        // stride that spreads 255 splitters over all S samples
-        int stride = (int)((3 * K * S + 2 * (SS_BUCKETS - 1) * N - 1) / (2 * (SS_BUCKETS - 1) * N));     // ceil(1.5 K S / (255 N))
-        stride = stride < 1 ? 1 : (stride > full ? full : stride);
-        if (S == 512) FRCNN_LAUNCH(topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
-        else FRCNN_LAUNCH(topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
-        FRCNN_CHECK_LAUNCH("topk_sample_kernel");
-        FRCNN_LAUNCH(topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);
-        FRCNN_CHECK_LAUNCH("topk_count_kernel");
-        FRCNN_LAUNCH(topk_place_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, ctl, sorted);
-        FRCNN_CHECK_LAUNCH("topk_place_kernel");
+        if (!sampled) {                                                         // (the proposal prologue has done it otherwise)
+            int S, stride;
+            ss_plan(N, K, &S, &stride);
+            if (S == 512) FRCNN_LAUNCH(topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+            else FRCNN_LAUNCH(topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+            FRCNN_CHECK_LAUNCH("topk_sample_kernel");
+        }
+        static const bool two_launches = [] { const char *e = getenv("FRCNN_TOPK_FUSED"); return e && atoi(e) == 0; }();
+        if (gb <= SS_PART_MAX_WG && !two_launches) {
+            FRCNN_LAUNCH(topk_partition_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl, sorted);
+            FRCNN_CHECK_LAUNCH("topk_partition_kernel");
+        } else {
+            FRCNN_LAUNCH(topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);
+            FRCNN_CHECK_LAUNCH("topk_count_kernel");
+            FRCNN_LAUNCH(topk_place_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, ctl, sorted);
+            FRCNN_CHECK_LAUNCH("topk_place_kernel");
+        }
         FRCNN_LAUNCH(topk_bucket_kernel, dim3(SS_BUCKETS, N < 65536 ? 4 : 8), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, ctl,
                      sorted, out_idx, out_scores, (float4 *)out_boxes, out_count);
         FRCNN_CHECK_LAUNCH("topk_bucket_kernel");
@@ -384,7 +396,7 @@ FRCNN_EXPORT int frcnn_topk_sorted(const float *scores, const float *boxes_in, i
     FRCNN_REQUIRE(scores && out_idx && out_scores && workspace, "topk: NULL pointer");
     FRCNN_REQUIRE((boxes_in == nullptr) == (out_boxes == nullptr), "topk: boxes_in and out_boxes must both be given or both NULL");
     FRCNN_REQUIRE(N <= (1 << 22), "topk: N=%lld above the rank-sort limit 4194304", (long long)N);
-    return frcnn_launch_topk(scores, boxes_in, N, K, 1, out_idx, out_scores, out_boxes, out_count, workspace, workspace_bytes, s);
+    return frcnn_launch_topk(scores, boxes_in, N, K, 1, out_idx, out_scores, out_boxes, out_count, workspace, workspace_bytes, false, s);
 }
 
 // generic variant used by the nms() op: every score is live (negative scores included)
@@ -400,5 +412,5 @@ FRCNN_EXPORT int frcnn_argsort_desc(const float *scores, const float *boxes_in, 
     FRCNN_REQUIRE(scores && out_idx && out_scores && workspace, "argsort: NULL pointer");
     FRCNN_REQUIRE((boxes_in == nullptr) == (out_boxes == nullptr), "argsort: boxes_in and out_boxes must both be given or both NULL");
     FRCNN_REQUIRE(N <= (1 << 22), "argsort: N too large");
-    return frcnn_launch_topk(scores, boxes_in, N, N, 0, out_idx, out_scores, out_boxes, out_count, workspace, workspace_bytes, s);
+    return frcnn_launch_topk(scores, boxes_in, N, N, 0, out_idx, out_scores, out_boxes, out_count, workspace, workspace_bytes, false, s);
 }
