@@ -107,8 +107,8 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "nms_kernel": 16 * K + 8 * K + 8 * 2 * nblk,                      # compulsory: boxes in, a word per box + the two bitmaps (negligible)
         "nms_filter_kernel": 16 * K + 16 * K,                             # boxes in, compacted survivors out
         "nms_emit_kernel": 8 * nblk + 16 * P + 8 * P + 16 * P,            # bitmap + kept boxes in, keep + rois out
-        "rpn_colmax_kernel": 16 * (N + G), "rpn_label_kernel": 16 * (N + G) + 24 * N, "rpn_match_kernel": 2 * 16 * (N + G) + 24 * N,
-        "rpn_sample_kernel": 9 * N,
+        "rpn_colmax_kernel": 16 * (N + G), "rpn_label_kernel": 16 * (N + G) + 24 * N, "rpn_match_kernel": 2 * 16 * (N + G) + 24 * N + 5 * N,   # + label byte and Philox key out
+        "rpn_sample_kernel": 9 * N, "rpn_apply_kernel": 5 * N + 8 * 256,       # label + key in, ~256 demotions out (sampler's second half, FPN size)
         "head_targets_kernel": 16 * (P + G) + 44 * R,
         "roi_pool_fwd_lds_kernel": feat_bytes + 16 * R + 6 * pooled,      # features + rois in, out (fp32) + argmax (16-bit, the autograd pair) out
         "roi_pool_bwd_lds_kernel": 6 * pooled + feat_bytes,               # grad_out + 16-bit argmax in, grad_feat out

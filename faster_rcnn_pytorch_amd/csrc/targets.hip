@@ -367,66 +367,222 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// rpn_match_kernel<SAMPLE>: RPNTargetMaker.forward in ONE launch (device-RNG mode).  1024 anchors per workgroup, all workgroups
-// co-resident (the launcher checks the count against the chip), three phases:
-//   (1) per-GT best anchor: wave shuffles -> LDS -> one atomicMax per workgroup and GT box (colkey, a 64-byte line per box);
+// rpn_match_kernel<INLINE>: RPNTargetMaker.forward (device-RNG mode).  1024 anchors per workgroup, all workgroups co-resident (the
+// launcher checks the count against the chip), three phases:
+//   (1) per-GT best anchor: wave shuffles -> LDS (all GT boxes of a 64-box round) -> one atomicMax per workgroup and GT box
+//       (colkey, a 64-byte line per box), issued by 64 threads at once: one memory round trip per round, not per box;
 //   (2) after a GRID BARRIER (an agent-scope arrival counter every workgroup bumps and then polls) every anchor takes its label
-//       from its own IoU row and the now final column maxima, encodes its regression target, counts positives / negatives;
-//   (3) SAMPLE (N <= 24 576): the workgroup that finishes phase 2 LAST (a second ticket, acq_rel) runs the sampler on the labels all
-//       workgroups have written -- round 2 had three launches here (rpn_colmax -> rpn_label -> rpn_sample), each at the ~5 us floor.
-// The control block {barrier, ticket, philox snapshot} and colkey live in a workspace that is ZERO before the first call; the last
-// workgroup leaves barrier, ticket and colkey zero for the next call (no memset node in the pipeline, HIP-graph friendly).
-// A wait that runs out of spins (a workgroup that was never scheduled: cannot happen while the grid fits the chip) raises counts[2].
+//       from its own IoU row and the now final column maxima, encodes its regression target, and -- the SAMPLER's first half --
+//       draws its Philox key, stores it and counts it into a 2048-bin histogram of the key's top 11 bits (LDS, then one global
+//       atomic per non-empty bin);
+//   (3) the subsampling (models/model.py:225-236: keep 128 positives / 256 - n_pos negatives at random = the candidates with the
+//       smallest keys, ties by anchor index).  The bin b* that holds the keep-th smallest key follows from the histogram; a
+//       candidate below b* stays, one above is demoted, and only the ~n / 2048 candidates INSIDE b* need an exact order: they go
+//       to a short list that one workgroup ranks.  INLINE (N <= 24 576): the workgroup that finishes phase 2 LAST (a ticket) does
+//       all of it -- one coalesced sweep over labels and keys.  Otherwise rpn_apply_kernel does the sweep chip-wide and its last
+//       workgroup ranks the list.  (Round 3a: the last workgroup compacted all ~15 000 candidates into LDS, drew their keys there
+//       and ran a four-pass radix select over them: 22 of the kernel's 42 us; FPN size took three histogram launches + an apply.)
+// The control block {barrier, tickets, philox snapshot}, colkey, the histogram and the list counters live in a workspace that is
+// ZERO before the first call; the last workgroup leaves them zero for the next call (no memset node in the pipeline, HIP-graph
+// friendly).  A wait that runs out of spins (a workgroup that was never scheduled: cannot happen while the grid fits the chip)
+// raises counts[2].
 // ------------------------------------------------------------------------------------------------
-struct RpnCtl { int32_t bar, ticket, n_pos, n_neg; unsigned long long snap[2]; };
+struct RpnCtl { int32_t bar, ticket, n_pos, n_neg; unsigned long long snap[2]; int32_t ticket2, pad[7]; };
+#ifdef RPN_TRACE                        // developer build: phase stamps of rpn_match_kernel (build_dbg/rpn_trace.py)
+__device__ unsigned long long g_rpn_trace[16];
+extern "C" __attribute__((visibility("default"))) void frcnn_rpn_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rpn_trace), sizeof(g_rpn_trace)); }
+#define RPN_T(cond, slot) do { if (cond) g_rpn_trace[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RPN_T(cond, slot) do {} while (0)
+#endif
 #define RPN_BAR_SPINS (1 << 22)
 #define RPN_MAX_G 4096
+#define RSB 2048                          // bins of the key histogram (top 11 bits)
+#define RPN_BL_CAP 4096                   // boundary-bin list capacity per class (expected length n / 2048)
+struct RpnSel2 { unsigned hist[2][RSB]; unsigned nb[2]; unsigned pad[14]; };          // [class 0 = neg, 1 = pos]; zero between calls
+struct RpnBList { unsigned long long e[2][RPN_BL_CAP]; };                             // (key << 32 | anchor index) of the boundary bin's candidates
 
-template <bool SAMPLE>
+// ascending search over the 2048-bin histogram: bin of the `want`-th smallest key (1-based), the count below it, the bin's size.
+// Any block size >= 256: threads 0 .. 255 own 8 bins each.  s_tmp: 8 ints.
+__device__ __forceinline__ void find_bin_2048(const unsigned *__restrict__ hist, int want, int *s_tmp, int *bin, int *below, int *inbin)
+{
+    const int t = threadIdx.x;
+    unsigned c[8];
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const int b = 8 * t + q; c[q] = b < RSB ? __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; local += (int)c[q]; }
+    const int lane = t & 63, wave = t >> 6;
+    int inc = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o);
+        if (lane >= o) inc += v;
+    }
+    __syncthreads();
+    if (lane == 63 && wave < 4) s_tmp[wave] = inc;
+    if (t == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; s_tmp[7] = 0; }
+    __syncthreads();
+    if (wave < 4) {
+        int base = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) if (w < wave) base += s_tmp[w];
+        const int excl = base + inc - local;
+        if (excl < want && want <= excl + local) {
+            int acc = excl, q = 0;
+            for (; q < 7; ++q) {
+                if (acc + (int)c[q] >= want) break;
+                acc += (int)c[q];
+            }
+            s_tmp[4] = 8 * t + q; s_tmp[5] = acc; s_tmp[7] = (int)c[q];
+        }
+    }
+    __syncthreads();
+    *bin = s_tmp[4]; *below = s_tmp[5]; *inbin = s_tmp[7];
+    __syncthreads();
+}
+
+struct RpnCut { bool drop; int bin, want; };      // class state: demote above `bin`, keep below, `want` of the candidates inside it stay
+__device__ __forceinline__ RpnCut rpn_cut(const RpnSel2 *sel, int n_pos, int n_neg, int c, int *s_tmp)
+{
+    RpnCut r;
+    r.drop = c == 1 ? (n_pos > 128) : (n_neg > 256 - n_pos);
+    const int keep = c == 1 ? 128 : 256 - min(n_pos, 128);
+    int below = 0, inbin = 0;
+    r.bin = 0;
+    if (r.drop) find_bin_2048(sel->hist[c], keep, s_tmp, &r.bin, &below, &inbin);       // (uniform: n_pos / n_neg are the same in every thread)
+    r.want = keep - below;
+    return r;
+}
+// the sweep over anchors [i0, i1) (step = block size): demote above the cut, list the candidates inside the boundary bin
+template <int U>
+__device__ __forceinline__ void rpn_apply_sweep(int i0, int i1, const int8_t *__restrict__ label8, const unsigned *__restrict__ keys, RpnCut cn, RpnCut cp,
+                                                RpnSel2 *__restrict__ sel, RpnBList *__restrict__ bl, int64_t *__restrict__ out_cls)
+{
+    // U anchors per thread and round, labels and keys loaded unconditionally (clamped) so that the 2 U loads overlap: with the loads
+    // under the label test the single-workgroup sweep of config V paid one round trip per anchor and thread (17 us)
+    const int bs = (int)blockDim.x;
+    for (int base = i0; base < i1; base += U * bs) {
+        int lab[U];
+        unsigned k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(base + u * bs + (int)threadIdx.x, i1 - 1);
+            lab[u] = label8[i];
+            k[u] = keys[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * bs + (int)threadIdx.x;
+            if (i >= i1 || lab[u] < 0) continue;
+            const RpnCut &c = lab[u] == 1 ? cp : cn;
+            if (!c.drop) continue;
+            const int bin = (int)(k[u] >> 21);
+            if (bin > c.bin) out_cls[i] = -1;
+            else if (bin == c.bin) {
+                const unsigned slot = atomicAdd(&sel->nb[lab[u]], 1u);
+                if (slot < RPN_BL_CAP) bl->e[lab[u]][slot] = ((unsigned long long)k[u] << 32) | (unsigned)i;
+            }
+        }
+    }
+}
+// one workgroup, after every sweep has finished: the boundary bin's candidates in (key, anchor index) order -- the first `want` stay;
+// then the sampler's zero-between-calls state goes back to zero.  s_e: RPN_BL_CAP u64 of LDS.
+__device__ __forceinline__ void rpn_apply_resolve(RpnCut cn, RpnCut cp, RpnSel2 *__restrict__ sel, const RpnBList *__restrict__ bl, int64_t *__restrict__ out_cls,
+                                                  int32_t *__restrict__ counts, unsigned long long *s_e)
+{
+    for (int c = 0; c < 2; ++c) {
+        const RpnCut &ct = c == 1 ? cp : cn;
+        if (!ct.drop) continue;                                      // uniform
+        const int m_raw = (int)__hip_atomic_load(&sel->nb[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int m = min(m_raw, RPN_BL_CAP);
+        if (m_raw > RPN_BL_CAP && threadIdx.x == 0) counts[2] = 8;   // cannot happen below ~8 M anchors (the entry point's limit)
+        __syncthreads();
+        for (int q = threadIdx.x; q < m; q += blockDim.x) s_e[q] = __hip_atomic_load(&bl->e[c][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        for (int q = threadIdx.x; q < m; q += blockDim.x) {
+            const unsigned long long me = s_e[q];
+            int rank = 0;
+            for (int o = 0; o < m; ++o) rank += s_e[o] < me;         // broadcast reads; the pairs are distinct (the index is part of them)
+            if (rank >= ct.want) out_cls[(int)(unsigned)me] = -1;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2 * RSB; b += blockDim.x) (&sel->hist[0][0])[b] = 0u;
+    if (threadIdx.x < 2) sel->nb[threadIdx.x] = 0u;
+}
+
+// wave-wide maximum of a float on DPP row shifts / broadcasts (no LDS crossbar): every lane of the wave must be active
+__device__ __forceinline__ float wave_max_f32_dpp(float v)
+{
+    const float ninf = -__builtin_inff();
+#define DPP_MAX(ctrl, rmask)                                                                                                       \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ninf), __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false)))
+    DPP_MAX(0x111, 0xf);    // row_shr:1
+    DPP_MAX(0x112, 0xf);    // row_shr:2
+    DPP_MAX(0x114, 0xf);    // row_shr:4
+    DPP_MAX(0x118, 0xf);    // row_shr:8   -> lane 15 of every row holds the row's maximum
+    DPP_MAX(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+    DPP_MAX(0x143, 0xc);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+#undef DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+template <bool INLINE>
 __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const float4 *__restrict__ anchors, int N, const float4 *__restrict__ gt, int G,
-                                                         unsigned long long *__restrict__ colkey, RpnCtl *__restrict__ ctl,
+                                                         unsigned long long *__restrict__ colkey, RpnCtl *__restrict__ ctl, RpnSel2 *__restrict__ sel,
+                                                         RpnBList *__restrict__ bl,
                                                          unsigned long long seed, unsigned long long offset, unsigned long long *__restrict__ philox_state,
                                                          int64_t *__restrict__ out_cls, float4 *__restrict__ out_reg, int8_t *__restrict__ label8,
-                                                         int32_t *__restrict__ list, unsigned *__restrict__ keys, int32_t *__restrict__ counts)
+                                                         unsigned *__restrict__ keys, int32_t *__restrict__ counts)
 {
-    __shared__ unsigned long long s_k[16];
+    __shared__ unsigned long long s_big[INLINE ? RPN_BL_CAP : 16 * 64];   // phase 1: per-wave maxima of a round of GT boxes; INLINE: later the boundary list
+    unsigned long long (*s_k)[64] = (unsigned long long (*)[64])s_big;
+    __shared__ unsigned s_hist[2][RSB];
     __shared__ int s_cnt2[2][16];
+    __shared__ int s_tmp[8];
     __shared__ int s_flag;
-    __shared__ typename std::conditional<SAMPLE, RpnSampleLds, int>::type Ls_store;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * 1024 + tid;
     const int nb = (int)gridDim.x;
+    RPN_T(blockIdx.x == 0 && tid == 0, 0);
     if (philox_state && blockIdx.x == 0 && tid == 0) {              // this call's (seed, offset); the stream moves on (frcnn_hip.h)
         const unsigned long long sd = philox_state[0], of = philox_state[1];
-        ctl->snap[0] = sd; ctl->snap[1] = of;
+        __hip_atomic_store(&ctl->snap[0], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->snap[1], of, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         philox_state[1] = of + 1ull;
     }
+    for (int b = tid; b < 2 * RSB; b += 1024) (&s_hist[0][0])[b] = 0u;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     bool live = false;
     if (i < N) { a = anchors[i]; live = variant == 1 || anchor_inside(a); }
-    // ---- (1) column maxima
+    // ---- (1) column maxima, 64 GT boxes per round
     const bool any_live = __syncthreads_or(live) != 0;
     if (any_live) {
-        for (int g = 0; g < G; ++g) {
-            unsigned long long key = 0ull;
-            if (live) {
-                const float v = iou_variant(variant, a, gt[g]);
-                if (v >= 0.0f) key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);   // NaN never wins
+        for (int g0 = 0; g0 < G; g0 += 64) {
+            const int gn = min(64, G - g0);
+            for (int g = 0; g < gn; ++g) {
+                // the wave's best (IoU, lowest anchor index): maximum IoU over the lanes, then the first lane that holds it (lanes
+                // are anchors in ascending order) -- 7 DPP steps and a ballot instead of twelve ds_bpermute for the 64-bit key
+                float v = -1.0f;
+                if (live) { const float t = iou_variant(variant, a, gt[g0 + g]); if (t >= 0.0f) v = t; }   // NaN never wins
+                const float m = wave_max_f32_dpp(v);
+                const unsigned long long who = __ballot(v == m);
+                if (lane == 0)
+                    s_k[wave][g] = m >= 0.0f ? ((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)(i + __builtin_ctzll(who))) : 0ull;
             }
-            key = wave_max_u64(key);
-            if (lane == 0) s_k[wave] = key;
             __syncthreads();
-            if (tid == 0) {
-                unsigned long long m = s_k[0];
+            if (tid < gn) {
+                unsigned long long m = s_k[0][tid];
 #pragma unroll
-                for (int q = 1; q < 16; ++q) m = s_k[q] > m ? s_k[q] : m;
-                if (m != 0ull && m > __hip_atomic_load(&colkey[(size_t)g * CK_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    atomicMax(&colkey[(size_t)g * CK_STRIDE], m);
+                for (int q = 1; q < 16; ++q) m = s_k[q][tid] > m ? s_k[q][tid] : m;
+                unsigned long long *ck = &colkey[(size_t)(g0 + tid) * CK_STRIDE];
+                if (m != 0ull && m > __hip_atomic_load(ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ck, m);
             }
             __syncthreads();
         }
     }
     // ---- grid barrier
+    RPN_T(blockIdx.x == 0 && tid == 0, 1);
     if (tid == 0) {
         __hip_atomic_fetch_add(&ctl->bar, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0, ok = 1;
@@ -439,7 +595,12 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
     }
     __syncthreads();
     if (!s_flag) { if (tid == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 4; counts[3] = 0; } return; }   // (control words stay dirty; the caller sees the error flag)
-    // ---- (2) labels
+    // ---- (2) labels, keys, key histogram
+    RPN_T(blockIdx.x == 0 && tid == 0, 2);
+    if (philox_state) {
+        seed = __hip_atomic_load(&ctl->snap[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        offset = __hip_atomic_load(&ctl->snap[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     int lab = -1;
     if (i < N) {
         float4 reg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -462,6 +623,11 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
         out_cls[i] = lab;
         out_reg[i] = reg;
         label8[i] = (int8_t)lab;
+        if (lab >= 0) {
+            const unsigned k = philox_first(seed, offset, (unsigned)lab, (unsigned)i);
+            keys[i] = k;
+            atomicAdd(&s_hist[lab][k >> 21], 1u);
+        }
     }
     const unsigned long long bp = __ballot(lab == 1), bn = __ballot(lab == 0);
     if (lane == 0) { s_cnt2[0][wave] = __builtin_popcountll(bp); s_cnt2[1][wave] = __builtin_popcountll(bn); }
@@ -472,24 +638,61 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
         for (int q = 0; q < 16; ++q) c += s_cnt2[tid][q];
         if (c) atomicAdd(tid == 0 ? &ctl->n_pos : &ctl->n_neg, c);  // (summed in the zero-kept control block: no ordering against a clearing store)
     }
-    // ---- (3) the last workgroup hands out the counts, resets the control words and (SAMPLE) draws the samples
+    for (int b = tid; b < 2 * RSB; b += 1024) {
+        const unsigned v = (&s_hist[0][0])[b];
+        if (v) atomicAdd(&(&sel->hist[0][0])[b], v);
+    }
+    // ---- (3) the last workgroup hands out the counts, resets the control words and (INLINE) finishes the sampling
+    RPN_T(blockIdx.x == 0 && tid == 0, 3);
     __syncthreads();
     if (tid == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
     __syncthreads();
     if (!s_flag) return;
+    RPN_T(tid == 0, 4);
     for (int g = tid; g < G; g += 1024) colkey[(size_t)g * CK_STRIDE] = 0ull;
+    const int n_pos = __hip_atomic_load(&ctl->n_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n_neg = __hip_atomic_load(&ctl->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (tid == 0) {
-        counts[0] = __hip_atomic_load(&ctl->n_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        counts[1] = __hip_atomic_load(&ctl->n_neg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        counts[2] = 0; counts[3] = 0;
+        counts[0] = n_pos; counts[1] = n_neg; counts[2] = 0; counts[3] = 0;
         __hip_atomic_store(&ctl->n_pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->n_neg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ctl->bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();                                                // the sampler reads counts[0..1]
-    if constexpr (SAMPLE) {
-        if (philox_state) { seed = ctl->snap[0]; offset = ctl->snap[1]; }
-        rpn_sample_body(*(RpnSampleLds *)&Ls_store, N, label8, out_cls, nullptr, 0, nullptr, 0, seed, offset, list, keys, counts);
+    RPN_T(tid == 0, 5);
+    if constexpr (INLINE) {
+        const RpnCut cn = rpn_cut(sel, n_pos, n_neg, 0, s_tmp), cp = rpn_cut(sel, n_pos, n_neg, 1, s_tmp);
+        if (cn.drop || cp.drop) rpn_apply_sweep<RS_LDS_MAX / 1024>(0, N, label8, keys, cn, cp, sel, bl, out_cls);   // one round: N <= RS_LDS_MAX
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the list's entries and counters are in memory before anybody reads them back
+        __syncthreads();
+        rpn_apply_resolve(cn, cp, sel, bl, out_cls, counts, s_big);
     }
+    RPN_T(tid == 0, 6);
+}
+
+// the sampler's second half for FPN-sized N: the sweep chip-wide, the list by the workgroup that finishes last
+__global__ __launch_bounds__(1024) void rpn_apply_kernel(int N, const int8_t *__restrict__ label8, const unsigned *__restrict__ keys, RpnCtl *__restrict__ ctl,
+                                                         RpnSel2 *__restrict__ sel, RpnBList *__restrict__ bl, int64_t *__restrict__ out_cls,
+                                                         int32_t *__restrict__ counts)
+{
+    __shared__ unsigned long long s_e[RPN_BL_CAP];
+    __shared__ int s_tmp[8];
+    __shared__ int s_flag;
+    const int n_pos = counts[0], n_neg = counts[1];
+    const RpnCut cn = rpn_cut(sel, n_pos, n_neg, 0, s_tmp), cp = rpn_cut(sel, n_pos, n_neg, 1, s_tmp);
+    if (!cn.drop && !cp.drop) {                                      // nothing to sample: the histogram still has to go back to zero
+        if (blockIdx.x == 0) rpn_apply_resolve(cn, cp, sel, bl, out_cls, counts, s_e);
+        return;
+    }
+    const int per = (N + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = (int)blockIdx.x * per;
+    rpn_apply_sweep<2>(i0, min(N, i0 + per), label8, keys, cn, cp, sel, bl, out_cls);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_flag) return;
+    if (threadIdx.x == 0) __hip_atomic_store(&ctl->ticket2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    rpn_apply_resolve(cn, cp, sel, bl, out_cls, counts, s_e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,7 +701,6 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
 // bits of the Philox key, both classes in the same pass) and an apply pass that demotes every candidate whose key is
 // above the exact threshold.  Each launch re-derives the digit chosen so far from the previous level's histogram.
 // ------------------------------------------------------------------------------------------------
-#define RSB 2048
 struct RpnSelCtl { unsigned hist[2][3][RSB]; };          // [class 0 = neg, 1 = pos][level][bin]
 
 // ascending search over a 2048-bin histogram: bin of the `want`-th smallest key (1-based) and the count below it
@@ -773,7 +975,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-struct RpnWs { unsigned long long *colkey, *colkey2, *snap; RpnCtl *ctl; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
+struct RpnWs { unsigned long long *colkey, *colkey2, *snap; RpnCtl *ctl; RpnSel2 *sel2; RpnBList *bl; int8_t *label8; int32_t *list; unsigned *keys; RpnSelCtl *sel; size_t total; };
 static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
 {
     RpnWs w; char *p = (char *)ws; size_t o = 0;
@@ -783,6 +985,8 @@ static RpnWs carve_rpn(void *ws, int64_t N, int64_t G)
     w.ctl = (RpnCtl *)take(sizeof(RpnCtl));
     w.snap = (unsigned long long *)take(16);
     w.colkey = (unsigned long long *)take((size_t)RPN_MAX_G * 8 * 8);
+    w.sel2 = (RpnSel2 *)take(sizeof(RpnSel2));                      // the fused sampler's key histogram + list counters: zero between calls
+    w.bl = (RpnBList *)take(sizeof(RpnBList));
     w.colkey2 = (unsigned long long *)take((size_t)G * 8 * 8);      // the staged (three-launch) path's own maxima: cleared per call, so that
                                                                     // the fused kernel's colkey keeps its "zero between calls" invariant
     w.label8 = (int8_t *)take((size_t)N);
@@ -818,29 +1022,23 @@ FRCNN_EXPORT int frcnn_rpn_targets(int variant, const float *anchors, int64_t N,
     static const bool no_fuse = [] { const char *e = getenv("FRCNN_RPN_FUSED"); return e && !strcmp(e, "0"); }();
     const int64_t nb1024 = (N + 1023) / 1024;
     if (!perm_pos && !perm_neg && !no_fuse && !force_block) {
-        // device-RNG mode: ONE launch for column maxima, labels and (N <= 24 576) sampling; every workgroup must be resident for the
-        // in-kernel barrier: one 1024-thread workgroup per CU with the sampler's 112 KB of LDS, two without
-        const bool sample = N <= RS_LDS_MAX;
-        if (nb1024 <= (sample ? n_cus : 2 * n_cus)) {
-            if (sample)
+        // device-RNG mode: ONE launch for column maxima, labels and (N <= 24 576) sampling, two above; every workgroup must be
+        // resident for the in-kernel barrier: two 1024-thread workgroups per CU (at most 57 KB of LDS each)
+        const bool inl = N <= RS_LDS_MAX;                               // the last workgroup finishes the sampling itself
+        if (nb1024 <= 2 * n_cus) {
+            if (inl)
                 FRCNN_LAUNCH(rpn_match_kernel<true>, dim3((unsigned)nb1024), dim3(1024), 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
-                             w.colkey, w.ctl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
-                             (float4 *)out_reg, w.label8, w.list, w.keys, out_counts);
+                             w.colkey, w.ctl, w.sel2, w.bl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
+                             (float4 *)out_reg, w.label8, w.keys, out_counts);
             else
                 FRCNN_LAUNCH(rpn_match_kernel<false>, dim3((unsigned)nb1024), dim3(1024), 0, s, variant, (const float4 *)anchors, (int)N, (const float4 *)gt, (int)G,
-                             w.colkey, w.ctl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
-                             (float4 *)out_reg, w.label8, w.list, w.keys, out_counts);
+                             w.colkey, w.ctl, w.sel2, w.bl, (unsigned long long)seed, (unsigned long long)offset, (unsigned long long *)philox_state_dev, out_cls,
+                             (float4 *)out_reg, w.label8, w.keys, out_counts);
             FRCNN_CHECK_LAUNCH("rpn_match_kernel");
-            if (sample) return FRCNN_OK;
-            // chip-wide radix sampler for FPN-sized N (the snapshot of the device RNG stream sits in the control block)
-            const unsigned long long *snapf = philox_state_dev ? w.ctl->snap : nullptr;
-            if (hipMemsetAsync(w.sel, 0, sizeof(RpnSelCtl), s) != hipSuccess) return frcnn_set_error(FRCNN_ERR_LAUNCH, "rpn_targets: memset failed");
-            const int gbf = (int)((N + 2047) / 2048) < 1024 ? (int)((N + 2047) / 2048) : 1024;
-            FRCNN_LAUNCH(rpn_samp_hist_kernel<0>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
-            FRCNN_LAUNCH(rpn_samp_hist_kernel<1>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
-            FRCNN_LAUNCH(rpn_samp_hist_kernel<2>, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts);
-            FRCNN_LAUNCH(rpn_samp_apply_kernel, dim3(gbf), dim3(256), 0, s, w.label8, (int)N, (unsigned long long)seed, (unsigned long long)offset, snapf, w.sel, out_counts, out_cls);
-            FRCNN_CHECK_LAUNCH("rpn_samp kernels");
+            if (inl) return FRCNN_OK;
+            const int ga = (int)(nb1024 < n_cus ? nb1024 : n_cus);
+            FRCNN_LAUNCH(rpn_apply_kernel, dim3((unsigned)ga), dim3(1024), 0, s, (int)N, w.label8, w.keys, w.ctl, w.sel2, w.bl, out_cls, out_counts);
+            FRCNN_CHECK_LAUNCH("rpn_apply_kernel");
             return FRCNN_OK;
         }
     }
