@@ -557,7 +557,7 @@ __device__ __forceinline__ void nms_resolve_block_dense(int b, int n, int nblk, 
 // dependency chain starts from.  As two launches the stage cost sup + resolve = 42 + 60 us on the bench frame; fused, the resolver's
 // chain runs underneath the relation kernel and only the last rows' two or three round trips stick out.
 // ------------------------------------------------------------------------------------------------
-template <bool CLS>
+template <bool CLS, bool DENSE>
 __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ boxes, const int32_t *__restrict__ cls, const int32_t *__restrict__ n_dev,
                                                   int K, float thr, int nblk, int nzw, int n_res, u64 *__restrict__ sup, u64 *__restrict__ nz,
                                                   u64 *__restrict__ kept, u64 *__restrict__ rem, int32_t *__restrict__ done,
@@ -567,10 +567,10 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
     constexpr size_t LDS_BYTES = sizeof(NmsResLds) > sizeof(TileLds) ? sizeof(NmsResLds) : sizeof(TileLds);
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_BYTES];
     const int n = n_dev ? min(max(*n_dev, 0), K) : K;
-    const bool dense = nblk <= NMS_DENSE_MAX_BLOCKS;
+    constexpr bool dense = DENSE;                                   // host's choice (nms_use_dense); two instantiations: the generic form does not carry the dense resolver's registers
     if ((int)blockIdx.x < n_res) {
         if (n == 0 && ea.out_count && blockIdx.x == 0 && threadIdx.x == 0) *ea.out_count = 0;   // no live block takes a ticket
-        if (dense) nms_resolve_block_dense((int)blockIdx.x, n, nblk, sup, kept, rem, done, abort_flag, (NmsResLds *)s_raw, boxes, ea);
+        if constexpr (dense) nms_resolve_block_dense((int)blockIdx.x, n, nblk, sup, kept, rem, done, abort_flag, (NmsResLds *)s_raw, boxes, ea);
         else nms_resolve_wave((int)blockIdx.x, n, K, nblk, nzw, sup, nz, kept, rem, done, abort_flag);
         return;
     }
@@ -788,6 +788,13 @@ struct NmsWs {
     float4 *cbox; int32_t *cidx, *ccls, *look, *ctl;
     char *zero_begin; size_t zero_bytes, total;
 };
+// dense per-tile relation + block resolver (nms_resolve_block_dense) or the generic per-box layout: FRCNN_NMS_DENSE_MIN = smallest block
+// count that takes the dense form (measured below)
+static bool nms_use_dense(int nblk)
+{
+    static const int lo = [] { const char *e = getenv("FRCNN_NMS_DENSE_MIN"); return e ? atoi(e) : 0; }();
+    return nblk <= NMS_DENSE_MAX_BLOCKS && nblk >= lo;
+}
 static bool nms_use_cascade(int64_t K)
 {
     static const int mode = [] { const char *e = getenv("FRCNN_NMS_CASCADE"); return e ? atoi(e) : 1; }();
@@ -856,14 +863,18 @@ static int launch_level(const float4 *boxes, const int32_t *cls, const int32_t *
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         return cus * 4;
     }();
+    const bool dense = nms_use_dense(nblk);
+#define NMS_LAUNCH_ARGS boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem, L.done, abort_flag, ea
     auto launch = [&](unsigned grid, int n_res_arg) {
-        if (cls)
-            FRCNN_LAUNCH(nms_kernel<true>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
-                         L.done, abort_flag, ea);
-        else
-            FRCNN_LAUNCH(nms_kernel<false>, dim3(grid), dim3(256), 0, s, boxes, cls, n_dev, Kl, thr, nblk, L.nzw, n_res_arg, L.sup, L.nz, L.kept, L.rem,
-                         L.done, abort_flag, ea);
+        if (cls) {
+            if (dense) FRCNN_LAUNCH((nms_kernel<true, true>), dim3(grid), dim3(256), 0, s, NMS_LAUNCH_ARGS);
+            else FRCNN_LAUNCH((nms_kernel<true, false>), dim3(grid), dim3(256), 0, s, NMS_LAUNCH_ARGS);
+        } else {
+            if (dense) FRCNN_LAUNCH((nms_kernel<false, true>), dim3(grid), dim3(256), 0, s, NMS_LAUNCH_ARGS);
+            else FRCNN_LAUNCH((nms_kernel<false, false>), dim3(grid), dim3(256), 0, s, NMS_LAUNCH_ARGS);
+        }
     };
+#undef NMS_LAUNCH_ARGS
 #ifdef NMS_TILES_ONLY                  // developer timing build: the relation alone (results are meaningless)
     if (true) { launch(n_tile_wg, 0); } else
 #endif
@@ -890,7 +901,7 @@ int frcnn_launch_nms(const float *boxes, const int32_t *cls, const int32_t *n_bo
     // level 0: the T best-scored boxes (all K without a cascade)
     // a single level on the dense resolver writes the outputs itself (the last resolver workgroup); otherwise nms_emit_kernel does
     static const bool fold_ok = [] { const char *e = getenv("FRCNN_NMS_FOLD_EMIT"); return !e || atoi(e) != 0; }();
-    const bool fold_emit = fold_ok && !casc && w.L[0].nblk <= NMS_DENSE_MAX_BLOCKS;
+    const bool fold_emit = fold_ok && !casc && nms_use_dense(w.L[0].nblk);
     const NmsEmitArgs no_emit = {0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const NmsEmitArgs ea = {(int)post_k, out_keep, (float4 *)out_rois, src_map, out_src, out_count, w.ctl + 4};
     int rc = launch_level((const float4 *)boxes, cls, n_boxes_dev, w.T, thr, w.L[0], w.ctl, fold_emit ? ea : no_emit, s);
