@@ -469,6 +469,12 @@ def main():
             rec["eager_submission"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"], "step_ms": eager["step_ms"]}
             also.append(rec)
             release()
+        # the headline configuration under bf16 autocast (NOT the headline: the reference trains in fp32): what the matrix cores
+        # give the VGG16 backbone, with the same fp32 box path
+        rec = run_config(args, "vgg", "bf16", args.also_steps, 5, False, rank, world, device, with_cpu=False)
+        rec["config"]["note"] = "short eager run inside the headline command: %d timed steps, 5 warm-up; bf16 autocast of the torch layers" % args.also_steps
+        also.append(rec)
+        release()
         out["also"] = also
     if rank == 0:
         print(json.dumps(out), flush=True)
