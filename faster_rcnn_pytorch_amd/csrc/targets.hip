@@ -387,7 +387,25 @@ __global__ __launch_bounds__(1024) void rpn_sample_kernel(int N, int8_t *__restr
 // friendly).  A wait that runs out of spins (a workgroup that was never scheduled: cannot happen while the grid fits the chip)
 // raises counts[2].
 // ------------------------------------------------------------------------------------------------
-struct RpnCtl { int32_t bar, ticket, n_pos, n_neg; unsigned long long snap[2]; int32_t ticket2, pad[7]; };
+// Arrival counters are two-level (eight per-residue counters on their own 64-byte lines, then one top counter): 263 workgroups
+// bumping and polling ONE word took 13 us of the FPN-size launch (the polls queue behind the read-modify-writes of the same line).
+struct RpnArrive { int32_t sub[8][16]; int32_t top[16]; };
+struct RpnCtl { int32_t n_pos, n_neg, ticket2, pad0; unsigned long long snap[2]; int32_t pad1[8]; int32_t flag[16]; RpnArrive bar, ticket; };
+// true in exactly one caller: the last of `nb` workgroups to arrive (one thread per workgroup calls it)
+__device__ __forceinline__ bool rpn_arrive_last(RpnArrive *a, int nb)
+{
+    if (nb <= 32) return __hip_atomic_fetch_add(&a->top[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;   // few arrivals: one level, one round trip
+    const int x = (int)blockIdx.x & 7;
+    const int n_x = (nb - x + 7) / 8;                              // workgroups with my residue
+    if (__hip_atomic_fetch_add(&a->sub[x][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n_x - 1) return false;
+    return __hip_atomic_fetch_add(&a->top[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8 - 1;
+}
+// threads 0 .. 8 of one workgroup put the counters back to zero (after everybody has arrived)
+__device__ __forceinline__ void rpn_arrive_reset(RpnArrive *a, int t)
+{
+    if (t < 8) __hip_atomic_store(&a->sub[t][0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (t == 8) __hip_atomic_store(&a->top[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 #ifdef RPN_TRACE                        // developer build: phase stamps of rpn_match_kernel (build_dbg/rpn_trace.py)
 __device__ unsigned long long g_rpn_trace[16];
 extern "C" __attribute__((visibility("default"))) void frcnn_rpn_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rpn_trace), sizeof(g_rpn_trace)); }
@@ -454,7 +472,7 @@ __device__ __forceinline__ RpnCut rpn_cut(const RpnSel2 *sel, int n_pos, int n_n
     return r;
 }
 // the sweep over anchors [i0, i1) (step = block size): demote above the cut, list the candidates inside the boundary bin
-template <int U>
+template <int U, bool SAME_LAUNCH>
 __device__ __forceinline__ void rpn_apply_sweep(int i0, int i1, const int8_t *__restrict__ label8, const unsigned *__restrict__ keys, RpnCut cn, RpnCut cp,
                                                 RpnSel2 *__restrict__ sel, RpnBList *__restrict__ bl, int64_t *__restrict__ out_cls)
 {
@@ -467,8 +485,10 @@ __device__ __forceinline__ void rpn_apply_sweep(int i0, int i1, const int8_t *__
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = min(base + u * bs + (int)threadIdx.x, i1 - 1);
-            lab[u] = label8[i];
-            k[u] = keys[i];
+            if (SAME_LAUNCH) {                                   // written by other workgroups of this launch: agent-scope loads
+                lab[u] = __hip_atomic_load(&label8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k[u] = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else { lab[u] = label8[i]; k[u] = keys[i]; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -577,20 +597,23 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
                 for (int q = 1; q < 16; ++q) m = s_k[q][tid] > m ? s_k[q][tid] : m;
                 unsigned long long *ck = &colkey[(size_t)(g0 + tid) * CK_STRIDE];
                 if (m != 0ull && m > __hip_atomic_load(ck, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ck, m);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before my workgroup arrives at the barrier
             }
             __syncthreads();
         }
     }
     // ---- grid barrier
     RPN_T(blockIdx.x == 0 && tid == 0, 1);
+    // (everything the other side of the barrier reads -- colkey, the Philox snapshot -- was written with agent-scope atomics that have
+    // been performed, and is read with agent-scope loads: no cache write-back / invalidate needed)
     if (tid == 0) {
-        __hip_atomic_fetch_add(&ctl->bar, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rpn_arrive_last(&ctl->bar, nb)) __hip_atomic_store(&ctl->flag[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0, ok = 1;
-        while (__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nb) {
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&ctl->flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
             if (++spins > RPN_BAR_SPINS) { ok = 0; break; }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_flag = ok;
     }
     __syncthreads();
@@ -620,12 +643,14 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
             if (best >= 0.7f) lab = 1;
             reg = encode4(xy_to_cxcy4(gt[arg]), xy_to_cxcy4(a));
         }
-        out_cls[i] = lab;
+        // what the sampling workgroup reads back (or overwrites) in the SAME launch goes out write-through: with an acknowledged store
+        // behind every ticket no L2 write-back / invalidate pair is needed around it (that pair cost ~3 us of the INLINE launch)
+        __hip_atomic_store(&out_cls[i], (int64_t)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         out_reg[i] = reg;
-        label8[i] = (int8_t)lab;
+        __hip_atomic_store(&label8[i], (int8_t)lab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lab >= 0) {
             const unsigned k = philox_first(seed, offset, (unsigned)lab, (unsigned)i);
-            keys[i] = k;
+            __hip_atomic_store(&keys[i], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             atomicAdd(&s_hist[lab][k >> 21], 1u);
         }
     }
@@ -638,6 +663,7 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
         for (int q = 0; q < 16; ++q) c += s_cnt2[tid][q];
         if (c) atomicAdd(tid == 0 ? &ctl->n_pos : &ctl->n_neg, c);  // (summed in the zero-kept control block: no ordering against a clearing store)
     }
+    RPN_T(blockIdx.x == 0 && tid == 0, 7);
     for (int b = tid; b < 2 * RSB; b += 1024) {
         const unsigned v = (&s_hist[0][0])[b];
         if (v) atomicAdd(&(&sel->hist[0][0])[b], v);
@@ -645,7 +671,10 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
     // ---- (3) the last workgroup hands out the counts, resets the control words and (INLINE) finishes the sampling
     RPN_T(blockIdx.x == 0 && tid == 0, 3);
     __syncthreads();
-    if (tid == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+    // (labels, keys, classes, counters: all written through and acknowledged before the ticket)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_flag = rpn_arrive_last(&ctl->ticket, nb);
     __syncthreads();
     if (!s_flag) return;
     RPN_T(tid == 0, 4);
@@ -656,12 +685,14 @@ __global__ __launch_bounds__(1024) void rpn_match_kernel(int variant, const floa
     if (tid == 0) {
         counts[0] = n_pos; counts[1] = n_neg; counts[2] = 0; counts[3] = 0;
         __hip_atomic_store(&ctl->n_pos, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->n_neg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&ctl->bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(&ctl->ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->flag[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (tid >= 64 && tid < 64 + 9) rpn_arrive_reset(&ctl->bar, tid - 64);
+    if (tid >= 128 && tid < 128 + 9) rpn_arrive_reset(&ctl->ticket, tid - 128);
     RPN_T(tid == 0, 5);
     if constexpr (INLINE) {
         const RpnCut cn = rpn_cut(sel, n_pos, n_neg, 0, s_tmp), cp = rpn_cut(sel, n_pos, n_neg, 1, s_tmp);
-        if (cn.drop || cp.drop) rpn_apply_sweep<RS_LDS_MAX / 1024>(0, N, label8, keys, cn, cp, sel, bl, out_cls);   // one round: N <= RS_LDS_MAX
+        if (cn.drop || cp.drop) rpn_apply_sweep<RS_LDS_MAX / 1024, true>(0, N, label8, keys, cn, cp, sel, bl, out_cls);   // one round: N <= RS_LDS_MAX
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the list's entries and counters are in memory before anybody reads them back
         __syncthreads();
         rpn_apply_resolve(cn, cp, sel, bl, out_cls, counts, s_big);
@@ -685,7 +716,7 @@ __global__ __launch_bounds__(1024) void rpn_apply_kernel(int N, const int8_t *__
     }
     const int per = (N + (int)gridDim.x - 1) / (int)gridDim.x;
     const int i0 = (int)blockIdx.x * per;
-    rpn_apply_sweep<2>(i0, min(N, i0 + per), label8, keys, cn, cp, sel, bl, out_cls);
+    rpn_apply_sweep<2, false>(i0, min(N, i0 + per), label8, keys, cn, cp, sel, bl, out_cls);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
