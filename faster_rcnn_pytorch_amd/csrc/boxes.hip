@@ -143,7 +143,7 @@ FRCNN_EXPORT int frcnn_pairwise_iou(const float *set1, int64_t n1, const float *
 // Algorithmic bytes per anchor: 16 (reg) + 8 (cls) [+16 anchors] in, 16 (box) + 4 (score) out.
 // The first lanes also clear the pipeline's control words (topk count, nms count) and the NMS stage's pull counters.
 // ------------------------------------------------------------------------------------------
-// SS = 512 / 2048: the last SS / 64 workgroups of the grid draw the top-k stage's splitters instead (topk_dev.h): the score of a
+// SS = 512 / SS_LARGE: the first SS / 64 workgroups of the grid draw the top-k stage's splitters instead (topk_dev.h): the score of a
 // sampled anchor comes from the same per-anchor function, so it is bit-identical to the one the prologue workgroups store.
 template <bool HAS_ANCHORS>
 __device__ __forceinline__ float prologue_one(const float4 *__restrict__ reg, const float2 *__restrict__ cls, const float4 *__restrict__ anchors,
@@ -171,18 +171,19 @@ __global__ __launch_bounds__(256) void proposal_prologue_kernel(const float4 *__
                                                                 int n_ctrl, int32_t *__restrict__ zero2, int n_zero2,
                                                                 SsCtl *__restrict__ ss_ctl, int ss_stride)
 {
+    // the sampling workgroups come FIRST in the grid: they are the longest (S decodes + S x 64 compares each) and would otherwise start
+    // after every prologue workgroup has been dispatched -- the launch's tail (21 us at FPN size with them last)
     if constexpr (SS > 0) {
-        const int n_pro = (int)gridDim.x - SS / 64;
-        if ((int)blockIdx.x >= n_pro) {
+        if ((int)blockIdx.x < SS / 64) {
             __shared__ uint4 s_k4[SS / 4];
             __shared__ int s_part[4][64];
             ss_sample_body<SS>([&](int i) { float4 b; return prologue_one<HAS_ANCHORS>(reg, cls, anchors, d, i, min_size, &b); }, (int)N, ss_stride, ss_ctl,
-                               (int)blockIdx.x - n_pro, s_k4, s_part);
+                               (int)blockIdx.x, s_k4, s_part);
             return;
         }
     }
     const int n_wg = (int)gridDim.x - SS / 64;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = (int64_t)((int)blockIdx.x - SS / 64) * 256 + threadIdx.x;
     if (ctrl_zero && i < n_ctrl) ctrl_zero[i] = 0;
     if (zero2)                                                  // second region: the NMS stage's per-box pull counters + flags
         for (int64_t j = i; j < n_zero2; j += (int64_t)n_wg * 256) zero2[j] = 0;
@@ -207,11 +208,11 @@ int frcnn_launch_prologue(const float *reg, const float *cls, const float *ancho
     if (anchors) {
         if (S == 0) FRCNN_LAUNCH((proposal_prologue_kernel<true, 0>), grid, block, 0, s, PRO_ARGS);
         else if (S == 512) FRCNN_LAUNCH((proposal_prologue_kernel<true, 512>), grid, block, 0, s, PRO_ARGS);
-        else FRCNN_LAUNCH((proposal_prologue_kernel<true, 2048>), grid, block, 0, s, PRO_ARGS);
+        else FRCNN_LAUNCH((proposal_prologue_kernel<true, SS_LARGE>), grid, block, 0, s, PRO_ARGS);
     } else {
         if (S == 0) FRCNN_LAUNCH((proposal_prologue_kernel<false, 0>), grid, block, 0, s, PRO_ARGS);
         else if (S == 512) FRCNN_LAUNCH((proposal_prologue_kernel<false, 512>), grid, block, 0, s, PRO_ARGS);
-        else FRCNN_LAUNCH((proposal_prologue_kernel<false, 2048>), grid, block, 0, s, PRO_ARGS);
+        else FRCNN_LAUNCH((proposal_prologue_kernel<false, SS_LARGE>), grid, block, 0, s, PRO_ARGS);
     }
 #undef PRO_ARGS
     FRCNN_CHECK_LAUNCH("proposal_prologue_kernel");

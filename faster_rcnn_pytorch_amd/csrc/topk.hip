@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void topk_place_kernel(const float *__restrict
 
 // topk_count_kernel + topk_place_kernel as ONE launch for grids that are certainly co-resident (<= SS_PART_MAX_WG workgroups of 256
 // threads and ~4 KB of LDS): every key's bucket is searched once, the block's histogram goes to the global counts, and a grid barrier
-// (arrival counter in the control block, zeroed by the sampling workgroup of the launch before; sc1 polls, bounded) separates that
+// (two-level arrival counters and a polled flag in the control block, zeroed by the sampling workgroup of the launch before; bounded) separates that
 // from the scan + placement.  Between the phases a thread keeps its four keys, buckets and slots in registers.
 #define SS_PART_MAX_WG 1024
 #define SS_BARRIER_SPINS (1 << 22)
@@ -253,10 +253,15 @@ __global__ __launch_bounds__(256) void topk_partition_kernel(const float *__rest
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my adds have been performed before my workgroup arrives
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&ctl->pad[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7;
+        bool last;
+        if (nb <= 32) last = __hip_atomic_fetch_add(&ctl->bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+        else last = __hip_atomic_fetch_add(&ctl->bar[x][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (nb - x + 7) / 8 - 1 &&
+                    __hip_atomic_fetch_add(&ctl->bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8 - 1;
+        if (last) __hip_atomic_store(&ctl->flag[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
-        while (__hip_atomic_load(&ctl->pad[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x && ++spins < SS_BARRIER_SPINS)
-            __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(&ctl->flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < SS_BARRIER_SPINS)
+            __builtin_amdgcn_s_sleep(4);
     }
     __syncthreads();
     const int total = __hip_atomic_load(&ctl->cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,7 +357,7 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
             int S, stride;
             ss_plan(N, K, &S, &stride);
             if (S == 512) FRCNN_LAUNCH(topk_sample_kernel<512>, dim3(512 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
-            else FRCNN_LAUNCH(topk_sample_kernel<2048>, dim3(2048 / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
+            else FRCNN_LAUNCH(topk_sample_kernel<SS_LARGE>, dim3(SS_LARGE / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
             FRCNN_CHECK_LAUNCH("topk_sample_kernel");
         }
         static const bool two_launches = [] { const char *e = getenv("FRCNN_TOPK_FUSED"); return e && atoi(e) == 0; }();

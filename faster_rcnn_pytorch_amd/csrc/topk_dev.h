@@ -6,9 +6,14 @@
 
 #define SS_BUCKETS 256
 #define SS_MIN_N 4096
+#ifndef SS_LARGE
+#define SS_LARGE 2048                   // samples for N >= 65536 (1024: the fused prologue launch 23 -> 16 us, but twice the bucket size: topk_bucket 17 -> 35 us)
+#endif
 
 typedef unsigned long long ss_u64;
-struct SsCtl { ss_u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; };
+// bar: the partition launch's grid barrier -- eight per-residue arrival counters and a top counter on their own 64-byte lines, and the
+// flag the waiters poll (hundreds of workgroups bumping AND polling one word queue behind each other: 13 us in the RPN target maker)
+struct SsCtl { ss_u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; int bar[9][16]; int flag[16]; };
 
 // order-preserving map float -> uint32 (total order; -0 < +0)
 __device__ __forceinline__ uint32_t f2key(float f)
@@ -18,11 +23,11 @@ __device__ __forceinline__ uint32_t f2key(float f)
 }
 __device__ __forceinline__ ss_u64 ss_key(float sc, int idx) { return ((ss_u64)f2key(sc) << 32) | (ss_u64)(uint32_t)(~idx); }
 
-// samples per sort and splitter stride: 512 samples for the sizes of one feature map, 2048 above; the stride covers ranks up to
+// samples per sort and splitter stride: 512 samples for the sizes of one feature map, SS_LARGE above; the stride covers ranks up to
 // ~1.5 K (at least), the whole distribution at most
 static inline void ss_plan(int64_t N, int64_t K, int *S_out, int *stride_out)
 {
-    const int S = N < 65536 ? 512 : 2048;
+    const int S = N < 65536 ? 512 : SS_LARGE;
     const int full = S / SS_BUCKETS;                                        // stride that spreads 255 splitters over all S samples
     int stride = (int)((3 * K * S + 2 * (SS_BUCKETS - 1) * N - 1) / (2 * (SS_BUCKETS - 1) * N));     // ceil(1.5 K S / (255 N))
     *S_out = S;
@@ -44,7 +49,7 @@ __device__ __forceinline__ void ss_sample_body(F score_at, int N, int stride, Ss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = rb * 64 + lane;
     for (int tq = threadIdx.x; tq < S; tq += 256) s_k[tq] = f2key(score_at((int)(((long long)tq * N) / S)));
-    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->pad[0] = 0; ctl->split[0] = ~0ull; } }
+    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->flag[0] = 0; ctl->split[0] = ~0ull; } if (threadIdx.x < 9) ctl->bar[threadIdx.x][0] = 0; }
     __syncthreads();
     const int idx = (int)(((long long)t * N) / S);
     const uint32_t k = s_k[t];
