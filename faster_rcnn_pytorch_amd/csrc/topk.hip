@@ -217,13 +217,40 @@ __global__ __launch_bounds__(256) void topk_place_kernel(const float *__restrict
 // from the scan + placement.  Between the phases a thread keeps its four keys, buckets and slots in registers.
 #define SS_PART_MAX_WG 1024
 #define SS_BARRIER_SPINS (1 << 22)
-__global__ __launch_bounds__(256) void topk_partition_kernel(const float *__restrict__ scores, int N, int proposal_mode, SsCtl *__restrict__ ctl,
-                                                             u64 *__restrict__ sorted)
+// grid barrier of the partition launch: two-level arrival counters, the waiters poll the flag of generation `gen` (1, 2)
+__device__ __forceinline__ void ss_grid_barrier(SsCtl *__restrict__ ctl, int gen)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // what I wrote through / added has been performed before my workgroup arrives
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7;
+        int (*bar)[16] = ctl->bar + 9 * (gen - 1);
+        bool last;
+        if (nb <= 32) last = __hip_atomic_fetch_add(&bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
+        else last = __hip_atomic_fetch_add(&bar[x][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (nb - x + 7) / 8 - 1 &&
+                    __hip_atomic_fetch_add(&bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8 - 1;
+        if (last) __hip_atomic_store(&ctl->flag[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&ctl->flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen && ++spins < SS_BARRIER_SPINS)
+            __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+}
+
+// BUCKETS = true: the ranking of the buckets (topk_bucket_kernel's job) follows behind a second barrier in the same launch: bucket
+// b, b + grid, ... by workgroup b while the bucket's first rank is below the output count.  The placed keys are written through
+// and read back with agent-scope loads.
+template <bool BUCKETS>
+__global__ __launch_bounds__(256) void topk_partition_kernel(const float *__restrict__ scores, const float4 *__restrict__ boxes_in, int N, int K,
+                                                             int proposal_mode, SsCtl *__restrict__ ctl, u64 *__restrict__ sorted,
+                                                             int64_t *__restrict__ out_idx, float *__restrict__ out_scores,
+                                                             float4 *__restrict__ out_boxes, int32_t *__restrict__ out_count)
 {
     __shared__ u64 s_split[SS_BUCKETS];
     __shared__ int s_base[SS_BUCKETS], s_cnt[SS_BUCKETS];
     __shared__ int s_w[4];
     __shared__ int s_valid;
+    __shared__ u64 s_k[BUCKETS ? 1024 : 1];
     s_split[threadIdx.x] = ctl->split[threadIdx.x];
     s_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_valid = 0;
@@ -250,28 +277,76 @@ __global__ __launch_bounds__(256) void topk_partition_kernel(const float *__rest
     const int c = s_cnt[threadIdx.x];
     if (c) atomicAdd(&ctl->cnt[threadIdx.x], c);
     if (threadIdx.x == 0 && s_valid) atomicAdd(&ctl->n_valid, s_valid);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my adds have been performed before my workgroup arrives
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7;
-        bool last;
-        if (nb <= 32) last = __hip_atomic_fetch_add(&ctl->bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1;
-        else last = __hip_atomic_fetch_add(&ctl->bar[x][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (nb - x + 7) / 8 - 1 &&
-                    __hip_atomic_fetch_add(&ctl->bar[8][0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 8 - 1;
-        if (last) __hip_atomic_store(&ctl->flag[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while (__hip_atomic_load(&ctl->flag[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && ++spins < SS_BARRIER_SPINS)
-            __builtin_amdgcn_s_sleep(4);
-    }
-    __syncthreads();
+    ss_grid_barrier(ctl, 1);
     const int total = __hip_atomic_load(&ctl->cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_base[threadIdx.x] = ss_scan256(total, s_w);
+    const int excl = ss_scan256(total, s_w);
+    s_base[threadIdx.x] = excl;
     __syncthreads();
     if (c) s_base[threadIdx.x] += atomicAdd(&ctl->cursor[threadIdx.x], c);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < SS_PER_THREAD; ++e)
-        if (bk[e] >= 0) sorted[s_base[bk[e]] + slot[e]] = k[e];
+        if (bk[e] >= 0) {
+            if (BUCKETS) __hip_atomic_store(&sorted[s_base[bk[e]] + slot[e]], k[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else sorted[s_base[bk[e]] + slot[e]] = k[e];
+        }
+    if constexpr (BUCKETS) {
+        ss_grid_barrier(ctl, 2);
+        s_base[threadIdx.x] = excl;                                 // the buckets' first ranks
+        s_cnt[threadIdx.x] = total;
+        const int n_valid = __hip_atomic_load(&ctl->n_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int n_out = n_valid < K ? n_valid : K;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n_out;
+        __syncthreads();
+        // work item = (bucket, part): the bucket's rows are split over `parts` workgroups, every one of which stages the whole bucket in
+        // LDS (one agent-scope load per key: the rows come out of LDS too)
+        const int parts = N < 65536 ? 2 : 8;
+        for (int it = (int)blockIdx.x; it < SS_BUCKETS * parts; it += (int)gridDim.x) {
+            const int bkt = it / parts, part = it - bkt * parts;
+            const int base = s_base[bkt], m = s_cnt[bkt];
+            if (base >= n_out) break;                               // the buckets are in rank order
+            if (m == 0) continue;
+            const u64 *seg = sorted + base;
+            const int per = (m + parts - 1) / parts;
+            const int e0 = part * per, e1 = min(m, e0 + per);
+            auto emit = [&](u64 kk, int r) {
+                const int rank = base + r;
+                if (rank < n_out) {
+                    const int idx = (int)(~(uint32_t)kk);
+                    out_idx[rank] = idx;
+                    out_scores[rank] = scores[idx];
+                    if (out_boxes) out_boxes[rank] = boxes_in[idx];
+                }
+            };
+            if (m <= 1024) {
+                __syncthreads();
+                for (int t = threadIdx.x; t < m; t += 256) s_k[t] = __hip_atomic_load(&seg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+                    const u64 kk = s_k[e];
+                    int r = 0;
+#pragma unroll 8
+                    for (int j = 0; j < m; ++j) r += s_k[j] > kk;   // broadcast ds_read_b64
+                    emit(kk, r);
+                }
+                continue;
+            }
+            for (int r0 = e0; r0 < e1; r0 += 256) {                 // an unlucky sample: row groups x 1024-key chunks
+                const int e = r0 + threadIdx.x;
+                const u64 kk = e < e1 ? __hip_atomic_load(&seg[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                int r = 0;
+                for (int c0 = 0; c0 < m; c0 += 1024) {
+                    const int cn = min(1024, m - c0);
+                    __syncthreads();
+                    for (int t = threadIdx.x; t < cn; t += 256) s_k[t] = __hip_atomic_load(&seg[c0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+#pragma unroll 8
+                    for (int j = 0; j < cn; ++j) r += s_k[j] > kk;
+                }
+                if (e < e1) emit(kk, r);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void topk_bucket_kernel(const float *__restrict__ scores, const float4 *__restrict__ boxes_in, int N, int K,
@@ -360,9 +435,22 @@ int frcnn_launch_topk(const float *scores, const float *boxes_in, int64_t N, int
             else FRCNN_LAUNCH(topk_sample_kernel<SS_LARGE>, dim3(SS_LARGE / 64), dim3(256), 0, s, scores, (int)N, stride, ctl);
             FRCNN_CHECK_LAUNCH("topk_sample_kernel");
         }
-        static const bool two_launches = [] { const char *e = getenv("FRCNN_TOPK_FUSED"); return e && atoi(e) == 0; }();
-        if (gb <= SS_PART_MAX_WG && !two_launches) {
-            FRCNN_LAUNCH(topk_partition_kernel, dim3(gb), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl, sorted);
+        // FRCNN_TOPK_FUSED: 2 = count + place + bucket ranking as ONE launch (two grid barriers), 1 = count + place fused and the ranking
+        // as its own launch, 0 = three launches.  The fused forms need every workgroup resident: <= SS_PART_MAX_WG workgroups.
+        // Default by size: the one-launch form wins at FPN size (31.6 against 17.0 + 17.5 us, HIP events in the training step) and loses
+        // at 600 x 1000 (22.2 against 8.8 + 7.7 us: ten dependent round trips and two barriers for ~20 000 keys).
+        static const int fuse_env = [] { const char *e = getenv("FRCNN_TOPK_FUSED"); return e ? atoi(e) : -1; }();
+        const int fuse = fuse_env >= 0 ? fuse_env : (N >= 65536 ? 2 : 1);
+        if (gb <= SS_PART_MAX_WG && fuse >= 2) {
+            const int grid = gb < 256 ? 256 : gb;                               // enough workgroups for the ranking phase (one or two work items each)
+            FRCNN_LAUNCH((topk_partition_kernel<true>), dim3(grid), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, proposal_mode, ctl, sorted,
+                         out_idx, out_scores, (float4 *)out_boxes, out_count);
+            FRCNN_CHECK_LAUNCH("topk_partition_kernel");
+            return FRCNN_OK;
+        }
+        if (gb <= SS_PART_MAX_WG && fuse == 1) {
+            FRCNN_LAUNCH((topk_partition_kernel<false>), dim3(gb), dim3(256), 0, s, scores, (const float4 *)boxes_in, (int)N, (int)K, proposal_mode, ctl, sorted,
+                         out_idx, out_scores, (float4 *)out_boxes, out_count);
             FRCNN_CHECK_LAUNCH("topk_partition_kernel");
         } else {
             FRCNN_LAUNCH(topk_count_kernel, dim3(gb < 1024 ? gb : 1024), dim3(256), 0, s, scores, (int)N, proposal_mode, ctl);

@@ -13,7 +13,7 @@
 typedef unsigned long long ss_u64;
 // bar: the partition launch's grid barrier -- eight per-residue arrival counters and a top counter on their own 64-byte lines, and the
 // flag the waiters poll (hundreds of workgroups bumping AND polling one word queue behind each other: 13 us in the RPN target maker)
-struct SsCtl { ss_u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; int bar[9][16]; int flag[16]; };
+struct SsCtl { ss_u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; int bar[18][16]; int flag[16]; };
 
 // order-preserving map float -> uint32 (total order; -0 < +0)
 __device__ __forceinline__ uint32_t f2key(float f)
@@ -49,7 +49,7 @@ __device__ __forceinline__ void ss_sample_body(F score_at, int N, int stride, Ss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = rb * 64 + lane;
     for (int tq = threadIdx.x; tq < S; tq += 256) s_k[tq] = f2key(score_at((int)(((long long)tq * N) / S)));
-    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->flag[0] = 0; ctl->split[0] = ~0ull; } if (threadIdx.x < 9) ctl->bar[threadIdx.x][0] = 0; }
+    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->flag[0] = 0; ctl->split[0] = ~0ull; } if (threadIdx.x < 18) ctl->bar[threadIdx.x][0] = 0; }
     __syncthreads();
     const int idx = (int)(((long long)t * N) / S);
     const uint32_t k = s_k[t];
