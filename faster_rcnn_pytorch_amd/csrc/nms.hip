@@ -406,7 +406,8 @@ __device__ __forceinline__ void nms_resolve_block_dense(int b, int n, int nblk, 
             __builtin_amdgcn_s_sleep(2);
             if (++spins > NMS_ROW_WAIT_SPINS) { if (lane == 0) atomicOr(abort_flag, 1); break; }   // the sweep loop sees the flag and ends
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (no acquire fence: every word read below was written through and is read with an agent-scope load; the fence's cache
+        // invalidate would also throw out the box lines the tile waves of this XCD keep re-reading)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         act = __ballot(mine && f == 2);
         fd = __hip_atomic_load(&fl[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

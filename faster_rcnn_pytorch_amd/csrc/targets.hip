@@ -500,7 +500,7 @@ __device__ __forceinline__ void rpn_apply_sweep(int i0, int i1, const int8_t *__
             if (bin > c.bin) out_cls[i] = -1;
             else if (bin == c.bin) {
                 const unsigned slot = atomicAdd(&sel->nb[lab[u]], 1u);
-                if (slot < RPN_BL_CAP) bl->e[lab[u]][slot] = ((unsigned long long)k[u] << 32) | (unsigned)i;
+                if (slot < RPN_BL_CAP) __hip_atomic_store(&bl->e[lab[u]][slot], ((unsigned long long)k[u] << 32) | (unsigned)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(1024) void rpn_apply_kernel(int N, const int8_t *__
     rpn_apply_sweep<2, false>(i0, min(N, i0 + per), label8, keys, cn, cp, sel, bl, out_cls);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    if (threadIdx.x == 0) s_flag = __hip_atomic_fetch_add(&ctl->ticket2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;   // (list entries and counters are written through and acknowledged)
     __syncthreads();
     if (!s_flag) return;
     if (threadIdx.x == 0) __hip_atomic_store(&ctl->ticket2, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
