@@ -422,13 +422,18 @@ struct RpnBList { unsigned long long e[2][RPN_BL_CAP]; };                       
 
 // ascending search over the 2048-bin histogram: bin of the `want`-th smallest key (1-based), the count below it, the bin's size.
 // Any block size >= 256: threads 0 .. 255 own 8 bins each.  s_tmp: 8 ints.
-__device__ __forceinline__ void find_bin_2048(const unsigned *__restrict__ hist, int want, int *s_tmp, int *bin, int *below, int *inbin)
+template <bool GLOBAL = true>
+__device__ __forceinline__ void find_bin_2048(const unsigned *hist, int want, int *s_tmp, int *bin, int *below, int *inbin)
 {
     const int t = threadIdx.x;
     unsigned c[8];
     int local = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { const int b = 8 * t + q; c[q] = b < RSB ? __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; local += (int)c[q]; }
+    for (int q = 0; q < 8; ++q) {
+        const int b = 8 * t + q;
+        c[q] = b < RSB ? (GLOBAL ? __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : hist[b]) : 0u;     // (!GLOBAL: a histogram in LDS)
+        local += (int)c[q];
+    }
     const int lane = t & 63, wave = t >> 6;
     int inc = local;
 #pragma unroll
@@ -878,7 +883,8 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     __shared__ __attribute__((aligned(16))) unsigned long long s_pk[HT_ROWS_MAX];   // (philox key << 16 | list position) of the survivors, dense
     __shared__ unsigned s_hist[16 * 256];
     __shared__ unsigned s_pref[4];
-    __shared__ int s_nsel;
+    __shared__ int s_nsel, s_nb;
+    __shared__ int s_tmp8[8];
     const int tid = threadIdx.x;
     // A negative device count is the upstream proposal stage reporting an aborted NMS scan (nms.hip): it must not silently
     // become "no proposals" (the step would train on the ground-truth boxes alone).  It is carried into counts[3] / the sticky
@@ -888,15 +894,26 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
     const int n_rois = min(max(n_rois_raw, 0), P_cap);
     const int n = n_rois + G;
 
+    RPN_T(tid == 0, 8);
     for (int j = tid; j < total; j += 1024) s_row[j] = -1;
     if (tid == 0) s_err = 0;
     // phase 1+2: IoU max/argmax and ordered compaction, 1024 candidates per round
     int npc = 0, nnc = 0;
-    for (int k0 = 0; k0 < n; k0 += 1024) {
+    // the candidates' boxes of all (<= 4) rounds are loaded up front: one round trip instead of one per round
+    float4 cand[HT_MAX / 1024];
+#pragma unroll
+    for (int r = 0; r < HT_MAX / 1024; ++r) {
+        const int k = min(r * 1024 + tid, max(n - 1, 0));
+        cand[r] = k < n_rois ? rois[k] : gt[k - n_rois];
+    }
+#pragma unroll
+    for (int r = 0; r < HT_MAX / 1024; ++r) {
+        const int k0 = r * 1024;
+        if (k0 >= n) break;                                         // uniform
         const int k = k0 + tid;
         int flag = -1;
         if (k < n) {
-            const float4 b = k < n_rois ? rois[k] : gt[k - n_rois];
+            const float4 b = cand[r];
             float best = -__builtin_inff();
             int arg = 0;
             for (int g = 0; g < G; ++g) {
@@ -908,14 +925,15 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
             else if (best < 0.5f && best >= 0.0f) flag = 0;
             s_flag[k] = (signed char)flag;
         }
-        int tp, tn;
-        const int bp = block_excl_scan_1024(flag == 1, s_w, &tp);
-        if (flag == 1) s_list[0][npc + bp] = (unsigned short)k;
-        const int bn = block_excl_scan_1024(flag == 0, s_w, &tn);
-        if (flag == 0) s_list[1][nnc + bn] = (unsigned short)k;
-        npc += tp; nnc += tn;
+        // ONE scan for both lists: positives counted in the low half-word, negatives in the high one (n <= 4096)
+        int tot;
+        const int pre = block_excl_scan_1024((flag == 1 ? 1 : 0) | (flag == 0 ? 0x10000 : 0), s_w, &tot);
+        if (flag == 1) s_list[0][npc + (pre & 0xFFFF)] = (unsigned short)k;
+        if (flag == 0) s_list[1][nnc + (pre >> 16)] = (unsigned short)k;
+        npc += tot & 0xFFFF; nnc += tot >> 16;
     }
     __syncthreads();
+    RPN_T(tid == 0, 9);
     const int n_pos = min(npc, max_pos);
     const int n_neg = min(total - n_pos, nnc);
     const bool host_mode = (perm_pos != nullptr) || (perm_neg != nullptr);
@@ -941,23 +959,59 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
             for (int q = tid; q < m; q += 1024) s_key[q] = philox_first(seed, offset, 2u + (unsigned)which, (unsigned)s_list[which][q]);
             if (tid == 0) s_nsel = 0;
             __syncthreads();
-            unsigned T = 0xFFFFFFFFu; int rem = 0, n_eq = 0;
-            if (quota < m) block_radix_select(m, quota, [&](int q) { return s_key[q]; }, [&](int) { return true; }, s_hist, s_pref, &T, &rem, &n_eq);
-            // selected: key < T, plus the first `rem` (in list order) with key == T
-            for (int q0 = 0; q0 < m; q0 += 1024) {
-                const int q = q0 + tid;
-                const bool eq = q < m && quota < m && s_key[q] == T;
-                int tot;
-                const int tie_rank = block_excl_scan_1024(eq, s_w, &tot);
-                const bool sel = q < m && (quota >= m || s_key[q] < T || (eq && tie_rank < rem));
-                rem -= tot;                                         // ties consumed by earlier rounds (rem may go negative: harmless)
-                if (sel) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)q;
+            RPN_T(tid == 0, 10 + 3 * which);
+            // selected = the `quota` smallest (key, list position) pairs.  A 2048-bin histogram of the keys' top 11 bits gives the bin
+            // that holds the quota-th smallest key: everything below it is in, and the ~m / 2048 candidates inside it are ranked among
+            // themselves (the RPN target maker's scheme; a four-pass radix select + tie scans took 4-5 us of this kernel per list).
+            bool done_sel = false;
+            if (quota < m) {
+                unsigned long long *s_bl = (unsigned long long *)(s_hist + RSB);          // boundary-bin list: 1024 entries behind the histogram
+                for (int b = tid; b < RSB; b += 1024) s_hist[b] = 0u;
+                if (tid == 0) s_nb = 0;
+                __syncthreads();
+                for (int q = tid; q < m; q += 1024) atomicAdd(&s_hist[s_key[q] >> 21], 1u);
+                __syncthreads();
+                int bin, below, inbin;
+                find_bin_2048<false>(s_hist, quota, s_tmp8, &bin, &below, &inbin);
+                if (inbin <= 1024) {                                 // (uniform; Philox keys: ~m / 2048 per bin)
+                    const int want = quota - below;
+                    for (int q = tid; q < m; q += 1024) {
+                        const int bq = (int)(s_key[q] >> 21);
+                        if (bq < bin) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)q;
+                        else if (bq == bin) s_bl[atomicAdd(&s_nb, 1)] = ((unsigned long long)s_key[q] << 16) | (unsigned)q;
+                    }
+                    __syncthreads();
+                    const int nb = s_nb;
+                    for (int e = tid; e < nb; e += 1024) {
+                        const unsigned long long me = s_bl[e];
+                        int rank = 0;
+                        for (int o = 0; o < nb; ++o) rank += s_bl[o] < me;
+                        if (rank < want) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)(me & 0xFFFFull);
+                    }
+                    done_sel = true;
+                }
             }
+            if (!done_sel) {                                         // everything is selected, or the (never seen) crowded boundary bin
+                unsigned T = 0xFFFFFFFFu; int rem = 0, n_eq = 0;
+                if (quota < m) block_radix_select(m, quota, [&](int q) { return s_key[q]; }, [&](int) { return true; }, s_hist, s_pref, &T, &rem, &n_eq);
+                // selected: key < T, plus the first `rem` (in list order) with key == T
+                for (int q0 = 0; q0 < m; q0 += 1024) {
+                    const int q = q0 + tid;
+                    const bool eq = q < m && quota < m && s_key[q] == T;
+                    int tot;
+                    const int tie_rank = block_excl_scan_1024(eq, s_w, &tot);
+                    const bool sel = q < m && (quota >= m || s_key[q] < T || (eq && tie_rank < rem));
+                    rem -= tot;                                     // ties consumed by earlier rounds (rem may go negative: harmless)
+                    if (sel) s_sel[atomicAdd(&s_nsel, 1)] = (unsigned short)q;
+                }
+            }
+            RPN_T(tid == 0, 11 + 3 * which);
             __syncthreads();
             const int ns = s_nsel;                                  // == quota
             // rank of a survivor = number of survivors with a smaller (key, position): the pairs are packed into one 64-bit word
             // and laid out densely, so the inner loop is two broadcast ds_read_b128 + four compares per four survivors (the first
             // form chased s_sel[o] -> s_key[..] with two dependent LDS reads per survivor: ~10 of the kernel's 46 us at 512 rows)
+            RPN_T(tid == 0, 12 + 3 * which);
             for (int a = tid; a < ((ns + 3) & ~3); a += 1024)
                 s_pk[a] = a < ns ? ((unsigned long long)s_key[s_sel[a]] << 16) | s_sel[a] : ~0ull;
             __syncthreads();
@@ -973,6 +1027,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
         }
     }
     __syncthreads();
+    RPN_T(tid == 0, 6);
     // phase 4: rows
     for (int j = tid; j < total; j += 1024) {
         const int k = s_row[j];
@@ -1001,6 +1056,7 @@ __global__ __launch_bounds__(1024) void head_targets_kernel(int variant, const f
         if (sticky && err) atomicOr(sticky, err);
         if (philox_state) philox_state[1] = offset + 1ull;           // one offset value consumed per call (barriers lie between the reads and this)
     }
+    RPN_T(tid == 0, 7);
 }
 
 // ------------------------------------------------------------------------------------------------
