@@ -580,6 +580,64 @@ def test_head_targets_host_perm_parity(ops, variant, label_offset, max_pos, tota
     assert np.allclose(reg.cpu().numpy(), reg_o, rtol=0, atol=1e-5)               # logf then /0.2: tolerance 1e-5
 
 
+@pytest.mark.parametrize("size", ["vgg-inline", "fpn-two-launches"])
+def test_rpn_targets_device_sampling_equals_reference_with_philox_permutations(ops, size):
+    """Device-RNG mode = the reference's randperm sampling (models/model.py:225-236) run with perm = argsort of the Philox keys
+    (oracle/philox_ref.py, pinned by the Random123 vectors): the oracle's host-permutation path, fed those permutations, gives the
+    EXACT expected labels -- for the one-launch form (N <= 24 576) and the rpn_match + rpn_apply form, with and without a
+    subsampled positive class."""
+    from oracle import philox_ref
+    rng = np.random.RandomState(21)
+    if size == "vgg-inline":
+        anchor, variant = orc.anchor_grid(600, 1000), 0
+    else:
+        anchor, variant = orc.tv_anchor_grid(800, 1344, [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], normalise=True), 1
+    ins = np.nonzero((anchor[:, 0] >= 0) & (anchor[:, 1] >= 0) & (anchor[:, 2] <= 1) & (anchor[:, 3] <= 1))[0]
+    for G, seed, offset in ((5, 11, 0), (1, (5 << 32) | 9, (1 << 32) | 7), (200, 3, 12345)):
+        gt = anchor[ins[rng.choice(len(ins), G, replace=False)]] if G > 100 else _gt(rng, G)
+        pre, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt, variant=variant)
+        pp = philox_ref.sampling_perm(seed, offset, 1, np.nonzero(pre == 1)[0])
+        pn = philox_ref.sampling_perm(seed, offset, 0, np.nonzero(pre == 0)[0])
+        cls_o, reg_o, _ = orc.rpn_targets(anchor, gt, pp, pn, variant=variant)
+        cls, reg, counts = ops.rpn_targets(T(anchor), T(gt), variant=variant, seed=seed, offset=offset)
+        assert counts.cpu().tolist()[:3] == [n_pos, n_neg, 0]
+        assert np.array_equal(cls.cpu().numpy(), cls_o), (size, G)                  # labels AFTER sampling: bit-exact
+        r = reg.cpu().numpy()
+        assert np.array_equal(r[:, :2], reg_o[:, :2]) and np.abs(r[:, 2:] - reg_o[:, 2:]).max() < 1e-6   # logf tolerance, as in the host-perm test
+        if G > 100:
+            assert n_pos > 128                                       # the positive class was subsampled too
+
+
+@pytest.mark.parametrize("variant,label_offset,max_pos,total,P", [(0, 1, 32, 128, 2000), (1, 0, 128, 512, 1000), (0, 1, 32, 128, 300)])
+def test_head_targets_device_sampling_equals_reference_with_philox_permutations(ops, variant, label_offset, max_pos, total, P):
+    """FastRcnnTargetMaker in device-RNG mode = the reference (models/model.py:318-345) with perm = argsort of the Philox keys of the
+    candidate lists (streams 2 = positives, 3 = negatives; element = candidate index into [rois; gt]): rows, classes, targets and
+    sampled RoIs bit-exact against the oracle's host-permutation path."""
+    from oracle import philox_ref
+    rng = np.random.RandomState(31 + P)
+    G = 6
+    gt = _gt(rng, G)
+    lab = rng.randint(0, 20, G).astype(np.int64)
+    rois = rand_boxes(rng, P, 0.05, 0.5)
+    n_near = P // 5                                                  # enough positives to subsample them as well
+    rois[:n_near] = np.clip(gt[rng.randint(0, G, n_near)] + rng.randn(n_near, 4).astype(np.float32) * 0.02, 0, 1)
+    npc, nnc = orc.head_target_counts(rois, gt, lab, variant=variant)
+    for seed, offset in ((5, 0), ((2 << 32) | 1, 99)):
+        keep_dev = ops.head_targets(T(rois), T(gt), T(lab), variant=variant, label_offset=label_offset, max_pos=max_pos, total=total,
+                                    seed=seed, offset=offset, want_keep=True)
+        # the candidate lists: identity permutations make the oracle return them in list order
+        full = orc.head_targets(rois, gt, lab, np.arange(npc), np.arange(nnc), variant=variant, label_offset=label_offset, max_pos=npc, total=npc + nnc)
+        pos_list, neg_list = full[3][:npc], full[3][npc:]
+        pp = philox_ref.sampling_perm(seed, offset, 2, pos_list)
+        pn = philox_ref.sampling_perm(seed, offset, 3, neg_list)
+        cls_o, reg_o, rois_o, keep_o = orc.head_targets(rois, gt, lab, pp, pn, variant=variant, label_offset=label_offset, max_pos=max_pos, total=total)
+        assert keep_dev[4].cpu().tolist()[:2] == [npc, nnc]
+        assert np.array_equal(keep_dev[3].cpu().numpy()[:len(keep_o)], keep_o)
+        assert np.array_equal(keep_dev[0].cpu().numpy()[:len(cls_o)], cls_o)
+        assert np.array_equal(keep_dev[2].cpu().numpy()[:len(rois_o)], rois_o)
+        assert np.allclose(keep_dev[1].cpu().numpy()[:len(reg_o)], reg_o, atol=1e-6)
+
+
 def test_head_targets_device_sampling_properties(ops):
     rng = np.random.RandomState(2)
     G, P = 4, 2000

@@ -295,3 +295,21 @@ def test_predict_post_known_answer():
     reg[0, 4 + 2] = np.log(2.0) / 0.2                                           # class 1, dw, un-normalised by 0.2
     _, _, _, pred, _ = model_ref.ref_predict_post(np.zeros((1, 3), np.float32), reg, np.array([[0.6, 0.2, 1.0, 0.4]], np.float32), 3, 0.05)
     assert np.abs(pred.reshape(3, 4)[1] - np.array([0.4, 0.2, 1.0, 0.4], np.float32)).max() < 1e-6
+
+
+def test_philox_reference_matches_random123_known_answers():
+    """oracle/philox_ref.py (the restatement of csrc/frcnn_common.h: philox_first that the device-sampling parity tests are built on)
+    against the Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors)."""
+    from oracle import philox_ref as P
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, out in kat:
+        assert tuple(int(x) for x in P.philox4x32_10(np.array(ctr), key)) == out
+    # vectorised form = element-wise form; first word; 64-bit seed / offset split
+    idx = np.array([0, 1, 77, 2 ** 31 + 5])
+    a = P.philox_first((7 << 32) | 3, (9 << 32) | 1, 2, idx)
+    for i, x in zip(idx, a):
+        assert int(x) == int(P.philox4x32_10(np.array([i, 2, 1, 9]), (3, 7))[0])
+    perm = P.sampling_perm(1, 0, 0, np.arange(50) * 3)
+    assert sorted(perm.tolist()) == list(range(50))
