@@ -1038,6 +1038,18 @@ def test_ms_roi_align_reference_scale_mode(ops):
     assert np.abs(dflt - got).max() > 1e-3                                   # the two conventions really differ on this frame
 
 
+@pytest.mark.parametrize("K", [300, 12000, 20000])
+def test_nms_zero_live_boxes_writes_a_zero_count(ops, K):
+    """A device-side live count of 0 (an image whose proposals were all filtered): no resolver workgroup runs, so nobody takes the
+    ticket that writes the outputs -- the count must still come out as 0 (dense form: block 0 writes it; cascade: nms_emit)."""
+    rng = np.random.RandomState(3)
+    b = rand_boxes(rng, K, 0.05, 0.3)
+    cnt = ops.nms_sorted(T(b), 0.7, post_k=min(K, 2000), n_boxes=T(np.array([0], np.int32)))[2]
+    assert int(cnt.item()) == 0
+    cnt = ops.nms_sorted(T(b), 0.7, post_k=min(K, 2000), n_boxes=T(np.array([K], np.int32)))[2]        # and the workspace is fine afterwards
+    assert int(cnt.item()) == min(len(orc.nms(b, 0.7)), 2000)
+
+
 def test_nms_all_identical_boxes_and_single_survivor(ops):
     K = 5000
     b = np.tile(np.array([[0.2, 0.2, 0.6, 0.7]], np.float32), (K, 1))
