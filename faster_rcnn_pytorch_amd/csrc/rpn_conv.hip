@@ -34,7 +34,8 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define RC3_HW (RC3_TW + 2)             // halo width
 #define RC3_HP ((RC3_TH + 2) * RC3_HW)  // halo pixels: 340
 #define RC3_PS 24                       // pixel / weight-row stride in LDS, in bf16 elements (48 bytes)
-#define RC3_STAGE_ELEMS (2 * RC3_HP * RC3_PS + 2 * 3 * RC3_C * RC3_PS)   // bf16 elements of the two double-buffered staging areas (106 KB)
+#define RC3_WSTEP (3 * RC3_C * 16)      // bf16 elements of one step's weights: 3 taps x 256 rows x 16 channels = 24 KB, lane-linear (no padding)
+#define RC3_STAGE_ELEMS (2 * RC3_HP * RC3_PS + 3 * RC3_WSTEP)   // bf16 elements of the pixel double buffer + the weight ring of three (106 KB)
 #define RC3_WH_ELEMS (8 * 2 * 32 * 2 * 8)                               // packed head weights (16 KB)
 #define RC3_LDS_BYTES ((size_t)(RC3_STAGE_ELEMS + RC3_WH_ELEMS) * 2 + RC3_C * 4)   // + b3 (1 KB): 123 KB of the CU's 160 KB
 
@@ -66,7 +67,15 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi)
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
-// W3 [256 out][256 in][3][3] fp32 -> W3p[chunk 16][tap 9][out 256][16 in] bf16 ; Wc [n_cls][256], Wr [n_reg][256] fp32 ->
+// Position of W3p element (chunk, tap, row m, channel k of the chunk): [chunk 16][tap 9][row block 8][half g 2][row-in-block 32][8], i.e.
+// inside a (tap, 32-row block) the 64 x 16-byte pieces lie in LANE order of the A fragment read (lane = 32 g + row: "8 consecutive
+// channels of my row").  The kernel stages the weights with global_load_lds_dwordx4, which writes wave-base + lane x 16 bytes: the LDS
+// image of a block is then lane-linear and its fragment read a conflict-free ds_read_b128 without any padding.
+__device__ __forceinline__ int rc3_wpos(int chunk, int tap, int m, int k)
+{
+    return (((chunk * 9 + tap) * 8 + (m >> 5)) * 2 + (k >> 3)) * 256 + (m & 31) * 8 + (k & 7);
+}
+// W3 [256 out][256 in][3][3] fp32 -> W3p (order: rc3_wpos) bf16 ; Wc [n_cls][256], Wr [n_reg][256] fp32 ->
 // Whp[ct 8][s 2][j 32][g 2][e 8] bf16 with channel = 32 ct + 16 s + 4 g + (e & 3) + 8 (e >> 2), rows j >= n_cls + n_reg zero
 __global__ __launch_bounds__(256) void rpn_conv_pack_kernel(const float *__restrict__ w3, const float *__restrict__ w_cls, int n_cls,
                                                             const float *__restrict__ w_reg, int n_reg, unsigned short *__restrict__ w3p,
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_kernel(const float *__restr
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 16 * 9 * 256 * 16) {
         const int k = i & 15, m = (i >> 4) & 255, tap = (i >> 12) % 9, chunk = (i >> 12) / 9;
-        w3p[i] = f2bf(w3[((size_t)m * RC3_C + chunk * 16 + k) * 9 + tap]);
+        w3p[rc3_wpos(chunk, tap, m, k)] = f2bf(w3[((size_t)m * RC3_C + chunk * 16 + k) * 9 + tap]);
     }
     if (i < 8 * 2 * 32 * 2 * 8) {
         const int e = i & 7, g = (i >> 3) & 1, j = (i >> 4) & 31, s = (i >> 9) & 1, ct = i >> 10;
@@ -95,8 +104,31 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_bwd_kernel(const float *__r
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 16 * 9 * 256 * 16) {
         const int k = i & 15, m = (i >> 4) & 255, tap = (i >> 12) % 9, chunk = (i >> 12) / 9;
-        w3p[i] = f2bf(w3[((size_t)(chunk * 16 + k) * RC3_C + m) * 9 + (8 - tap)]);
+        w3p[rc3_wpos(chunk, tap, m, k)] = f2bf(w3[((size_t)(chunk * 16 + k) * RC3_C + m) * 9 + (8 - tap)]);
     }
+}
+
+#ifdef RC3_TRACE                        // developer build: where a step's cycles go (wave 0 of workgroup 0; build_dbg/conv_trace.py)
+__device__ unsigned long long g_rc3_trace[16];
+extern "C" __attribute__((visibility("default"))) void frcnn_rc3_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rc3_trace), sizeof(g_rc3_trace)); }
+#define RC3_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define RC3_ACC(slot, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_rc3_trace[slot] += (b) - (a); } while (0)
+#else
+#define RC3_STAMP(var) do {} while (0)
+#define RC3_ACC(slot, a, b) do {} while (0)
+#endif
+// hand-placed vector-memory waits / loads (see the schedule in rpn_conv3x3_head_tile)
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier()                   // workgroup barrier that leaves vector-memory operations in flight (__syncthreads() would drain an LDS-DMA)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ unsigned ld_dword(const unsigned short *p)
+{
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
 }
 
 // NPT = position tiles (image rows) per wave: 4 = the full 8-row tile, 2 = a 4-row half tile (ysub = 0 / 4 inside the full tile)
@@ -107,12 +139,13 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
                                                                const float *__restrict__ b_reg, int n_reg, float *__restrict__ out_cls,
                                                                float *__restrict__ out_reg)
 {
-    // dynamic LDS (123 KB): [2][halo pixels x 24] (2 x 16 320 B), then [2][3 taps][256 rows x 24] (2 x 36 864 B); the epilogue reuses
-    // the first 32 KB.  The weights of a whole kernel ROW (3 taps) are staged per barrier: one barrier per tap (16 MFMAs per wave
-    // between barriers, one wave per SIMD) ran at 12 % of the matrix peak -- no better than MIOpen.
+    // dynamic LDS (123 KB): [2][halo pixels x 24] (2 x 16 320 B), then a RING OF THREE weight buffers [3 taps][8 row blocks][64 lanes x 16 B]
+    // (3 x 24 576 B, lane-linear: written by global_load_lds_dwordx4, see rc3_wpos); the epilogue reuses the first 64 KB.  The weights
+    // of a whole kernel ROW (3 taps) are staged per barrier: one barrier per tap (16 MFMAs per wave between barriers, one wave per
+    // SIMD) ran at 12 % of the matrix peak -- no better than MIOpen.
     extern __shared__ __attribute__((aligned(16))) unsigned short s_all[];
     unsigned short (*s_x)[RC3_HP * RC3_PS] = (unsigned short (*)[RC3_HP * RC3_PS])s_all;
-    unsigned short (*s_w)[3 * RC3_C * RC3_PS] = (unsigned short (*)[3 * RC3_C * RC3_PS])(s_all + 2 * RC3_HP * RC3_PS);
+    unsigned short (*s_w)[RC3_WSTEP] = (unsigned short (*)[RC3_WSTEP])(s_all + 2 * RC3_HP * RC3_PS);
     // behind them: the packed head weights and b3, copied once per tile so that the epilogue reads them at LDS latency
     unsigned short *s_wh = s_all + RC3_STAGE_ELEMS;
     float *s_b3 = (float *)(s_wh + RC3_WH_ELEMS);
@@ -156,25 +189,35 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
                                   (item && w >= 1 ? 4 : 0) | (item && w <= 16 ? 8 : 0));
     }
     struct XV { unsigned a[XL][XI], b[XL][XI]; };
-    auto load_x = [&](int chunk, XV &v) {
+    auto load_x = [&](int chunk, XV &v, int u0, int u1) {
         const unsigned cbase = (unsigned)chunk * 16u * (unsigned)plane;
 #pragma unroll
         for (int u = 0; u < XI; ++u) {
+            if (u < u0 || u >= u1) continue;
             const unsigned oa = cbase + x_off[u], ob = oa + (unsigned)plane;
+            // (inline asm: the compiler must not see these as loads -- with LDS-DMA pieces in flight it would wait vmcnt(0) at their
+            // first use; the counted waits are placed by hand, see vm_wait / the schedule below)
             if (!ODDW) {                                    // W even: every offset is even and the pair is one aligned dword
-                v.a[0][u] = *(const unsigned *)(xin + oa);
-                v.b[0][u] = *(const unsigned *)(xin + ob);
+                v.a[0][u] = ld_dword(xin + oa);
+                v.b[0][u] = ld_dword(xin + ob);
             } else {                                        // the dwords at (o & ~1) and the next one, clamped to the last dword of the level
                 const unsigned ea = oa & ~1u, eb = ob & ~1u;
-                v.a[0][u] = *(const unsigned *)(xin + ea); v.a[XL - 1][u] = *(const unsigned *)(xin + min(ea + 2u, end - 2u));
-                v.b[0][u] = *(const unsigned *)(xin + eb); v.b[XL - 1][u] = *(const unsigned *)(xin + min(eb + 2u, end - 2u));
+                v.a[0][u] = ld_dword(xin + ea); v.a[XL - 1][u] = ld_dword(xin + min(ea + 2u, end - 2u));
+                v.b[0][u] = ld_dword(xin + eb); v.b[XL - 1][u] = ld_dword(xin + min(eb + 2u, end - 2u));
             }
         }
     };
-    auto store_x = [&](int buf, int chunk, const XV &v) {
+    auto tie_x = [&](XV &v) {                               // the values of load_x are defined HERE for the compiler: after the wait in front of it
+#pragma unroll
+        for (int u = 0; u < XI; ++u)
+#pragma unroll
+            for (int l = 0; l < XL; ++l) { asm volatile("" : "+v"(v.a[l][u])); asm volatile("" : "+v"(v.b[l][u])); }
+    };
+    auto store_x = [&](int buf, int chunk, const XV &v, int u0, int u1) {
         const unsigned cbase = (unsigned)chunk * 16u * (unsigned)plane;
 #pragma unroll
         for (int u = 0; u < XI; ++u) {
+            if (u < u0 || u >= u1) continue;
             unsigned va = v.a[0][u], vb = v.b[0][u];
             if (ODDW) {
                 const unsigned oa = cbase + x_off[u], ob = oa + (unsigned)plane;
@@ -188,17 +231,24 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
             if (x_ok[u] & 8) dst[RC3_PS / 2] = a1 | (b1 << 16);                       // pixel 2w + 1
         }
     };
-    // weights of one (chunk, kernel row) step: 3 taps x 256 rows x 16 bf16 = 24 KB contiguous in W3p; thread t moves row t of each tap
-    auto load_w = [&](int step, u32x4 (&v)[6]) {
-        const u32x4 *src = (const u32x4 *)(w3p + (size_t)step * 3 * RC3_C * 16 + (size_t)t * 16);
+    // weights of one (chunk, kernel row) step: 24 KB contiguous in W3p, already in their LDS order: 24 pieces of 1 KB, six per wave, each
+    // ONE global_load_lds_dwordx4 (wave-uniform LDS base in M0, lane x 16 bytes) -- no registers, no ds_write, and the piece may stay
+    // in flight across barriers (a register-staged step could fly for one step only: the waves spent 30 % of their time in the
+    // s_waitcnt in front of the weight stores, PMC SQ_WAIT_INST_ANY)
+    auto issue_w_part = [&](int step, int buf, int q0, int q1) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { v[2 * k] = src[k * RC3_C * 2]; v[2 * k + 1] = src[k * RC3_C * 2 + 1]; }
+        for (int q = q0; q < q1; ++q) {
+            const int piece = wave * 6 + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w3p + (size_t)step * RC3_WSTEP + piece * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void *)(&s_w[buf][piece * 512]), 16, 0, 0);
+        }
     };
-    auto store_w = [&](int buf, const u32x4 (&v)[6]) {
+    auto issue_w = [&](int step, int buf) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u32x4 *dst = (u32x4 *)(&s_w[buf][(k * RC3_C + t) * RC3_PS]);
-            dst[0] = v[2 * k]; dst[1] = v[2 * k + 1];
+        for (int q = 0; q < 6; ++q) {
+            const int piece = wave * 6 + q;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w3p + (size_t)step * RC3_WSTEP + piece * 512 + lane * 8),
+                                             (__attribute__((address_space(3))) void *)(&s_w[buf][piece * 512]), 16, 0, 0);
         }
     };
 
@@ -218,27 +268,36 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
     //    immediately reload.  The body is unrolled over (2 chunks) x (3 rows) with unconditional, clamped loads so that the
     //    s_waitcnt before a weight store counts exactly the pixel loads issued after it.
     bf16x8 fa[2][4], fb[2][NPT];
-    auto load_frags = [&](auto P, int chunk, int ky, int kx) {
+    // part 0 = the position fragments, 1 / 2 = the first / last two channel-tile fragments, -1 = all.  Inside the loop they are issued
+    // in three portions behind consecutive MFMA groups: eight ds_read_b128 in one place cost ~100 cycles of the wave's only issue slot
+    // while the matrix pipe holds 32 cycles of work
+    auto load_frags = [&](auto P, int chunk, int ky, int kx, int part = -1) {
         constexpr int p = decltype(P)::value;
-        const unsigned short *sx = s_x[chunk & 1], *sw = s_w[(chunk * 3 + ky) & 1];
+        const unsigned short *sx = s_x[chunk & 1], *sw = s_w[(chunk * 3 + ky) % 3];
+        if (part < 0 || part == 0) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) fa[p][ct] = *(const bf16x8 *)(sw + (kx * RC3_C + 128 * wc + 32 * ct + li) * RC3_PS + 8 * g);
-#pragma unroll
-        for (int pt = 0; pt < NPT; ++pt) fb[p][pt] = *(const bf16x8 *)(sx + ((NPT * wp + pt + ky) * RC3_HW + li + kx) * RC3_PS + 8 * g);
-    };
-    auto mfma16 = [&](auto P) {
-        constexpr int p = decltype(P)::value;
+            for (int pt = 0; pt < NPT; ++pt) fb[p][pt] = *(const bf16x8 *)(sx + ((NPT * wp + pt + ky) * RC3_HW + li + kx) * RC3_PS + 8 * g);
+        }
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][ct], fb[p][pt], acc[ct][pt], 0, 0, 0);
+            if (part < 0 || part == 1 + (ct >> 1)) fa[p][ct] = *(const bf16x8 *)(sw + ((kx * 8 + 4 * wc + ct) * 64 + lane) * 8);
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
+    // Vector-memory schedule (all counted by hand; P = the pixel loads of one chunk and thread).  G(k) = the six DMA pieces of step k's
+    // weights, X(c) = chunk c's pixel loads.  Behind barrier k the ring slot of step k is free: X(c + 2) (ky = 0 only) and G(k + 3) are
+    // issued from there on -- G in single pieces BETWEEN the 4-MFMA groups of the next three taps (a DMA issue costs ~100 cycles of the
+    // wave's issue slot: M0 + address set-up; one group keeps the matrix pipe busy for 128): pieces 0, 1 under tap 2 of step k, pieces
+    // 2 .. 5 under taps 0 and 1 of step k + 1.  A step's weights are in flight for two steps.  The pixel store of chunk c + 1 (ky = 0) is
+    // spread over the groups of taps 0 and 1 as well.  In program order:
+    //   step 3c   : [wait X(c+1)] G(3c+2).2-5 | wait G(3c+1) | barrier | G(3c+3).0-1 X(c+2)
+    //   step 3c+1 :               G(3c+3).2-5 | wait G(3c+2) | barrier |        G(3c+4).0-1
+    //   step 3c+2 :               G(3c+4).2-5 | wait G(3c+3) | barrier |        G(3c+5).0-1
+    // so the operations younger than the awaited ones number 6 / 6 + P / 6 for the weights and 12 for X (8 in chunk 0, from the prologue).
+    constexpr int P = 2 * XI * XL;
     XV xv;
-    u32x4 wv[6];
-    load_x(0, xv);
-    load_w(0, wv);
+    load_x(0, xv, 0, XI);
+    issue_w(0, 0);
     if (HEAD) {
         u32x4 hv[4];
 #pragma unroll
@@ -248,28 +307,70 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         for (int k = 0; k < 4; ++k) ((u32x4 *)s_wh)[t + 256 * k] = hv[k];
         s_b3[t] = bv;
     }
-    store_x(0, 0, xv);
-    store_w(0, wv);
-    load_w(1, wv);
-    load_x(1, xv);
-    __syncthreads();
+    vm_wait<0>();
+    tie_x(xv);
+    store_x(0, 0, xv, 0, XI);
+    load_x(1, xv, 0, XI);
+    issue_w(1, 1);
+    issue_w_part(2, 2, 0, 2);
+    lds_barrier();
     load_frags(I0{}, 0, 0, 0);
-    auto do_step = [&](auto P, auto Q, auto KY, int chunk) {    // fragments of tap 0 are in set P on entry, and in set Q = 1 - P for the next step
+    auto mfma_group = [&](auto S_, int ct) {
+        constexpr int p = decltype(S_)::value;
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[p][ct], fb[p][pt], acc[ct][pt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto do_step = [&](auto P_, auto Q_, auto KY, int chunk) {  // fragments of tap 0 are in set P_ on entry, and in set Q_ = 1 - P_ for the next step
         constexpr int ky = decltype(KY)::value;
         const int step = chunk * 3 + ky;
-        load_frags(Q, chunk, ky, 1);
-        mfma16(P);
-        load_frags(P, chunk, ky, 2);
-        mfma16(Q);
-        store_w((step + 1) & 1, wv);                        // (step 47 stores a clamped reload into the idle buffer: nobody reads it)
-        load_w(min(step + 2, 47), wv);
+        const int wnext = min(step + 2, 47), snext = (step + 2) % 3;    // the weights whose pieces 2 .. 5 are still to be issued (clamped at the
+                                                                        // end: the last steps re-fetch step 47 into slots nobody reads again)
+        RC3_STAMP(t0);
         if (ky == 0) {
-            store_x((chunk + 1) & 1, min(chunk + 1, 15), xv);
-            load_x(min(chunk + 2, 15), xv);
+            if (chunk == 0) vm_wait<8>(); else vm_wait<12>();           // X(chunk + 1) has landed (long ago)
+            tie_x(xv);
         }
-        __syncthreads();
-        if (ky == 2) load_frags(Q, chunk + 1, 0, 0); else load_frags(Q, chunk, ky + 1, 0);
-        mfma16(P);
+        // Order inside a tap: two MFMA groups with one DMA piece behind each, THEN the fragment reads of the next tap, then the other two
+        // groups (with the pixel stores at ky = 0).  The compiler puts s_waitcnt lgkmcnt(0) in front of an LDS-DMA issue whenever LDS reads
+        // are outstanding (the DMA writes LDS); with the reads issued first the wait landed in front of the tap's first MFMA and exposed
+        // their whole latency, twice per step.
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {                                // tap 0 (its fragments were read under the previous tap)
+            mfma_group(P_, ct);
+            if (ct < 2) issue_w_part(wnext, snext, 2 + ct, 3 + ct);
+            else if (ky == 0) store_x((chunk + 1) & 1, min(chunk + 1, 15), xv, (ct - 2) * (XI / 4), (ct - 1) * (XI / 4));
+            if (ct >= 1) load_frags(Q_, chunk, ky, 1, ct - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        RC3_STAMP(t1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {                                // tap 1
+            mfma_group(Q_, ct);
+            if (ct < 2) issue_w_part(wnext, snext, 4 + ct, 5 + ct);
+            else if (ky == 0) store_x((chunk + 1) & 1, min(chunk + 1, 15), xv, ct == 2 ? 2 * (XI / 4) : 3 * (XI / 4), ct == 2 ? 3 * (XI / 4) : XI);
+            if (ct >= 1) load_frags(P_, chunk, ky, 2, ct - 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        RC3_STAMP(t2);
+        if (ky == 1) vm_wait<6 + P>(); else vm_wait<6>();               // G(step + 1) has landed
+        RC3_STAMP(t3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RC3_STAMP(t4);
+        lds_barrier();
+        RC3_STAMP(t5);
+        RC3_STAMP(t6);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {                                // tap 2 (fragments read before the barrier)
+            mfma_group(P_, ct);
+            if (ct < 2) issue_w_part(min(step + 3, 47), step % 3, ct, ct + 1);
+            else if (ky == 0) load_x(min(chunk + 2, 15), xv, ct == 2 ? 0 : XI / 2, ct == 2 ? XI / 2 : XI);   // X(chunk + 2), behind pieces 0, 1
+            if (ct >= 1) { if (ky == 2) load_frags(Q_, chunk + 1, 0, 0, ct - 1); else load_frags(Q_, chunk, ky + 1, 0, ct - 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        RC3_STAMP(t7);
+        RC3_ACC(0, t0, t1); RC3_ACC(1, t1, t2); RC3_ACC(2, t2, t3); RC3_ACC(3, t3, t4); RC3_ACC(4, t4, t5); RC3_ACC(5, t5, t6); RC3_ACC(6, t6, t7); RC3_ACC(7, t0, t7);
+        if (ky == 0) RC3_ACC(8, t2, t3);
     };
     for (int chunk = 0; chunk < 16; chunk += 2) {
         do_step(I0{}, I1{}, I0{}, chunk);
@@ -279,7 +380,9 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         do_step(I0{}, I1{}, I1{}, chunk + 1);
         do_step(I1{}, I0{}, std::integral_constant<int, 2>{}, chunk + 1);
     }
-    __syncthreads();                                        // the stray staging stores of the last step are done before the epilogue reuses LDS
+    vm_wait<0>();                                           // the stray DMA pieces and pixel loads of the last steps are done ...
+    tie_x(xv);
+    lds_barrier();                                          // ... in every wave before the epilogue reuses LDS
 
     // ---- epilogue: raw (bf16), h = relu(raw + b3) as the B operand of the heads' product.
     // Accumulator register r of a lane is channel cb + (r & 3) + 8 (r >> 2) + 4 g at pixel (yy, x0 + li): registers (r, r + 1) are
