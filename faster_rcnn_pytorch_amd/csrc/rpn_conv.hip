@@ -372,6 +372,9 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         RC3_ACC(0, t0, t1); RC3_ACC(1, t1, t2); RC3_ACC(2, t2, t3); RC3_ACC(3, t3, t4); RC3_ACC(4, t4, t5); RC3_ACC(5, t5, t6); RC3_ACC(6, t6, t7); RC3_ACC(7, t0, t7);
         if (ky == 0) RC3_ACC(8, t2, t3);
     };
+#ifdef RC3_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
+#endif
     for (int chunk = 0; chunk < 16; chunk += 2) {
         do_step(I0{}, I1{}, I0{}, chunk);
         do_step(I1{}, I0{}, I1{}, chunk);
@@ -380,6 +383,9 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
         do_step(I0{}, I1{}, I1{}, chunk + 1);
         do_step(I1{}, I0{}, std::integral_constant<int, 2>{}, chunk + 1);
     }
+#ifdef RC3_TRACE
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_rc3_trace[9] += __builtin_amdgcn_s_memrealtime() - tr0; g_rc3_trace[10] += __builtin_readcyclecounter() - tc0; }
+#endif
     vm_wait<0>();                                           // the stray DMA pieces and pixel loads of the last steps are done ...
     tie_x(xv);
     lds_barrier();                                          // ... in every wave before the epilogue reuses LDS
