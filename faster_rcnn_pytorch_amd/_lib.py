@@ -53,6 +53,7 @@ SIGNATURES = {
     "frcnn_detection_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_preprocess_image": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_preprocess_boxes": (_i, [_vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
+    "frcnn_diag_occupy": (_i, [_i, _i, _vp]),
     "frcnn_prof_enable": (_i, [_i]),
     "frcnn_prof_collect": (_i, []),
     "frcnn_prof_reset": (_i, []),
@@ -94,6 +95,11 @@ def check(rc, what=""):
 
 def workspace_bytes(op, n1, n2=0):
     return int(lib.frcnn_workspace_bytes(op, n1, n2))
+
+
+def diag_occupy(n_workgroups, microseconds, stream):
+    """Resident do-nothing workgroups on `stream` (a torch.cuda.Stream): see include/frcnn_hip.h."""
+    check(lib.frcnn_diag_occupy(int(n_workgroups), int(microseconds), C.c_void_p(stream.cuda_stream)))
 
 
 def prof_enable(on=True):

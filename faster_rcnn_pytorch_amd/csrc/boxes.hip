@@ -228,3 +228,20 @@ FRCNN_EXPORT int frcnn_proposal_prologue(const float *reg, const float *cls, con
     FRCNN_REQUIRE(N < ((int64_t)1 << 31), "prologue: N too large");
     return frcnn_launch_prologue(reg, cls, anchors, nullptr, N, min_size_norm, out_boxes, out_scores, nullptr, 0, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }
+
+// ------------------------------------------------------------------------------------------
+// diagnostics: resident do-nothing workgroups (include/frcnn_hip.h: frcnn_diag_occupy)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diag_occupy_kernel(unsigned long long ticks)            // ticks of the 100 MHz s_memrealtime counter
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);          // bounded: leaves after `ticks` whatever happens
+}
+
+FRCNN_EXPORT int frcnn_diag_occupy(int n_workgroups, int microseconds, void *stream)
+{
+    FRCNN_REQUIRE(n_workgroups > 0 && n_workgroups <= 4096 && microseconds > 0 && microseconds <= 100000, "diag_occupy: 1 .. 4096 workgroups, 1 .. 100000 us");
+    FRCNN_LAUNCH(diag_occupy_kernel, dim3((unsigned)n_workgroups), dim3(256), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+    FRCNN_CHECK_LAUNCH("diag_occupy_kernel");
+    return FRCNN_OK;
+}

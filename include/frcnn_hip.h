@@ -306,6 +306,12 @@ int frcnn_prof_get(int kernel_id, double *total_ms, int64_t *launches);
 /* per-launch durations (ms, launch order) of one kernel since the last reset: copies min(cap, n), returns n. */
 int64_t frcnn_prof_get_samples(int kernel_id, float *out_ms, int64_t cap);
 
+/* Diagnostics: n_workgroups workgroups of 256 threads that do nothing but stay resident for `microseconds` (bounded: <= 100 000) on
+ * `stream` -- a stand-in for another tenant's persistent kernels (RCCL's channels during the gradient all-reduce) when testing that the
+ * launches with in-kernel hand-offs (nms_kernel, rpn_match_kernel, topk_partition_kernel) still complete and stay exact next to them
+ * (tests/test_gpu_ops.py: test_in_kernel_handoffs_next_to_resident_foreign_workgroups).  Not used by the product path.            */
+int frcnn_diag_occupy(int n_workgroups, int microseconds, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

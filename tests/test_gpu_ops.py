@@ -354,6 +354,38 @@ def test_nms_in_kernel_handoff_under_uneven_load(ops):
     assert bad == 0, "%d of 150 launches differ from the oracle" % bad
 
 
+def test_in_kernel_handoffs_next_to_resident_foreign_workgroups(ops):
+    """Multi-GPU readiness without the hardware: during training RCCL keeps persistent workgroups resident on the GPU while the hot
+    path runs.  The launches with in-kernel hand-offs (tile -> resolver flags and the output ticket in nms_kernel, the grid barriers of
+    rpn_match_kernel and topk_partition_kernel) assume their OWN workgroups become resident, not that the chip is empty: here 32, then
+    96 foreign workgroups (frcnn_diag_occupy: a stand-in for RCCL's channels) sit on a side stream for the whole time, and every result
+    must equal the oracle's -- proposals (top-k + NMS) and RPN targets with device sampling, at 600x1000."""
+    from faster_rcnn_pytorch_amd import _lib
+    from oracle import philox_ref
+    rng = np.random.RandomState(17)
+    H, W = 600, 1000
+    anchor = orc.anchor_grid(H, W)
+    N = anchor.shape[0]
+    reg, cls = rpn_outputs(rng, N, "trained")
+    rois_o, src_o = orc.region_proposal(reg, cls, anchor, 1 / 1000, 12000, 0.7, 2000)
+    gt = _gt(rng, 6)
+    pre, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt)
+    pp = philox_ref.sampling_perm(5, 3, 1, np.nonzero(pre == 1)[0]); pn = philox_ref.sampling_perm(5, 3, 0, np.nonzero(pre == 0)[0])
+    cls_o = orc.rpn_targets(anchor, gt, pp, pn)[0]
+    treg, tcls, tanch, tgt = T(reg), T(cls), T(anchor), T(gt)
+    side = torch.cuda.Stream()
+    bad = 0
+    for n_foreign in (32, 96):
+        for it in range(25):
+            _lib.diag_occupy(n_foreign, 400, side)                       # 400 us of residency: longer than the launches below take
+            rois, cnt, src = ops.region_proposal(treg, tcls, tanch, 1 / 1000, 12000, 0.7, 2000, want_src=True)
+            tc = ops.rpn_targets(tanch, tgt, seed=5, offset=3)[0]
+            n = int(cnt.item())
+            bad += int(n != len(rois_o) or not np.array_equal(src[:n].cpu().numpy(), src_o) or not np.array_equal(tc.cpu().numpy(), cls_o))
+            side.synchronize()
+    assert bad == 0, "%d of 50 iterations differ from the oracle" % bad
+
+
 # ------------------------------------------------------------------------------------------ whole proposal stage
 @pytest.mark.parametrize("regime,mode", [("init", "train"), ("trained", "train"), ("trained", "test")])
 def test_region_proposal_full_size_bit_exact(ops, regime, mode):
