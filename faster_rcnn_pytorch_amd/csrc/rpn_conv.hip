@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_bwd_kernel(const float *__r
     }
 }
 
-#ifdef RC3_TRACE                        // developer build: where a step's cycles go (wave 0 of workgroup 0; build_dbg/conv_trace.py)
+#ifdef RC3_TRACE                        // developer build: where a step's cycles go (wave 0 of workgroup 0; tools/dev/conv_trace.py)
 __device__ unsigned long long g_rc3_trace[16];
 extern "C" __attribute__((visibility("default"))) void frcnn_rc3_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rc3_trace), sizeof(g_rc3_trace)); }
 #define RC3_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()

@@ -406,7 +406,7 @@ __device__ __forceinline__ void rpn_arrive_reset(RpnArrive *a, int t)
     if (t < 8) __hip_atomic_store(&a->sub[t][0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else if (t == 8) __hip_atomic_store(&a->top[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-#ifdef RPN_TRACE                        // developer build: phase stamps of rpn_match_kernel (build_dbg/rpn_trace.py)
+#ifdef RPN_TRACE                        // developer build: phase stamps of rpn_match_kernel (tools/dev/rpn_trace.py)
 __device__ unsigned long long g_rpn_trace[16];
 extern "C" __attribute__((visibility("default"))) void frcnn_rpn_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rpn_trace), sizeof(g_rpn_trace)); }
 #define RPN_T(cond, slot) do { if (cond) g_rpn_trace[slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
