@@ -386,6 +386,40 @@ def test_in_kernel_handoffs_next_to_resident_foreign_workgroups(ops):
     assert bad == 0, "%d of 50 iterations differ from the oracle" % bad
 
 
+@pytest.mark.parametrize("env", ["FRCNN_TOPK_FUSED=0", "FRCNN_TOPK_FUSED=2", "FRCNN_NMS_FOLD_EMIT=0", "FRCNN_NMS_DENSE_MIN=1000", "FRCNN_RPN_FUSED=0"])
+def test_alternative_launch_forms_give_the_same_results(env):
+    """The library keeps the forms it measured against each other (three / two / one top-k launches, NMS outputs by nms_emit_kernel,
+    the generic NMS relation layout below 16 384 boxes, the staged RPN target maker) behind environment switches that are read once
+    per process: a child process per switch runs the proposal stage and the RPN target maker at 600x1000 and must reproduce the
+    oracle's outputs exactly, like the default forms do in the tests above."""
+    import os, subprocess, sys, tempfile
+    from oracle import philox_ref
+    rng = np.random.RandomState(23)
+    anchor = orc.anchor_grid(600, 1000)
+    N = anchor.shape[0]
+    reg, cls = rpn_outputs(rng, N, "trained")
+    rois_o, src_o = orc.region_proposal(reg, cls, anchor, 1 / 1000, 12000, 0.7, 2000)
+    gt = _gt(rng, 5)
+    pre, _, _ = orc.rpn_targets(anchor, gt)
+    pp = philox_ref.sampling_perm(9, 4, 1, np.nonzero(pre == 1)[0]); pn = philox_ref.sampling_perm(9, 4, 0, np.nonzero(pre == 0)[0])
+    cls_o = orc.rpn_targets(anchor, gt, pp, pn)[0]
+    code = ("import numpy as np, torch, sys; from faster_rcnn_pytorch_amd import ops; d = sys.argv[1];"
+            "L = lambda n: torch.from_numpy(np.load(d + '/' + n + '.npy')).cuda();"
+            "rois, cnt, src = ops.region_proposal(L('reg'), L('cls'), L('anchor'), 1 / 1000, 12000, 0.7, 2000, want_src=True);"
+            "n = int(cnt.item()); np.save(d + '/src.npy', src[:n].cpu().numpy()); np.save(d + '/rois.npy', rois[:n].cpu().numpy());"
+            "np.save(d + '/tcls.npy', ops.rpn_targets(L('anchor'), L('gt'), seed=9, offset=4)[0].cpu().numpy())")
+    with tempfile.TemporaryDirectory() as d:
+        for n, a in (("reg", reg), ("cls", cls), ("anchor", anchor), ("gt", gt)):
+            np.save(os.path.join(d, n + ".npy"), a)
+        k, v = env.split("=")
+        e = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        e[k] = v
+        subprocess.run([sys.executable, "-c", code, d], check=True, env=e, timeout=300)
+        assert np.array_equal(np.load(os.path.join(d, "src.npy")), src_o), env
+        assert np.array_equal(np.load(os.path.join(d, "rois.npy")), rois_o), env
+        assert np.array_equal(np.load(os.path.join(d, "tcls.npy")), cls_o), env
+
+
 # ------------------------------------------------------------------------------------------ whole proposal stage
 @pytest.mark.parametrize("regime,mode", [("init", "train"), ("trained", "train"), ("trained", "test")])
 def test_region_proposal_full_size_bit_exact(ops, regime, mode):
