@@ -37,7 +37,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define RC3_WSTEP (3 * RC3_C * 16)      // bf16 elements of one step's weights: 3 taps x 256 rows x 16 channels = 24 KB, lane-linear (no padding)
 #define RC3_STAGE_ELEMS (2 * RC3_HP * RC3_PS + 3 * RC3_WSTEP)   // bf16 elements of the pixel double buffer + the weight ring of three (106 KB)
 #define RC3_WH_ELEMS (8 * 2 * 32 * 2 * 8)                               // packed head weights (16 KB)
-#define RC3_LDS_BYTES ((size_t)(RC3_STAGE_ELEMS + RC3_WH_ELEMS) * 2 + RC3_C * 4)   // + b3 (1 KB): 123 KB of the CU's 160 KB
+#define RC3_LDS_BYTES ((size_t)(RC3_STAGE_ELEMS + RC3_WH_ELEMS) * 2 + RC3_C * 4 + 64 * 4)   // + b3 (1 KB) + the heads' biases: 123 KB of the CU's 160 KB
 
 struct ConvLevels {
     int n_levels;
@@ -143,12 +143,17 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
     // (3 x 24 576 B, lane-linear: written by global_load_lds_dwordx4, see rc3_wpos); the epilogue reuses the first 64 KB.  The weights
     // of a whole kernel ROW (3 taps) are staged per barrier: one barrier per tap (16 MFMAs per wave between barriers, one wave per
     // SIMD) ran at 12 % of the matrix peak -- no better than MIOpen.
+#ifdef RC3_TRACE
+    const unsigned long long tt0 = __builtin_readcyclecounter();
+    struct TileStamp { unsigned long long t0; __device__ ~TileStamp() { if (blockIdx.x == 0 && threadIdx.x == 0) g_rc3_trace[11] += __builtin_readcyclecounter() - t0; } } tile_stamp{tt0};
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned short s_all[];
     unsigned short (*s_x)[RC3_HP * RC3_PS] = (unsigned short (*)[RC3_HP * RC3_PS])s_all;
     unsigned short (*s_w)[RC3_WSTEP] = (unsigned short (*)[RC3_WSTEP])(s_all + 2 * RC3_HP * RC3_PS);
     // behind them: the packed head weights and b3, copied once per tile so that the epilogue reads them at LDS latency
     unsigned short *s_wh = s_all + RC3_STAGE_ELEMS;
     float *s_b3 = (float *)(s_wh + RC3_WH_ELEMS);
+    float *s_bh = s_b3 + RC3_C;                             // the heads' biases (cls, then reg; 64 slots)
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, g = lane >> 5;
     const int wc = wave & 1, wp = wave >> 1;               // channel half, tile-row half
@@ -306,6 +311,8 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((u32x4 *)s_wh)[t + 256 * k] = hv[k];
         s_b3[t] = bv;
+        // (16 dependent global loads per lane in the last loop of the epilogue, each behind its own s_waitcnt vmcnt(0), until round 3)
+        if (t < 64) s_bh[t] = t < n_cls ? b_cls[t] : (t < n_cls + n_reg ? b_reg[t - n_cls] : 0.0f);
     }
     vm_wait<0>();
     tie_x(xv);
@@ -374,6 +381,7 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
     };
 #ifdef RC3_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime(), tc0 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_rc3_trace[12] += tc0 - tt0;
 #endif
     for (int chunk = 0; chunk < 16; chunk += 2) {
         do_step(I0{}, I1{}, I0{}, chunk);
@@ -480,7 +488,7 @@ __device__ __forceinline__ void rpn_conv3x3_head_tile(int lvl, int tile, int ysu
             const int j = (r & 3) + 8 * (r >> 2) + 4 * g;
             if (j < J) {
                 const float v = s_part[(((0 * 2 + wp) * NPT + pt) * 16 + r) * 64 + lane] + s_part[(((1 * 2 + wp) * NPT + pt) * 16 + r) * 64 + lane] +
-                                (j < n_cls ? b_cls[j] : b_reg[j - n_cls]);
+                                s_bh[j];
                 if (j < n_cls) oc[p * n_cls + j] = v; else orr[p * n_reg + (j - n_cls)] = v;
             }
         }
