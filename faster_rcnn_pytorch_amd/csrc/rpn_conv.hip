@@ -892,10 +892,12 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
             store_a((i + 1) & 1, S0); store_f(y + 2, S0);
             load_a(y + 3, S0); load_f(y + 4, S0);
         }
-        if (i + 1 < n_rows) {
+        {   // odd row: only the COMPUTE depends on whether the row exists.  The stores and (clamped) loads run regardless: with them under
+            // the condition, the paths into the loop's back edge carried different sets of outstanding loads and the compiler fell back
+            // to s_waitcnt vmcnt(0) in front of every LDS store -- the two-rows-ahead prefetch was one row deep (ISA, round 3)
             const int y = y_first + i + 1;
             __syncthreads();
-            compute(y, (i + 1) & 1);
+            if (i + 1 < n_rows) compute(y, (i + 1) & 1);
             store_a(i & 1, S1); store_f(y + 2, S1);
             load_a(y + 3, S1); load_f(y + 4, S1);
         }

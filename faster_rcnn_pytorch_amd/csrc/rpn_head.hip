@@ -132,7 +132,12 @@ __global__ __launch_bounds__(64 * WAVES) void rpn_head_tail_kernel(HeadLevels L,
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = 32 * t + li;
-            const float bias = j < n_cls ? b_cls[j] : (j < n_cls + n_reg ? b_reg[j - n_cls] : 0.0f);
+            float bias = j < n_cls ? b_cls[j] : (j < n_cls + n_reg ? b_reg[j - n_cls] : 0.0f);
+            // an unconditional use of the loaded value in front of the predicated stores: the compiler sinks "v += bias" into each store's
+            // branch, and on the merge of a path that waited for the load with one that did not it re-emits s_waitcnt vmcnt(0) in EVERY
+            // branch -- which then also waits for the previous branch's store to be acknowledged: 16 dependent round trips per tile
+            // (ISA, round 3: most of this kernel's time)
+            asm volatile("v_mov_b32 %0, %0" : "+v"(bias));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // C/D layout of the 32x32 MFMA: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
