@@ -12,20 +12,25 @@
 //      fraction of the boxes.  On the 600x1000 training frame (12 000 boxes, ~90 % suppressed) the pair count drops from 72 M to
 //      ~2 M (top 2048) + ~3-10 M (rest x S0) + ~1-8 M (survivors); results are identical by construction.
 //
-//  nms_kernel<CLS>   : one LEVEL (relation + resolution in one launch).  Tile workgroups enumerate the lower-triangular 64 x 64
-//      tiles of the suppression relation in PULL orientation (one wave per tile; lane = the lower-scored box; the 64 candidate
-//      suppressors staged in LDS and read back as wave-uniform broadcast ds_read_b128; 16 VALU per pair, no division: see sup_half).
-//      Only NON-ZERO words are stored (sup[i][rb]) + a per-box bitmap of which words are non-zero (nz).  Resolver workgroups (one
-//      64-box wave each, dispatched first) wait for their row's tile flags and then apply (1): a box walks its non-zero words in
-//      ascending order, several words per round trip.  Boxes may carry NaN / inf coordinates: such a pair is never decided by the
-//      division-free test (every compare with NaN is false), falls through to the exact IEEE division, and comes out as
-//      torchvision's `NaN > thr` = false (tests/test_gpu_ops.py: test_nms_nan_and_inf_boxes_follow_torchvision_semantics).
+//  nms_kernel<CLS, DENSE> : one LEVEL (relation + resolution [+ outputs] in one launch).  Tile workgroups enumerate the lower-triangular
+//      64 x 64 tiles of the suppression relation in PULL orientation (one wave per tile; lane = the lower-scored box; the 64 candidate
+//      suppressors staged in LDS and read back as wave-uniform broadcast ds_read_b128; no division: sup_half_pos, 11 VALU per pair
+//      on packed fp32, sup_half, 16, on the diagonal / tail / non-positive-area tiles).
+//      DENSE (K <= 16 384: every proposal stage and predict list): one coalesced 512-byte store per non-empty tile, a four-wave
+//      resolver workgroup per 64-box block, the outputs written by the resolver workgroup that finishes last -- see
+//      nms_resolve_block_dense.  Otherwise: non-zero words only (sup[i][rb]) + a per-box bitmap of which words are non-zero (nz),
+//      one-wave resolvers that walk a box's words in ascending order (nms_resolve_wave), outputs by nms_emit_kernel.
+//      Resolver workgroups are dispatched first, wait for their row's tile flags and then apply (1).  Boxes may carry NaN / inf
+//      coordinates: such a pair is never decided by the division-free test (every compare with NaN is false), falls through to the
+//      exact IEEE division, and comes out as torchvision's `NaN > thr` = false
+//      (tests/test_gpu_ops.py: test_nms_nan_and_inf_boxes_follow_torchvision_semantics).
 //  nms_filter_kernel<CLS> : the cascade step (2): every box below the top T against S0 (compacted into LDS by each workgroup from the
 //      level-0 kept bitmap); survivors are compacted IN ORDER into a second box array by a ticketed decoupled look-back over the
 //      workgroups' survivor counts (workgroups take their logical block from an atomic ticket, so a block only ever waits for
 //      blocks that are already running).
-//  nms_emit_kernel   : kept bitmaps of the level(s) -> the first post_k kept positions (score order), boxes, source indices, count.
-// K <= NMS_CASCADE_MIN boxes (the FPN stage's 4000, predict's per-image lists) run one level directly.
+//  nms_emit_kernel   : kept bitmaps of the level(s) -> the first post_k kept positions (score order), boxes, source indices, count
+//      (cascade and generic layout; a dense single level writes them itself).
+// K <= NMS_CASCADE_MIN boxes (both proposal stages, predict's per-image lists) run one level directly.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include <cstdlib>

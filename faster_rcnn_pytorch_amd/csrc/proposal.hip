@@ -1,9 +1,10 @@
 // proposal.hip -- RegionProposal.forward (models/model.py:12-58; FPN: models/new_model.py:49-86) as ONE
-// C call that enqueues five kernels and never touches the host:
-//   proposal_prologue -> topk_rank -> topk_scatter -> nms_mask -> nms_scan
-// The reference's version is ~20 eager launches, a full torch.sort, three boolean-index host syncs
-// and torchvision's NMS (device mask -> host scan).  Counts stay on the device (top-k count feeds
-// the NMS kernels through a device int32), so the step is graph-capturable.
+// C call that never touches the host.  Launches at 600x1000 (N = 20 646): proposal_prologue (decode + scores, with the sample sort's
+// splitter sampling in its first workgroups) -> topk_partition (count + place behind a grid barrier) -> topk_bucket (ranks, gathers the
+// boxes) -> nms_kernel (relation + resolution + outputs); at FPN size the bucket ranking rides in the partition launch: three launches.
+// The reference's version is ~20 eager launches, a full torch.sort, three boolean-index host syncs and torchvision's NMS (device mask ->
+// host scan).  Counts stay on the device (the top-k count feeds the NMS kernel through a device int32), so the step is
+// graph-capturable; the prologue also clears the NMS stage's zero region: no memset node.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 

@@ -4,13 +4,16 @@
 //            models/model_.py:127-179 (VGG head), models/new_model.py:157-206 (FPN head).
 // The reference builds an [n_anchor, G] IoU matrix with ~25 eager launches, syncs the host 4-6
 // times (boolean indexing, `if n_pos > 128`) and draws torch.randperm on the CPU.  Here:
-//   rpn_colmax_kernel : per-GT best anchor, packed (iou_bits << 32 | ~index) + atomicMax (LDS, then global)
-//   rpn_label_kernel  : per-anchor max/argmax over the G boxes held in SGPRs (scalar loads), label,
-//                       encode(), counts -- the IoU matrix is never materialised
-//   rpn_sample_kernel : one workgroup; either consumes the reference's permutations (parity mode) or
-//                       selects by smallest Philox key with an LDS radix select (no host sync)
-//   head_targets_kernel: one workgroup does IoU + ordered compaction + sampling + encode for <= 4096
-//                       candidates and writes the fixed [total] rows.
+//   rpn_match_kernel  : device-RNG mode (the product's default): column maxima -> grid barrier -> labels + Philox keys + key histogram
+//                       -> (N <= 24 576) the last workgroup finishes the sampling: ONE launch; FPN size: + rpn_apply_kernel.
+//                       The IoU matrix is never materialised.
+//   rpn_colmax_kernel -> rpn_label_kernel -> rpn_sample_kernel : the staged form (parity mode: the sampler consumes the reference's
+//                       permutations; also device-RNG with a radix select, kept behind FRCNN_RPN_FUSED=0 / FRCNN_RPN_SAMPLE=block)
+//   rpn_samp_hist / rpn_samp_apply : the staged chip-wide sampler for grids that cannot be co-resident
+//   head_targets_kernel: one workgroup does IoU + ordered compaction + sampling (key histogram + boundary-bin ranking) + encode for
+//                       <= 4096 candidates and writes the fixed [total] rows.
+// Sampling semantics in device-RNG mode: keep the candidates with the smallest (Philox4x32-10 key, position) pairs = the reference's
+// randperm sampling run with perm = argsort of the keys (oracle/philox_ref.py; tests compare bit for bit).
 #include "frcnn_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -18,7 +21,8 @@
 #include "frcnn_internal.h"
 
 #define EPS_JACCARD 1e-5f
-#define RS_LDS_MAX 24576              // rpn_sample keeps the Philox keys of up to this many anchors in LDS (96 KB)
+#define RS_LDS_MAX 24576              // rpn_sample_kernel keeps the Philox keys of up to this many anchors in LDS (96 KB); also the largest N
+                                      // whose sampling the last workgroup of rpn_match_kernel finishes itself (one sweep round of 24 per thread)
 
 // IoU of candidate box `b` against gt `g` in the operand order of the reference variant
 __device__ __forceinline__ float iou_variant(int variant, float4 b, float4 g)

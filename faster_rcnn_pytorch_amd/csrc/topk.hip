@@ -106,13 +106,15 @@ __global__ __launch_bounds__(256) void topk_scatter_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // N >= 4096: SAMPLE SORT on the composite key  key64 = f2key(score) << 32 | ~index  (all keys distinct, order = score descending,
 // index ascending, so ties need no special case and cannot unbalance anything):
-//   topk_sample_kernel   one workgroup rank-sorts 512 / 1024 evenly spaced samples and keeps every stride-th as a splitter (255);
-//   topk_count_kernel    every key finds its bucket (binary search over the splitters in LDS) -> 256 bucket sizes, #valid;
-//   topk_place_kernel    exclusive scan of the sizes (recomputed per block) + one atomic slot per key: buckets become contiguous
-//                        segments of a scratch array (order inside a segment is arbitrary);
-//   topk_bucket_kernel   one workgroup per bucket whose first rank is < K: rank inside the bucket (~80^2 compares at N = 20 646;
-//                        the keys are staged in LDS) + the bucket's base = the exact rank; index, score and box are scattered to
-//                        that position (the gather at model.py:48 stays fused).
+//   splitters            S = 512 / 2048 evenly spaced samples rank-sorted among themselves, every stride-th kept (255): ss_sample_body in
+//                        topk_dev.h -- inside the proposal prologue's launch, or topk_sample_kernel for the generic entry points;
+//   topk_partition       every key finds its bucket (binary search over the splitters in LDS) -> bucket sizes, #valid; GRID BARRIER;
+//                        exclusive scan of the sizes + one atomic slot per key: buckets become contiguous segments of a scratch array
+//                        (order inside a segment is arbitrary); <true>: a second barrier, then the ranking below in the same launch
+//                        (topk_count_kernel / topk_place_kernel: the same as two launches, for grids that cannot be co-resident);
+//   topk_bucket_kernel   one workgroup per bucket (and part) whose first rank is < K: rank inside the bucket (~80^2 compares at
+//                        N = 20 646; the keys are staged in LDS) + the bucket's base = the exact rank; index, score and box are
+//                        scattered to that position (the gather at model.py:48 stays fused).
 // Work N * (8 + N / 256) compares instead of N^2: the chip-wide rank sort above took 34 us + 11 us (scatter) at N = 20 646 and
 // the radix-select pre-filter of round 1 57 us + 6 us at N = 268 569 (four histogram / compaction launches before its rank sort).
 // ------------------------------------------------------------------------------------------------
