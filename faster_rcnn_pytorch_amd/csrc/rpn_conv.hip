@@ -892,12 +892,11 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
             store_a((i + 1) & 1, S0); store_f(y + 2, S0);
             load_a(y + 3, S0); load_f(y + 4, S0);
         }
-        {   // odd row: only the COMPUTE depends on whether the row exists.  The stores and (clamped) loads run regardless: with them under
-            // the condition, the paths into the loop's back edge carried different sets of outstanding loads and the compiler fell back
-            // to s_waitcnt vmcnt(0) in front of every LDS store -- the two-rows-ahead prefetch was one row deep (ISA, round 3)
+        if (i + 1 < n_rows) {   // (making only the compute conditional -- so that the compiler can count vmcnt across the back edge instead of
+                                // waiting vmcnt(0) in front of the stores -- measured 7 us SLOWER on the same box: 202.5 against 195 us)
             const int y = y_first + i + 1;
             __syncthreads();
-            if (i + 1 < n_rows) compute(y, (i + 1) & 1);
+            compute(y, (i + 1) & 1);
             store_a(i & 1, S1); store_f(y + 2, S1);
             load_a(y + 3, S1); load_f(y + 4, S1);
         }
