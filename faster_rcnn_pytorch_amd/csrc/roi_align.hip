@@ -217,6 +217,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
     const size_t plane = (size_t)H * W;
     int cb = (fh >= 1 && fw >= 1 && fp <= RA_FWD_LDS) ? min(RA_FWD_LDS / fp, RA_FWD_CG) : 0;
     if (__syncthreads_or(!inside && grp < 5)) cb = 0;     // (cannot happen for finite boxes; keeps the LDS path in-bounds regardless)
+    if (cb > 0) {                                        // equal passes, a multiple of the loads in flight where the buffer allows: 19 + 13 channels
+        const int ncg = c_end - c0, npass = (ncg + cb - 1) / cb;     // cost 3 + 2 rounds of dependent loads per pixel, 16 + 16 cost 2 + 2
+        int eq = (ncg + npass - 1) / npass;
+        eq = (eq + RA_FWD_INFLIGHT - 1) / RA_FWD_INFLIGHT * RA_FWD_INFLIGHT;
+        cb = min(cb, eq);
+    }
     int o[4][4];
     {
         const int stride = cb == 0 ? W : fwp, by = cb == 0 ? 0 : y0, bx = cb == 0 ? 0 : x0;
@@ -253,8 +259,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
         __syncthreads();
         // 32-bit element offsets from the level's base (a level has < 2^31 elements: checked by the host)
         const unsigned off0 = (unsigned)cbase * (unsigned)plane + (unsigned)(y0 * W + x0), uplane = (unsigned)plane;
+#ifdef RA_FWD_ROWCOL                   // round 2's mapping: lane = (column t % 32, row group t / 32): lanes with column >= fw idle
         for (int yb = rg; yb < fh; yb += 8)
             for (int xx = xi; xx < fw; xx += 32) {
+#else                                  // lane = footprint pixel t, t + 256, ..: every lane has work whatever the footprint's width (one
+                                       // float division per pixel and lane; rounds of dependent loads: ceil(fh fw / 256) instead of
+                                       // ceil(fh / 8) ceil(fw / 32) per eight channels)
+        (void)xi; (void)rg;
+        const float inv_fw = 1.0f / (float)fw;
+        for (int i = t; i < fh * fw; i += 256) {
+            {
+                int yb = (int)(((float)i + 0.5f) * inv_fw);
+                int xx = i - yb * fw;
+                if (xx < 0) { --yb; xx += fw; } else if (xx >= fw) { ++yb; xx -= fw; }
+#endif
                 unsigned off = off0 + (unsigned)(yb * W + xx);
                 float *dst = s_f + yb * fwp + xx;
                 for (int c = 0; c < n; c += RA_FWD_INFLIGHT, off += RA_FWD_INFLIGHT * uplane) {
@@ -265,6 +283,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
                     for (int u = 0; u < RA_FWD_INFLIGHT; ++u) if (c + u < n) dst[(c + u) * fp] = v[u];
                 }
             }
+#ifndef RA_FWD_ROWCOL
+        }
+#endif
         __syncthreads();
         if (grp < 5)
             for (int c = grp; c < n; c += 5) {
