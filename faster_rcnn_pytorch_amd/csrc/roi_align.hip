@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
         {
             const float *src = grad_out + ((size_t)s_list[0].r * C + c0) * 49;
 #pragma unroll
-            for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
+            for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];   // unconditional (clamped; masked at the LDS store): no exec-masked block per load
         }
         for (int i = 0; i < m; ++i) {
             const int buf = i & 1;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
             if (i + 1 < m) {
                 const float *src = grad_out + ((size_t)s_list[i + 1].r * C + c0) * 49;
 #pragma unroll
-                for (int u = 0; u < RT_PF; ++u) if (t + 256 * u < ne) pg[u] = src[t + 256 * u];
+                for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];   // unconditional (clamped; masked at the LDS store): no exec-masked block per load
             }
             {
                 // the two tables are spread over three waves (one 1-D bilinear set-up pair per lane): wave 1 builds Wx (lanes 64..119 =
