@@ -153,6 +153,19 @@ def test_topk_large_n_with_heavy_ties_and_few_valid(ops):
     assert int(cnt.item()) == 500 and np.array_equal(idx[:500].cpu().numpy(), idx_o)
 
 
+def test_topk_above_the_coresident_grid_limit(ops):
+    """N > 1 048 576 scores: the partition's grid (N / 1024 workgroups) is above what the launcher treats as certainly co-resident, so
+    the sample sort takes its barrier-free three-launch form (topk_count / topk_place / topk_bucket) by itself."""
+    rng = np.random.RandomState(8)
+    N, K = 1_100_000, 5000
+    s = rng.rand(N).astype(np.float32)
+    s[rng.rand(N) < 0.2] = -1.0
+    order = np.lexsort((np.arange(N), -s.astype(np.float64)))[:K]          # score descending, index ascending
+    idx, sc, _, cnt = ops.topk_sorted(T(s), K)
+    assert int(cnt.item()) == K
+    assert np.array_equal(idx.cpu().numpy(), order) and np.array_equal(sc.cpu().numpy(), s[order])
+
+
 def test_topk_ties_resolve_by_index(ops):
     rng = np.random.RandomState(7)
     N = 5000
