@@ -687,6 +687,30 @@ def test_rpn_targets_device_sampling_equals_reference_with_philox_permutations(o
             assert n_pos > 128                                       # the positive class was subsampled too
 
 
+def test_rpn_targets_staged_chipwide_sampler_equals_reference_with_philox_permutations():
+    """The staged form at FPN size (rpn_colmax -> rpn_label -> three histogram levels -> apply: what the launcher falls back to when the
+    fused grid could not be co-resident) draws the same Philox keys: a child process with FRCNN_RPN_FUSED=0 must reproduce the labels
+    the oracle gives for the Philox permutations, with a subsampled positive class."""
+    import os, subprocess, sys, tempfile
+    from oracle import philox_ref
+    rng = np.random.RandomState(33)
+    anchor = orc.tv_anchor_grid(800, 1344, [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)], normalise=True)
+    ins = np.nonzero((anchor[:, 0] >= 0) & (anchor[:, 1] >= 0) & (anchor[:, 2] <= 1) & (anchor[:, 3] <= 1))[0]
+    gt = anchor[ins[rng.choice(len(ins), 180, replace=False)]]
+    pre, _, (n_pos, n_neg) = orc.rpn_targets(anchor, gt, variant=1)
+    assert n_pos > 128
+    pp = philox_ref.sampling_perm(21, 6, 1, np.nonzero(pre == 1)[0]); pn = philox_ref.sampling_perm(21, 6, 0, np.nonzero(pre == 0)[0])
+    cls_o = orc.rpn_targets(anchor, gt, pp, pn, variant=1)[0]
+    code = ("import numpy as np, torch, sys; from faster_rcnn_pytorch_amd import ops; d = sys.argv[1];"
+            "a = torch.from_numpy(np.load(d + '/anchor.npy')).cuda(); g = torch.from_numpy(np.load(d + '/gt.npy')).cuda();"
+            "np.save(d + '/out.npy', ops.rpn_targets(a, g, variant=1, seed=21, offset=6)[0].cpu().numpy())")
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "anchor.npy"), anchor), np.save(os.path.join(d, "gt.npy"), gt)
+        env = dict(os.environ, FRCNN_RPN_FUSED="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", code, d], check=True, env=env, timeout=300)
+        assert np.array_equal(np.load(os.path.join(d, "out.npy")), cls_o)
+
+
 @pytest.mark.parametrize("variant,label_offset,max_pos,total,P", [(0, 1, 32, 128, 2000), (1, 0, 128, 512, 1000), (0, 1, 32, 128, 300)])
 def test_head_targets_device_sampling_equals_reference_with_philox_permutations(ops, variant, label_offset, max_pos, total, P):
     """FastRcnnTargetMaker in device-RNG mode = the reference (models/model.py:318-345) with perm = argsort of the Philox keys of the
