@@ -339,6 +339,9 @@ static_assert(128 + RT_TH * 7 <= 256 && 64 + RT_TW * 7 <= 128, "weight-table lan
 #define RT_ATTR
 #endif
 #define RT_GS 49                         // LDS stride of a channel's 49 dOut values
+#define RT_TS 112                        // LDS stride of a channel PAIR's 7 x 8 column-reduced values: [bin row][column][2]
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static_assert(RT_TH == 16 && RT_TW == 8 && RT_CB == 32, "the pixel-lane phase maps 256 lanes to 16 x 8 pixels x 2 channel halves");
 #ifndef RS_SPLIT
 #define RS_SPLIT 24                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ... (12 / 16 / 24 / 48: 110 / 110 / 106 / 126 us for the four launches)
 #endif
@@ -402,23 +405,29 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
     if (t == 0) cnt[tile] = base;
 }
 
-// One workgroup: turns the list lengths into work items.  A non-empty tile q gets nseg(q) consecutive items from base[q] (an exclusive
-// prefix sum in tile order, so the assignment -- and with it the summation order -- is a function of the lists alone); an empty
-// tile gets none (its pixels are zero-filled by the fill workgroups of the main launch).  If the items do not fit the table the
-// split threshold is doubled until they do (cap >= tiles).  An item is ONE 16-byte record (tile, first entry, end entry,
-// seg | nseg << 8): a workgroup of the main kernel needs a single load before it can start; unused records carry tile = -1.
+// One workgroup: turns the list lengths into work items.  A non-empty tile q gets nseg(q) consecutive item NUMBERS from tbase[q] (an
+// exclusive prefix sum in tile order, so the cut of a list into segments -- and with it the summation order -- is a function of the
+// lists alone); an empty tile gets none (its pixels are zero-filled by the fill workgroups of the main launch).  If the items do not
+// fit the table the split threshold is doubled until they do (cap >= tiles).  The item RECORDS (tile, first entry, end entry,
+// seg | nseg << 8 -- one 16-byte load and a workgroup of the main kernel can start) are laid out LONGEST SEGMENT FIRST (a counting
+// sort by length; ties in arrival order, which moves records but no sums): the main kernel's workgroups are dispatched in record order
+// and each advances one RoI per step, so this is longest-processing-time-first scheduling over the CUs.  In tile order the launch took
+// as long as two rounds of the longest segments (57 us); sorted, [see profiles/README.md].  slot[item number] = record position, which
+// is also where a segment's partial tile goes (the combine kernel looks it up); unused records carry tile = -1.
 __device__ __forceinline__ int ra_items(int n, int split) { return n == 0 ? 0 : ra_nseg(n, split); }
 __global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
-                                                                  int32_t *__restrict__ tnseg, int4 *__restrict__ items)
+                                                                  int32_t *__restrict__ tnseg, int4 *__restrict__ items, int32_t *__restrict__ slot)
 {
     // block-wide exclusive scan of the per-thread item counts: wave scans by shuffles, 16 wave totals through LDS (two barriers;
     // the first version used a 256-thread Hillis-Steele scan with 16 barriers and took 8-10 us)
     __shared__ int s_wsum[16];
     __shared__ int s_total;
+    __shared__ int s_hist[64];                             // bucket b = 63 - min(length, 63)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (tiles + 1023) / 1024, q0 = t * per, q1 = min(q0 + per, tiles);
     int split = RS_SPLIT;
     int mine = 0, incl = 0;
+    if (t < 64) s_hist[t] = 0;
     for (;;) {
         mine = 0;
         for (int q = q0; q < q1; ++q) mine += ra_items(cnt[q], split);
@@ -433,13 +442,28 @@ __global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int
         if (s_total <= cap_items) break;
         split *= 2;                                        // (terminates: at split >= max(cnt) every tile has at most one item and tiles <= cap)
     }
-    int base = s_wsum[wave] + incl - mine;                 // exclusive prefix of my chunk
+    const int base0 = s_wsum[wave] + incl - mine;          // exclusive prefix of my chunk
     const int total = s_total;
     for (int q = q0; q < q1; ++q) {
         const int n = cnt[q], ns = ra_items(n, split);
+        for (int sgm = 0; sgm < ns; ++sgm) {
+            const int len = (int)((long long)n * (sgm + 1) / ns) - (int)((long long)n * sgm / ns);
+            atomicAdd(&s_hist[63 - min(len, 63)], 1);
+        }
+    }
+    __syncthreads();
+    if (t == 0) { int a = 0; for (int b = 0; b < 64; ++b) { const int v = s_hist[b]; s_hist[b] = a; a += v; } }
+    __syncthreads();
+    int base = base0;
+    for (int q = q0; q < q1; ++q) {
+        const int n = cnt[q], ns = ra_items(n, split);
         tbase[q] = base; tnseg[q] = ns;
-        for (int sgm = 0; sgm < ns; ++sgm)
-            items[base + sgm] = make_int4(q, (int)((long long)n * sgm / ns), (int)((long long)n * (sgm + 1) / ns), sgm | (ns << 8));
+        for (int sgm = 0; sgm < ns; ++sgm) {
+            const int lo = (int)((long long)n * sgm / ns), hi = (int)((long long)n * (sgm + 1) / ns);
+            const int k = atomicAdd(&s_hist[63 - min(hi - lo, 63)], 1);
+            items[k] = make_int4(q, lo, hi, sgm | (ns << 8));
+            slot[base + sgm] = k;
+        }
         base += ns;
     }
     for (int i = total + t; i < cap_items; i += 1024) items[i] = make_int4(-1, 0, 0, 0);
@@ -448,21 +472,37 @@ __global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int
 #define RF_CH 4                          // channels per fill workgroup
 struct FillLevels { int fill0[FRCNN_MAX_LEVELS + 1]; };   // first fill workgroup of level l: (row blocks of l) x (C / RF_CH) each
 
+#ifdef RT_TRACE      // developer build (tools/dev/ra_trace.py): per workgroup {start, first barrier, end, steps, XCC/CU id, kind} in 10 ns ticks
+__device__ unsigned long long g_rt_trace[32768][6];
+extern "C" __attribute__((visibility("default"))) void frcnn_ra_trace_read(void *dst) { hipDeviceSynchronize(); hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rt_trace), sizeof(g_rt_trace)); }
+#define RT_T(slot) do { if (threadIdx.x == 0 && blockIdx.x < 32768) g_rt_trace[blockIdx.x][slot] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RT_TV(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 32768) g_rt_trace[blockIdx.x][slot] = (unsigned long long)(v); } while (0)
+#else
+#define RT_T(slot) do { } while (0)
+#define RT_TV(slot, v) do { } while (0)
+#endif
 template <typename TOUT>
 __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, FillLevels FL, int C, int aligned,
                                                                          const float *__restrict__ grad_out, int n_cg, int cap, int n_item_blocks,
                                                                          const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
                                                                          const int4 *__restrict__ items, float *__restrict__ part)
 {
-    __shared__ float s_g[2][RT_CB * RT_GS];
-    __shared__ __attribute__((aligned(16))) float s_wy[2][RT_TH * 8];
+    __shared__ __attribute__((aligned(16))) float s_g[2][RT_CB * RT_GS];
+    __shared__ __attribute__((aligned(16))) float s_T[(RT_CB / 2) * RT_TS];   // column-reduced dOut of the current RoI: [channel pair][bin row][column][2]
+    __shared__ float s_wy[2][RT_TH * 8];
     __shared__ float s_wx[2][RT_TW * 8];
+    __shared__ unsigned long long s_mk[2][4];              // non-zero masks of the tables: [0] Wx (bit column * 7 + bin), [1] Wy rows 0..8, [2] Wy rows 9..15
     __shared__ RoiEnt s_list[RS_CHUNK];
     const int t = threadIdx.x;
+    RT_T(0); RT_TV(2, 0); RT_TV(5, (int)blockIdx.x >= n_item_blocks ? 2 : 1);
     if ((int)blockIdx.x >= n_item_blocks) {
         // ---- fill workgroup: 16 rows x the whole width x RF_CH channels of one level; zero where the owning tile's list is EMPTY
         // (nobody else writes those pixels).  A wave covers 64 consecutive pixels: 256-byte stores, where a tile's own zero-fill
-        // would write 32-byte pieces (the empty tiles' stores were 40 of the kernel's 80 us).
+        // would write 32-byte pieces (the empty tiles' stores were 40 of the kernel's 80 us).  These blocks come LAST in the grid:
+        // 68 MB of zeros at the FPN shape take 11 us at ~6 TB/s after the item workgroups have drained.  Measured and not better
+        // (tools/dev/ra_trace.py): fill blocks first (they hold every slot for 5-10 us and the items start that much later), every
+        // block storing a fill unit before or after its own item (gfx9 counts stores in vmcnt: the first s_waitcnt vmcnt(0) of the
+        // RoI loop waits for them; at the end they keep the slot from the next item).
         const int f = (int)blockIdx.x - n_item_blocks;
         int l = 0;
 #pragma unroll
@@ -478,46 +518,63 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                 for (int y = 0; y < ny; ++y) store_grad<TOUT>(out + (size_t)y * W, 0.0f);
             }
         }
+        RT_T(2);
         return;
     }
     // block -> (work item, channel group)  (n_cg = 8: blockIdx % 8 = channel group = XCD, so each L2 holds one eighth of dOut).
-    // Items are numbered in tile order = fine levels first; they are DISPATCHED in reverse: the coarse levels, whose tiles carry
-    // the long lists once the RPN has learnt to propose large boxes, start first.
+    // Records are sorted longest segment first (plan kernel) and workgroups are dispatched in that order.
     const int cg = blockIdx.x % n_cg;
-    const int item = n_item_blocks / n_cg - 1 - (int)(blockIdx.x / n_cg);
+    const int item = (int)(blockIdx.x / n_cg);
     const int4 rec = items[item];
     const int tile = rec.x;
-    if (tile < 0) return;
+    if (tile < 0) { RT_TV(5, 0); return; }
     const int lo = rec.y, hi = rec.z, nseg = rec.w >> 8;
+    RT_TV(3, hi - lo);
+    { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); RT_TV(4, (hw & 0xFFFF) | (xcc << 16)); }
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
     const int tl = tile - TL.tile0[l];
     const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
     const int H = L.H[l], W = L.W[l];
-    const int cx = t % RT_TW, cc = t / RT_TW;             // phase B: lane -> (column cx, channel cc of the group)
+    // phase B1: lane -> (column cx, channel pair cp, bin rows 0..3 | 4..6);  phase B2: lane -> (pixel (py, px), channel pairs 8 hs .. 8 hs + 7)
+    const int cx = t & 7, cp = (t >> 3) & 15, hs = __builtin_amdgcn_readfirstlane(t >> 7);
+    const int px = t & 7, py = ((t >> 6) & 1) * 8 + ((t & 63) >> 3);
     const int c0 = cg * RT_CB;
     const int nc = min(RT_CB, C - c0);
     const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
     const RoiEnt *mine = ent + (size_t)tile * cap;
 
-    float acc[RT_TH];
+    f32x2 acc[8];                                         // my pixel's sums for my 8 channel pairs
 #pragma unroll
-    for (int y = 0; y < RT_TH; ++y) acc[y] = 0.0f;
-    int goff[RT_PF];                                       // LDS position of my staged element t + 256 u (channel stride RT_GS)
-#pragma unroll
-    for (int u = 0; u < RT_PF; ++u) { const int e = t + 256 * u; goff[u] = (e / 49) * RT_GS + e % 49; }
-
+    for (int q = 0; q < 8; ++q) acc[q] = f32x2{0.0f, 0.0f};
+    // dOut[r][c0 .. c0 + 31][7][7] is 6272 contiguous bytes and goes to LDS as it lies.  With whole channel groups and 16-byte aligned
+    // rows it is moved by global_load_lds_dwordx4 (six 1 KB pieces + 128 bytes, wave w: pieces w and w + 4, wave 2 the tail): no
+    // registers, no ds_write; otherwise through registers (zero-padded to 32 channels).
+    const bool dma = nc == RT_CB && ((size_t)C * 49) % 4 == 0 && ((size_t)grad_out & 15) == 0;
+    const int wv4 = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
+    auto stage_dma = [&](int r, int buf) {
+        const float *src = grad_out + ((size_t)r * C + c0) * 49 + ln * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + wv4 * 256),
+                                         (__attribute__((address_space(3))) void *)(&s_g[buf][wv4 * 256]), 16, 0, 0);
+        if (wv4 < 2)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (wv4 + 4) * 256),
+                                             (__attribute__((address_space(3))) void *)(&s_g[buf][(wv4 + 4) * 256]), 16, 0, 0);
+        if (wv4 == 2 && ln < 8)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 6 * 256),
+                                             (__attribute__((address_space(3))) void *)(&s_g[buf][6 * 256]), 16, 0, 0);
+    };
     // the segment's entries go through LDS in chunks (a global load per RoI in the dependent chain cost 1-2 us each)
     for (int cb = lo; cb < hi; cb += RS_CHUNK) {
         const int m = min(RS_CHUNK, hi - cb);
         __syncthreads();                                   // the previous chunk's readers of s_list and of the table buffers are done
         if (t < m) s_list[t] = mine[cb + t];
         __syncthreads();
-        float pg[RT_PF];                                   // prefetched dOut elements t + 256 u of the next RoI
+        float pg[RT_PF];                                   // register path: prefetched dOut elements t + 256 u of the next RoI
 #pragma unroll
         for (int u = 0; u < RT_PF; ++u) pg[u] = 0.0f;
-        {
+        if (dma) stage_dma(s_list[0].r, 0);
+        else {
             const float *src = grad_out + ((size_t)s_list[0].r * C + c0) * 49;
 #pragma unroll
             for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];   // unconditional (clamped; masked at the LDS store): no exec-masked block per load
@@ -525,92 +582,129 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
         for (int i = 0; i < m; ++i) {
             const int buf = i & 1;
             const RoiEnt en = s_list[i];
-            // A: dOut tile -> LDS (zero-padded to RT_CB channels), weight tables of this RoI restricted to the tile
+            // A: dOut tile -> LDS, weight tables of this RoI restricted to the tile
+            if (!dma) {
 #pragma unroll
-            for (int u = 0; u < RT_PF; ++u)
-                if (t + 256 * u < RT_CB * 49) s_g[buf][goff[u]] = t + 256 * u < ne ? pg[u] : 0.0f;
-            if (i + 1 < m) {
-                const float *src = grad_out + ((size_t)s_list[i + 1].r * C + c0) * 49;
+                for (int u = 0; u < RT_PF; ++u)
+                    if (t + 256 * u < RT_CB * 49) s_g[buf][t + 256 * u] = t + 256 * u < ne ? pg[u] : 0.0f;
+                if (i + 1 < m) {
+                    const float *src = grad_out + ((size_t)s_list[i + 1].r * C + c0) * 49;
 #pragma unroll
-                for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];   // unconditional (clamped; masked at the LDS store): no exec-masked block per load
+                    for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];
+                }
             }
             {
                 // the two tables are spread over three waves (one 1-D bilinear set-up pair per lane): wave 1 builds Wx (lanes 64..119 =
                 // (column, bin)), waves 2 and 3 build Wy (lanes 128..239 = (row, bin)); wave 0 only moves dOut.  (All of it on wave 0 / 1
                 // put ~110 instructions on the critical path of every RoI step.)
-                if (t >= 64 && t < 64 + RT_TW * 7) {
+                if (t >= 64 && t < 128) {
                     const int q7 = t - 64, bin = q7 % 7, rc = q7 / 7;
                     const int x = tx0 + rc;
                     float wv = 0.0f;
+                    if (q7 < RT_TW * 7) {
 #pragma unroll
-                    for (int ix = 0; ix < 2; ++ix) {
-                        const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
-                        if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
+                        for (int ix = 0; ix < 2; ++ix) {
+                            const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
+                            if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
+                        }
+                        s_wx[buf][rc * 8 + bin] = wv;
                     }
-                    s_wx[buf][rc * 8 + bin] = wv;
+                    const unsigned long long bm = __ballot(wv != 0.0f);
+                    if (t == 64) s_mk[buf][0] = bm;
                 }
-                if (t >= 128 && t < 128 + RT_TH * 7) {
-                    const int q7 = t - 128, bin = q7 % 7, rc = q7 / 7;
+                if (t >= 128) {
+                    // wave 2: rows 0..8 (63 lanes), wave 3: rows 9..15 (49 lanes) -- a row's seven bins never straddle the two masks
+                    const int q6 = t & 63, q7 = (t >= 192 ? 63 : 0) + q6, bin = q7 % 7, rc = q7 / 7;
                     const int y = ty0 + rc;
                     float wv = 0.0f;
+                    if (q6 < (t >= 192 ? 49 : 63)) {
 #pragma unroll
-                    for (int iy = 0; iy < 2; ++iy) {
-                        const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
-                        if (q.ok) wv += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
+                        for (int iy = 0; iy < 2; ++iy) {
+                            const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
+                            if (q.ok) wv += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
+                        }
+                        s_wy[buf][rc * 8 + bin] = 0.25f * wv;
                     }
-                    s_wy[buf][rc * 8 + bin] = 0.25f * wv;
+                    const unsigned long long bm = __ballot(wv != 0.0f);
+                    if (q6 == 0) s_mk[buf][t >= 192 ? 2 : 1] = bm;
                 }
+            }
+            if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this RoI's dOut have landed
+            __syncthreads();
+#ifdef RT_TRACE
+            if (cb == lo && i == 0) RT_T(1);
+#endif
+            if (dma && i + 1 < m) stage_dma(s_list[i + 1].r, buf ^ 1);   // flies during B1 and B2 (the last readers of that buffer passed two barriers ago)
+            // B1: lane (column, channel pair, half of the bin rows): T[ph] = sum over the bins that reach my column of dOut[c][ph][bin] *
+            // Wx[column][bin], two channels per packed FMA.  The bins that reach a pixel are CONSECUTIVE (sample positions grow with the
+            // bin): first bin and count come from the table's non-zero mask; the trip count is the wave's maximum.  On its own pyramid
+            // level a RoI is 14..28 pixels wide, a bin 2..4 pixels, and a pixel hears from at most two bins: 2 x 7 products per channel
+            // where the dense form did 49.  (Adding the zero-weight terms changes nothing: bit-identical to the dense sums.)
+            {
+                const unsigned bx = (unsigned)(s_mk[buf][0] >> (cx * 7)) & 127u;
+                const int b0 = bx ? __builtin_ctz(bx) : 0, spx = bx ? 32 - __builtin_clz(bx) - b0 : 0;
+                int nbx = 0;
+                while (nbx < 7 && __ballot(spx > nbx) != 0ull) ++nbx;
+                f32x2 T[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) T[q] = f32x2{0.0f, 0.0f};
+                for (int j = 0; j < nbx; ++j) {
+                    const int b = min(b0 + j, 6);
+                    const float w = j < spx ? s_wx[buf][cx * 8 + b] : 0.0f;
+                    const f32x2 w2 = {w, w};
+                    const float *gp = &s_g[buf][cp * (2 * RT_GS) + hs * 28 + b];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < 3 || hs == 0) T[q] = __builtin_elementwise_fma(f32x2{gp[q * 7], gp[q * 7 + RT_GS]}, w2, T[q]);
+                }
+                f32x2 *tp = (f32x2 *)&s_T[cp * RT_TS + (hs * 32 + cx) * 2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < 3 || hs == 0) tp[q * 8] = T[q];
             }
             __syncthreads();
-            // B: T[ph] for (cc, cx), then the tile rows the footprint reaches (uniform bounds, from the list entry)
-            const int ya = __builtin_amdgcn_readfirstlane(en.rows & 0xFF), yb = __builtin_amdgcn_readfirstlane(en.rows >> 8);
-            float wx[7];
+            // B2: lane (pixel, 8 channel pairs): acc[pair] += sum over the bin rows that reach my row of Wy[row][bin] * T[pair][bin][column]
+            {
+                const unsigned by = (unsigned)(s_mk[buf][py >= 9 ? 2 : 1] >> ((py >= 9 ? py - 9 : py) * 7)) & 127u;
+                const int p0 = by ? __builtin_ctz(by) : 0, spy = by ? 32 - __builtin_clz(by) - p0 : 0;
+                int nby = 0;
+                while (nby < 7 && __ballot(spy > nby) != 0ull) ++nby;       // 0: the footprint misses this wave's eight rows
+                for (int j = 0; j < nby; ++j) {
+                    const int p = min(p0 + j, 6);
+                    const float w = j < spy ? s_wy[buf][py * 8 + p] : 0.0f;
+                    const f32x2 w2 = {w, w};
+                    const f32x2 *tp = (const f32x2 *)&s_T[hs * 8 * RT_TS + (p * 8 + px) * 2];
 #pragma unroll
-            for (int pw = 0; pw < 7; ++pw) wx[pw] = s_wx[buf][cx * 8 + pw];
-            // (reading the channel's 49 values as ds_read_b128 -- 52-float stride, or rows padded to 8 floats -- did not pay: 89 / 84 us against 80)
-            const float *gch = &s_g[buf][cc * RT_GS];
-            float T[7];
-#pragma unroll
-            for (int ph = 0; ph < 7; ++ph) {
-                float a = gch[ph * 7] * wx[0];
-#pragma unroll
-                for (int pw = 1; pw < 7; ++pw) a = __builtin_fmaf(gch[ph * 7 + pw], wx[pw], a);
-                T[ph] = a;
-            }
-#pragma unroll
-            for (int y = 0; y < RT_TH; ++y) {
-                if (y >= ya && y <= yb) {                 // scalar branch
-                    const float4 w0 = *(const float4 *)&s_wy[buf][y * 8], w1 = *(const float4 *)&s_wy[buf][y * 8 + 4];
-                    float a = acc[y];
-                    a = __builtin_fmaf(w0.x, T[0], a); a = __builtin_fmaf(w0.y, T[1], a); a = __builtin_fmaf(w0.z, T[2], a);
-                    a = __builtin_fmaf(w0.w, T[3], a); a = __builtin_fmaf(w1.x, T[4], a); a = __builtin_fmaf(w1.y, T[5], a);
-                    acc[y] = __builtin_fmaf(w1.z, T[6], a);
+                    for (int q = 0; q < 8; ++q) acc[q] = __builtin_elementwise_fma(w2, tp[q * (RT_TS / 2)], acc[q]);
                 }
             }
-            // no barrier here: the next A writes the OTHER buffers; the one after that is fenced by the next barrier
+            // no barrier here: the next A writes the OTHER table buffers, and its barrier stands between these reads of s_T and the next B1
         }
     }
     if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
-        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
-        {
+        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (hs * 16 * RT_TH + py) * RT_TW + px;
 #pragma unroll
-            for (int y = 0; y < RT_TH; ++y) dst[y * RT_TW] = acc[y];
-        }
+        for (int q = 0; q < 8; ++q) { dst[(2 * q) * (RT_TH * RT_TW)] = acc[q].x; dst[(2 * q + 1) * (RT_TH * RT_TW)] = acc[q].y; }
+        RT_T(2);
         return;
     }
-    // ---- the tile is complete: one coalesced store per row and channel
-    if (tx0 + cx < W && cc < nc) {
-        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;
+    // ---- the tile is complete: a wave stores eight 32-byte row pieces per channel
+    if (tx0 + px < W && ty0 + py < H) {
+        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + hs * 16) * H + ty0 + py) * W + tx0 + px;
 #pragma unroll
-        for (int y = 0; y < RT_TH; ++y)
-            if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[y]);
+        for (int q = 0; q < 8; ++q) {
+            if (hs * 16 + 2 * q < nc) store_grad<TOUT>(out + (size_t)(2 * q) * H * W, acc[q].x);
+            if (hs * 16 + 2 * q + 1 < nc) store_grad<TOUT>(out + (size_t)(2 * q + 1) * H * W, acc[q].y);
+        }
     }
+    RT_T(2);
 }
 
 // split tiles only: partial tiles added in segment order, plane written once
 template <typename TOUT>
 __global__ __launch_bounds__(256) void roi_align_bwd_combine_kernel(MsLevels L, TileLevels TL, int C, int n_cg, const int32_t *__restrict__ tbase,
-                                                                    const int32_t *__restrict__ tnseg, const float *__restrict__ part)
+                                                                    const int32_t *__restrict__ tnseg, const int32_t *__restrict__ slot,
+                                                                    const float *__restrict__ part)
 {
     const int t = threadIdx.x;
     const int cg = blockIdx.x % n_cg, tile = blockIdx.x / n_cg;
@@ -625,13 +719,17 @@ __global__ __launch_bounds__(256) void roi_align_bwd_combine_kernel(MsLevels L, 
     const int cx = t % RT_TW, cc = t / RT_TW;
     const int c0 = cg * RT_CB;
     const int nc = min(RT_CB, C - c0);
-    const float *src = part + ((size_t)tbase[tile] * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
-    const size_t stride = (size_t)n_cg * (RT_CB * RT_TH * RT_TW);   // from one segment's partial tile to the next
+    const int32_t *sl = slot + tbase[tile];                          // record position of segment s = where its partial tile lies
+    const size_t mine = (size_t)cg * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
+    const size_t stride = (size_t)n_cg * (RT_CB * RT_TH * RT_TW);   // from one record's partial tiles to the next
     float acc[RT_TH];
+    {
+        const float *p = part + (size_t)sl[0] * stride + mine;
 #pragma unroll
-    for (int y = 0; y < RT_TH; ++y) acc[y] = src[y * RT_TW];
+        for (int y = 0; y < RT_TH; ++y) acc[y] = p[y * RT_TW];
+    }
     for (int sgm = 1; sgm < nseg; ++sgm) {
-        const float *p = src + (size_t)sgm * stride;
+        const float *p = part + (size_t)sl[sgm] * stride + mine;
 #pragma unroll
         for (int y = 0; y < RT_TH; ++y) acc[y] += p[y * RT_TW];
     }
@@ -701,7 +799,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
 }
 
 // workspace of the 7 x 7 tile gather: list lengths, lists (capacity R per tile), the plan, partial tiles of split tiles
-struct RaBwdWs { int32_t *cnt, *tbase, *tnseg; int4 *items; RoiEnt *ent; float *part; int cap_items; size_t total; };
+struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *slot; int4 *items; RoiEnt *ent; float *part; int cap_items; size_t total; };
 static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
 {
     RaBwdWs w; char *p = (char *)ws; size_t o = 0;
@@ -713,6 +811,7 @@ static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
     w.tbase = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.tnseg = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.items = (int4 *)take((size_t)(cap_items + RS_NSEG) * sizeof(int4));
+    w.slot = (int32_t *)take((size_t)(cap_items + RS_NSEG) * 4);
     w.ent = (RoiEnt *)take((size_t)tiles * (size_t)(R > 0 ? R : 1) * sizeof(RoiEnt));
     w.part = (float *)take((size_t)cap_items * n_cg * (RT_CB * RT_TH * RT_TW) * sizeof(float));
     w.total = o;
@@ -760,7 +859,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
                      k_min, s0, k0, cap, w.cnt, w.ent);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
-        FRCNN_LAUNCH(roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items);
+        FRCNN_LAUNCH(roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items, w.slot);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
         FillLevels FLv;
         int64_t fills = 0;
@@ -775,7 +874,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
                      grad_out, n_cg, cap, (int)n_item_blocks, w.cnt, w.ent, w.items, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
         FRCNN_LAUNCH((roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
-                     w.tnseg, w.part);
+                     w.tnseg, w.slot, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_combine_kernel");
         return FRCNN_OK;
     }
