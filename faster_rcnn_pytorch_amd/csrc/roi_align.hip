@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 #define RT_PF ((RT_CB * 49 + 255) / 256) // dOut elements prefetched per lane
 static_assert(128 + RT_TH * 7 <= 256 && 64 + RT_TW * 7 <= 128, "weight-table lanes do not fit the workgroup");
 #ifndef RT_ATTR
-#define RT_ATTR
+#define RT_ATTR __attribute__((amdgpu_waves_per_eu(5, 8)))   // at most 96 registers (the register path; left alone it takes 97 = four workgroups a CU); the DMA path needs 73: six, which is what the LDS holds
 #endif
 #define RT_GS 49                         // LDS stride of a channel's 49 dOut values
 #define RT_TS 112                        // LDS stride of a channel PAIR's 7 x 8 column-reduced values: [bin row][column][2]
@@ -348,23 +348,109 @@ static_assert(RT_TH == 16 && RT_TW == 8 && RT_CB == 32, "the pixel-lane phase ma
 #ifndef RS_NSEG
 #define RS_NSEG 32                       // ... at most this many
 #endif
+#ifndef RS_CHUNK
 #define RS_CHUNK 64                      // list entries staged in LDS at a time
+#endif
+#ifndef RT_RING
+#define RT_RING 2                        // dOut / record buffers: RoI i is worked on while RT_RING - 1 later ones are in flight (3: no faster per step, and its 31 KB of LDS hold five workgroups a CU where 23.6 KB hold six: 70 against 65 us for the four launches)
+#endif
 
 struct TileLevels { int tile0[FRCNN_MAX_LEVELS + 1]; int tiles_x[FRCNN_MAX_LEVELS]; };
-struct __attribute__((aligned(8))) RoiEnt { int r; float sh, sw, bh, bw; int rows; };   // rows = first | last << 8 tile row the RoI reaches
+struct __attribute__((aligned(16))) RoiEnt { int r; float sh, sw, bh, bw; int rows; int rec; int pad; };   // rows = first | last << 8 tile row the RoI reaches; rec = its record for this tile, -1: none
+
+// The weight tables of one (RoI, tile) pair -- a 1 KB RECORD of 256 dwords:
+//   [  0, 64)  Wx[column 8][bin 8]      sum of the bilinear weights the two x samples of the bin put on the column (bin 7 unused)
+//   [ 64,192)  Wy[row 16][bin 8]        the same for the rows, times 1 / 4 (the sample count)
+//   [192,200)  column c: first bin with a non-zero weight | number of bins up to the last one << 8   (the bins that reach a pixel are
+//   [200]      the largest such number over the columns                                               CONSECUTIVE: sample positions grow with the bin)
+//   [201,205)  row group g (rows 4 g .. 4 g + 3): first bin that reaches any of the four rows | count << 8
+// They depend on the pair alone, and round 3's tile kernel rebuilt them in each of its C / 32 channel-group workgroups: ~65 of the ~170
+// VALU instructions a wave issued per RoI step, in a kernel that is VALU-issue bound (tools/dev/ra_trace.py).  Now wave-sized blocks
+// appended to the lists launch build every pair's record ONCE into a pool indexed (RoI, position of the tile in the RoI's footprint),
+// and the tile kernel fetches a record with one global_load_lds_dwordx4 of one wave.  A RoI whose footprint spans more than RA_MAXT
+// tiles has no records (rec = -1): its tables are built in the tile kernel by the same function (one wave, straight into LDS).
+#define RA_MAXT 16
+#define RA_REC 256
+#define RA_REC_COL 192
+#define RA_REC_NBX 200
+#define RA_REC_RG 201
+
+// pixel bounds of the samples of a RoI on its level (the lists kernel's hit test and the record index use the same numbers)
+struct RaFoot { int x0, x1, y0, y1; };
+__device__ __forceinline__ RaFoot ra_footprint(const AlignGeom &g, int H, int W)
+{
+    const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
+    const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
+    RaFoot f;
+    f.y0 = min(ya.lo, yb.lo); f.y1 = max(ya.hi, yb.hi); f.x0 = min(xa.lo, xb.lo); f.x1 = max(xa.hi, xb.hi);
+    return f;
+}
+
+// One whole wave builds the record of (RoI geometry, tile at (ty0, tx0)) into rec (global or LDS).
+__device__ __forceinline__ void ra_tables_wave(int H, int W, int ty0, int tx0, float sh, float sw, float bh, float bw, float *rec)
+{
+    const int lane = threadIdx.x & 63, bin = lane % 7, rc = lane / 7;
+    unsigned long long bm[3];
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {                 // 0: the 8 columns, 1: rows 0..7, 2: rows 8..15 -- (row | column, bin) = 56 lanes
+        const int D = pass == 0 ? W : H;
+        const int pix = pass == 0 ? tx0 + rc : ty0 + (pass - 1) * 8 + rc;
+        const float s0 = pass == 0 ? sw : sh, bs = pass == 0 ? bw : bh;
+        float wv = 0.0f;
+        if (lane < 56) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const Lin q = lin_setup(D, s0 + (float)bin * bs + ((float)i + 0.5f) * bs / 2.0f);
+                if (q.ok) wv += (q.lo == pix ? q.wlo : 0.0f) + (q.hi == pix ? q.whi : 0.0f);
+            }
+            rec[pass == 0 ? rc * 8 + bin : 64 + ((pass - 1) * 8 + rc) * 8 + bin] = pass == 0 ? wv : 0.25f * wv;
+        }
+        bm[pass] = __ballot(wv != 0.0f);                   // bit (row | column) * 7 + bin
+    }
+    if (lane < 8) {
+        const unsigned m = (unsigned)(bm[0] >> (lane * 7)) & 127u;
+        const int b0 = m ? __builtin_ctz(m) : 0, sp = m ? 32 - __builtin_clz(m) - b0 : 0;
+        ((unsigned *)rec)[RA_REC_COL + lane] = (unsigned)b0 | ((unsigned)sp << 8);
+        const unsigned long long any1 = __ballot(sp > 1), any2 = __ballot(sp > 2), any3 = __ballot(sp > 3), any4 = __ballot(sp > 4),
+                                 any5 = __ballot(sp > 5), any6 = __ballot(sp > 6), any0 = __ballot(sp > 0);
+        if (lane == 0)
+            ((unsigned *)rec)[RA_REC_NBX] = (any0 != 0) + (any1 != 0) + (any2 != 0) + (any3 != 0) + (any4 != 0) + (any5 != 0) + (any6 != 0);
+    }
+    if (lane >= 8 && lane < 12) {
+        const int g = lane - 8;
+        const unsigned m28 = (unsigned)(bm[1 + (g >> 1)] >> ((g & 1) * 28)) & 0xFFFFFFFu;
+        const unsigned u = (m28 | (m28 >> 7) | (m28 >> 14) | (m28 >> 21)) & 127u;
+        const int p0 = u ? __builtin_ctz(u) : 0, nb = u ? 32 - __builtin_clz(u) - p0 : 0;
+        ((unsigned *)rec)[RA_REC_RG + g] = (unsigned)p0 | ((unsigned)nb << 8);
+    }
+}
 
 template <typename TOUT> __device__ __forceinline__ void store_grad(TOUT *p, float v);
 template <> __device__ __forceinline__ void store_grad<float>(float *p, float v) { *p = v; }
 
 __device__ __forceinline__ int ra_nseg(int n, int split) { return n <= split ? 1 : min(RS_NSEG, (n + split - 1) / split); }
 
-// cnt[tile] = list length; ent[tile * cap + i] = the i-th RoI (index order) whose footprint meets the tile
+// cnt[tile] = list length; ent[tile * cap + i] = the i-th RoI (index order) whose footprint meets the tile.  Blocks >= tiles (when pool
+// is not NULL): wave w of block tiles + b builds record 4 b + w = (RoI, position in its footprint) -- see RA_MAXT above.
 __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, TileLevels TL, const float4 *__restrict__ rois, int R, int aligned,
-                                                                  int k_min, float s0, int k0, int cap, int32_t *__restrict__ cnt,
-                                                                  RoiEnt *__restrict__ ent)
+                                                                  int k_min, float s0, int k0, int cap, int tiles, int32_t *__restrict__ cnt,
+                                                                  RoiEnt *__restrict__ ent, float *__restrict__ pool)
 {
     __shared__ int s_woff[5];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if ((int)blockIdx.x >= tiles) {
+        const int q = ((int)blockIdx.x - tiles) * 4 + wave, r = q / RA_MAXT, k = q % RA_MAXT;
+        if (r >= R) return;
+        const float4 b = rois[r];
+        const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
+        const int H = L.H[l], W = L.W[l];
+        const AlignGeom g = align_geom(b, L.scale[l], 7, 7, 2, aligned != 0);
+        const RaFoot f = ra_footprint(g, H, W);
+        const int txa = f.x0 / RT_TW, ntx = f.x1 / RT_TW - txa + 1, tya = f.y0 / RT_TH, nty = f.y1 / RT_TH - tya + 1;
+        if (ntx * nty > RA_MAXT || k >= ntx * nty) return;
+        ra_tables_wave(H, W, (tya + k / ntx) * RT_TH, (txa + k % ntx) * RT_TW, g.sh, g.sw, g.bh, g.bw, pool + (size_t)q * RA_REC);
+        return;
+    }
     const int tile = blockIdx.x;
     int l = 0;
 #pragma unroll
@@ -379,18 +465,18 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
         const int r = rbase + t;
         bool hit = false;
         RoiEnt e;
-        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f; e.rows = 0;
+        e.r = r; e.sh = e.sw = e.bh = e.bw = 0.0f; e.rows = 0; e.rec = -1; e.pad = 0;
         if (r < R) {
             const float4 b = rois[r];
             const int lr = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
             if (lr == l) {
                 const AlignGeom g = align_geom(b, scale, 7, 7, 2, aligned != 0);
-                const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
-                const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
-                const int y0 = min(ya.lo, yb.lo), y1 = max(ya.hi, yb.hi), x0 = min(xa.lo, xb.lo), x1 = max(xa.hi, xb.hi);
-                hit = y0 < ty0 + RT_TH && y1 >= ty0 && x0 < tx0 + RT_TW && x1 >= tx0;
+                const RaFoot f = ra_footprint(g, H, W);
+                hit = f.y0 < ty0 + RT_TH && f.y1 >= ty0 && f.x0 < tx0 + RT_TW && f.x1 >= tx0;
                 e.sh = g.sh; e.sw = g.sw; e.bh = g.bh; e.bw = g.bw;
-                e.rows = max(y0 - ty0, 0) | (min(y1 - ty0, RT_TH - 1) << 8);
+                e.rows = max(f.y0 - ty0, 0) | (min(f.y1 - ty0, RT_TH - 1) << 8);
+                const int txa = f.x0 / RT_TW, ntx = f.x1 / RT_TW - txa + 1, tya = f.y0 / RT_TH, nty = f.y1 / RT_TH - tya + 1;
+                if (pool && ntx * nty <= RA_MAXT) e.rec = r * RA_MAXT + (ty0 / RT_TH - tya) * ntx + (tx0 / RT_TW - txa);
             }
         }
         const unsigned long long bm = __ballot(hit);
@@ -472,6 +558,21 @@ __global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int
 #define RF_CH 4                          // channels per fill workgroup
 struct FillLevels { int fill0[FRCNN_MAX_LEVELS + 1]; };   // first fill workgroup of level l: (row blocks of l) x (C / RF_CH) each
 
+// 16 bytes per lane, global -> LDS at lds + lane * 16, as INLINE ASSEMBLY: behind the builtin the compiler tracks the transfer and puts
+// s_waitcnt vmcnt(0) in front of the next LDS read that might alias it (every read of the other ring buffers) and into __syncthreads() --
+// each RoI step then paid the full L2 round trip (1 us a step with no arithmetic at all).  The waits are counted by hand (ra_vm_wait).
+__device__ __forceinline__ void ra_dma16(const float *g, const float *lds)
+{
+    const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");   // (m0 is a reserved register the compiler sets right in front of the few instructions that read it; no other one here does)
+}
+template <int N> __device__ __forceinline__ void ra_vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ra_barrier()               // workgroup barrier that leaves the LDS-DMA in flight
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 #ifdef RT_TRACE      // developer build (tools/dev/ra_trace.py): per workgroup {start, first barrier, end, steps, XCC/CU id, kind} in 10 ns ticks
 __device__ unsigned long long g_rt_trace[32768][6];
 extern "C" __attribute__((visibility("default"))) void frcnn_ra_trace_read(void *dst) { hipDeviceSynchronize(); hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rt_trace), sizeof(g_rt_trace)); }
@@ -481,21 +582,22 @@ extern "C" __attribute__((visibility("default"))) void frcnn_ra_trace_read(void 
 #define RT_T(slot) do { } while (0)
 #define RT_TV(slot, v) do { } while (0)
 #endif
-template <typename TOUT>
+template <typename TOUT, bool DMA>
 __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, FillLevels FL, int C, int aligned,
-                                                                         const float *__restrict__ grad_out, int n_cg, int cap, int n_item_blocks,
+                                                                         const float *__restrict__ grad_out, int n_cg, int cap, int n_item_blocks, int n_first, int n_fill,
                                                                          const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
-                                                                         const int4 *__restrict__ items, float *__restrict__ part)
+                                                                         const int4 *__restrict__ items, const float *__restrict__ pool, float *__restrict__ part)
 {
-    __shared__ __attribute__((aligned(16))) float s_g[2][RT_CB * RT_GS];
+    __shared__ __attribute__((aligned(16))) float s_g[RT_RING][RT_CB * RT_GS];   // ring of three: dOut of the current RoI and of the next two (in flight)
     __shared__ __attribute__((aligned(16))) float s_T[(RT_CB / 2) * RT_TS];   // column-reduced dOut of the current RoI: [channel pair][bin row][column][2]
-    __shared__ float s_wy[2][RT_TH * 8];
-    __shared__ float s_wx[2][RT_TW * 8];
-    __shared__ unsigned long long s_mk[2][4];              // non-zero masks of the tables: [0] Wx (bit column * 7 + bin), [1] Wy rows 0..8, [2] Wy rows 9..15
+    __shared__ __attribute__((aligned(16))) float s_rec[RT_RING][RA_REC];   // likewise their weight-table records (layout: RA_REC_* above)
     __shared__ RoiEnt s_list[RS_CHUNK];
     const int t = threadIdx.x;
-    RT_T(0); RT_TV(2, 0); RT_TV(5, (int)blockIdx.x >= n_item_blocks ? 2 : 1);
-    if ((int)blockIdx.x >= n_item_blocks) {
+    // grid order: the first n_first item blocks (one full round of resident workgroups: the longest segments), the fill blocks, the other item blocks
+    const int bid = (int)blockIdx.x;
+    const bool is_fill = bid >= n_first && bid < n_first + n_fill;
+    RT_T(0); RT_TV(2, 0); RT_TV(5, is_fill ? 2 : 1);
+    if (is_fill) {
         // ---- fill workgroup: 16 rows x the whole width x RF_CH channels of one level; zero where the owning tile's list is EMPTY
         // (nobody else writes those pixels).  A wave covers 64 consecutive pixels: 256-byte stores, where a tile's own zero-fill
         // would write 32-byte pieces (the empty tiles' stores were 40 of the kernel's 80 us).  These blocks come LAST in the grid:
@@ -503,7 +605,7 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
         // (tools/dev/ra_trace.py): fill blocks first (they hold every slot for 5-10 us and the items start that much later), every
         // block storing a fill unit before or after its own item (gfx9 counts stores in vmcnt: the first s_waitcnt vmcnt(0) of the
         // RoI loop waits for them; at the end they keep the slot from the next item).
-        const int f = (int)blockIdx.x - n_item_blocks;
+        const int f = bid - n_first;
         int l = 0;
 #pragma unroll
         for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && f >= FL.fill0[q]) ? 1 : 0;
@@ -523,8 +625,9 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
     }
     // block -> (work item, channel group)  (n_cg = 8: blockIdx % 8 = channel group = XCD, so each L2 holds one eighth of dOut).
     // Records are sorted longest segment first (plan kernel) and workgroups are dispatched in that order.
-    const int cg = blockIdx.x % n_cg;
-    const int item = (int)(blockIdx.x / n_cg);
+    const int ib = bid < n_first ? bid : bid - n_fill;
+    const int cg = ib % n_cg;
+    const int item = ib / n_cg;
     const int4 rec = items[item];
     const int tile = rec.x;
     if (tile < 0) { RT_TV(5, 0); return; }
@@ -537,32 +640,36 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
     const int tl = tile - TL.tile0[l];
     const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
     const int H = L.H[l], W = L.W[l];
-    // phase B1: lane -> (column cx, channel pair cp, bin rows 0..3 | 4..6);  phase B2: lane -> (pixel (py, px), channel pairs 8 hs .. 8 hs + 7)
+    // phase B1: lane -> (column cx, channel pair cp, bin rows 0..3 | 4..6);  phase B2: lane -> (column px, rows 4 rg .. 4 rg + 3, channel pairs cq, cq + 8)
     const int cx = t & 7, cp = (t >> 3) & 15, hs = __builtin_amdgcn_readfirstlane(t >> 7);
-    const int px = t & 7, py = ((t >> 6) & 1) * 8 + ((t & 63) >> 3);
+    const int px = t & 7, cq = (t >> 3) & 7, rg = __builtin_amdgcn_readfirstlane(t >> 6);
     const int c0 = cg * RT_CB;
     const int nc = min(RT_CB, C - c0);
     const int ne = nc * 49;                               // valid dOut elements of one RoI for this channel group
     const RoiEnt *mine = ent + (size_t)tile * cap;
 
-    f32x2 acc[8];                                         // my pixel's sums for my 8 channel pairs
+    f32x2 acc[8];                                         // acc[2 r + p]: row 4 rg + r, channel pair cq + 8 p
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = f32x2{0.0f, 0.0f};
-    // dOut[r][c0 .. c0 + 31][7][7] is 6272 contiguous bytes and goes to LDS as it lies.  With whole channel groups and 16-byte aligned
-    // rows it is moved by global_load_lds_dwordx4 (six 1 KB pieces + 128 bytes, wave w: pieces w and w + 4, wave 2 the tail): no
-    // registers, no ds_write; otherwise through registers (zero-padded to 32 channels).
-    const bool dma = nc == RT_CB && ((size_t)C * 49) % 4 == 0 && ((size_t)grad_out & 15) == 0;
+    // dOut[r][c0 .. c0 + 31][7][7] is 6272 contiguous bytes and goes to LDS as it lies.  DMA (C a multiple of 32, 16-byte aligned dOut --
+    // the launcher decides): moved by global_load_lds_dwordx4 (six 1 KB pieces + 128 bytes, wave w: pieces w and w + 4, wave 2 the
+    // tail), no registers, no ds_write, two RoIs ahead; otherwise through registers, one RoI ahead (zero-padded to 32 channels).  Two
+    // instantiations, because a register-path load anywhere in the loop makes the compiler wait for vmcnt(0) at the loop's joins.
+    constexpr bool dma = DMA;
     const int wv4 = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
     auto stage_dma = [&](int r, int buf) {
         const float *src = grad_out + ((size_t)r * C + c0) * 49 + ln * 4;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + wv4 * 256),
-                                         (__attribute__((address_space(3))) void *)(&s_g[buf][wv4 * 256]), 16, 0, 0);
-        if (wv4 < 2)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (wv4 + 4) * 256),
-                                             (__attribute__((address_space(3))) void *)(&s_g[buf][(wv4 + 4) * 256]), 16, 0, 0);
-        if (wv4 == 2 && ln < 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 6 * 256),
-                                             (__attribute__((address_space(3))) void *)(&s_g[buf][6 * 256]), 16, 0, 0);
+        ra_dma16(src + wv4 * 256, &s_g[buf][wv4 * 256]);
+        if (wv4 < 2) ra_dma16(src + (wv4 + 4) * 256, &s_g[buf][(wv4 + 4) * 256]);
+        if (wv4 == 2 && ln < 8) ra_dma16(src + 6 * 256, &s_g[buf][6 * 256]);
+    };
+    // wave 3 brings the RoI's weight-table record: one global_load_lds_dwordx4 from the pool, or built here when the RoI has none
+    auto stage_rec = [&](const RoiEnt &e, int buf) {
+        if (wv4 != 3) return;
+        const int rec = __builtin_amdgcn_readfirstlane(e.rec);
+        if (rec >= 0) ra_dma16(pool + (size_t)rec * RA_REC + ln * 4, &s_rec[buf][0]);
+        else
+            ra_tables_wave(H, W, ty0, tx0, e.sh, e.sw, e.bh, e.bw, &s_rec[buf][0]);
     };
     // the segment's entries go through LDS in chunks (a global load per RoI in the dependent chain cost 1-2 us each)
     for (int cb = lo; cb < hi; cb += RS_CHUNK) {
@@ -573,16 +680,18 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
         float pg[RT_PF];                                   // register path: prefetched dOut elements t + 256 u of the next RoI
 #pragma unroll
         for (int u = 0; u < RT_PF; ++u) pg[u] = 0.0f;
+        // dOut and record of the next RT_RING - 1 RoIs are requested while RoI i is worked on
+        stage_rec(s_list[0], 0);
         if (dma) stage_dma(s_list[0].r, 0);
-        else {
+        if (RT_RING == 3 && m > 1) { stage_rec(s_list[1], 1); if (dma) stage_dma(s_list[1].r, 1); }
+        if (!dma) {
             const float *src = grad_out + ((size_t)s_list[0].r * C + c0) * 49;
 #pragma unroll
             for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];   // unconditional (clamped; masked at the LDS store): no exec-masked block per load
         }
+        int buf = 0;
         for (int i = 0; i < m; ++i) {
-            const int buf = i & 1;
-            const RoiEnt en = s_list[i];
-            // A: dOut tile -> LDS, weight tables of this RoI restricted to the tile
+            // A (register path only): dOut tile -> LDS
             if (!dma) {
 #pragma unroll
                 for (int u = 0; u < RT_PF; ++u)
@@ -593,64 +702,39 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                     for (int u = 0; u < RT_PF; ++u) pg[u] = src[min(t + 256 * u, ne - 1)];
                 }
             }
+            // RoI i's pieces have landed when at most the requests for RoI i + 1 are outstanding: two per wave (wave 3: its dOut piece
+            // and the record -- one if that RoI's tables are built here).  The register path waits for everything.
             {
-                // the two tables are spread over three waves (one 1-D bilinear set-up pair per lane): wave 1 builds Wx (lanes 64..119 =
-                // (column, bin)), waves 2 and 3 build Wy (lanes 128..239 = (row, bin)); wave 0 only moves dOut.  (All of it on wave 0 / 1
-                // put ~110 instructions on the critical path of every RoI step.)
-                if (t >= 64 && t < 128) {
-                    const int q7 = t - 64, bin = q7 % 7, rc = q7 / 7;
-                    const int x = tx0 + rc;
-                    float wv = 0.0f;
-                    if (q7 < RT_TW * 7) {
-#pragma unroll
-                        for (int ix = 0; ix < 2; ++ix) {
-                            const Lin q = lin_setup(W, en.sw + (float)bin * en.bw + ((float)ix + 0.5f) * en.bw / 2.0f);
-                            if (q.ok) wv += (q.lo == x ? q.wlo : 0.0f) + (q.hi == x ? q.whi : 0.0f);
-                        }
-                        s_wx[buf][rc * 8 + bin] = wv;
-                    }
-                    const unsigned long long bm = __ballot(wv != 0.0f);
-                    if (t == 64) s_mk[buf][0] = bm;
-                }
-                if (t >= 128) {
-                    // wave 2: rows 0..8 (63 lanes), wave 3: rows 9..15 (49 lanes) -- a row's seven bins never straddle the two masks
-                    const int q6 = t & 63, q7 = (t >= 192 ? 63 : 0) + q6, bin = q7 % 7, rc = q7 / 7;
-                    const int y = ty0 + rc;
-                    float wv = 0.0f;
-                    if (q6 < (t >= 192 ? 49 : 63)) {
-#pragma unroll
-                        for (int iy = 0; iy < 2; ++iy) {
-                            const Lin q = lin_setup(H, en.sh + (float)bin * en.bh + ((float)iy + 0.5f) * en.bh / 2.0f);
-                            if (q.ok) wv += (q.lo == y ? q.wlo : 0.0f) + (q.hi == y ? q.whi : 0.0f);
-                        }
-                        s_wy[buf][rc * 8 + bin] = 0.25f * wv;
-                    }
-                    const unsigned long long bm = __ballot(wv != 0.0f);
-                    if (q6 == 0) s_mk[buf][t >= 192 ? 2 : 1] = bm;
-                }
+                const int later = RT_RING == 2 || !dma || i + 1 >= m ? 0 : wv4 != 3 ? 2 : 1 + (__builtin_amdgcn_readfirstlane(s_list[min(i + 1, m - 1)].rec) >= 0 ? 1 : 0);
+                if (later == 2) ra_vm_wait<2>();
+                else if (later == 1) ra_vm_wait<1>();
+                else ra_vm_wait<0>();
             }
-            if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my pieces of this RoI's dOut have landed
-            __syncthreads();
+            ra_barrier();
 #ifdef RT_TRACE
             if (cb == lo && i == 0) RT_T(1);
 #endif
-            if (dma && i + 1 < m) stage_dma(s_list[i + 1].r, buf ^ 1);   // flies during B1 and B2 (the last readers of that buffer passed two barriers ago)
+            if (i + RT_RING - 1 < m) {                     // into the buffers RoI i - 1 used (their last readers passed this barrier)
+                const int nb2 = buf == 0 ? RT_RING - 1 : buf - 1;
+                stage_rec(s_list[i + RT_RING - 1], nb2);
+                if (dma) stage_dma(s_list[i + RT_RING - 1].r, nb2);
+            }
             // B1: lane (column, channel pair, half of the bin rows): T[ph] = sum over the bins that reach my column of dOut[c][ph][bin] *
             // Wx[column][bin], two channels per packed FMA.  The bins that reach a pixel are CONSECUTIVE (sample positions grow with the
-            // bin): first bin and count come from the table's non-zero mask; the trip count is the wave's maximum.  On its own pyramid
+            // bin): first bin and count come with the record; the trip count is the largest count of the tile's columns.  On its own pyramid
             // level a RoI is 14..28 pixels wide, a bin 2..4 pixels, and a pixel hears from at most two bins: 2 x 7 products per channel
             // where the dense form did 49.  (Adding the zero-weight terms changes nothing: bit-identical to the dense sums.)
             {
-                const unsigned bx = (unsigned)(s_mk[buf][0] >> (cx * 7)) & 127u;
-                const int b0 = bx ? __builtin_ctz(bx) : 0, spx = bx ? 32 - __builtin_clz(bx) - b0 : 0;
-                int nbx = 0;
-                while (nbx < 7 && __ballot(spx > nbx) != 0ull) ++nbx;
+                const unsigned *ri = (const unsigned *)s_rec[buf];
+                const unsigned ci = ri[RA_REC_COL + cx];
+                const int b0 = ci & 255u, spx = ci >> 8;
+                const int nbx = __builtin_amdgcn_readfirstlane(ri[RA_REC_NBX]);
                 f32x2 T[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) T[q] = f32x2{0.0f, 0.0f};
                 for (int j = 0; j < nbx; ++j) {
                     const int b = min(b0 + j, 6);
-                    const float w = j < spx ? s_wx[buf][cx * 8 + b] : 0.0f;
+                    const float w = j < spx ? s_rec[buf][cx * 8 + b] : 0.0f;
                     const f32x2 w2 = {w, w};
                     const float *gp = &s_g[buf][cp * (2 * RT_GS) + hs * 28 + b];
 #pragma unroll
@@ -662,40 +746,57 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
                 for (int q = 0; q < 4; ++q)
                     if (q < 3 || hs == 0) tp[q * 8] = T[q];
             }
-            __syncthreads();
-            // B2: lane (pixel, 8 channel pairs): acc[pair] += sum over the bin rows that reach my row of Wy[row][bin] * T[pair][bin][column]
+            ra_barrier();
+            // B2: lane (column, rows 4 rg .. 4 rg + 3 with rg = my wave, channel pairs cq and cq + 8): acc[row][pair] += sum over the bin rows
+            // that reach ANY of my four rows of Wy[row][bin] * T[pair][bin][column].  Four adjacent rows hear from three bins where
+            // each alone hears from two: 3 x 16 bytes of T per lane where one row per lane read 2 x 64.  The bin range is the wave's
+            // (scalar); the 4 x 7 weights of the wave's rows come with ONE ds_read_b32 (lane -> (row, bin offset)) and reach the packed
+            // FMAs as scalar operands through v_readlane.
             {
-                const unsigned by = (unsigned)(s_mk[buf][py >= 9 ? 2 : 1] >> ((py >= 9 ? py - 9 : py) * 7)) & 127u;
-                const int p0 = by ? __builtin_ctz(by) : 0, spy = by ? 32 - __builtin_clz(by) - p0 : 0;
-                int nby = 0;
-                while (nby < 7 && __ballot(spy > nby) != 0ull) ++nby;       // 0: the footprint misses this wave's eight rows
-                for (int j = 0; j < nby; ++j) {
-                    const int p = min(p0 + j, 6);
-                    const float w = j < spy ? s_wy[buf][py * 8 + p] : 0.0f;
-                    const f32x2 w2 = {w, w};
-                    const f32x2 *tp = (const f32x2 *)&s_T[hs * 8 * RT_TS + (p * 8 + px) * 2];
+                const unsigned gi = __builtin_amdgcn_readfirstlane(((const unsigned *)s_rec[buf])[RA_REC_RG + rg]);
+                const int p0 = gi & 255u, nb = gi >> 8;
+                if (nb != 0) {                               // else: the footprint misses this wave's four rows
+                    const int wr = (t >> 3) & 3, wj = p0 + (t & 7);
+                    const float wv = wj <= 6 ? s_rec[buf][64 + (rg * 4 + wr) * 8 + wj] : 0.0f;    // lane (row wr, bin p0 + (lane & 7)); zero outside the row's own bins
+                    const f32x2 *tp = (const f32x2 *)&s_T[cq * RT_TS + (p0 * 8 + px) * 2];
+                    for (int j = 0; j < nb; ++j) {
+                        const f32x2 t0 = tp[j * 8], t1 = tp[j * 8 + 4 * RT_TS];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc[q] = __builtin_elementwise_fma(w2, tp[q * (RT_TS / 2)], acc[q]);
+                        for (int r = 0; r < 4; ++r) {
+                            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), r * 8 + j));
+                            const f32x2 w2 = {w, w};
+                            acc[2 * r] = __builtin_elementwise_fma(w2, t0, acc[2 * r]);
+                            acc[2 * r + 1] = __builtin_elementwise_fma(w2, t1, acc[2 * r + 1]);
+                        }
+                    }
                 }
             }
-            // no barrier here: the next A writes the OTHER table buffers, and its barrier stands between these reads of s_T and the next B1
+            // no barrier here: the next step's barrier stands between these reads of s_T / s_rec and their next writers
+            buf = buf == RT_RING - 1 ? 0 : buf + 1;
         }
     }
     if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
-        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + (hs * 16 * RT_TH + py) * RT_TW + px;
+        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + ((2 * cq) * RT_TH + rg * 4) * RT_TW + px;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { dst[(2 * q) * (RT_TH * RT_TW)] = acc[q].x; dst[(2 * q + 1) * (RT_TH * RT_TW)] = acc[q].y; }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                dst[((16 * p) * RT_TH + r) * RT_TW] = acc[2 * r + p].x;
+                dst[((16 * p + 1) * RT_TH + r) * RT_TW] = acc[2 * r + p].y;
+            }
         RT_T(2);
         return;
     }
-    // ---- the tile is complete: a wave stores eight 32-byte row pieces per channel
-    if (tx0 + px < W && ty0 + py < H) {
-        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + hs * 16) * H + ty0 + py) * W + tx0 + px;
+    // ---- the tile is complete: a wave stores eight 32-byte row pieces per instruction
+    if (tx0 + px < W) {
+        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + 2 * cq) * H + ty0 + rg * 4) * W + tx0 + px;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (hs * 16 + 2 * q < nc) store_grad<TOUT>(out + (size_t)(2 * q) * H * W, acc[q].x);
-            if (hs * 16 + 2 * q + 1 < nc) store_grad<TOUT>(out + (size_t)(2 * q + 1) * H * W, acc[q].y);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                if (ty0 + rg * 4 + r < H && 2 * cq + 16 * p < nc) store_grad<TOUT>(out + ((size_t)(16 * p) * H + r) * W, acc[2 * r + p].x);
+                if (ty0 + rg * 4 + r < H && 2 * cq + 16 * p + 1 < nc) store_grad<TOUT>(out + ((size_t)(16 * p + 1) * H + r) * W, acc[2 * r + p].y);
+            }
     }
     RT_T(2);
 }
@@ -799,7 +900,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
 }
 
 // workspace of the 7 x 7 tile gather: list lengths, lists (capacity R per tile), the plan, partial tiles of split tiles
-struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *slot; int4 *items; RoiEnt *ent; float *part; int cap_items; size_t total; };
+struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *slot; int4 *items; RoiEnt *ent; float *pool, *part; int cap_items; size_t total; };
 static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
 {
     RaBwdWs w; char *p = (char *)ws; size_t o = 0;
@@ -813,6 +914,7 @@ static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
     w.items = (int4 *)take((size_t)(cap_items + RS_NSEG) * sizeof(int4));
     w.slot = (int32_t *)take((size_t)(cap_items + RS_NSEG) * 4);
     w.ent = (RoiEnt *)take((size_t)tiles * (size_t)(R > 0 ? R : 1) * sizeof(RoiEnt));
+    w.pool = (float *)take((size_t)(R > 0 ? R : 1) * RA_MAXT * RA_REC * sizeof(float));
     w.part = (float *)take((size_t)cap_items * n_cg * (RT_CB * RT_TH * RT_TW) * sizeof(float));
     w.total = o;
     return w;
@@ -856,8 +958,11 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         if (workspace_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "ms_roi_align_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
         const RaBwdWs w = carve_ra_bwd(workspace, tiles, R, n_cg);
         const int cap = (int)(R > 0 ? R : 1);
-        FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)tiles), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R, aligned,
-                     k_min, s0, k0, cap, w.cnt, w.ent);
+        static const bool use_records = [] { const char *e = getenv("FRCNN_RA_RECORDS"); return !e || atoi(e) != 0; }();
+        const int64_t table_blocks = use_records ? (R * RA_MAXT + 3) / 4 : 0;
+        FRCNN_REQUIRE(tiles + table_blocks < ((int64_t)1 << 31) && R * RA_MAXT < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)(tiles + table_blocks)), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R,
+                     aligned, k_min, s0, k0, cap, tiles, w.cnt, w.ent, use_records ? w.pool : nullptr);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
         FRCNN_LAUNCH(roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items, w.slot);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
@@ -870,8 +975,21 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         FLv.fill0[FRCNN_MAX_LEVELS] = (int)fills;
         const int64_t n_item_blocks = (int64_t)w.cap_items * n_cg;
         FRCNN_REQUIRE(n_item_blocks + fills < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
-        FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
-                     grad_out, n_cg, cap, (int)n_item_blocks, w.cnt, w.ent, w.items, w.part);
+        static const int resident = [] {                   // workgroups of the tile kernel the device holds at once
+            int dev = 0, cus = 256, per = 5;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, roi_align_bwd_tile_kernel<float, true>, 256, 0) != hipSuccess || per < 1) per = 5;
+            const char *e = getenv("FRCNN_RA_FIRST");
+            return e ? atoi(e) : cus * per;
+        }();
+        const int n_first = (int)std::min<int64_t>(n_item_blocks, (int64_t)resident / n_cg * n_cg);
+        if (C % RT_CB == 0 && ((size_t)grad_out & 15) == 0)
+            FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float, true>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
+                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part);
+        else
+            FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float, false>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
+                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
         FRCNN_LAUNCH((roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
                      w.tnseg, w.slot, w.part);

@@ -909,6 +909,32 @@ def test_ms_roi_align_bwd_plan_coarsens_when_the_item_table_is_too_small(ops):
     assert np.allclose(a, ref, rtol=2e-4, atol=2e-3), float(np.abs(a - ref).max())
 
 
+def test_ms_roi_align_bwd_records_and_in_kernel_tables_give_the_same_bits(ops):
+    """The weight tables of a (RoI, tile) pair are built once by the lists launch and fetched by the tile kernel as 1 KB records; a RoI
+    whose footprint spans more than 16 tiles -- or every RoI, with FRCNN_RA_RECORDS=0 (read once per process: a child process) -- has
+    them built inside the tile kernel by the same function.  Same bits either way, on the DMA (C = 256) and the register (C = 40) path."""
+    import os, subprocess, sys, tempfile
+    rng = np.random.RandomState(17)
+    code = ("import numpy as np, torch, sys; from faster_rcnn_pytorch_amd import ops; d = sys.argv[1]; C = int(sys.argv[2]);"
+            "rois = torch.from_numpy(np.load(d + '/rois.npy')).cuda(); go = torch.from_numpy(np.load(d + '/go%d.npy' % C)).cuda();"
+            "fts = [torch.zeros((1, C, h, w), device='cuda', requires_grad=True) for h, w in ((100, 168), (50, 84), (25, 42), (13, 21))];"
+            "ops.ms_roi_align(fts, rois, 7, 2).backward(go);"
+            "np.save(d + '/g%d.npy' % C, np.concatenate([f.grad.cpu().numpy().ravel() for f in fts]))")
+    rois = rand_boxes(rng, 200, 0.02, 0.7) * np.array([672, 400, 672, 400], np.float32)
+    rois[:8] = [[0, 0, 672, 400]] * 8                                             # whole image on the coarsest level: 2 x 3 tiles
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "rois.npy"), rois)
+        for Cc in (256, 40):
+            go = rng.randn(200, Cc, 7, 7).astype(np.float32)
+            np.save(os.path.join(d, "go%d.npy" % Cc), go)
+            fts = [torch.zeros((1, Cc, h, w), device=DEV, requires_grad=True) for h, w in ((100, 168), (50, 84), (25, 42), (13, 21))]
+            ops.ms_roi_align(fts, T(rois), 7, 2).backward(T(go))
+            here = np.concatenate([f.grad.cpu().numpy().ravel() for f in fts])
+            env = dict(os.environ, FRCNN_RA_RECORDS="0", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            subprocess.run([sys.executable, "-c", code, d, str(Cc)], check=True, env=env, timeout=300)
+            assert np.array_equal(np.load(os.path.join(d, "g%d.npy" % Cc)), here), Cc
+
+
 def test_ms_roi_align_bwd_tile_gather_is_reproducible_and_overwrites(ops):
     """The 7x7 / sampling-ratio-2 backward owns tiles instead of scattering atomics: two runs give identical bits, stale
     contents of the gradient buffers do not leak (the library overwrites), clustered RoIs (64 on one spot) and R = 0 work."""
