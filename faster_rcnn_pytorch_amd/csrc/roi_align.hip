@@ -306,25 +306,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 // Four launches:
 //  roi_align_bwd_lists_kernel   one workgroup per 16 x 8 pixel tile of any level: scans the RoIs (level + footprint recomputed
 //      from the box, ~150 instructions per RoI), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot
-//      compaction) as a list in the workspace, with the tile rows each of them reaches.  (Round 1 had every (tile, channel
-//      group) workgroup of the main kernel repeat this scan: 8x the work, and four barriers before the first useful load.)
-//  roi_align_bwd_plan_kernel    one workgroup: lists -> work items.  A list longer than RS_SPLIT entries is cut into segments.
-//  roi_align_bwd_tile_kernel    item workgroup = (tile, segment, 32 channels): lane = (column, channel) keeps 16 row accumulators in
-//      registers and walks its segment of the list; per RoI
-//        A: stores the prefetched dOut[r][32 ch][7][7] to LDS and builds the two separable weight tables restricted to the tile,
-//           Wy[16][7] and Wx[8][7] (lane = (row|col, bin): two 1-D bilinear set-ups each, gathered, no scatter / zero pass),
-//        B: forms its seven T[ph] = sum_pw dOut[c][ph][pw] * Wx[x][pw] in registers and adds sum_ph Wy[y][ph] * T[ph] to the
-//           accumulators of the rows the RoI reaches -- one barrier per RoI, LDS tables double-buffered.
+//      compaction) as a list in the workspace.  (Round 1 had every (tile, channel group) workgroup of the main kernel repeat
+//      this scan: 8x the work, and four barriers before the first useful load.)  One more workgroup per RoI builds the weight-table
+//      RECORDS of its (RoI, tile) pairs (RA_MAXT below).
+//  roi_align_bwd_plan_kernel    one workgroup: lists -> work items, longest first.  A list longer than RS_SPLIT entries is cut into segments.
+//  roi_align_bwd_tile_kernel    item workgroup = (tile, segment, 32 channels), one RoI per step.  dOut[r][32 ch][7][7] and the pair's record
+//      arrive by LDS-DMA one RoI ahead; then
+//        B1: lane (column, channel pair, half of the bin rows): T[bin row] = sum over the bins that reach the column of dOut * Wx -> LDS,
+//        B2: lane (column, four rows, two channel pairs): acc[row][pair] += sum over the bin rows that reach the four rows of Wy * T.
+//      The tables are SPARSE along both axes: on its own pyramid level a RoI is 14..28 pixels wide, a bin 2..4, and a pixel hears from
+//      at most two bins of the seven (the record carries first bin and count per column and per group of four rows; small RoIs on
+//      the finest level hear from up to seven and simply loop longer).  Round 2 multiplied all 7 x 7: 161 FMAs per lane and RoI
+//      where 2 x 7 + 3 x 8 packed ones do now -- same sums bit for bit, because the skipped terms are exact zeros.
 //      An unsplit tile is written exactly once, straight to the gradient plane; a segment writes its partial tile to the workspace.
 //      Fill workgroups in the same launch zero the pixels of tiles whose list is empty (whole rows: 256-byte stores).
 //  roi_align_bwd_combine_kernel adds the partial tiles of a split tile in SEGMENT ORDER and writes the plane.
 // The fp32 sum order is a function of the RoI list alone: bit-reproducible gradients, no atomics, nothing cleared beforehand.
-// Why segments: a workgroup advances one RoI per ~1 us, so the gather takes as long as the longest list.  Which tiles are hot moves
-// with training: on a fresh RPN the 147 tiles of the stride-8 level meet 30 RoIs on average and up to 71; 15 SGD steps later the
-// stride-16 level's 44 tiles meet 53 on average and up to 116 (tools/dev/roi_stats.py).  Round 2's first answer, a second kernel with
-// eight waves per tile for the COARSE levels, guessed the hot level from the pyramid shape, paid the scan 16 times per tile and took
-// 67-75 us; together with the fine kernel 137 us per step, this design 106.
-// (Tile shape sweep, micro-benchmark / FPN step: 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch 89/178.)
+// Why segments: a workgroup advances one RoI per ~1.2 us (a chain of LDS round trips and two barriers -- not issue- or bandwidth-
+// bound: halving the instructions per step or fetching two RoIs ahead did not shorten it, more resident workgroups did), so the
+// gather takes as long as the longest list.  Which tiles are hot moves with training: on a fresh RPN the 147 tiles of the stride-8
+// level meet 30 RoIs on average and up to 71; 15 SGD steps later the stride-16 level's 44 tiles meet 53 on average and up to 116
+// (tools/dev/roi_stats.py).  Round 2's first answer, a second kernel with eight waves per tile for the COARSE levels, guessed the
+// hot level from the pyramid shape, paid the scan 16 times per tile and took 67-75 us; together with the fine kernel 137 us per
+// step; the dense round-2 form of this design 106, this one 61 (tools/dev/ra_bwd_time.py, ra_trace.py).
+// (Tile shape sweep of the dense form, micro-benchmark / FPN step: 16x32x8ch 93/246 us, 16x16x16ch 74/191, 16x8x32ch 62/162, 16x4x64ch 89/178.)
 #ifndef RT_TH
 #define RT_TH 16
 #endif
@@ -343,7 +348,7 @@ static_assert(128 + RT_TH * 7 <= 256 && 64 + RT_TW * 7 <= 128, "weight-table lan
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 static_assert(RT_TH == 16 && RT_TW == 8 && RT_CB == 32, "the pixel-lane phase maps 256 lanes to 16 x 8 pixels x 2 channel halves");
 #ifndef RS_SPLIT
-#define RS_SPLIT 24                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ... (12 / 16 / 24 / 48: 110 / 110 / 106 / 126 us for the four launches)
+#define RS_SPLIT 32                      // a tile's list is cut into ceil(n / RS_SPLIT) segments ... (8 / 12 / 16 / 24 / 32 / 40: 83 / 77 / 74 / 64 / 61 / 64 us for the four launches, RoIs of a trained RPN; every segment pays ~3 us to start and 128 KB of partial tiles)
 #endif
 #ifndef RS_NSEG
 #define RS_NSEG 32                       // ... at most this many
@@ -364,9 +369,9 @@ struct __attribute__((aligned(16))) RoiEnt { int r; float sh, sw, bh, bw; int ro
 //   [192,200)  column c: first bin with a non-zero weight | number of bins up to the last one << 8   (the bins that reach a pixel are
 //   [200]      the largest such number over the columns                                               CONSECUTIVE: sample positions grow with the bin)
 //   [201,205)  row group g (rows 4 g .. 4 g + 3): first bin that reaches any of the four rows | count << 8
-// They depend on the pair alone, and round 3's tile kernel rebuilt them in each of its C / 32 channel-group workgroups: ~65 of the ~170
-// VALU instructions a wave issued per RoI step, in a kernel that is VALU-issue bound (tools/dev/ra_trace.py).  Now wave-sized blocks
-// appended to the lists launch build every pair's record ONCE into a pool indexed (RoI, position of the tile in the RoI's footprint),
+// They depend on the pair alone, and the tile kernel used to rebuild them in each of its C / 32 channel-group workgroups: ~65 of the ~170
+// VALU instructions a wave issued per RoI step.  Now one workgroup per RoI, appended to the lists launch, builds every pair's record
+// ONCE into a pool indexed (RoI, position of the tile in the RoI's footprint),
 // and the tile kernel fetches a record with one global_load_lds_dwordx4 of one wave.  A RoI whose footprint spans more than RA_MAXT
 // tiles has no records (rec = -1): its tables are built in the tile kernel by the same function (one wave, straight into LDS).
 #define RA_MAXT 16
@@ -431,24 +436,24 @@ template <> __device__ __forceinline__ void store_grad<float>(float *p, float v)
 __device__ __forceinline__ int ra_nseg(int n, int split) { return n <= split ? 1 : min(RS_NSEG, (n + split - 1) / split); }
 
 // cnt[tile] = list length; ent[tile * cap + i] = the i-th RoI (index order) whose footprint meets the tile.  Blocks >= tiles (when pool
-// is not NULL): wave w of block tiles + b builds record 4 b + w = (RoI, position in its footprint) -- see RA_MAXT above.
+// is not NULL): block tiles + r builds the records of RoI r, one footprint tile per wave and round -- see RA_MAXT above.
 __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, TileLevels TL, const float4 *__restrict__ rois, int R, int aligned,
                                                                   int k_min, float s0, int k0, int cap, int tiles, int32_t *__restrict__ cnt,
                                                                   RoiEnt *__restrict__ ent, float *__restrict__ pool)
 {
     __shared__ int s_woff[5];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if ((int)blockIdx.x >= tiles) {
-        const int q = ((int)blockIdx.x - tiles) * 4 + wave, r = q / RA_MAXT, k = q % RA_MAXT;
-        if (r >= R) return;
+    if ((int)blockIdx.x >= tiles) {                        // block tiles + r: the records of RoI r, wave w those of footprint tiles w, w + 4, ...
+        const int r = (int)blockIdx.x - tiles;
         const float4 b = rois[r];
         const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
         const int H = L.H[l], W = L.W[l];
         const AlignGeom g = align_geom(b, L.scale[l], 7, 7, 2, aligned != 0);
         const RaFoot f = ra_footprint(g, H, W);
         const int txa = f.x0 / RT_TW, ntx = f.x1 / RT_TW - txa + 1, tya = f.y0 / RT_TH, nty = f.y1 / RT_TH - tya + 1;
-        if (ntx * nty > RA_MAXT || k >= ntx * nty) return;
-        ra_tables_wave(H, W, (tya + k / ntx) * RT_TH, (txa + k % ntx) * RT_TW, g.sh, g.sw, g.bh, g.bw, pool + (size_t)q * RA_REC);
+        if (ntx * nty > RA_MAXT) return;
+        for (int k = wave; k < ntx * nty; k += 4)
+            ra_tables_wave(H, W, (tya + k / ntx) * RT_TH, (txa + k % ntx) * RT_TW, g.sh, g.sw, g.bh, g.bw, pool + ((size_t)r * RA_MAXT + k) * RA_REC);
         return;
     }
     const int tile = blockIdx.x;
@@ -497,8 +502,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
 // fit the table the split threshold is doubled until they do (cap >= tiles).  The item RECORDS (tile, first entry, end entry,
 // seg | nseg << 8 -- one 16-byte load and a workgroup of the main kernel can start) are laid out LONGEST SEGMENT FIRST (a counting
 // sort by length; ties in arrival order, which moves records but no sums): the main kernel's workgroups are dispatched in record order
-// and each advances one RoI per step, so this is longest-processing-time-first scheduling over the CUs.  In tile order the launch took
-// as long as two rounds of the longest segments (57 us); sorted, [see profiles/README.md].  slot[item number] = record position, which
+// and each advances one RoI per step, so this is longest-processing-time-first scheduling over the CUs (worth 0-10 us, most on a
+// fresh RPN whose long lists sit on the fine level, at the END of the tile order).  slot[item number] = record position, which
 // is also where a segment's partial tile goes (the combine kernel looks it up); unused records carry tile = -1.
 __device__ __forceinline__ int ra_items(int n, int split) { return n == 0 ? 0 : ra_nseg(n, split); }
 __global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
@@ -959,7 +964,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         const RaBwdWs w = carve_ra_bwd(workspace, tiles, R, n_cg);
         const int cap = (int)(R > 0 ? R : 1);
         static const bool use_records = [] { const char *e = getenv("FRCNN_RA_RECORDS"); return !e || atoi(e) != 0; }();
-        const int64_t table_blocks = use_records ? (R * RA_MAXT + 3) / 4 : 0;
+        const int64_t table_blocks = use_records ? R : 0;
         FRCNN_REQUIRE(tiles + table_blocks < ((int64_t)1 << 31) && R * RA_MAXT < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
         FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)(tiles + table_blocks)), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R,
                      aligned, k_min, s0, k0, cap, tiles, w.cnt, w.ent, use_records ? w.pool : nullptr);
