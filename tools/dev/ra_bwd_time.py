@@ -69,5 +69,19 @@ for key in os.environ.get("KEYS", "rois0,rois15,rois29").split(","):
         e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) * 1e3 / 20)
     import hashlib
+    feats = [torch.randn(s, device=dev, generator=torch.Generator(device=dev).manual_seed(6)) for s in shapes]
+    fptrs, _, _, _ = _level_tables(feats, scales)
+    out = torch.empty((len(r), 256, 7, 7), device=dev)
+    def fwd():
+        check(lib.frcnn_ms_roi_align_fwd(fptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), 4, 256, _ptr(rois), len(r), 7, 7, 2, 0, 2, 224.0, 4, _ptr(out), None, _stream()), "fwd")
+    for _ in range(5): fwd()
+    torch.cuda.synchronize()
+    tf = []
+    for _ in range(5):
+        e0.record()
+        for _ in range(20): fwd()
+        e1.record(); torch.cuda.synchronize()
+        tf.append(e0.elapsed_time(e1) * 1e3 / 20)
+    print("   forward: median %.1f us  min %.1f us   sha1 %s" % (float(np.median(tf)), min(tf), hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]))
     h = hashlib.sha1(b"".join(x.cpu().numpy().tobytes() for x in grads)).hexdigest()[:12]
     print("   backward (4 launches back to back): median %.1f us  min %.1f us   sha1 %s" % (float(np.median(ts)), min(ts), h))
