@@ -259,7 +259,8 @@ int frcnn_ms_roi_align_fwd(const float *const *feats_host /*[n_levels] device pt
                            float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/, void *stream);
 /* grad_feats[l] [C,H_l,W_l] are OVERWRITTEN with the gradient of every level (zero where no RoI reaches); the caller does
  * not clear them.  7x7 / sampling_ratio 2: tile-owner gather (per-tile RoI lists, long lists summed by segments in a fixed
- * order), no atomics, bit-reproducible; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists + partial tiles).  Other
+ * order), no atomics, bit-reproducible; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists, weight-table records of
+ * the (RoI, tile) pairs, partial tiles; its contents on entry do not matter).  Other
  * shapes: memset + fp32 atomics inside the library (sum order not fixed, tolerance 1e-4; no workspace needed).             */
 size_t frcnn_ms_roi_align_bwd_workspace(const int *H_host, const int *W_host, int n_levels, int C, int64_t R);
 int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host, const int *H_host, const int *W_host,
