@@ -698,7 +698,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_head_fwd(const void *const *feat_levels_bf16, vo
 // ------------------------------------------------------------------------------------------------------------------------------
 #define WG_SEG 64                        // pixels per row segment (4 K steps)
 #define WG_AS 72                         // LDS row stride in bf16 elements (144 bytes: 9 x 16, conflict-free ds_read_b128 down a column of rows)
-#define WG_NCT 1                         // output-channel tiles (32 channels) per wave (2: 288 accumulators, spills: 740 scratch stores)
+#define WG_NCT 1                         // (accumulator sets per wave; two whole output-channel tiles x nine taps per wave = 288 accumulators spilled: 740 scratch stores)
 #define WG_CO (128 * WG_NCT)
 #define WG_CI 32
 #define WG_MAX_SPLITS 32
@@ -844,22 +844,25 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
             }
         }
     };
-    // wave w owns the output-channel tiles WG_NCT w .. WG_NCT w + WG_NCT - 1: a feature fragment read from LDS feeds WG_NCT MFMAs (all four
-    // waves read the SAME nine feature fragments per K step; with one tile per wave the LDS read volume, 160 KB per row segment and CU,
-    // took as long as the MFMAs themselves)
+    // Who multiplies what.  With wave w = output-channel tile w x all nine taps every wave read the SAME nine feature fragments per K step:
+    // 4 x (1 + 9) x 1 KB = 40 KB of LDS reads per K step and CU, 320 cycles of the LDS pipe against 288 of MFMA.  Now wave (h = w & 1,
+    // v = w >> 1) owns the output-channel tiles 2 h and 2 h + 1 for the taps 4 v .. 4 v + 3, plus tap 8 for tile 2 h + v: nine MFMAs as
+    // before (accumulator s < 8: tile 2 h + (s >> 2), tap 4 v + (s & 3); s = 8: tile 2 h + v, tap 8), 2 + 5 fragment reads: 28 KB.
+    // Every accumulator still sums its K range in the same order: the partials are bit-identical to the former assignment's.
+    const int wh = wave & 1, wvv = wave >> 1;
     auto compute = [&](int y, int buf) {
-        const unsigned short *sa = s_a[buf] + (32 * WG_NCT * wave + li) * WG_AS + 8 * g;
+        const unsigned short *sa = s_a[buf] + (64 * wh + li) * WG_AS + 8 * g;
         // one wave per SIMD: nothing overlaps the LDS fragment reads with the MFMAs unless the code does.  The fragments of K step
-        // ks + 1 are read into the other register set while the MFMAs of step ks run (two sets x (1 + 9) fragments = 80 registers).
-        bf16x8 fa[2][WG_NCT], fb[2][9];
+        // ks + 1 are read into the other register set while the MFMAs of step ks run.
+        bf16x8 fa[2][2], fb[2][5];
         auto frags = [&](int p, int ks) {
+            fa[p][0] = *(const bf16x8 *)(sa + 16 * ks);
+            fa[p][1] = *(const bf16x8 *)(sa + 32 * WG_AS + 16 * ks);
 #pragma unroll
-            for (int ct = 0; ct < WG_NCT; ++ct) fa[p][ct] = *(const bf16x8 *)(sa + ct * 32 * WG_AS + 16 * ks);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int j = 0; j < 5; ++j) {
+                const int tap = j < 4 ? 4 * wvv + j : 8, ky = tap / 3, kx = tap - 3 * ky;       // (uniform: wvv is scalar)
                 const int slot = (y + ky) & 3;                          // row y + ky - 1 lives in slot (y + ky - 1 + 1) & 3
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) fb[p][3 * ky + kx] = *(const bf16x8 *)(&s_f[kx][slot][li * WG_AS + 16 * ks + 8 * g]);
+                fb[p][j] = *(const bf16x8 *)(&s_f[kx][slot][li * WG_AS + 16 * ks + 8 * g]);
             }
         };
         frags(0, 0);
@@ -867,10 +870,9 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
         for (int ks = 0; ks < WG_SEG / 16; ++ks) {
             if (ks + 1 < WG_SEG / 16) frags((ks + 1) & 1, ks + 1);
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-#pragma unroll
-                for (int ct = 0; ct < WG_NCT; ++ct)
-                    acc[ct][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][ct], fb[ks & 1][k], acc[ct][k], 0, 0, 0);
+            for (int s8 = 0; s8 < 8; ++s8)
+                acc[0][s8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][s8 >> 2], fb[ks & 1][s8 & 3], acc[0][s8], 0, 0, 0);
+            acc[0][8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wvv ? fa[ks & 1][1] : fa[ks & 1][0], fb[ks & 1][4], acc[0][8], 0, 0, 0);
         }
     };
     // ---- prime: feature rows y_first - 1 .. y_first + 1 and the d_raw row y_first go straight to LDS; the two register sets take
@@ -935,19 +937,20 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
         else rpn_wgrad_run<false>(L.x[lvl], L.d[lvl], H, W, strip * WG_SEG, y_first, n_rows, ci0, co0, s_a, s_f, acc);
         seg += n_rows;
     }
-    // ---- my partial, laid out [split][co][tap][ci]: register r of acc[ct][tap] is (co = co0 + 32 (WG_NCT wave + ct) + (r & 3) + 8 (r >> 2) + 4 g,
-    //      ci = ci0 + li), so the 32 lanes of a half-wave store 128 contiguous bytes (the weight's own [co][ci][tap] order made every
-    //      store instruction touch ~18 cache lines: ~30 us of the kernel for 38 MB of partials)
+    // ---- my partial, laid out [split][co][tap][ci]: register r of accumulator s (tile / tap: see compute) is (co = co0 + 32 tile + (r & 3) +
+    //      8 (r >> 2) + 4 g, ci = ci0 + li), so the 32 lanes of a half-wave store 128 contiguous bytes (the weight's own [co][ci][tap]
+    //      order made every store instruction touch ~18 cache lines: ~30 us of the kernel for 38 MB of partials)
     float *dst = part + (size_t)split * RC3_C * RC3_C * 9;
+    const int wh = wave & 1, wvv = wave >> 1;
 #pragma unroll
-    for (int ct = 0; ct < WG_NCT; ++ct)
+    for (int s9 = 0; s9 < 9; ++s9) {
+        const int tile = s9 < 8 ? 2 * wh + (s9 >> 2) : 2 * wh + wvv, tap = s9 < 8 ? 4 * wvv + (s9 & 3) : 8;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + 32 * (WG_NCT * wave + ct) + (r & 3) + 8 * (r >> 2) + 4 * g;
-                dst[((size_t)co * 9 + tap) * RC3_C + ci0 + li] = acc[ct][tap][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * tile + (r & 3) + 8 * (r >> 2) + 4 * g;
+            dst[((size_t)co * 9 + tap) * RC3_C + ci0 + li] = acc[0][s9][r];
+        }
+    }
 }
 
 // dW = sum of the split partials, in split order (fixed: bit-reproducible); partials are [co][tap][ci], the weight is [co][ci][tap]
