@@ -112,9 +112,13 @@ __global__ __launch_bounds__(256) void rpn_conv_pack_bwd_kernel(const float *__r
 __device__ unsigned long long g_rc3_trace[16];
 extern "C" __attribute__((visibility("default"))) void frcnn_rc3_trace_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rc3_trace), sizeof(g_rc3_trace)); }
 #define RC3_STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+__device__ unsigned long long g_wg_blocks[1024][4];    // wgrad: per workgroup {start, loop end, end (s_memrealtime, 10 ns), row segments}
+extern "C" __attribute__((visibility("default"))) void frcnn_wg_blocks_read(void *dst) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wg_blocks), sizeof(g_wg_blocks)); }
+#define WG_BLK(slot, v) do { if (threadIdx.x == 0) g_wg_blocks[blockIdx.y * gridDim.x + blockIdx.x][slot] = (v); } while (0)
 #define RC3_ACC(slot, a, b) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_rc3_trace[slot] += (b) - (a); } while (0)
 #else
 #define RC3_STAMP(var) do {} while (0)
+#define WG_BLK(slot, v) do {} while (0)
 #define RC3_ACC(slot, a, b) do {} while (0)
 #endif
 // hand-placed vector-memory waits / loads (see the schedule in rpn_conv3x3_head_tile)
@@ -710,8 +714,21 @@ struct WgradLevels {
     int seg0[FRCNN_MAX_LEVELS + 1];                // first row segment of level l in the global order (level, strip, row)
     int split0[WG_MAX_SPLITS + 1];                 // first row segment of split s
 };
-#define WG_SLOW_COST 3                   // cost of a generically staged row segment relative to a 16-byte staged one (host-side balancing)
-#define WG_RUN_COST 0                    // cost of starting a column strip (two exposed round trips), in fast row segments
+// host-side balancing of the K splits, in HALF fast row segments (measured with tools/dev/wgrad_trace.py: 1.2 us per 16-byte staged row
+// segment, 2.4-2.7 per generically staged one of an even-width level, 5-7 on the odd-width level with its strip starts; with the
+// round-2 weights 1 / 3 / 3 / 0 the split holding the two smallest levels ran 165 us against 137-150 for the others)
+#ifndef WG_FAST_COST
+#define WG_FAST_COST 2
+#endif
+#ifndef WG_SLOW_COST
+#define WG_SLOW_COST 5                   // generic staging, even width (dword loads)
+#endif
+#ifndef WG_ODD_COST
+#define WG_ODD_COST 14                   // generic staging, odd width (2-byte loads)
+#endif
+#ifndef WG_RUN_COST
+#define WG_RUN_COST 10                   // starting a column strip: its window of exposed loads
+#endif
 #define WG_LDS_BYTES ((2 * WG_CO * WG_AS + 3 * 4 * WG_CI * WG_AS) * 2)     // 73 728 + 55 296 = 129 024 bytes of the CU's 160 KB
 
 // one run = consecutive rows [y_first, y_first + n_rows) of one 64-pixel column strip of one level.
@@ -889,10 +906,16 @@ __device__ __forceinline__ void rpn_wgrad_run(const unsigned short *__restrict__
     for (int i = 0; i < n_rows; i += 2) {
         {   // even row of the pair: set S0 carries (d_raw y + 1, features y + 2)
             const int y = y_first + i;
+            RC3_STAMP(w0);
             __syncthreads();
+            RC3_STAMP(w1);
             compute(y, i & 1);
+            RC3_STAMP(w2);
             store_a((i + 1) & 1, S0); store_f(y + 2, S0);
+            RC3_STAMP(w3);
             load_a(y + 3, S0); load_f(y + 4, S0);
+            RC3_STAMP(w4);
+            if (blockIdx.y == 0) { RC3_ACC(0, w0, w1); RC3_ACC(1, w1, w2); RC3_ACC(2, w2, w3); RC3_ACC(3, w3, w4); RC3_ACC(4, w0, w0 + 1); }
         }
         if (i + 1 < n_rows) {   // (making only the compute conditional -- so that the compiler can count vmcnt across the back edge instead of
                                 // waiting vmcnt(0) in front of the stores -- measured 7 us SLOWER on the same box: 202.5 against 195 us)
@@ -924,6 +947,7 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
     // and ranges stay contiguous because every new run (strip) costs a window of exposed loads.
     int seg = L.split0[split];
     const int seg_end = L.split0[split + 1];
+    WG_BLK(0, __builtin_amdgcn_s_memrealtime()); WG_BLK(3, (unsigned long long)(seg_end - seg));
     while (seg < seg_end) {
         int lvl = 0;
 #pragma unroll
@@ -940,6 +964,7 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
     // ---- my partial, laid out [split][co][tap][ci]: register r of accumulator s (tile / tap: see compute) is (co = co0 + 32 tile + (r & 3) +
     //      8 (r >> 2) + 4 g, ci = ci0 + li), so the 32 lanes of a half-wave store 128 contiguous bytes (the weight's own [co][ci][tap]
     //      order made every store instruction touch ~18 cache lines: ~30 us of the kernel for 38 MB of partials)
+    WG_BLK(1, __builtin_amdgcn_s_memrealtime());
     float *dst = part + (size_t)split * RC3_C * RC3_C * 9;
     const int wh = wave & 1, wvv = wave >> 1;
 #pragma unroll
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(256) void rpn_conv3x3_wgrad_kernel(WgradLevels L, f
             dst[((size_t)co * 9 + tap) * RC3_C + ci0 + li] = acc[0][s9][r];
         }
     }
+    WG_BLK(2, __builtin_amdgcn_s_memrealtime());
 }
 
 // dW = sum of the split partials, in split order (fixed: bit-reproducible); partials are [co][tap][ci], the weight is [co][ci][tap]
@@ -989,7 +1015,7 @@ FRCNN_EXPORT int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const
         L.H[l] = H[k]; L.W[l] = W[k];
         L.seg0[l] = (int)segs;
         const bool fast = (W[k] & 7) == 0 && ((((uintptr_t)feat_levels_bf16[k]) | ((uintptr_t)d_raw_levels_bf16[k])) & 15) == 0;
-        lvl_cost[l] = fast ? 1 : WG_SLOW_COST;
+        lvl_cost[l] = fast ? WG_FAST_COST : (W[k] & 1) ? WG_ODD_COST : WG_SLOW_COST;
         if (l < n_levels) {                                         // + WG_RUN_COST per column strip: its window of exposed loads
             const int64_t strips = (W[k] + WG_SEG - 1) / WG_SEG, n = (int64_t)H[k] * strips;
             segs += n; cost += n * lvl_cost[l] + strips * WG_RUN_COST;
