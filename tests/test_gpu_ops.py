@@ -935,6 +935,22 @@ def test_ms_roi_align_bwd_records_and_in_kernel_tables_give_the_same_bits(ops):
             assert np.array_equal(np.load(os.path.join(d, "g%d.npy" % Cc)), here), Cc
 
 
+def test_ms_roi_align_bwd_mixed_record_and_in_kernel_tables_on_the_dma_path(ops):
+    """One 50 x 84 level, C = 64 (whole channel groups: the LDS-DMA instantiation of the tile kernel): small RoIs have records, RoIs
+    spanning more than 16 tiles have their tables built by wave 3 of the tile kernel -- in the same lists, so the counted vmcnt waits see
+    both kinds of predecessor (two or one outstanding transfer).  Gradient = the oracle's."""
+    rng = np.random.RandomState(29)
+    Cc, Hh, Ww = 64, 50, 84
+    small = rand_boxes(rng, 120, 0.03, 0.25) * np.array([Ww, Hh, Ww, Hh], np.float32) * 16.0
+    big = rand_boxes(rng, 40, 0.6, 0.95) * np.array([Ww, Hh, Ww, Hh], np.float32) * 16.0
+    rois = np.concatenate([small, big])[rng.permutation(160)].astype(np.float32)
+    go = rng.randn(160, Cc, 7, 7).astype(np.float32)
+    ft = torch.zeros((1, Cc, Hh, Ww), device=DEV, requires_grad=True)
+    ops.ms_roi_align([ft], T(rois), 7, 2, scales=(1.0 / 16.0,)).backward(T(go))
+    ref = orc.roi_align_bwd(go, (Cc, Hh, Ww), rois, 1.0 / 16.0, 2, False)
+    assert np.allclose(ft.grad[0].cpu().numpy(), ref, rtol=2e-4, atol=1e-3), float(np.abs(ft.grad[0].cpu().numpy() - ref).max())
+
+
 def test_ms_roi_align_bwd_tile_gather_is_reproducible_and_overwrites(ops):
     """The 7x7 / sampling-ratio-2 backward owns tiles instead of scattering atomics: two runs give identical bits, stale
     contents of the gradient buffers do not leak (the library overwrites), clustered RoIs (64 on one spot) and R = 0 work."""
