@@ -18,6 +18,7 @@ for it in range(N):
     wh = (rng.rand(R, 2) * (0.08 if mode == 0 else 0.5 if mode == 1 else 0.95) + 0.005)
     b = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1) * np.array([1344, 800, 1344, 800])
     if mode == 2: b[: R // 4] = b[0] + rng.randn(R // 4, 4) * 3          # a pile on one spot
+    b = np.clip(b, 0, [1343, 799, 1343, 799])                                # (inside the image: every sample valid, the mass check below holds)
     b = np.stack([np.minimum(b[:, 0], b[:, 2]), np.minimum(b[:, 1], b[:, 3]), np.maximum(b[:, 0], b[:, 2]) + 1, np.maximum(b[:, 1], b[:, 3]) + 1], 1).astype(np.float32)
     rois = torch.from_numpy(b).to(dev)
     go = torch.randn((R, 256, 7, 7), device=dev)
