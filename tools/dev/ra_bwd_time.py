@@ -72,8 +72,13 @@ for key in os.environ.get("KEYS", "rois0,rois15,rois29").split(","):
     feats = [torch.randn(s, device=dev, generator=torch.Generator(device=dev).manual_seed(6)) for s in shapes]
     fptrs, _, _, _ = _level_tables(feats, scales)
     out = torch.empty((len(r), 256, 7, 7), device=dev)
+    frois = rois
+    if os.environ.get('SORT'):                               # experiment: largest footprints first (longest-processing-time-first over the CUs)
+        fa = (w * sc_np) * (h * sc_np) if False else None
+        area = ((r[:, 2] - r[:, 0]) * np.asarray(scales)[k]) * ((r[:, 3] - r[:, 1]) * np.asarray(scales)[k])
+        frois = torch.from_numpy(r[np.argsort(-area)].copy()).to(dev)
     def fwd():
-        check(lib.frcnn_ms_roi_align_fwd(fptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), 4, 256, _ptr(rois), len(r), 7, 7, 2, 0, 2, 224.0, 4, _ptr(out), None, _stream()), "fwd")
+        check(lib.frcnn_ms_roi_align_fwd(fptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), 4, 256, _ptr(frois), len(r), 7, 7, 2, 0, 2, 224.0, 4, _ptr(out), None, _stream()), "fwd")
     for _ in range(5): fwd()
     torch.cuda.synchronize()
     tf = []
