@@ -59,6 +59,7 @@ import torch  # noqa: E402
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s HBM3E spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
+MFMA_PEAK_F32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 / 16x16x4_f32: the fp32 vector rate (MI355X_MICROARCH.md:42,430; 155 measured)
 
 CONFIGS = {
     "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
@@ -81,7 +82,9 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "roi_pool_fwd_lds_kernel": "hbm", "roi_pool_bwd_lds_kernel": "hbm", "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm",
          "roi_align_fwd77_kernel": "hbm", "roi_align_fwd_nhwc_kernel": "hbm", "roi_align_bwd_tile_kernel": "hbm", "roi_align_bwd_nhwc_kernel": "hbm",
          "roi_align_bwd_combine_kernel": "hbm", "rpn_conv3x3_head_kernel": "mfma", "rpn_conv3x3_bwd_data_kernel": "mfma",
-         "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm"}
+         "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
+         "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma"}
+F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel")
 
 
 def synth_frame(cfg, rank, step):
@@ -122,9 +125,10 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
 
 def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
-    conv = 2 * 256 * 9 * 256 * P_head                                     # C = 256 in the FPN head these kernels are built for
-    return {"rpn_conv3x3_head_kernel": conv + 2 * 256 * 6 * A * P_head,   # raw = conv3x3 + both 1x1 heads
-            "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv}.get(kernel)
+    conv = 2 * C * 9 * C * P_head                                         # C -> C 3x3 on every RPN position (model.py:68-70, new_model.py:96-98)
+    return {"rpn_conv3x3_head_kernel": conv + 2 * C * 6 * A * P_head,     # raw = conv3x3 + both 1x1 heads
+            "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv,
+            "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv}.get(kernel)
 
 
 def percentiles(v):
@@ -152,6 +156,42 @@ def load_pmc(config, amp):
             return json.load(f)["kernels"], os.path.relpath(cands[-1], ROOT)
     except (OSError, ValueError, KeyError):
         return {}, None
+
+
+def timed_region(step, steps, warmup, device, armed=None, before_step=None):
+    """The bench contract's timing rule, for any device (the world-size-2 gloo test runs it on the CPU): W untimed warm-up steps, then
+    EXACTLY K steps bracketed by a barrier + device synchronisation on both sides; the job's time is the MAX over ranks.  Returns
+    {dt (max over ranks, s), dt_local, per_rank_ms (ms per step of every rank, indexed by rank), step_ms (rank-local, from device
+    events at the step boundaries; [] on the CPU), last (what the last step returned)}."""
+    from faster_rcnn_pytorch_amd import parallel
+    cuda = device.type == "cuda"
+    sync = torch.cuda.synchronize if cuda else (lambda: None)
+    for i in range(warmup):
+        step(i)
+        sync()
+    if armed:
+        armed()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if cuda else None   # step boundaries on the main stream (no sync)
+    parallel.barrier()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        if marks:
+            marks[i].record()
+        if before_step:
+            before_step(i)
+        last = step(warmup + i)
+    if marks:
+        marks[steps].record()
+    sync()
+    parallel.barrier()
+    sync()
+    dt_local = time.perf_counter() - t0
+    dt = parallel.max_over_ranks(dt_local, device)
+    per_rank_ms = [round(v / steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if marks else []
+    return {"dt": dt, "dt_local": dt_local, "per_rank_ms": per_rank_ms, "step_ms": step_ms, "last": last}
 
 
 def run_config(args, config, amp, steps, warmup, graph, rank, world, device, with_cpu):
@@ -254,40 +294,29 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     # long-lived: freeze it and keep the collector off while steps are timed (reference counting still frees the step's tensors).
     if not args.gc_on:
         gc.collect(); gc.freeze(); gc.disable()
-    log("warm-up")
-    for i in range(warmup):
-        step(i)
-        torch.cuda.synchronize()
-    log("warm-up done (%d steps)" % warmup)
     events = not args.no_kernel_events and not graph
-    if events:
-        _lib.prof_reset()
-    del counts[:]
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # step boundaries on the main stream (no sync)
-    ms0 = torch.cuda.memory_stats(device)
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        marks[i].record()
+    ms0 = {}
+
+    def armed():                                      # between the warm-up and the timed region
+        log("warm-up done (%d steps)" % warmup)
+        if events:
+            _lib.prof_reset()
+        del counts[:]
+        ms0.update(torch.cuda.memory_stats(device))
+
+    def before(i):
         if events:
             _lib.prof_enable(i % args.event_every == 0)    # the HIP-event brackets cost ~0.2 ms per step: sample every n-th timed step
-        loss = step(warmup + i)
-    marks[steps].record()
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt_local = time.perf_counter() - t0
+    log("warm-up")
+    tr = timed_region(step, steps, warmup, device, armed=armed, before_step=before)
     _lib.prof_enable(False)
-    dt = parallel.max_over_ranks(dt_local, device)
-    per_rank_ms = [round(v / steps * 1e3, 3) for v in parallel.gather_over_ranks(dt_local, device)]
+    dt, per_rank_ms, step_ms, loss = tr["dt"], tr["per_rank_ms"], tr["step_ms"], tr["last"]
     log("timed region: %d steps in %.3f s" % (steps, dt))
     gc.enable()
     ms1 = torch.cuda.memory_stats(device)
     allocator = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_ooms")}
     final_loss = float(loss.detach())
     model.check_device_status()                      # sticky device-side error word (aborted scan / short sample): raises if set
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     n_sampled = len(range(0, steps, args.event_every))               # timed steps whose kernels were bracketed
     if graph and not args.no_kernel_events:
         # a captured graph cannot carry the per-kernel event brackets: the live kernel times of --graph come from a short EAGER pass
@@ -303,119 +332,200 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
         counts[:] = [g[2] for g in graphs]                           # persistent copies written inside the captured steps
     samples = {} if args.no_kernel_events else _lib.prof_samples()
     n_props = [int(c.item()) for c in counts if c is not None]       # device counts, read after the timed region
-    mean_props = sum(n_props) / len(n_props) if n_props else None
     backend = torch.distributed.get_backend() if world > 1 else None
     world_seen = torch.distributed.get_world_size() if world > 1 else 1
     ddp = parallel.ddp_report(net)
 
-    record = None
-    if rank == 0:
-        ms_per_step = dt / steps * 1e3
-        value = world * steps / dt
-        shape = cfg["shape"]
-        pmc, pmc_src = load_pmc(config, amp)
+    if rank != 0:
+        return None
+    pmc, pmc_src = load_pmc(config, amp)
+    cpu = cpu_baseline(config, cfg, args.cpu_steps, args.lr) if with_cpu else None
+    return build_record(config, amp, world=world, steps=steps, warmup=warmup, dt=dt, per_rank_ms=per_rank_ms, step_ms=step_ms,
+                        samples=samples, n_sampled=n_sampled, n_props=n_props, graph=graph, pmc=pmc, pmc_src=pmc_src, cpu=cpu,
+                        allocator=allocator, ddp=ddp, backend=backend, world_seen=world_seen, final_loss=final_loss, gc_on=args.gc_on)
 
-        def pmc_traffic(name):
-            return pmc[name]["traffic_bytes"] if name in pmc else None
-        # the compulsory bytes of NMS are negligible, so it is ALSO priced against the fp32 VALU issue peak: pair IoUs x 16
-        # VALU ops (counted in the ISA of nms.hip's pair loop).  The pair count is the FULL K (K - 1) / 2 of torchvision's mask
-        # kernel, also where the cascade (nms.hip) evaluates fewer pairs -- `pairs_evaluated` is not known on the host.
-        valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 16}
-        per_kernel = {}
-        for name, v in samples.items():
-            n = len(v)
-            us = sum(v) / n * 1e3
-            med, p10, p90 = (x * 1e3 for x in percentiles(v))
-            ab = algorithmic_bytes(name, **shape)
-            per_kernel[name] = {"bound": BOUND.get(name, "latency"), "avg_us": round(us, 2), "median_us": round(med, 2), "p10_us": round(p10, 2),
-                                "p90_us": round(p90, 2), "launches": n, "launches_per_img": round(n / max(n_sampled, 1), 2),
-                                "us_per_img": round(sum(v) * 1e3 / max(n_sampled, 1), 2),
-                                "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
-                                "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
-            af = algorithmic_flops(name, **shape)
-            if af:
-                per_kernel[name]["algorithmic_flops"] = af
-                per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
-                per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / MFMA_PEAK_BF16_TFLOPS, 5)
-        # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
-        nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
-        if "nms_kernel" in per_kernel and nms_us > 0:
-            d = per_kernel["nms_kernel"]
-            d["valu_lane_ops_full_pair_count"] = valu_ops["nms_kernel"]
-            d["nms_stage_us_per_img"] = round(nms_us, 2)
-            d["valu_frac_of_78.6T"] = round(valu_ops["nms_kernel"] / (nms_us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
-            d["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (nms_us * 1e-6), 0)
 
-        def roofline_of(name):
-            d = per_kernel[name]
-            if d["bound"] == "valu" and d.get("valu_lane_ops_full_pair_count"):
-                # priced against the fp32 VALU issue peak: its compulsory HBM bytes are negligible (the GB/s figure is kept beside it)
-                return {"kernel": name, "bound": "valu", "achieved": round(d["valu_lane_ops_full_pair_count"] / (d["nms_stage_us_per_img"] * 1e-6) * 1e-12, 3),
-                        "peak": round(VALU_PEAK_LANE_OPS * 1e-12, 1), "unit": "T lane-ops/s", "frac": d["valu_frac_of_78.6T"],
-                        "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"], "median_launch_us": d["median_us"],
-                        "nms_stage_us_per_img": d["nms_stage_us_per_img"], "valu_lane_ops": d["valu_lane_ops_full_pair_count"],
-                        "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
-                        "note": "all NMS launches of one image over the full K(K-1)/2 pair count x 16 VALU; the cascade evaluates fewer pairs than that"}
-            if d["bound"] == "mfma" and d.get("algorithmic_flops"):
-                return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": MFMA_PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
-                        "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
-            return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
-                    "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
-        roofline = None
-        if per_kernel:
-            dom = max(per_kernel, key=lambda k: per_kernel[k]["us_per_img"])
-            roofline = roofline_of(dom)
-            roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
-            if roofline["bound"] not in ("hbm", "mfma", "valu"):
-                roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
-                                    "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
-            hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm" and per_kernel[k]["algorithmic_bytes"]]
-            if hbm:
-                roofline["hbm_kernel"] = roofline_of(max(hbm, key=lambda k: per_kernel[k]["us_per_img"]))
-            if graph:
-                roofline["measured_in"] = "an eager pass of %d steps after the timed graph replays (a captured graph cannot carry the event brackets)" % n_sampled
-        hot_us = sum(v["us_per_img"] for v in per_kernel.values())
-        smed, sp10, sp90 = percentiles(step_ms)
-        cpu = cpu_baseline(config, cfg, args.cpu_steps, args.lr) if with_cpu else None
-        st = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("proposal_prologue", "topk_", "nms_", "level_ids")))
-        record = {
-            "metric": cfg["metric"], "value": round(value, 3), "unit": "images/s",
-            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
-            "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox",
-                       "submission": "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)"},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "step_ms": {"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
-                        "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
-                        "source": "HIP events at the step boundaries on the main stream (rank 0)"},
-            "allocator_in_timed_region": allocator,
-            "conditions": {
-                "gemm_selection": ("PyTorch TunableOp: rocBLAS / hipBLASLt solution timed and picked per GEMM shape during the initialisation pass"
-                                   if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default heuristics"),
-                "tunableop_results": (("read from a results file of an earlier run + tuned now for new shapes" if TUNABLEOP_CACHED else "tuned in this process")
-                                      if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else None),
-                "python_gc": "on" if args.gc_on else "frozen after initialisation, off while the timed steps run (--gc-on to leave it on)",
-                "off_switches": "--no-tunableop --gc-on give the untuned, collector-on figure"},
-            "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
-                            "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms), "ddp": ddp},
-            "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1),
-                         "launches_per_img": round(sum(v["launches_per_img"] for v in per_kernel.values()), 1),
-                         # proposals actually produced: mean of the device-side counts of the timed steps (capacity P is an upper bound)
-                         "mean_proposals_per_img": round(mean_props, 1) if mean_props is not None else None,
-                         "proposals_per_s": round(value * mean_props, 1) if mean_props is not None else None,
-                         # BASELINE.json's second figure: NMS + RoI pooling forward/backward, HIP-event us per image
-                         "nms_plus_roi_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
-                         # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
-                         "proposal_stage_us_per_img": round(st, 1),
-                         "proposal_stage_proposals_per_s": round(mean_props / (st * 1e-6), 0) if (st and mean_props is not None) else None,
-                         "kernels": per_kernel},
-            "final_loss": round(final_loss, 4), "device_status": 0,
-        }
+def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms, samples, n_sampled, n_props, graph, pmc, pmc_src, cpu,
+                 allocator, ddp, backend, world_seen, final_loss, gc_on=False):
+    """The FULL bench record (written to bench_detail.json) from plain measured values: no GPU, no torch.  `samples` = kernel name ->
+    list of launch times in ms (frcnn_prof_samples), `dt` = max-over-ranks seconds of the timed region, `n_props` = device-side
+    proposal counts of the timed steps.  compact_record() cuts it down to the line the driver parses."""
+    cfg = CONFIGS[config]
+    mean_props = sum(n_props) / len(n_props) if n_props else None
+    ms_per_step = dt / steps * 1e3
+    value = world * steps / dt
+    shape = cfg["shape"]
+
+    def pmc_traffic(name):
+        return pmc[name]["traffic_bytes"] if name in pmc else None
+    # SURVEY 8(d): the compulsory bytes of NMS are negligible, so it is ALSO priced against the fp32 VALU issue peak: pair IoUs x 16
+    # VALU ops (counted in the ISA of nms.hip's pair loop).  The pair count is the FULL K (K - 1) / 2 of torchvision's mask
+    # kernel (the cascade of nms.hip only runs above 16 384 boxes, i.e. never in a training step).  16 = the checked form's count; the
+    # packed path the bulk of the tiles takes ISSUES 11 per pair: `frac_on_issued_instructions` prices the kernel on those.
+    valu_ops = {"nms_kernel": (shape["K"] * (shape["K"] - 1) // 2) * 16}
+    per_kernel = {}
+    for name, v in samples.items():
+        n = len(v)
+        us = sum(v) / n * 1e3
+        med, p10, p90 = (x * 1e3 for x in percentiles(v))
+        ab = algorithmic_bytes(name, **shape)
+        per_kernel[name] = {"bound": BOUND.get(name, "latency"), "avg_us": round(us, 2), "median_us": round(med, 2), "p10_us": round(p10, 2),
+                            "p90_us": round(p90, 2), "launches": n, "launches_per_img": round(n / max(n_sampled, 1), 2),
+                            "us_per_img": round(sum(v) * 1e3 / max(n_sampled, 1), 2),
+                            "algorithmic_bytes": ab, "GB_s": round(ab / us * 1e-3, 2) if ab else None,
+                            "hbm_frac": round(ab / us * 1e-3 / HBM_PEAK_GBS, 5) if ab else None, "pmc_traffic_bytes": pmc_traffic(name)}
+        af = algorithmic_flops(name, **shape)
+        if af:
+            per_kernel[name]["algorithmic_flops"] = af
+            per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
+            per_kernel[name]["mfma_peak_TFLOP_s"] = MFMA_PEAK_F32_TFLOPS if name in F32_MFMA_KERNELS else MFMA_PEAK_BF16_TFLOPS
+            per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / per_kernel[name]["mfma_peak_TFLOP_s"], 5)
+    # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
+    nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
+    if "nms_kernel" in per_kernel and nms_us > 0:
+        d = per_kernel["nms_kernel"]
+        d["valu_lane_ops_full_pair_count"] = valu_ops["nms_kernel"]
+        d["nms_stage_us_per_img"] = round(nms_us, 2)
+        d["valu_frac_of_78.6T"] = round(valu_ops["nms_kernel"] / (nms_us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
+        d["pair_iou_per_s"] = round(shape["K"] * (shape["K"] - 1) / 2 / (nms_us * 1e-6), 0)
+        d["valu_frac_on_issued_11_per_pair"] = round(valu_ops["nms_kernel"] / 16 * 11 / (nms_us * 1e-6) / VALU_PEAK_LANE_OPS, 3)
+
+    def roofline_of(name):
+        d = per_kernel[name]
+        if d["bound"] == "valu" and d.get("valu_lane_ops_full_pair_count"):
+            # priced against the fp32 VALU issue peak: its compulsory HBM bytes are negligible (the GB/s figure is kept beside it)
+            return {"kernel": name, "bound": "valu", "achieved": round(d["valu_lane_ops_full_pair_count"] / (d["nms_stage_us_per_img"] * 1e-6) * 1e-12, 3),
+                    "peak": round(VALU_PEAK_LANE_OPS * 1e-12, 1), "unit": "T lane-ops/s", "frac": d["valu_frac_of_78.6T"],
+                    "frac_on_issued_instructions": d["valu_frac_on_issued_11_per_pair"],
+                    "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"], "median_launch_us": d["median_us"],
+                    "nms_stage_us_per_img": d["nms_stage_us_per_img"], "valu_lane_ops": d["valu_lane_ops_full_pair_count"],
+                    "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
+                    "note": "all NMS launches of one image over the full K(K-1)/2 pair count x 16 VALU (the checked form; 11 issued on the packed path)"}
+        if d["bound"] == "mfma" and d.get("algorithmic_flops"):
+            return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": d["mfma_peak_TFLOP_s"], "unit": "TFLOP/s",
+                    "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                    "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
+        return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
+    roofline = None
+    if per_kernel:
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["us_per_img"])
+        roofline = roofline_of(dom)
+        roofline["traffic_source"] = (pmc_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over bench.py, separate passes)") if pmc_src else None
+        if roofline["bound"] not in ("hbm", "mfma", "valu"):
+            roofline["note"] = ("this kernel is %s-bound: its compulsory HBM bytes are negligible, so the HBM fraction says nothing about "
+                                "its quality; see hbm_kernel for the largest HBM-bound kernel" % roofline["bound"])
+        hbm = [k for k in per_kernel if per_kernel[k]["bound"] == "hbm" and per_kernel[k]["algorithmic_bytes"]]
+        if hbm:
+            roofline["hbm_kernel"] = roofline_of(max(hbm, key=lambda k: per_kernel[k]["us_per_img"]))
+        if graph:
+            roofline["measured_in"] = "an eager pass of %d steps after the timed graph replays (a captured graph cannot carry the event brackets)" % n_sampled
+    hot_us = sum(v["us_per_img"] for v in per_kernel.values())
+    smed, sp10, sp90 = percentiles(step_ms)
+    st = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("proposal_prologue", "topk_", "nms_", "level_ids")))
+    record = {
+        "metric": cfg["metric"], "value": round(value, 3), "unit": "images/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
+        "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox",
+                   "submission": "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "step_ms": ({"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
+                     "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
+                     "source": "HIP events at the step boundaries on the main stream (rank 0)"} if step_ms else None),
+        "allocator_in_timed_region": allocator,
+        "conditions": {
+            "gemm_selection": ("PyTorch TunableOp: rocBLAS / hipBLASLt solution timed and picked per GEMM shape during the initialisation pass"
+                               if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "library default heuristics"),
+            "tunableop_results": (("read from a results file of an earlier run + tuned now for new shapes" if TUNABLEOP_CACHED else "tuned in this process")
+                                  if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else None),
+            "python_gc": "on" if gc_on else "frozen after initialisation, off while the timed steps run (--gc-on to leave it on)",
+            "off_switches": "--no-tunableop --gc-on give the untuned, collector-on figure"},
+        "distributed": {"backend": backend, "world_size_seen_by_rank0": world_seen, "per_rank_ms_per_step": per_rank_ms,
+                        "min_ms": min(per_rank_ms), "max_ms": max(per_rank_ms), "ddp": ddp},
+        "hot_path": {"sum_kernel_us_per_img": round(hot_us, 1),
+                     "launches_per_img": round(sum(v["launches_per_img"] for v in per_kernel.values()), 1),
+                     # proposals actually produced: mean of the device-side counts of the timed steps (capacity P is an upper bound)
+                     "mean_proposals_per_img": round(mean_props, 1) if mean_props is not None else None,
+                     "proposals_per_s": round(value * mean_props, 1) if mean_props is not None else None,
+                     # BASELINE.json's second figure: NMS + RoI pooling forward/backward, HIP-event us per image
+                     "nms_plus_roi_us_per_img": round(sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith(("nms_", "roi_"))), 1),
+                     # SURVEY 8(d) "proposals/s" unit: one image's proposal stage = prologue -> top-k -> NMS -> P rois
+                     "proposal_stage_us_per_img": round(st, 1),
+                     "proposal_stage_proposals_per_s": round(mean_props / (st * 1e-6), 0) if (st and mean_props is not None) else None,
+                     "kernels": per_kernel},
+        "final_loss": round(final_loss, 4), "device_status": 0,
+    }
     return record
+
+
+COMPACT_LIMIT = 4096          # the driver keeps a ~10 KB tail of stdout: the line it parses stays well below that (tests/test_bench_record.py)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d} if d is not None else None
+
+
+def compact_record(full, also=()):
+    """The ONE JSON line rank 0 prints last on stdout: the contract's keys + roofline + cpu_baseline + the hot-path totals, and a
+    compact `also` list; per-kernel records, percentiles, conditions, allocator counters go to bench_detail.json (emit())."""
+    out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data"))
+    out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission"))
+    rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
+    roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions",))
+    if roof is not None and full["roofline"].get("hbm_kernel"):
+        roof["hbm_kernel"] = _pick(full["roofline"]["hbm_kernel"], rk)
+    out["roofline"] = roof
+    out["cpu_baseline"] = full.get("cpu_baseline")
+    out["hot_path"] = _pick(full.get("hot_path"), ("sum_kernel_us_per_img", "launches_per_img", "mean_proposals_per_img", "proposals_per_s",
+                                                   "nms_plus_roi_us_per_img", "proposal_stage_us_per_img"))
+    if full["n_gpus"] > 1:
+        dd = full["distributed"]
+        out["distributed"] = {"backend": dd["backend"], "per_rank_ms_per_step": dd["per_rank_ms_per_step"],
+                              "ddp": _pick(dd.get("ddp"), ("num_parameter_tensors", "total_parameter_size_bytes", "bucket_cap_bytes"))}
+    if also:
+        out["also"] = []
+        for rec in also:
+            e = {"config": rec["config"]["workload"].split(",")[0], "dtype": rec["dtype"].split("(")[0], "submission": rec["config"]["submission"].split(" (")[0],
+                 "value": rec["value"], "ms_per_step": rec["ms_per_step"], "roofline": _pick(rec.get("roofline"), ("kernel", "bound", "frac", "avg_launch_us")),
+                 "nms_plus_roi_us_per_img": (rec.get("hot_path") or {}).get("nms_plus_roi_us_per_img")}
+            if rec.get("eager_submission"):
+                e["eager_value"] = rec["eager_submission"]["value"]
+            out["also"].append(e)
+    out["detail"] = "bench_detail.json"
+    return out
+
+
+def emit(full, also=()):
+    """Full records -> bench_detail.json (repo root, and gpurun_out/ when it exists) + a per-kernel table on stderr; the compact line ->
+    stdout, LAST."""
+    detail = dict(full)
+    if also:
+        detail["also"] = list(also)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    json.dump(detail, f, indent=1)
+            except OSError as e:
+                print("[bench] could not write %s/bench_detail.json: %s" % (d, e), file=sys.stderr)
+    for rec in [full] + list(also):
+        ks = (rec.get("hot_path") or {}).get("kernels") or {}
+        print("[bench] %s | %s | %s" % (rec["config"]["workload"].split(",")[0], rec["dtype"], rec["config"]["submission"]), file=sys.stderr)
+        for name, v in sorted(ks.items(), key=lambda kv: -kv[1]["us_per_img"]):
+            print("[bench]   %-36s %5.2f /img  avg %8.2f us  %-7s %s" % (name, v["launches_per_img"], v["avg_us"], v["bound"],
+                  ("%.0f GB/s" % v["GB_s"]) if v.get("GB_s") else (("%.0f TFLOP/s" % v["TFLOP_s"]) if v.get("TFLOP_s") else "")), file=sys.stderr)
+    line = json.dumps(compact_record(full, also))
+    if len(line) >= COMPACT_LIMIT:                     # never let the line outgrow the driver's capture again: shed the optional parts
+        slim = compact_record(full, ())
+        slim["also_dropped"] = "line would exceed %d bytes; see bench_detail.json" % COMPACT_LIMIT
+        line = json.dumps(slim)
+    sys.stderr.flush()
+    print(line, flush=True)
 
 
 def main():
@@ -456,11 +566,11 @@ def main():
     out = run_config(args, args.config, args.amp, args.steps, args.warmup, args.graph, rank, world, device,
                      with_cpu=(not args.no_cpu_baseline and world == 1))
     release()
+    also = []
     if rank == 0 and world == 1 and not args.no_also and args.config == "vgg" and args.amp == "none" and not args.graph:
         # BASELINE.json configs[3] / configs[4] and its "RoIAlign + NMS us/img" figure, timed by the same command (short runs).
         # The FPN step enqueues ~2500 launches from Python and is host-bound when submitted launch by launch (its eager figure moves
         # +-8 % between boxes); both entries are therefore timed as HIP-graph replays (--graph), with the eager figure beside it.
-        also = []
         for amp in ("none", "bf16"):
             rec = run_config(args, "fpn", amp, args.also_steps, 5, True, rank, world, device, with_cpu=False)
             rec["config"]["note"] = "short run inside the headline command: %d timed steps, 5 warm-up" % args.also_steps
@@ -469,15 +579,8 @@ def main():
             rec["eager_submission"] = {"value": eager["value"], "ms_per_step": eager["ms_per_step"], "step_ms": eager["step_ms"]}
             also.append(rec)
             release()
-        # the headline configuration under bf16 autocast (NOT the headline: the reference trains in fp32): what the matrix cores
-        # give the VGG16 backbone, with the same fp32 box path
-        rec = run_config(args, "vgg", "bf16", args.also_steps, 5, False, rank, world, device, with_cpu=False)
-        rec["config"]["note"] = "short eager run inside the headline command: %d timed steps, 5 warm-up; bf16 autocast of the torch layers" % args.also_steps
-        also.append(rec)
-        release()
-        out["also"] = also
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, also)
     parallel.shutdown()
 
 
