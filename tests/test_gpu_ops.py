@@ -229,31 +229,62 @@ def test_nms_bit_exact_vs_oracle(ops, K, thr):
     assert int(cnt.item()) == len(ko) and np.array_equal(keep[:len(ko)].cpu().numpy(), ko)
 
 
-@pytest.mark.parametrize("live", [1, 64, 1500, 2047, 2048, 2049, 2111, 2112, 4097, 11999])
-def test_nms_cascade_live_count_around_the_level_boundary(ops, live):
-    """K = 12 000 takes the cascade (top 2048 -> filter -> survivors); the device-side live count may fall anywhere relative to the
-    level boundary, including an empty second level."""
-    rng = np.random.RandomState(5)
-    K = 12000
+def _spread_boxes(rng, K, lo=0.05, hi=0.35):
     c = rng.rand(K, 2).astype(np.float32) * 0.7 + 0.15
-    wh = (rng.rand(K, 2).astype(np.float32) * 0.3 + 0.05)
-    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    wh = (rng.rand(K, 2).astype(np.float32) * (hi - lo) + lo)
+    return np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+
+
+CASCADE_K = 20000              # > NMS_CASCADE_MIN = 16 384 (csrc/nms.hip): the two-level cascade is what runs, in the default environment
+
+
+@pytest.mark.parametrize("live", [1, 64, 1500, 2047, 2048, 2049, 2111, 2112, 2113, 4097, 16383, 16384, 16385, 19967, 19968, 19969, 19999, 20000])
+def test_nms_cascade_live_count_around_the_level_boundary(ops, live):
+    """K = 20 000 > NMS_CASCADE_MIN takes the cascade (top NMS_T_MAX = 2048 -> nms_filter_kernel -> survivors through nms_kernel again
+    -> two-level nms_emit_kernel); the device-side live count may fall anywhere relative to the level boundary (2048), the second level's
+    64-box block boundaries and the end of the buffer, including an empty second level.  Keep lists, rois and counts vs the oracle."""
+    rng = np.random.RandomState(5)
+    K = CASCADE_K
+    b = _spread_boxes(rng, K)
     ko = orc.nms(b[:live], 0.7)
     keep, rois, cnt = ops.nms_sorted(T(b), 0.7, n_boxes=T(np.array([live], np.int32)), want_rois=True)
     n = int(cnt.item())
     assert n == len(ko) and np.array_equal(keep[:n].cpu().numpy(), ko) and np.array_equal(rois[:n].cpu().numpy(), b[ko])
-    post = max(1, len(ko) // 2)                                   # post_k cuts inside level 0 or level 1
-    keep, _, cnt = ops.nms_sorted(T(b), 0.7, post_k=post, n_boxes=T(np.array([live], np.int32)))
-    assert int(cnt.item()) == post and np.array_equal(keep[:post].cpu().numpy(), ko[:post])
+    n0 = int((ko < 2048).sum())                                   # kept boxes of level 0
+    for post in sorted({1, max(1, n0 // 2), max(1, n0 - 1), max(1, n0), min(len(ko), n0 + 1), max(1, (n0 + len(ko)) // 2), len(ko)}):
+        keep, _, cnt = ops.nms_sorted(T(b), 0.7, post_k=post, n_boxes=T(np.array([live], np.int32)))   # post_k cuts inside level 0 / at the seam / inside level 1
+        assert int(cnt.item()) == post and np.array_equal(keep[:post].cpu().numpy(), ko[:post]), post
+
+
+@pytest.mark.parametrize("K,thr", [(16385, 0.7), (20000, 0.7), (20000, 0.3), (40000, 0.5), (40000, 0.7)])
+def test_nms_cascade_keep_lists_vs_oracle(ops, K, thr):
+    """keep LISTS (not counts) of the cascade at the sizes FRCNN.predict's class-aware lists reach (up to
+    1000 x 90 candidates, new_model.py _suppress), through every entry point: nms_sorted, nms (sorts by score first), batched_nms."""
+    rng = np.random.RandomState(K + int(thr * 10))
+    b = _spread_boxes(rng, K, 0.03, 0.28)
+    ko = orc.nms(b, thr)
+    keep, rois, cnt = ops.nms_sorted(T(b), thr, want_rois=True)
+    n = int(cnt.item())
+    assert n == len(ko) and np.array_equal(keep[:n].cpu().numpy(), ko) and np.array_equal(rois[:n].cpu().numpy(), b[ko])
+    sc = ((rng.permutation(K) + 1) / np.float32(K + 1)).astype(np.float32)       # distinct scores: the order is unambiguous
+    assert len(np.unique(sc)) == K
+    order = np.argsort(-sc, kind="stable")
+    assert np.array_equal(ops.nms(T(b), T(sc), thr).cpu().numpy(), orc.nms(b, thr, order=order))
+    ncls = 90
+    cls = rng.randint(0, ncls, K).astype(np.int64)
+    got = ops.batched_nms(T(b), T(sc), T(cls), thr).cpu().numpy()
+    exp = np.concatenate([np.nonzero(cls == q)[0][orc.nms(b[cls == q], thr, order=np.argsort(-sc[cls == q], kind="stable"))] for q in range(ncls)])
+    exp = exp[np.argsort(-sc[exp], kind="stable")]
+    assert np.array_equal(got, exp)
 
 
 @pytest.mark.parametrize("regime", ["heavy", "sparse", "chain"])
 def test_nms_cascade_regimes(ops, regime):
-    """The cascade's three stages under different survivor fractions: 'heavy' = piles of near-duplicates (almost everything dies in
-    the filter), 'sparse' = almost nothing overlaps (everything survives into level 1), 'chain' = a long suppression chain that
-    crosses the level boundary (box i overlaps box i + 1 only: kept / removed alternate, decided one from the other)."""
+    """The cascade's three stages (K = 18 000 > NMS_CASCADE_MIN) under different survivor fractions: 'heavy' = piles of near-duplicates
+    (almost everything dies in the filter), 'sparse' = almost nothing overlaps (everything survives into level 1), 'chain' = a long
+    suppression chain that crosses the level boundary (box i overlaps box i + 1 only: kept / removed alternate, decided one from the other)."""
     rng = np.random.RandomState(9)
-    K = 9000
+    K = 18000
     if regime == "heavy":
         centers = rng.rand(40, 2).astype(np.float32) * 0.6 + 0.2
         c = centers[rng.randint(0, 40, K)] + rng.randn(K, 2).astype(np.float32) * 0.004
