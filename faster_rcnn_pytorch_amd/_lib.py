@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
 OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV, OP_RPN_CONV_WGRAD = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
@@ -20,6 +20,8 @@ _vp, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_ui
 # name -> (restype, argtypes); must list EVERY symbol include/frcnn_hip.h declares (tests check this)
 SIGNATURES = {
     "frcnn_abi_version": (_i, []),
+    "frcnn_layout_check": (_i, []),
+    "frcnn_layout_stamp": (_u64, []),
     "frcnn_last_error": (C.c_char_p, []),
     "frcnn_workspace_bytes": (_sz, [_i, _i64, _i64]),
     "frcnn_anchor_base_host": (_i, [_i, _vp, _i, _vp, _i, _vp]),
@@ -78,9 +80,11 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.frcnn_abi_version() != ABI_VERSION:
-        raise ImportError("libfrcnn_hip.so ABI version %d, expected %d (rebuild: make -C faster_rcnn_pytorch_amd/csrc)"
-                          % (lib.frcnn_abi_version(), ABI_VERSION))
+    ver = lib.frcnn_abi_version()
+    if ver < 0:                          # the library's own objects disagree about a shared layout (csrc/frcnn_layout.h): never run its kernels
+        raise ImportError("libfrcnn_hip.so refuses to load: %s" % (lib.frcnn_last_error() or b"").decode())
+    if ver != ABI_VERSION:
+        raise ImportError("libfrcnn_hip.so ABI version %d, expected %d (rebuild: make -C faster_rcnn_pytorch_amd/csrc)" % (ver, ABI_VERSION))
     return lib
 
 

@@ -1,6 +1,7 @@
 // api.cpp -- host-only part of libfrcnn_hip.so: status strings, workspace sizing,
 // host-side anchor bases, and the per-kernel HIP-event timing facility.
 #include "frcnn_common.h"
+#include "frcnn_layout.h"
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -20,7 +21,32 @@ int frcnn_set_error(int code, const char *fmt, ...)
     return code;
 }
 
-FRCNN_EXPORT int frcnn_abi_version(void) { return FRCNN_ABI_VERSION; }
+// ---- layout stamps (frcnn_layout.h): every object of the library registers the stamp it was compiled with ----
+#define FRCNN_N_OBJECTS 12             // the eleven .hip objects + api.o (csrc/Makefile: SRCS_HIP)
+struct LayoutReg { const char *object; uint64_t stamp; };
+static std::vector<LayoutReg> &layout_registry() { static std::vector<LayoutReg> r; return r; }     // function-local: static initialisers of other objects may run first
+void frcnn_layout_register(const char *object, uint64_t stamp) { layout_registry().push_back({object, stamp}); }
+FRCNN_LAYOUT_STAMP(api);
+
+int frcnn_layout_check_impl(void)
+{
+    const uint64_t mine = frcnn_layout_stamp_value();
+    const std::vector<LayoutReg> &r = layout_registry();
+    for (const LayoutReg &e : r)
+        if (e.stamp != mine)
+            return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "layout stamp mismatch: object '%s' was compiled against other versions of the shared headers "
+                                   "(%016llx, api.o has %016llx): stale object -- rebuild the library from clean (make -C faster_rcnn_pytorch_amd/csrc clean all)",
+                                   e.object, (unsigned long long)e.stamp, (unsigned long long)mine);
+    if ((int)r.size() != FRCNN_N_OBJECTS)
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "layout stamp: %d objects registered, %d expected (an object was linked without its stamp)",
+                               (int)r.size(), FRCNN_N_OBJECTS);
+    return FRCNN_OK;
+}
+FRCNN_EXPORT int frcnn_layout_check(void) { return frcnn_layout_check_impl(); }
+FRCNN_EXPORT uint64_t frcnn_layout_stamp(void) { return frcnn_layout_stamp_value(); }
+
+// the ABI version, or FRCNN_ERR_UNSUPPORTED (negative; message in frcnn_last_error) when the library's objects disagree about a layout
+FRCNN_EXPORT int frcnn_abi_version(void) { const int rc = frcnn_layout_check_impl(); return rc ? rc : FRCNN_ABI_VERSION; }
 FRCNN_EXPORT const char *frcnn_last_error(void) { return g_err; }
 
 // ---- workspace layout sizes (must agree with the carving in topk.hip / nms.hip / targets.hip) ----

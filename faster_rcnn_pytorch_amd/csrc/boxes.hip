@@ -5,6 +5,8 @@
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include "topk_dev.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(boxes);
 
 // ------------------------------------------------------------------------------------------
 // anchor of flat index i from the level table (anchor.py:34-55; models/new_model.py:46-47)

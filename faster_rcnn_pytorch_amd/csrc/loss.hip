@@ -12,6 +12,8 @@
 // first int32 of the workspace: it must be ZERO before the first call and the last workgroup leaves it zero (frcnn_hip.h).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(loss);
 
 struct LossAcc { float rpn_ce, rpn_sl1, head_ce, head_sl1; int rpn_valid; int pad[3]; };      // one 32-byte slot per workgroup
 #define LOSS_MAX_BLOCKS 256                                                                    // per part (RPN rows, head rows)

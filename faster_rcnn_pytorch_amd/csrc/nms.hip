@@ -9,8 +9,10 @@
 //  (2) it can be CASCADED: let S0 = the kept boxes among the T best-scored ones (final: they depend on nothing below them).  A box
 //      below the top T that a member of S0 suppresses is removed -- final -- and removed boxes never suppress anybody.  What is left
 //      ("survivors") is suppressed by no member of S0, so its fate depends on the survivors alone: an independent NMS problem over a
-//      fraction of the boxes.  On the 600x1000 training frame (12 000 boxes, ~90 % suppressed) the pair count drops from 72 M to
-//      ~2 M (top 2048) + ~3-10 M (rest x S0) + ~1-8 M (survivors); results are identical by construction.
+//      fraction of the boxes; results are identical by construction.  The cascade runs ABOVE NMS_CASCADE_MIN = 16 384 boxes only
+//      (FRCNN.predict's class-aware candidate lists, up to 1000 x 90 boxes); the proposal stages (12 000 / 6 000 / 4 000 / 2 000
+//      boxes) run ONE dense level, which is faster there (a single launch; round 2 measured the cascade at 12 000 boxes: 2 + 3-10
+//      + 1-8 M pairs instead of 72 M, but three more launches and two more hand-offs).
 //
 //  nms_kernel<CLS, DENSE> : one LEVEL (relation + resolution [+ outputs] in one launch).  Tile workgroups enumerate the lower-triangular
 //      64 x 64 tiles of the suppression relation in PULL orientation (one wave per tile; lane = the lower-scored box; the 64 candidate
@@ -33,6 +35,8 @@
 // K <= NMS_CASCADE_MIN boxes (both proposal stages, predict's per-image lists) run one level directly.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(nms);
 #include <cstdlib>
 #include <cstring>
 
@@ -803,9 +807,7 @@ static bool nms_use_dense(int nblk)
 }
 static bool nms_use_cascade(int64_t K)
 {
-    static const int mode = [] { const char *e = getenv("FRCNN_NMS_CASCADE"); return e ? atoi(e) : 1; }();
-    static const int kmin = [] { const char *e = getenv("FRCNN_NMS_CASCADE_MIN"); return e ? atoi(e) : NMS_CASCADE_MIN; }();
-    return mode != 0 && K > kmin;
+    return K > NMS_CASCADE_MIN;
 }
 static NmsWs carve_nms(void *ws, int64_t K)
 {

@@ -15,6 +15,8 @@
 // for 480x640 -> 800x1066) but at these sizes the two passes are launch/latency bound (~10 us).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(preprocess);
 #include <cmath>
 
 #define RS_BITS 22

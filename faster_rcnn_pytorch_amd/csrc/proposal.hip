@@ -7,6 +7,8 @@
 // graph-capturable; the prologue also clears the NMS stage's zero region: no memset node.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(proposal);
 
 struct ProposalWs {
     float *boxes, *scores, *sscores, *sboxes;

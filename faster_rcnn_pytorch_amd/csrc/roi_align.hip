@@ -18,6 +18,8 @@
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(roi_align);
 #include <cstdlib>
 #include <cstring>
 
@@ -985,8 +987,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
             hipDeviceProp_t pr;
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, roi_align_bwd_tile_kernel<float, true>, 256, 0) != hipSuccess || per < 1) per = 5;
-            const char *e = getenv("FRCNN_RA_FIRST");
-            return e ? atoi(e) : cus * per;
+            return cus * per;
         }();
         const int n_first = (int)std::min<int64_t>(n_item_blocks, (int64_t)resident / n_cg * n_cg);
         if (C % RT_CB == 0 && ((size_t)grad_out & 15) == 0)

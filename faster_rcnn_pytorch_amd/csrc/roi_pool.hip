@@ -10,6 +10,8 @@
 // Algorithmic bytes: fwd 4*C*H*W + 16R + 8*R*C*PH*PW; bwd the same.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(roi_pool);
 #include <cfloat>
 
 #ifndef ROI_FWD_RB

@@ -22,6 +22,8 @@
 //   added through LDS, the biases are added and cls / reg are written.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(rpn_conv);
 #include <atomic>
 #include <type_traits>
 

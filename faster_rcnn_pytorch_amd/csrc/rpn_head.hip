@@ -16,6 +16,8 @@
 // accumulate / bias / outputs so that box regression stays fp32) is a template instance of the same kernel.
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(rpn_head);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

@@ -19,6 +19,8 @@
 #include <cstring>
 #include <type_traits>
 #include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(targets);
 
 #define EPS_JACCARD 1e-5f
 #define RS_LDS_MAX 24576              // rpn_sample_kernel keeps the Philox keys of up to this many anchors in LDS (96 KB); also the largest N

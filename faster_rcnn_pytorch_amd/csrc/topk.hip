@@ -16,6 +16,8 @@
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
 #include "topk_dev.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(topk);
 #include <cstdlib>
 
 #define TOPK_ROWS 256
@@ -210,7 +212,11 @@ __global__ __launch_bounds__(256) void topk_place_kernel(const float *__restrict
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < SS_PER_THREAD; ++e)
-        if (bk[e] >= 0) sorted[s_base[bk[e]] + slot[e]] = k[e];
+        if (bk[e] >= 0) {
+            const int pos = s_base[bk[e]] + slot[e];
+            if (ss_in_range(pos, 1, N)) sorted[pos] = k[e];
+            else ss_mark_bad(ctl);
+        }
 }
 
 // topk_count_kernel + topk_place_kernel as ONE launch for grids that are certainly co-resident (<= SS_PART_MAX_WG workgroups of 256
@@ -289,15 +295,18 @@ __global__ __launch_bounds__(256) void topk_partition_kernel(const float *__rest
 #pragma unroll
     for (int e = 0; e < SS_PER_THREAD; ++e)
         if (bk[e] >= 0) {
-            if (BUCKETS) __hip_atomic_store(&sorted[s_base[bk[e]] + slot[e]], k[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else sorted[s_base[bk[e]] + slot[e]] = k[e];
+            const int pos = s_base[bk[e]] + slot[e];
+            if (!ss_in_range(pos, 1, N)) ss_mark_bad(ctl);         // counts / cursors not reset by this build's sampling workgroup: no wild store
+            else if (BUCKETS) __hip_atomic_store(&sorted[pos], k[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else sorted[pos] = k[e];
         }
     if constexpr (BUCKETS) {
         ss_grid_barrier(ctl, 2);
         s_base[threadIdx.x] = excl;                                 // the buckets' first ranks
         s_cnt[threadIdx.x] = total;
         const int n_valid = __hip_atomic_load(&ctl->n_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int n_out = n_valid < K ? n_valid : K;
+        const bool bad = __hip_atomic_load(&ctl->pad[SS_PAD_BAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || n_valid < 0 || n_valid > N;
+        const int n_out = bad ? -1 : (n_valid < K ? n_valid : K);
         if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = n_out;
         __syncthreads();
         // work item = (bucket, part): the bucket's rows are split over `parts` workgroups, every one of which stages the whole bucket in
@@ -306,8 +315,9 @@ __global__ __launch_bounds__(256) void topk_partition_kernel(const float *__rest
         for (int it = (int)blockIdx.x; it < SS_BUCKETS * parts; it += (int)gridDim.x) {
             const int bkt = it / parts, part = it - bkt * parts;
             const int base = s_base[bkt], m = s_cnt[bkt];
-            if (base >= n_out) break;                               // the buckets are in rank order
+            if (base >= n_out) break;                               // the buckets are in rank order (n_out = -1: nothing is ranked)
             if (m == 0) continue;
+            if (!ss_in_range(base, m, N)) break;
             const u64 *seg = sorted + base;
             const int per = (m + parts - 1) / parts;
             const int e0 = part * per, e1 = min(m, e0 + per);
@@ -315,6 +325,7 @@ __global__ __launch_bounds__(256) void topk_partition_kernel(const float *__rest
                 const int rank = base + r;
                 if (rank < n_out) {
                     const int idx = (int)(~(uint32_t)kk);
+                    if ((unsigned)idx >= (unsigned)N) return;
                     out_idx[rank] = idx;
                     out_scores[rank] = scores[idx];
                     if (out_boxes) out_boxes[rank] = boxes_in[idx];
@@ -367,9 +378,10 @@ __global__ __launch_bounds__(256) void topk_bucket_kernel(const float *__restric
     __syncthreads();
     const int base = s_b[0], m = s_b[1];
     const int n_valid = ctl->n_valid;
-    const int n_out = n_valid < K ? n_valid : K;
+    const bool bad = ctl->pad[SS_PAD_BAD] != 0 || n_valid < 0 || n_valid > N;
+    const int n_out = bad ? -1 : (n_valid < K ? n_valid : K);
     if (bkt == 0 && part == 0 && threadIdx.x == 0) *out_count = n_out;
-    if (base >= n_out || m == 0) return;
+    if (base >= n_out || m == 0 || !ss_in_range(base, m, N)) return;
     const u64 *seg = sorted + base;
     const int per = (m + nparts - 1) / nparts;
     const int e0 = part * per, e1 = min(m, e0 + per);              // my rows
@@ -378,6 +390,7 @@ __global__ __launch_bounds__(256) void topk_bucket_kernel(const float *__restric
         const int rank = base + r;
         if (rank < n_out) {
             const int idx = (int)(~(uint32_t)k);
+            if ((unsigned)idx >= (unsigned)N) return;
             out_idx[rank] = idx;
             out_scores[rank] = scores[idx];
             if (out_boxes) out_boxes[rank] = boxes_in[idx];

@@ -10,10 +10,19 @@
 #define SS_LARGE 2048                   // samples for N >= 65536 (1024: the fused prologue launch 23 -> 16 us, but twice the bucket size: topk_bucket 17 -> 35 us)
 #endif
 
+#define SS_PAD_BAD 1                    // SsCtl::pad[1]: set by a placement / ranking kernel that found the control block inconsistent (see ss_in_range)
+
 typedef unsigned long long ss_u64;
 // bar: the partition launch's grid barrier -- eight per-residue arrival counters and a top counter on their own 64-byte lines, and the
 // flag the waiters poll (hundreds of workgroups bumping AND polling one word queue behind each other: 13 us in the RPN target maker)
 struct SsCtl { ss_u64 split[SS_BUCKETS]; int cnt[SS_BUCKETS]; int cursor[SS_BUCKETS]; int n_valid; int pad[15]; int bar[18][16]; int flag[16]; };
+
+// Memory-safety fence (round 4): every address the top-k kernels derive from the control block's counts and cursors
+// is range-checked against N before it is used.  A control block that was not reset by the sampling workgroup of the SAME build (a stale
+// object, a caller's uninitialised workspace) then yields a count of -1 downstream (NMS sees no live box, head_targets raises
+// FRCNN_HT_ERR_SHORT, the loss is NaN, check_device_status() reports) -- not a wild store.
+__device__ __forceinline__ bool ss_in_range(int base, int len, int N) { return base >= 0 && len >= 0 && (unsigned)base + (unsigned)len <= (unsigned)N; }
+__device__ __forceinline__ void ss_mark_bad(SsCtl *ctl) { __hip_atomic_store(&ctl->pad[SS_PAD_BAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // order-preserving map float -> uint32 (total order; -0 < +0)
 __device__ __forceinline__ uint32_t f2key(float f)
@@ -25,7 +34,7 @@ __device__ __forceinline__ ss_u64 ss_key(float sc, int idx) { return ((ss_u64)f2
 
 // samples per sort and splitter stride: 512 samples for the sizes of one feature map, SS_LARGE above; the stride covers ranks up to
 // ~1.5 K (at least), the whole distribution at most
-static inline void ss_plan(int64_t N, int64_t K, int *S_out, int *stride_out)
+static inline constexpr void ss_plan(int64_t N, int64_t K, int *S_out, int *stride_out)
 {
     const int S = N < 65536 ? 512 : SS_LARGE;
     const int full = S / SS_BUCKETS;                                        // stride that spreads 255 splitters over all S samples
@@ -49,7 +58,7 @@ __device__ __forceinline__ void ss_sample_body(F score_at, int N, int stride, Ss
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = rb * 64 + lane;
     for (int tq = threadIdx.x; tq < S; tq += 256) s_k[tq] = f2key(score_at((int)(((long long)tq * N) / S)));
-    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->flag[0] = 0; ctl->split[0] = ~0ull; } if (threadIdx.x < 18) ctl->bar[threadIdx.x][0] = 0; }
+    if (rb == 0) { ctl->cnt[threadIdx.x] = 0; ctl->cursor[threadIdx.x] = 0; if (threadIdx.x == 0) { ctl->n_valid = 0; ctl->pad[SS_PAD_BAD] = 0; ctl->flag[0] = 0; ctl->split[0] = ~0ull; } if (threadIdx.x < 18) ctl->bar[threadIdx.x][0] = 0; }
     __syncthreads();
     const int idx = (int)(((long long)t * N) / S);
     const uint32_t k = s_k[t];

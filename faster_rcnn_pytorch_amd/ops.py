@@ -13,7 +13,6 @@ PyTorch is plumbing here (device memory, streams, autograd glue).  Every op requ
 fp32 tensors on a HIP device and raises otherwise: there is no CPU path in the product.
 """
 import ctypes as C
-import os as _os
 
 import numpy as np
 import torch
@@ -482,8 +481,7 @@ class _RPNConvHeadFn(torch.autograd.Function):
                                                  _ptr(dwc), _ptr(dbc), _ptr(dwr), _ptr(dbr), _ptr(db3), _ptr(ws), nb, _stream()), "rpn_head_tail_ml_bwd")
         # data gradient of the 3x3 convolution: the same implicit-GEMM kernel on the transposed, flipped weights, all levels in one launch
         d_feats = [None] * len(feats)
-        use_aten = _os.environ.get("FRCNN_CONV_BWD") == "aten"          # developer A/B switch: MIOpen for the data gradient too
-        if any(ctx.needs_input_grad[6:]) and not use_aten:
+        if any(ctx.needs_input_grad[6:]):
             d_feats = [torch.empty_like(f) for f in feats]
             H = _host_i32([f.shape[2] for f in feats])
             W = _host_i32([f.shape[3] for f in feats])
@@ -493,15 +491,7 @@ class _RPNConvHeadFn(torch.autograd.Function):
             with torch.cuda.device(dev):
                 check(lib.frcnn_rpn_conv_bwd_data(dptrs, fptrs, _np_ptr(H), _np_ptr(W), len(feats), Cc, _ptr(w3), _ptr(wsc), nbc, _stream()), "rpn_conv_bwd_data")
         # weight gradient: the hand-written split-K MFMA kernel, all levels in one launch + a fixed-order finalize
-        if not use_aten:
-            dw3 = rpn_conv_wgrad(feats, d_raws)
-        else:                                                           # (A/B: MIOpen per level, accumulated in fp32)
-            w3b = w3.to(torch.bfloat16)
-            dw3 = torch.zeros_like(w3)
-            for k, (f, d) in enumerate(zip(feats, d_raws)):
-                gi, gw, _ = torch.ops.aten.convolution_backward(d, f, w3b, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
-                dw3 += gw.float()
-                d_feats[k] = gi
+        dw3 = rpn_conv_wgrad(feats, d_raws)
         return (dw3, db3, dwc.reshape(ctx.w_shapes[0]), dbc, dwr.reshape(ctx.w_shapes[1]), dbr, *d_feats)
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 4
+#define FRCNN_ABI_VERSION 5
 
 typedef enum {
     FRCNN_OK = 0,
@@ -59,7 +59,13 @@ typedef enum {
     FRCNN_OP_RPN_CONV_WGRAD = 9   /* frcnn_rpn_conv_wgrad (per-split partial gradients) */
 } frcnn_op;
 
+/* FRCNN_ABI_VERSION, or FRCNN_ERR_UNSUPPORTED (message in frcnn_last_error) when the objects the library was linked from were compiled
+ * against different versions of its internal headers (a stale object; csrc/frcnn_layout.h): a binding must refuse such a library. */
 int frcnn_abi_version(void);
+/* The same check by itself (FRCNN_OK / FRCNN_ERR_UNSUPPORTED), and the stamp api.o was compiled with: a 64-bit hash of the sizes, field
+ * offsets and constants of every structure two translation units share by layout (AnchorDesc, the sample sort's control block + plan). */
+int frcnn_layout_check(void);
+uint64_t frcnn_layout_stamp(void);
 /* thread-local description of the last non-zero status returned on this thread */
 const char *frcnn_last_error(void);
 size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2);

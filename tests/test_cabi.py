@@ -39,7 +39,7 @@ def test_header_symbols_all_exported_and_bound(L):
 
 
 def test_abi_version_and_error_reporting(L):
-    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 4
+    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 5
     rc = L.lib.frcnn_nms(None, None, 10, 0.5, 10, None, None, None, None, 0, None)      # NULL out_count
     assert rc == -1 and b"nms" in L.lib.frcnn_last_error()
     with pytest.raises(L.FrcnnError):
@@ -68,3 +68,35 @@ def test_ops_refuse_cpu_tensors(L):
         ops.xy_to_cxcy(torch.zeros(4, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.nms(torch.zeros(4, 4), torch.zeros(4), 0.5)
+
+
+def test_layout_stamp_of_every_object_agrees(L):
+    """csrc/frcnn_layout.h: every translation unit registers a compile-time hash of the layouts it shares with the others (AnchorDesc,
+    the sample sort's control block and plan); the library checks them at load."""
+    assert L.lib.frcnn_layout_check() == 0
+    assert L.lib.frcnn_layout_stamp() != 0
+
+
+def test_a_stale_object_makes_the_library_refuse_to_load(tmp_path):
+    """The class of fault behind round 3's 14:49 abort: one object compiled against another version of a shared
+    header.  Here topk.hip is compiled with a skewed stamp and linked with the other, current objects: frcnn_abi_version() must return
+    FRCNN_ERR_UNSUPPORTED and name the object, and the Python binding must refuse the library (ImportError), before any kernel runs."""
+    csrc = os.path.join(ROOT, "faster_rcnn_pytorch_amd", "csrc")
+    obj = os.path.join(ROOT, "faster_rcnn_pytorch_amd", "lib", "obj")
+    if not os.path.exists(os.path.join(obj, "api.o")):
+        import __graft_entry__ as g
+        g.build()
+    flags = "--offload-arch=gfx950 -O1 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off".split()
+    skew = str(tmp_path / "topk_skew.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-DFRCNN_LAYOUT_TEST_SKEW=7", "-c", os.path.join(csrc, "topk.hip"), "-o", skew])
+    objs = [skew if f == "topk.o" else os.path.join(obj, f) for f in sorted(os.listdir(obj)) if f.endswith(".o")]
+    so = str(tmp_path / "libfrcnn_skew.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
+    lib = C.CDLL(so)
+    lib.frcnn_last_error.restype = C.c_char_p
+    assert lib.frcnn_layout_check() == -2 and lib.frcnn_abi_version() == -2           # FRCNN_ERR_UNSUPPORTED
+    msg = lib.frcnn_last_error().decode()
+    assert "'topk'" in msg and "stale object" in msg
+    code = "import os; os.environ['FRCNN_HIP_LIB'] = %r\nfrom faster_rcnn_pytorch_amd import _lib" % so
+    r = subprocess.run([os.sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "ImportError" in r.stderr and "refuses to load" in r.stderr and "'topk'" in r.stderr

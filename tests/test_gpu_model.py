@@ -265,9 +265,16 @@ def test_fpn_predict_with_a_candidate_list_above_the_nms_cascade_threshold(fpn_m
     x, _, _ = synth(29, H, W, 1)
     sd = {k: v.clone() for k, v in fpn_model.frcnn_head.state_dict().items()}
     g = torch.Generator().manual_seed(8)
+    seen = {}
+    h = fpn_model.frcnn_head.cls_head.register_forward_hook(lambda m, i, o: seen.__setitem__("rms", float(i[0].detach().float().pow(2).mean().sqrt())))
+    fpn_model.eval()
+    fpn_model.predict(x.to(DEV), 0.5)                       # a first pass only to learn the scale of the head's 1024-d features
+    h.remove()
+    std = 0.7 / (seen["rms"] * 32.0)                        # logits ~ N(0, 0.7): most of the 90 classes of a RoI sit above 0.005 ~ 0.45 / 91
     with torch.no_grad():
-        fpn_model.frcnn_head.cls_head.weight.copy_(torch.randn(fpn_model.frcnn_head.cls_head.weight.shape, generator=g) * 0.3)
-        fpn_model.frcnn_head.reg_head.weight.copy_(torch.randn(fpn_model.frcnn_head.reg_head.weight.shape, generator=g) * 0.5)
+        fpn_model.frcnn_head.cls_head.weight.copy_(torch.randn(fpn_model.frcnn_head.cls_head.weight.shape, generator=g) * std)
+        fpn_model.frcnn_head.cls_head.bias.zero_()
+        fpn_model.frcnn_head.reg_head.weight.copy_(torch.randn(fpn_model.frcnn_head.reg_head.weight.shape, generator=g) * std)
     try:
         n, n_cand = _predict_vs_oracle(fpn_model, x, 0.005, 91, None, fpn_model.frcnn_head, lambda _, rois: None, want_candidates=True,
                                        strict_cpu_softmax=False)
