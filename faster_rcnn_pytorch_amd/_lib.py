@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrc
 OK = 0
 ABI_VERSION = 5
 HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
-OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV, OP_RPN_CONV_WGRAD = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV, OP_RPN_CONV_WGRAD, OP_RPN_CONV_F32 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 _vp, _i, _i64, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
 
@@ -41,6 +41,9 @@ SIGNATURES = {
     "frcnn_rpn_conv_head_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "frcnn_rpn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "frcnn_rpn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
+    "frcnn_rpn_conv3x3_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_targets": (_i, [_i, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_head_targets": (_i, [_i, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _u64, _u64, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -22,7 +22,7 @@ int frcnn_set_error(int code, const char *fmt, ...)
 }
 
 // ---- layout stamps (frcnn_layout.h): every object of the library registers the stamp it was compiled with ----
-#define FRCNN_N_OBJECTS 12             // the eleven .hip objects + api.o (csrc/Makefile: SRCS_HIP)
+#define FRCNN_N_OBJECTS 13             // the twelve .hip objects + api.o (csrc/Makefile: SRCS_HIP)
 struct LayoutReg { const char *object; uint64_t stamp; };
 static std::vector<LayoutReg> &layout_registry() { static std::vector<LayoutReg> r; return r; }     // function-local: static initialisers of other objects may run first
 void frcnn_layout_register(const char *object, uint64_t stamp) { layout_registry().push_back({object, stamp}); }
@@ -59,6 +59,7 @@ size_t frcnn_ws_preprocess(int64_t in_hw, int64_t out_hw);
 size_t frcnn_ws_head_bwd(int64_t C);
 size_t frcnn_ws_rpn_conv(void);
 size_t frcnn_ws_rpn_conv_wgrad(void);
+size_t frcnn_ws_rpn_conv_f32(int64_t C);
 
 FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
 {
@@ -73,6 +74,7 @@ FRCNN_EXPORT size_t frcnn_workspace_bytes(int op, int64_t n1, int64_t n2)
     case FRCNN_OP_HEAD_BWD: return frcnn_ws_head_bwd(n1);
     case FRCNN_OP_RPN_CONV: return frcnn_ws_rpn_conv();
     case FRCNN_OP_RPN_CONV_WGRAD: return frcnn_ws_rpn_conv_wgrad();
+    case FRCNN_OP_RPN_CONV_F32: return frcnn_ws_rpn_conv_f32(n1);
     default: return 0;
     }
 }

@@ -1,0 +1,564 @@
+// rpn_conv_f32.hip -- the RPN head's 3x3 convolution in the reference's own precision (fp32), hand-written for gfx950:
+//   models/model.py:68-70, 79      self.inter_layer = nn.Conv2d(512, 512, 3, padding=1)  on the 37 x 62 VGG16 feature map
+//   models/new_model.py:96-98, 109 self.inter_layer = nn.Conv2d(256, 256, 3, padding=1)  on the five FPN levels
+// forward, data gradient and weight gradient on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain,
+// no reduced precision; 64 cycles per instruction and SIMD = the fp32 vector rate, 157 TFLOP/s per chip).  Until round 4 this
+// convolution was the one MIOpen call left on the hot path (igemm_fwd_gtcx35_nhwc_fp32 at 67 % of that peak, Winograd / igemm_wrw
+// for its backward).  The bias, the ReLU and both 1x1 heads stay in rpn_head.hip, which reads the bias-free output written here.
+//
+// rpn_conv3x3_f32_kernel (forward; data gradient = the same kernel on the weights transposed and flipped by rpn_conv_f32_pack_kernel):
+//   implicit GEMM  Y[co][p] = sum_{ci, tap} Wt[co][ci * 9 + tap] * X[ci][p + off(tap)],  M = co, N = flat positions p of one level, K = 9 C.
+//   Workgroup tile 128 co x 128 consecutive flat positions, 4 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulators per lane).
+//   K runs in chunks of 4 input channels x 9 taps.  The weights of a chunk are 36 CONTIGUOUS floats per output channel in the
+//   reference's own [co][ci][3][3] layout (no packing pass for the forward); the activations of a chunk are 4 ci x 3 dy plain copies
+//   of 130 consecutive floats of the flattened plane (p0 - 1 + (dy - 1) W ...): a tap's operand is then ONE ds_read_b32 at
+//   lane address + compile-time immediate, and the only thing the flat copy gets wrong -- the left / right neighbour of a pixel in
+//   the first / last column wraps to the neighbouring row -- is repaired by a v_cndmask with a per-lane edge flag (rows outside the
+//   image are zero-filled at staging time).  Both operands are double-buffered in LDS (2 x 25.8 KB), one barrier per chunk; the
+//   next chunk's global loads are issued before the current chunk's 72 MFMAs per wave.
+//   STREAM-K: the (tile, chunk) units of the whole problem are cut into G = 2 x CUs equal contiguous ranges, one per workgroup
+//   (600x1000: 72 tiles x 128 chunks = 9216 units = 18 per workgroup; FPN: 1404 x 64 = 89 856 = 175.5): every matrix pipe gets the
+//   same number of MFMAs whatever the shape.  A range that covers only part of a tile's K writes its accumulators to a slab
+//   (write-through), takes a ticket on the tile, and the workgroup that completes the tile adds the slabs IN RANGE ORDER and stores
+//   the tile: deterministic, no atomics on data, no memset (the ticket words are left zero).
+// rpn_conv3x3_f32_wgrad_kernel:
+//   dW[co][ci][tap] = sum_p dY[co][p] * X[ci][p + off(tap)]:  M = co, N = ci, K = positions, one accumulator tile per tap.
+//   Workgroup = one 32 co x 32 ci x 9 tap output tile; its four WAVES are four K ranges: every wave walks row segments of 16
+//   pixels down column strips with its own private LDS ring (dY segment double-buffered, three feature rows + one in flight), nine
+//   MFMAs per column pair off one dY fragment read and nine feature fragment reads at immediates, no workgroup barrier in the loop.
+//   At the end the four waves' accumulators are added through LDS in wave order and the tile is written once: at 600x1000 (256
+//   tiles = one workgroup per CU, one strip per wave) there are NO global partials; at FPN size (64 tiles) four workgroups share a
+//   tile through slabs + ticket + fixed-order sum like above.
+#include "frcnn_common.h"
+#include "frcnn_internal.h"
+#include "frcnn_layout.h"
+#include <algorithm>
+FRCNN_LAYOUT_STAMP(rpn_conv_f32);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CF_MT 128                      // output channels per workgroup tile
+#define CF_NT 128                      // flat positions per workgroup tile
+#define CF_CI 4                        // input channels per K chunk
+#define CF_KK (CF_CI * 9)              // 36 K values per chunk
+#define CF_AS 37                       // LDS row stride of the weight tile (floats): odd -> the 32 rows of a fragment read hit 32 banks
+#define CF_RS 144                      // LDS row stride of one (ci, dy) activation copy: 130 used; 6 * 144 = 32 (mod 64): the two k halves hit disjoint banks
+#define CF_ROWS (CF_CI * 3)
+#define CF_SLAB (CF_MT * CF_NT)        // floats per partial slab
+#define CF_MAX_TILES 8192              // ticket words in the control block
+
+struct CfLevel { const float *x; float *y; int H, W, HW, tile0; };
+struct CfArgs {
+    CfLevel lv[FRCNN_MAX_LEVELS];
+    int n_levels, C, n_co_tiles, n_pos_tiles, Kc, n_units, G;
+};
+struct CfTile { const float *x; float *y; int W, HW, p0, co0, tile; };
+
+__device__ __forceinline__ CfTile cf_tile(const CfArgs &a, int t)
+{
+    const int ct = t / a.n_pos_tiles, pt = t - ct * a.n_pos_tiles;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && pt >= a.lv[q].tile0) ? 1 : 0;
+    CfTile T;
+    T.x = a.lv[l].x; T.y = a.lv[l].y; T.W = a.lv[l].W; T.HW = a.lv[l].HW;
+    T.p0 = (pt - a.lv[l].tile0) * CF_NT;
+    T.co0 = ct * CF_MT;
+    T.tile = t;
+    return T;
+}
+
+__device__ __forceinline__ long long cf_start(int s, int U, int G) { return ((long long)s * U) / G; }
+
+__global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const float *__restrict__ w, float *__restrict__ part, int *__restrict__ cnt)
+{
+    __shared__ float sA[2][CF_MT * CF_AS];
+    __shared__ float sB[2][CF_ROWS * CF_RS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int G = a.G, U = a.n_units, Kc = a.Kc;
+    // logical range id: workgroups are dealt round-robin to the 8 XCDs, so the ranges of one XCD are made neighbours (shared weight /
+    // activation lines stay in that XCD's L2)
+    const int sigma = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int u0 = (int)cf_start(sigma, U, G), u1 = (int)cf_start(sigma + 1, U, G);
+    if (u0 >= u1) return;
+    const int Ktot = a.C * 9;
+
+    // Per-thread staging slots, fixed for the whole kernel: five 16-byte pieces of the weight tile (piece idx = tid + 256 q of 128 rows x 9
+    // pieces) and seven elements of the activation copies (six passes of two (ci, dy) rows x 128 + the two halo columns of every row).
+    // Only 32-bit offsets from wave-uniform bases live in registers (the first version kept 64-bit addresses and recomputed row / column
+    // splits per chunk: 253 spilled registers, and every spill reload inside the load sequence waited for the loads issued before it).
+    unsigned a_off[5];
+    int a_lds[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int idx = tid + 256 * q, row = idx / 9, pc = idx - row * 9;
+        a_off[q] = (unsigned)(row * Ktot + pc * 4);
+        a_lds[q] = row * CF_AS + pc * 4;
+    }
+    // activation copies: pass q < 6 covers the (ci, dy) rows 2q and 2q + 1 (thread half `hi`), column j = tid & 127; pass 6 = the two halo
+    // columns (-1, 128) of row tid >> 1 for the first 24 threads.  Row -> (ci, dy) are compile-time constants selected by `hi`.
+    const int hi = tid >> 7, bj = tid & 127;
+    const int h_row = (tid >> 1) % CF_ROWS, h_ci = h_row / 3, h_dy = h_row - 3 * h_ci - 1, h_j = (tid & 1) ? CF_NT : -1;
+    const bool a_tail = tid < 128, b_tail = tid < 2 * CF_ROWS;
+    float4 ra[5];
+    float rb[7];
+    unsigned rb_ok = 0;                                              // bit q: element q of the next chunk lies inside the plane (applied at the LDS store)
+    auto issue_loads = [&](const CfTile &T, int chunk) {
+        const float *wb = w + (size_t)T.co0 * Ktot + chunk * CF_KK;                 // wave-uniform bases, 32-bit lane offsets
+        const float *xb = T.x + (size_t)chunk * CF_CI * T.HW;
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (q < 4 || a_tail) ra[q] = *(const float4 *)(wb + a_off[q]);
+        unsigned okm = 0;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            int ci, dy, j;
+            if (q < 6) { ci = hi ? (2 * q + 1) / 3 : (2 * q) / 3; dy = hi ? (2 * q + 1) % 3 - 1 : (2 * q) % 3 - 1; j = bj; }
+            else { ci = h_ci; dy = h_dy; j = h_j; }
+            const int f = T.p0 + j + dy * T.W;
+            const bool ok = f >= 0 && f < T.HW && (q < 6 || b_tail);
+            rb[q] = xb[ok ? (unsigned)(ci * T.HW + f) : 0u];                      // unconditional load at a clamped offset; the zero is selected at the LDS store
+            okm |= ok ? (1u << q) : 0u;
+        }
+        rb_ok = okm;
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+            if (q < 4 || a_tail) {
+                float *d = &sA[buf][a_lds[q]];
+                d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
+            }
+        float *db = &sB[buf][hi * CF_RS + bj + 1];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) db[2 * q * CF_RS] = (rb_ok >> q) & 1u ? rb[q] : 0.0f;
+        if (b_tail) sB[buf][h_row * CF_RS + h_j + 1] = (rb_ok >> 6) & 1u ? rb[6] : 0.0f;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    // output element (mi, ni, r) of this lane: co = co0 + wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*lh, p = p0 + wn*64 + ni*32 + li
+    auto store_tile = [&](const CfTile &T) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int p = T.p0 + wn * 64 + ni * 32 + li;
+            if (p < T.HW) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = T.co0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        T.y[(size_t)co * T.HW + p] = acc[mi][ni][r];
+                    }
+            }
+        }
+    };
+    auto finish_segment = [&](const CfTile &T, int first_chunk, int n_chunks) {
+        if (n_chunks == Kc) { store_tile(T); return; }
+        float *slab = part + ((size_t)sigma * 2 + (first_chunk == 0 ? 1 : 0)) * CF_SLAB;
+        // register order [wave][mi][ni][r][lane]: 256 contiguous bytes per store, one address per accumulator tile + immediates, write-through
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                float *dst = &slab[(wave * 4 + mi * 2 + ni) * 16 * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    asm volatile("global_store_dword %0, %1, off offset:%2 sc1" :: "v"(dst), "v"(acc[mi][ni][r]), "n"(r * 256) : "memory");
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the slab has been performed before the ticket announces it
+        __syncthreads();
+        if (tid == 0) s_last = (__hip_atomic_fetch_add(&cnt[T.tile], n_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_chunks == Kc) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        // this workgroup completed the tile: add every range's slab in range order (its own included: the order never depends on who is last)
+        const long long lo = (long long)T.tile * Kc, hi = lo + Kc - 1;
+        int s_first = (int)((lo * G) / U), s_end = (int)((hi * G) / U);
+        while (cf_start(s_first + 1, U, G) <= lo) ++s_first;
+        while (cf_start(s_first, U, G) > lo) --s_first;
+        while (cf_start(s_end + 1, U, G) <= hi) ++s_end;
+        while (cf_start(s_end, U, G) > hi) --s_end;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+        for (int s = s_first; s <= s_end; ++s) {
+            const long long st = cf_start(s, U, G);
+            const float *sl = part + ((size_t)s * 2 + (st <= lo ? 1 : 0)) * CF_SLAB;
+            // 16 agent-scope loads in flight off one address (immediate offsets), then the adds (written as acc += load the compiler waits
+            // for every load by itself: 64 dependent round trips per slab, 240 us per tile at 600x1000)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float *src = &sl[(wave * 4 + mi * 2 + ni) * 16 * 64 + lane];
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(t[r]) : "v"(src), "n"(r * 256) : "memory");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += t[r];
+                }
+        }
+        store_tile(T);
+        if (tid == 0) __hip_atomic_store(&cnt[T.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+    };
+
+    int tile = u0 / Kc, chunk = u0 - tile * Kc;
+    CfTile T = cf_tile(a, tile);
+    int seg_first = chunk;
+    bool el[2], er[2];
+    auto edge_flags = [&](const CfTile &Tt) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = (Tt.p0 + wn * 64 + ni * 32 + li) % Tt.W;
+            el[ni] = col == 0;
+            er[ni] = col == Tt.W - 1;
+        }
+    };
+    edge_flags(T);
+    issue_loads(T, chunk);
+    store_lds(0);
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int buf = (u - u0) & 1;
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == Kc) { nchunk = 0; ++ntile; }
+        CfTile Tn = T;
+        const bool more = u + 1 < u1;
+        if (more) {
+            if (ntile != tile) Tn = cf_tile(a, ntile);
+            issue_loads(Tn, nchunk);
+        }
+        const float *pa = &sA[buf][(wm * 64 + li) * CF_AS + 18 * lh];
+        const float *pb = &sB[buf][6 * lh * CF_RS + wn * 64 + li];
+        // 18 k steps (ci pair cp, tap t), operands of step s + 1 read from LDS before the four MFMAs of step s are issued
+        float oa[2][2], ob[2][2];
+        auto fetch = [&](int s, int slot) {
+            const int cp = s / 9, t = s - cp * 9, dy = t / 3, dx = t % 3 - 1;
+            oa[slot][0] = pa[cp * 9 + t]; oa[slot][1] = pa[32 * CF_AS + cp * 9 + t];
+            ob[slot][0] = pb[(cp * 3 + dy) * CF_RS + 1 + dx]; ob[slot][1] = pb[(cp * 3 + dy) * CF_RS + 1 + dx + 32];
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int slot = s & 1, dx = (s % 9) % 3 - 1;
+            if (s + 1 < 18) fetch(s + 1, slot ^ 1);
+            float b0 = ob[slot][0], b1 = ob[slot][1];
+            if (dx == -1) { b0 = el[0] ? 0.0f : b0; b1 = el[1] ? 0.0f : b1; }
+            if (dx == 1) { b0 = er[0] ? 0.0f : b0; b1 = er[1] ? 0.0f : b1; }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_lds(buf ^ 1);
+        if (!more || ntile != tile) {
+            finish_segment(T, seg_first, chunk + 1 - seg_first);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+            seg_first = 0;
+            if (more) { T = Tn; edge_flags(T); }
+        }
+        tile = ntile; chunk = nchunk;
+        __syncthreads();
+    }
+}
+
+// Wt[ci][co][e] = W[co][ci][8 - e]: the data gradient dX = conv(dY, Wt) runs on the forward kernel.  32 x 32 (co, ci) blocks through LDS:
+// reads are 288 contiguous floats per co, writes 288 contiguous floats per ci.
+__global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__restrict__ w, float *__restrict__ wt, int C)
+{
+    __shared__ float s[32][32 * 9 + 1];
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+        const int r = e / 288, q = e - r * 288;
+        s[r][q] = w[((size_t)(co0 + r) * C + ci0) * 9 + q];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+        const int r = e / 288, q = e - r * 288;                     // r = ci, q = co * 9 + tap
+        const int co = q / 9, t = q - co * 9;
+        wt[((size_t)(ci0 + r) * C + co0) * 9 + q] = s[co][r * 9 + (8 - t)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weight gradient
+#define CW_TC 16                       // columns per row segment (8 MFMA k steps)
+#define CW_YS 17                       // LDS row stride of the dY segment [32 co][16]
+#define CW_XS 19                       // LDS row stride of a feature row segment [32 ci][18]
+#define CW_YB (32 * CW_YS)
+#define CW_XB (32 * CW_XS)
+#define CW_WAVE_LDS (2 * CW_YB + 4 * CW_XB)
+
+struct CwLevel { const float *x; const float *dy; int H, W, HW, n_strips, unit0; };
+struct CwArgs {
+    CwLevel lv[FRCNN_MAX_LEVELS];
+    int n_levels, C, n_units, S;       // S = workgroups per output tile (K split beyond the four waves)
+};
+
+__global__ __launch_bounds__(256, 1) void rpn_conv3x3_f32_wgrad_kernel(CwArgs a, float *__restrict__ dw, float *__restrict__ part, int *__restrict__ cnt)
+{
+    __shared__ float s_all[4 * CW_WAVE_LDS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int C = a.C, nt = C / 32;
+    const int tile = (int)blockIdx.x / a.S, split = (int)blockIdx.x - tile * a.S;
+    const int co0 = (tile / nt) * 32, ci0 = (tile % nt) * 32;
+    float *sY = s_all + wave * CW_WAVE_LDS, *sX = sY + 2 * CW_YB;
+    const int q = split * 4 + wave, nq = a.S * 4;
+    const int u0 = (int)(((long long)q * a.n_units) / nq), u1 = (int)(((long long)(q + 1) * a.n_units) / nq);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    float ry[8], rx[9];
+    // unit -> (level, strip, row)
+    int lvl = 0, strip = 0, row = 0;
+    auto decode = [&](int u) {
+        int l = 0;
+#pragma unroll
+        for (int k = 1; k < FRCNN_MAX_LEVELS; ++k) l += (k < a.n_levels && u >= a.lv[k].unit0) ? 1 : 0;
+        const int v = u - a.lv[l].unit0;
+        lvl = l; strip = v / a.lv[l].H; row = v - strip * a.lv[l].H;
+    };
+    auto load_y = [&](int l, int st, int r) {                       // dY[co0 + co][r][st*16 + col] -> ry
+        const int W = a.lv[l].W, HW = a.lv[l].HW;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = lane + 64 * k, co = e >> 4, col = st * CW_TC + (e & 15);
+            ry[k] = col < W ? a.lv[l].dy[(size_t)(co0 + co) * HW + r * W + col] : 0.0f;
+        }
+    };
+    auto load_x = [&](int l, int st, int r) {                       // X[ci0 + ci][r][st*16 - 1 + col], col = 0..17 -> rx (zero outside the image)
+        const int W = a.lv[l].W, H = a.lv[l].H, HW = a.lv[l].HW;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int e = lane + 64 * k, ci = e / 18, c = st * CW_TC - 1 + (e - ci * 18);
+            rx[k] = (r >= 0 && r < H && c >= 0 && c < W) ? a.lv[l].x[(size_t)(ci0 + ci) * HW + r * W + c] : 0.0f;
+        }
+    };
+    auto put_y = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int e = lane + 64 * k; sY[buf * CW_YB + (e >> 4) * CW_YS + (e & 15)] = ry[k]; }
+    };
+    auto put_x = [&](int r) {                                       // feature row r lives in ring slot (r + 1) & 3
+        const int slot = (r + 1) & 3;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const int e = lane + 64 * k, ci = e / 18; sX[slot * CW_XB + ci * CW_XS + (e - ci * 18)] = rx[k]; }
+    };
+
+    if (u0 < u1) {
+        decode(u0);
+        int ybuf = 0;
+        bool fresh = true;                                          // the ring does not hold this strip's rows yet
+        for (int u = u0; u < u1; ++u) {
+            if (fresh) {
+                load_y(lvl, strip, row); put_y(ybuf);
+                load_x(lvl, strip, row - 1); put_x(row - 1);
+                load_x(lvl, strip, row); put_x(row);
+                load_x(lvl, strip, row + 1); put_x(row + 1);
+                fresh = false;
+            }
+            // next unit's operands into registers while this unit's MFMAs run
+            int nl = lvl, ns = strip, nr = row + 1;
+            const bool more = u + 1 < u1;
+            bool nfresh = false;
+            if (more && nr == a.lv[lvl].H) {                        // the next unit starts another strip: its rows are staged at the top of its iteration
+                const int pl = lvl, ps = strip, pr = row;
+                decode(u + 1);
+                nl = lvl; ns = strip; nr = row;
+                lvl = pl; strip = ps; row = pr;
+                nfresh = true;
+            }
+            if (more && !nfresh) { load_y(nl, ns, nr); load_x(nl, ns, nr + 1); }
+            const float *py = sY + ybuf * CW_YB + li * CW_YS + lh;
+            const float *px0 = sX + ((row + 0) & 3) * CW_XB + li * CW_XS + lh;      // feature row (row - 1): slot (row) & 3
+            const float *px1 = sX + ((row + 1) & 3) * CW_XB + li * CW_XS + lh;
+            const float *px2 = sX + ((row + 2) & 3) * CW_XB + li * CW_XS + lh;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float av = py[2 * ks];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int dy = t / 3, dx = t % 3 - 1;
+                    const float *px = dy == 0 ? px0 : (dy == 1 ? px1 : px2);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, px[2 * ks + dx + 1], acc[t], 0, 0, 0);
+                }
+            }
+            if (more && !nfresh) { put_y(ybuf ^ 1); put_x(nr + 1); ybuf ^= 1; }
+            fresh = nfresh;
+            lvl = nl; strip = ns; row = nr;
+        }
+    }
+    // ---- the four waves' accumulators added through LDS in wave order, three taps at a time; then the tile (or this workgroup's slab)
+    __syncthreads();
+    float *dst = a.S > 1 ? part + ((size_t)tile * a.S + split) * (32 * 32 * 9) : nullptr;
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_all[((wave * 3 + tt) * 16 + r) * 64 + lane] = acc[g * 3 + tt][r];
+        __syncthreads();
+        for (int e = tid; e < 3 * 16 * 64; e += 256) {
+            const float v = ((s_all[e] + s_all[3072 + e]) + s_all[2 * 3072 + e]) + s_all[3 * 3072 + e];
+            const int tt = e / 1024, r = (e >> 6) & 15, l = e & 63;
+            const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31, t = g * 3 + tt;
+            if (dst) __hip_atomic_store(&dst[(co * 32 + ci) * 9 + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dw[((size_t)(co0 + co) * C + ci0 + ci) * 9 + t] = v;
+        }
+        __syncthreads();
+    }
+    if (a.S == 1) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = (__hip_atomic_fetch_add(&cnt[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    for (int e = tid; e < 32 * 32 * 9; e += 256) {
+        float v = 0.0f;
+        for (int s = 0; s < a.S; ++s) v += __hip_atomic_load(&part[((size_t)tile * a.S + s) * (32 * 32 * 9) + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int co = e / 288, rem = e - co * 288;
+        dw[((size_t)(co0 + co) * C + ci0) * 9 + rem] = v;
+    }
+    if (tid == 0) __hip_atomic_store(&cnt[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+// workspace (dedicated, ZERO before the first call, left zero by every call): [ticket words | transposed weights | slabs]
+struct CfWs { int *cnt; float *wt, *part; size_t total; };
+static int cf_ranges()
+{
+    static const int g = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 2 * cus;                                              // two workgroups of 51.7 KB LDS per CU
+    }();
+    return g;
+}
+static CfWs cf_carve(void *ws, int C)
+{
+    CfWs w; char *p = (char *)ws; size_t o = 0;
+    auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
+    w.cnt = (int *)take(CF_MAX_TILES * sizeof(int));
+    w.wt = (float *)take((size_t)C * C * 9 * sizeof(float));
+    const size_t fwd = (size_t)cf_ranges() * 2 * CF_SLAB * sizeof(float);
+    const size_t wg_tiles = (size_t)(C / 32) * (C / 32);           // weight gradient: tiles x workgroups per tile <= max(tiles, CUs) slabs of one tile
+    const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / 2) * (32 * 32 * 9) * sizeof(float);
+    w.part = (float *)take(fwd > wg ? fwd : wg);
+    w.total = o;
+    return w;
+}
+size_t frcnn_ws_rpn_conv_f32(int64_t C) { return (C > 0 && C <= 4096) ? cf_carve(nullptr, (int)C).total : 0; }
+
+static int cf_run(const float *const *in, float *const *out, const int *H, const int *W, int n_levels, int C, const float *w, const CfWs &ws,
+                  hipStream_t s)
+{
+    CfArgs a;
+    a.n_levels = n_levels; a.C = C; a.n_co_tiles = C / CF_MT; a.Kc = C / CF_CI;
+    int tiles = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        if (l < n_levels) {
+            a.lv[l] = {in[l], out[l], H[l], W[l], H[l] * W[l], tiles};
+            tiles += (H[l] * W[l] + CF_NT - 1) / CF_NT;
+        } else a.lv[l] = {nullptr, nullptr, 1, 1, 1, 1 << 30};
+    }
+    a.n_pos_tiles = tiles;
+    const long long n_tiles = (long long)tiles * a.n_co_tiles, units = n_tiles * a.Kc;
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    a.n_units = (int)units;
+    a.G = (int)std::min<long long>(cf_ranges(), units);
+    FRCNN_LAUNCH(rpn_conv3x3_f32_kernel, dim3((unsigned)a.G), dim3(256), 0, s, a, w, ws.part, ws.cnt);
+    FRCNN_CHECK_LAUNCH("rpn_conv3x3_f32_kernel");
+    return FRCNN_OK;
+}
+
+static int cf_check(const void *const *p0, const void *const *p1, const int *H, const int *W, int n_levels, int C, const void *w, void *ws, size_t ws_bytes,
+                    const char *what)
+{
+    FRCNN_REQUIRE(p0 && p1 && H && W && w && ws, "%s: NULL pointer", what);
+    FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS, "%s: 1 <= n_levels <= %d", what, FRCNN_MAX_LEVELS);
+    if (C <= 0 || C % CF_MT != 0 || C > 4096) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of %d", what, C, CF_MT);
+    for (int l = 0; l < n_levels; ++l) {
+        FRCNN_REQUIRE(p0[l] && p1[l] && H[l] > 0 && W[l] > 0, "%s: bad level %d", what, l);
+        FRCNN_REQUIRE((long long)H[l] * W[l] * C < (1ll << 31), "%s: level %d too large", what, l);
+    }
+    if (ws_bytes < frcnn_ws_rpn_conv_f32(C)) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, frcnn_ws_rpn_conv_f32(C));
+    return FRCNN_OK;
+}
+
+FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float *const *outs_dev, const int *H_host, const int *W_host, int n_levels, int C,
+                                           const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
+                      "rpn_conv3x3_f32_fwd");
+    if (rc) return rc;
+    return cf_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, cf_carve(workspace, C), (hipStream_t)stream);
+}
+
+FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, float *const *d_feats_dev, const int *H_host, const int *W_host, int n_levels,
+                                                int C, const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
+                      "rpn_conv3x3_f32_bwd_data");
+    if (rc) return rc;
+    const CfWs ws = cf_carve(workspace, C);
+    hipStream_t s = (hipStream_t)stream;
+    FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)(C / 32), (unsigned)(C / 32)), dim3(256), 0, s, w3_dev, ws.wt, C);
+    FRCNN_CHECK_LAUNCH("rpn_conv_f32_pack_kernel");
+    return cf_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, ws.wt, ws, s);
+}
+
+FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, const float *const *d_outs_dev, const int *H_host, const int *W_host, int n_levels,
+                                             int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, dw_dev, workspace, workspace_bytes,
+                      "rpn_conv3x3_f32_wgrad");
+    if (rc) return rc;
+    const CfWs ws = cf_carve(workspace, C);
+    CwArgs a;
+    a.n_levels = n_levels; a.C = C;
+    long long units = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        if (l < n_levels) {
+            const int ns = (W_host[l] + CW_TC - 1) / CW_TC;
+            a.lv[l] = {feats_dev[l], d_outs_dev[l], H_host[l], W_host[l], H_host[l] * W_host[l], ns, (int)units};
+            units += (long long)ns * H_host[l];
+        } else a.lv[l] = {nullptr, nullptr, 1, 1, 1, 1, 1 << 30};
+    }
+    FRCNN_REQUIRE(units < (1ll << 30), "rpn_conv3x3_f32_wgrad: too many row segments");
+    a.n_units = (int)units;
+    const int tiles = (C / 32) * (C / 32);
+    static const int cus = [] {
+        int dev = 0, c = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        return c;
+    }();
+    int S = cus / tiles;                                            // one workgroup per CU: 256 tiles at C = 512 -> 1, 64 tiles at C = 256 -> 4
+    if (S < 1) S = 1;
+    if (S > 16) S = 16;
+    while (S > 1 && (long long)S * 4 > units) --S;
+    a.S = S;
+    FRCNN_LAUNCH(rpn_conv3x3_f32_wgrad_kernel, dim3((unsigned)(tiles * S)), dim3(256), 0, (hipStream_t)stream, a, dw_dev, ws.part, ws.cnt);
+    FRCNN_CHECK_LAUNCH("rpn_conv3x3_f32_wgrad_kernel");
+    return FRCNN_OK;
+}

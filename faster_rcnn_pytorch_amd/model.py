@@ -93,8 +93,9 @@ class RegionProposalNetwork(nn.Module):
 
     def forward(self, features):
         if features.is_cuda and features.dtype == torch.float32 and features.size(0) == 1:
-            # 3x3 on MIOpen without its bias; bias + ReLU + both 1x1 heads + the NHWC layout in one MFMA kernel
-            raw = torch.nn.functional.conv2d(features, self.inter_layer.weight, None, padding=1)
+            # the 3x3 without its bias on the fp32 matrix cores (csrc/rpn_conv_f32.hip: forward, data and weight gradient hand-written);
+            # bias + ReLU + both 1x1 heads + the NHWC layout in one more MFMA kernel
+            raw = ops.rpn_conv3x3([features], self.inter_layer.weight)[0]
             return ops.rpn_head_tail(raw, self.inter_layer.bias, self.cls_layer.weight, self.cls_layer.bias,
                                      self.reg_layer.weight, self.reg_layer.bias)
         batch_size = features.size(0)                                              # reference form (autocast / batch > 1)

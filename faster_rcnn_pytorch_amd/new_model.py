@@ -185,7 +185,7 @@ class RPNHead(nn.Module):
         self.fused_bf16_conv = True          # under bf16 autocast: the hand-written implicit-GEMM head (csrc/rpn_conv.hip) instead of MIOpen + tail
 
     def forward_levels(self, feats):
-        """All levels at once: 3x3 per level on MIOpen without its bias, then ONE MFMA kernel for bias + ReLU + both 1x1 heads
+        """All levels at once: the 3x3 without its bias (fp32: the hand-written MFMA kernel; bf16 tensors outside the fused path: MIOpen), then ONE MFMA kernel for bias + ReLU + both 1x1 heads
         + the NHWC layout + the concatenation (new_model.py:37-44).  Under bf16 autocast the 3x3 outputs are bf16 and the
         heads contract on the bf16 matrix cores with fp32 accumulate; predictions (hence box regression) stay fp32."""
         f0 = feats[0]
@@ -197,7 +197,10 @@ class RPNHead(nn.Module):
                 return ops.rpn_conv_head_levels([f.to(torch.bfloat16) for f in feats], self.inter_layer.weight, self.inter_layer.bias,
                                                 self.cls_layer.weight, self.cls_layer.bias, self.reg_layer.weight, self.reg_layer.bias)
         if f0.is_cuda and f0.size(0) == 1 and f0.dtype in (torch.float32, torch.bfloat16):
-            raws = [torch.nn.functional.conv2d(f, self.inter_layer.weight, None, padding=1) for f in feats]
+            if f0.dtype == torch.float32 and not torch.is_autocast_enabled():
+                raws = ops.rpn_conv3x3(list(feats), self.inter_layer.weight)      # fp32 MFMA implicit GEMM, all levels in one launch (csrc/rpn_conv_f32.hip)
+            else:
+                raws = [torch.nn.functional.conv2d(f, self.inter_layer.weight, None, padding=1) for f in feats]
             if raws[0].dtype in (torch.float32, torch.bfloat16) and all(r.dtype == raws[0].dtype for r in raws):
                 with torch.autocast("cuda", enabled=False):
                     return ops.rpn_head_tail_levels(raws, self.inter_layer.bias, self.cls_layer.weight, self.cls_layer.bias,

@@ -530,6 +530,89 @@ def rpn_conv_wgrad(feats, d_raws):
     return dw
 
 
+# --------------------------------------------------------------------------------------------
+# the RPN head's 3x3 convolution in fp32 (models/model.py:68-70,79; models/new_model.py:96-98,109) on the fp32 matrix cores
+# --------------------------------------------------------------------------------------------
+def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
+    dev = ins[0].device
+    H = _host_i32([t.shape[2] for t in ins])
+    W = _host_i32([t.shape[3] for t in ins])
+    ip = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
+    op = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
+    nb = _lib.workspace_bytes(_lib.OP_RPN_CONV_F32, C_)
+    if nb == 0:
+        raise _lib.FrcnnError("%s: C = %d is outside what the fp32 conv kernels are built for (a multiple of 128)" % (what, C_))
+    ws = _ctrl_workspace(dev, "rpn_conv_f32", nb)     # ticket words zero on first use, left zero by every call; slabs + transposed weights behind them
+    with torch.cuda.device(dev):
+        check(fn(ip, op, _np_ptr(H), _np_ptr(W), len(ins), C_, _ptr(w_or_dw), _ptr(ws), ws.numel(), _stream()), what)
+
+
+def _conv_f32_levels(ts, name):
+    ts = [_req(t, torch.float32, name) for t in ts]
+    if not ts:
+        raise ValueError("rpn_conv3x3: no feature level")
+    Cc = ts[0].shape[1]
+    for t in ts:
+        if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != Cc:
+            raise ValueError("rpn_conv3x3: every level must be [1,C,h,w] (batch 1 per GPU) with the same C")
+    return ts, Cc
+
+
+def rpn_conv3x3_fwd(feats, w3):
+    """Bias-free 3x3 convolution (padding 1) of every level with the shared weight w3 [C,C,3,3]: fp32 [1,C,h,w] -> fp32 [1,C,h,w]."""
+    feats, Cc = _conv_f32_levels(feats, "feature map")
+    w3 = _req(w3, name="w3")
+    if tuple(w3.shape) != (Cc, Cc, 3, 3):
+        raise ValueError("rpn_conv3x3: weight must be [C,C,3,3] with C = %d" % Cc)
+    outs = [torch.empty_like(f) for f in feats]
+    _conv_f32_call(lib.frcnn_rpn_conv3x3_f32_fwd, "rpn_conv3x3_f32_fwd", feats, outs, Cc, w3)
+    return outs
+
+
+def rpn_conv3x3_bwd_data(d_outs, w3):
+    """Gradient of rpn_conv3x3_fwd with respect to its inputs (the same kernel on the transposed, flipped weights)."""
+    d_outs, Cc = _conv_f32_levels(d_outs, "d_out")
+    w3 = _req(w3, name="w3")
+    outs = [torch.empty_like(d) for d in d_outs]
+    _conv_f32_call(lib.frcnn_rpn_conv3x3_f32_bwd_data, "rpn_conv3x3_f32_bwd_data", d_outs, outs, Cc, w3)
+    return outs
+
+
+def rpn_conv3x3_wgrad(feats, d_outs):
+    """Gradient of rpn_conv3x3_fwd with respect to w3, summed over the levels: fp32 [C,C,3,3]."""
+    feats, Cc = _conv_f32_levels(feats, "feature map")
+    d_outs, _ = _conv_f32_levels(d_outs, "d_out")
+    if len(d_outs) != len(feats) or any(a.shape != b.shape for a, b in zip(feats, d_outs)):
+        raise ValueError("rpn_conv3x3_wgrad: feats and d_outs differ in shape")
+    dw = torch.empty((Cc, Cc, 3, 3), dtype=torch.float32, device=feats[0].device)
+    _conv_f32_call(lib.frcnn_rpn_conv3x3_f32_wgrad, "rpn_conv3x3_f32_wgrad", feats, d_outs, Cc, dw)
+    return dw
+
+
+class _RPNConv3x3F32Fn(torch.autograd.Function):
+    """args: (w3, *feats) -> the bias-free conv outputs of all levels (one launch); backward = data gradient + weight gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, w3, *feats):
+        outs = rpn_conv3x3_fwd(feats, w3)
+        ctx.save_for_backward(w3, *feats)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        w3 = ctx.saved_tensors[0]
+        feats = ctx.saved_tensors[1:]
+        g = [x.contiguous() for x in g]
+        d_feats = rpn_conv3x3_bwd_data(g, w3) if any(ctx.needs_input_grad[1:]) else [None] * len(feats)
+        dw = rpn_conv3x3_wgrad(feats, g) if ctx.needs_input_grad[0] else None
+        return (dw, *d_feats)
+
+
+def rpn_conv3x3(feats, w3):
+    """`inter_layer` without its bias for a list of fp32 levels [1,C,h,w]; differentiable (hand-written forward / backward kernels)."""
+    return list(_RPNConv3x3F32Fn.apply(w3, *feats))
+
+
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):
     """(pred_cls [1, sum P_l * A, 2], pred_reg [1, sum P_l * A, 4]) of the shared FPN RPN head on bf16 feature maps (models/new_model.py:37-44,
     89-114): one launch for conv3x3 + ReLU + both heads on the bf16 matrix cores; box regression outputs stay fp32."""

@@ -56,7 +56,8 @@ typedef enum {
     FRCNN_OP_PREPROCESS = 6,      /* n1 = (h << 32) | w of the source frame, n2 = (oh << 32) | ow of the resized frame */
     FRCNN_OP_HEAD_BWD = 7,        /* n1 = C (frcnn_rpn_head_tail_ml_bwd) */
     FRCNN_OP_RPN_CONV = 8,        /* frcnn_rpn_conv_head_fwd / frcnn_rpn_conv_bwd_data (packed bf16 weights) */
-    FRCNN_OP_RPN_CONV_WGRAD = 9   /* frcnn_rpn_conv_wgrad (per-split partial gradients) */
+    FRCNN_OP_RPN_CONV_WGRAD = 9,  /* frcnn_rpn_conv_wgrad (per-split partial gradients) */
+    FRCNN_OP_RPN_CONV_F32 = 10    /* n1 = C: frcnn_rpn_conv3x3_f32_fwd / _bwd_data / _wgrad (ticket words, transposed weights, slabs) */
 } frcnn_op;
 
 /* FRCNN_ABI_VERSION, or FRCNN_ERR_UNSUPPORTED (message in frcnn_last_error) when the objects the library was linked from were compiled
@@ -196,6 +197,23 @@ int frcnn_rpn_conv_bwd_data(const void *const *d_raw_levels_bf16, void *const *d
  * finalize (bit-reproducible).  workspace >= frcnn_workspace_bytes(FRCNN_OP_RPN_CONV_WGRAD, 0, 0).                                */
 int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const void *const *d_raw_levels_bf16, const int *H_host, const int *W_host, int n_levels,
                          int C, float *dw3, void *workspace, size_t workspace_bytes, void *stream);
+
+/* The RPN head's 3x3 convolution in fp32 -- `self.inter_layer` of models/model.py:68-70,79 (512 -> 512 on the VGG16 map) and
+ * models/new_model.py:96-98,109 (256 -> 256 on the FPN levels), WITHOUT its bias (frcnn_rpn_head_tail_* adds it) -- on
+ * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate, sums in a fixed order (bit-reproducible; a k-ordered fmaf chain per
+ * output inside a K range, K ranges added in range order).  feat_levels / out_levels: [C, H_l, W_l] fp32 NCHW, batch 1; w3 [C, C, 3, 3]
+ * in the reference's layout; C a multiple of 128.
+ * The three calls share ONE workspace of frcnn_workspace_bytes(FRCNN_OP_RPN_CONV_F32, C, 0) bytes that is DEDICATED to them and ZERO
+ * before the first call (its ticket words are left zero by every call); calls on one workspace must be stream-ordered.
+ *   _fwd      : out[co] = sum_ci conv3x3(feat[ci], w3[co][ci]), padding 1.
+ *   _bwd_data : d_feat[ci] = sum_co conv3x3(d_out[co], w3[co][ci] flipped): what autograd derives for the input.
+ *   _wgrad    : dw3[co][ci][ky][kx] = sum over levels and positions of d_out[co](y, x) * feat[ci](y + ky - 1, x + kx - 1) (fully overwritten). */
+int frcnn_rpn_conv3x3_f32_fwd(const float *const *feat_levels, float *const *out_levels, const int *H_host, const int *W_host, int n_levels, int C,
+                              const float *w3, void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_out_levels, float *const *d_feat_levels, const int *H_host, const int *W_host, int n_levels,
+                                   int C, const float *w3, void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feat_levels, const float *const *d_out_levels, const int *H_host, const int *W_host, int n_levels,
+                                int C, float *dw3, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

@@ -1455,3 +1455,78 @@ def test_rpn_conv_wgrad_bf16_vs_torch(ops, shapes):
     err = (got.double() - ref).abs().max().item()
     assert err < 1e-3 * ref.abs().max().item(), (err, ref.abs().max().item())
     assert torch.equal(got, ops.rpn_conv_wgrad(feats, d_raws))
+
+
+# ------------------------------------------------------------------------------------------ fp32 3x3 RPN conv (csrc/rpn_conv_f32.hip)
+CONV_F32_CASES = [
+    ("vgg600x1000", 512, [(37, 62)]),                                      # models/model.py:68-70 on the 600x1000 frame
+    ("fpn800x1344", 256, [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]),   # models/new_model.py:96-98, five levels
+    ("odd", 128, [(5, 7), (1, 1), (3, 130), (17, 2)]),                       # rows / columns shorter than a strip, a single pixel, a wrap inside a fragment
+    ("one_tile", 256, [(8, 16)]),
+]
+
+
+def _conv_ref64(feats, w):
+    import torch.nn.functional as F
+    return [F.conv2d(f.double().cpu(), w.double().cpu(), None, padding=1) for f in feats]
+
+
+@pytest.mark.parametrize("name,C,shapes", CONV_F32_CASES, ids=[c[0] for c in CONV_F32_CASES])
+def test_rpn_conv3x3_f32_forward_backward_vs_float64(ops, name, C, shapes):
+    """SURVEY A3 in the reference's precision: the hand-written fp32 MFMA 3x3 convolution (forward, data gradient, weight gradient)
+    against a float64 evaluation of the same convolution on the CPU.  Tolerance 1e-4 of the output scale (north_star); measured
+    ~1e-6: an fp32 fmaf chain over K = 9 C products.  Also: bit-reproducible run to run (fixed-order sums, no atomics on data)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(len(name) + C)
+    feats = [torch.randn(1, C, h, w, generator=g) for h, w in shapes]
+    wt = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    gouts = [torch.randn(1, C, h, w, generator=g) for h, w in shapes]
+    fd = [f.to(DEV) for f in feats]
+    gd = [t.to(DEV) for t in gouts]
+    wd = wt.to(DEV)
+    ref = _conv_ref64(feats, wt)
+    out = ops.rpn_conv3x3_fwd(fd, wd)
+    for o, r in zip(out, ref):
+        scale = float(r.abs().max())
+        assert o.shape == r.shape and float((o.double().cpu() - r).abs().max()) < 1e-4 * max(1.0, scale)
+        assert float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, scale)       # what an fp32 chain of this length really gives
+    out2 = ops.rpn_conv3x3_fwd(fd, wd)
+    assert all(torch.equal(a, b) for a, b in zip(out, out2))
+    # data gradient: d_feat = conv_transpose(d_out, w) = conv(d_out, w transposed and flipped)
+    dref = [F.conv_transpose2d(t.double(), wt.double(), None, padding=1) for t in gouts]
+    dgot = ops.rpn_conv3x3_bwd_data(gd, wd)
+    for o, r in zip(dgot, dref):
+        assert float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
+    assert all(torch.equal(a, b) for a, b in zip(dgot, ops.rpn_conv3x3_bwd_data(gd, wd)))
+    # weight gradient, summed over the levels
+    wref = torch.zeros(C, C, 3, 3, dtype=torch.float64)
+    for f, t in zip(feats, gouts):
+        wref += torch.nn.grad.conv2d_weight(f.double(), (C, C, 3, 3), t.double(), padding=1)
+    wgot = ops.rpn_conv3x3_wgrad(fd, gd)
+    err = float((wgot.double().cpu() - wref).abs().max())
+    assert err < 1e-4 * max(1.0, float(wref.abs().max())), err
+    assert torch.equal(wgot, ops.rpn_conv3x3_wgrad(fd, gd))
+
+
+def test_rpn_conv3x3_f32_autograd_matches_torch_conv(ops):
+    """The differentiable wrapper the two mirrors call (ops.rpn_conv3x3) against torch's own conv2d + autograd on the GPU (the vendor
+    path it replaces): values and all three gradients within 1e-4 of the scale."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    C_ = 256
+    shapes = [(24, 40), (12, 20), (6, 10)]
+    feats = [torch.randn(1, C_, h, w, generator=g).to(DEV).requires_grad_(True) for h, w in shapes]
+    wt = (torch.randn(C_, C_, 3, 3, generator=g) * 0.02).to(DEV).requires_grad_(True)
+    gout = [torch.randn(1, C_, h, w, generator=g).to(DEV) for h, w in shapes]
+    outs = ops.rpn_conv3x3(feats, wt)
+    sum((o * t).sum() for o, t in zip(outs, gout)).backward()
+    got = [f.grad.clone() for f in feats] + [wt.grad.clone()]
+    for f in feats:
+        f.grad = None
+    wt.grad = None
+    refs = [F.conv2d(f, wt, None, padding=1) for f in feats]
+    sum((o * t).sum() for o, t in zip(refs, gout)).backward()
+    for o, r in zip(outs, refs):
+        assert float((o - r).abs().max()) < 1e-4 * max(1.0, float(r.abs().max()))
+    for a, b in zip(got, [f.grad for f in feats] + [wt.grad]):
+        assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
