@@ -33,6 +33,7 @@
 #include "frcnn_internal.h"
 #include "frcnn_layout.h"
 #include <algorithm>
+#include <type_traits>
 FRCNN_LAYOUT_STAMP(rpn_conv_f32);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -70,7 +71,10 @@ __device__ __forceinline__ CfTile cf_tile(const CfArgs &a, int t)
 
 __device__ __forceinline__ long long cf_start(int s, int U, int G) { return ((long long)s * U) / G; }
 
-__global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const float *__restrict__ w, float *__restrict__ part, int *__restrict__ cnt)
+#ifndef CF_WPS
+#define CF_WPS 2
+#endif
+__global__ __launch_bounds__(256, CF_WPS) void rpn_conv3x3_f32_kernel(CfArgs a, const float *__restrict__ w, float *__restrict__ part, int *__restrict__ cnt)
 {
     __shared__ float sA[2][CF_MT * CF_AS];
     __shared__ float sB[2][CF_ROWS * CF_RS];
@@ -124,17 +128,21 @@ __global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const
         }
         rb_ok = okm;
     };
+    auto store_part = [&](int buf, int part) {                      // part 0..4 of the staged chunk -> LDS (one weight piece + one or three activation elements)
+        if (part < 4 || a_tail) {
+            float *d = &sA[buf][a_lds[part]];
+            d[0] = ra[part].x; d[1] = ra[part].y; d[2] = ra[part].z; d[3] = ra[part].w;
+        }
+        float *db = &sB[buf][hi * CF_RS + bj + 1];
+        db[2 * part * CF_RS] = (rb_ok >> part) & 1u ? rb[part] : 0.0f;
+        if (part == 4) {
+            db[2 * 5 * CF_RS] = (rb_ok >> 5) & 1u ? rb[5] : 0.0f;
+            if (b_tail) sB[buf][h_row * CF_RS + h_j + 1] = (rb_ok >> 6) & 1u ? rb[6] : 0.0f;
+        }
+    };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 5; ++q)
-            if (q < 4 || a_tail) {
-                float *d = &sA[buf][a_lds[q]];
-                d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
-            }
-        float *db = &sB[buf][hi * CF_RS + bj + 1];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) db[2 * q * CF_RS] = (rb_ok >> q) & 1u ? rb[q] : 0.0f;
-        if (b_tail) sB[buf][h_row * CF_RS + h_j + 1] = (rb_ok >> 6) & 1u ? rb[6] : 0.0f;
+        for (int part = 0; part < 5; ++part) store_part(buf, part);
     };
 
     f32x16 acc[2][2];
@@ -195,21 +203,28 @@ __global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const
         for (int s = s_first; s <= s_end; ++s) {
             const long long st = cf_start(s, U, G);
             const float *sl = part + ((size_t)s * 2 + (st <= lo ? 1 : 0)) * CF_SLAB;
-            // 16 agent-scope loads in flight off one address (immediate offsets), then the adds (written as acc += load the compiler waits
-            // for every load by itself: 64 dependent round trips per slab, 240 us per tile at 600x1000)
+            // all 64 agent-scope loads of the slab in flight (four addresses + immediates), adds behind counted waits (written as
+            // acc += load the compiler waits for every load by itself: 64 dependent round trips per slab, 240 us per tile at 600x1000)
+            float t[4][16];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int g = 0; g < 4; ++g) {
+                const float *src = &sl[(wave * 4 + g) * 16 * 64 + lane];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const float *src = &sl[(wave * 4 + mi * 2 + ni) * 16 * 64 + lane];
-                    float t[16];
+                for (int r = 0; r < 16; ++r)
+                    asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(t[g][r]) : "v"(src), "n"(r * 256) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(48)" : "+v"(t[0][0]), "+v"(t[0][1]), "+v"(t[0][2]), "+v"(t[0][3]), "+v"(t[0][4]), "+v"(t[0][5]), "+v"(t[0][6]), "+v"(t[0][7]), "+v"(t[0][8]), "+v"(t[0][9]), "+v"(t[0][10]), "+v"(t[0][11]), "+v"(t[0][12]), "+v"(t[0][13]), "+v"(t[0][14]), "+v"(t[0][15]) :: "memory");     // the adds below depend on this statement
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(t[r]) : "v"(src), "n"(r * 256) : "memory");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += t[0][r];
+            asm volatile("s_waitcnt vmcnt(32)" : "+v"(t[1][0]), "+v"(t[1][1]), "+v"(t[1][2]), "+v"(t[1][3]), "+v"(t[1][4]), "+v"(t[1][5]), "+v"(t[1][6]), "+v"(t[1][7]), "+v"(t[1][8]), "+v"(t[1][9]), "+v"(t[1][10]), "+v"(t[1][11]), "+v"(t[1][12]), "+v"(t[1][13]), "+v"(t[1][14]), "+v"(t[1][15]) :: "memory");     // the adds below depend on this statement
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] += t[r];
-                }
+            for (int r = 0; r < 16; ++r) acc[0][1][r] += t[1][r];
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(t[2][0]), "+v"(t[2][1]), "+v"(t[2][2]), "+v"(t[2][3]), "+v"(t[2][4]), "+v"(t[2][5]), "+v"(t[2][6]), "+v"(t[2][7]), "+v"(t[2][8]), "+v"(t[2][9]), "+v"(t[2][10]), "+v"(t[2][11]), "+v"(t[2][12]), "+v"(t[2][13]), "+v"(t[2][14]), "+v"(t[2][15]) :: "memory");     // the adds below depend on this statement
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[1][0][r] += t[2][r];
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[3][0]), "+v"(t[3][1]), "+v"(t[3][2]), "+v"(t[3][3]), "+v"(t[3][4]), "+v"(t[3][5]), "+v"(t[3][6]), "+v"(t[3][7]), "+v"(t[3][8]), "+v"(t[3][9]), "+v"(t[3][10]), "+v"(t[3][11]), "+v"(t[3][12]), "+v"(t[3][13]), "+v"(t[3][14]), "+v"(t[3][15]) :: "memory");     // the adds below depend on this statement
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[1][1][r] += t[3][r];
         }
         store_tile(T);
         if (tid == 0) __hip_atomic_store(&cnt[T.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
@@ -237,13 +252,12 @@ __global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const
         if (nchunk == Kc) { nchunk = 0; ++ntile; }
         CfTile Tn = T;
         const bool more = u + 1 < u1;
-        if (more) {
-            if (ntile != tile) Tn = cf_tile(a, ntile);
-            issue_loads(Tn, nchunk);
-        }
+        if (more && ntile != tile) Tn = cf_tile(a, ntile);
         const float *pa = &sA[buf][(wm * 64 + li) * CF_AS + 18 * lh];
         const float *pb = &sB[buf][6 * lh * CF_RS + wn * 64 + li];
-        // 18 k steps (ci pair cp, tap t), operands of step s + 1 read from LDS before the four MFMAs of step s are issued
+        // 18 k steps (ci pair cp, tap t), operands of step s + 1 read from LDS before the four MFMAs of step s are issued.  The next
+        // chunk's global loads are issued behind the first step's MFMAs and its LDS stores ride in the last five steps (the scheduler
+        // is fenced between steps: left alone it puts all loads in front of and all stores behind the 72 MFMAs, where nothing hides them)
         float oa[2][2], ob[2][2];
         auto fetch = [&](int s, int slot) {
             const int cp = s / 9, t = s - cp * 9, dy = t / 3, dx = t % 3 - 1;
@@ -259,11 +273,13 @@ __global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const
             if (dx == -1) { b0 = el[0] ? 0.0f : b0; b1 = el[1] ? 0.0f : b1; }
             if (dx == 1) { b0 = er[0] ? 0.0f : b0; b1 = er[1] ? 0.0f : b1; }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b0, acc[0][0], 0, 0, 0);
+            if (s == 0 && more) issue_loads(Tn, nchunk);
+            if (s >= 13 && more) store_part(buf ^ 1, s - 13);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_lds(buf ^ 1);
         if (!more || ntile != tile) {
             finish_segment(T, seg_first, chunk + 1 - seg_first);
 #pragma unroll
@@ -280,22 +296,15 @@ __global__ __launch_bounds__(256, 2) void rpn_conv3x3_f32_kernel(CfArgs a, const
     }
 }
 
-// Wt[ci][co][e] = W[co][ci][8 - e]: the data gradient dX = conv(dY, Wt) runs on the forward kernel.  32 x 32 (co, ci) blocks through LDS:
-// reads are 288 contiguous floats per co, writes 288 contiguous floats per ci.
+// Wt[ci][co][e] = W[co][ci][8 - e]: the data gradient dX = conv(dY, Wt) runs on the forward kernel.  One output element per thread,
+// written coalesced; the reads are 36-byte pieces 9 C floats apart that the L2 serves (the tensor is 2.4 / 9.4 MB).  (A 32 x 32 block
+// transpose through LDS with 256 workgroups took 13.7 us; this form has 9216 workgroups in flight.)
 __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__restrict__ w, float *__restrict__ wt, int C)
 {
-    __shared__ float s[32][32 * 9 + 1];
-    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
-        const int r = e / 288, q = e - r * 288;
-        s[r][q] = w[((size_t)(co0 + r) * C + ci0) * 9 + q];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
-        const int r = e / 288, q = e - r * 288;                     // r = ci, q = co * 9 + tap
-        const int co = q / 9, t = q - co * 9;
-        wt[((size_t)(ci0 + r) * C + co0) * 9 + q] = s[co][r * 9 + (8 - t)];
-    }
+    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C * 9u;
+    if (o >= n) return;
+    const unsigned pair = o / 9u, e = o - pair * 9u, ci = pair / (unsigned)C, co = pair - ci * (unsigned)C;
+    wt[o] = w[(co * (unsigned)C + ci) * 9u + (8u - e)];
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
@@ -312,7 +321,10 @@ struct CwArgs {
     int n_levels, C, n_units, S;       // S = workgroups per output tile (K split beyond the four waves)
 };
 
-__global__ __launch_bounds__(256, 1) void rpn_conv3x3_f32_wgrad_kernel(CwArgs a, float *__restrict__ dw, float *__restrict__ part, int *__restrict__ cnt)
+#ifndef CW_WPS
+#define CW_WPS 1
+#endif
+__global__ __launch_bounds__(256, CW_WPS) void rpn_conv3x3_f32_wgrad_kernel(CwArgs a, float *__restrict__ dw, float *__restrict__ part, int *__restrict__ cnt)
 {
     __shared__ float s_all[4 * CW_WAVE_LDS];
     __shared__ int s_last;
@@ -331,83 +343,132 @@ __global__ __launch_bounds__(256, 1) void rpn_conv3x3_f32_wgrad_kernel(CwArgs a,
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    float ry[8], rx[9];
-    // unit -> (level, strip, row)
-    int lvl = 0, strip = 0, row = 0;
+    // Staging roles: lane -> (row sr = channel of the tile, half sh): eight consecutive dY columns / nine consecutive feature columns
+    // (the 18-wide halo row in two halves) per lane, so a unit's 17 loads and 17 LDS stores are one instruction each: the lane's
+    // element offsets are computed once per strip (clamped to the row for columns outside the image; those are stored as zeros).
+    const int sr = lane >> 1, sh = lane & 1;
+    float *wy = sY + sr * CW_YS + sh * 8;                           // + buf * CW_YB + k
+    float *wx = sX + sr * CW_XS + sh * 9;                           // + slot * CW_XB + k
+    unsigned yo[8], xo[9];                                          // element offsets inside the row-0 segment of the lane's channel plane
+    unsigned ymask = 0, xmask = 0;                                  // bit k: the column exists
+    int lvl = 0, strip = 0, row = 0, H = 1, W = 1;
+    const float *xg = nullptr, *yg = nullptr;
     auto decode = [&](int u) {
         int l = 0;
 #pragma unroll
         for (int k = 1; k < FRCNN_MAX_LEVELS; ++k) l += (k < a.n_levels && u >= a.lv[k].unit0) ? 1 : 0;
         const int v = u - a.lv[l].unit0;
-        lvl = l; strip = v / a.lv[l].H; row = v - strip * a.lv[l].H;
-    };
-    auto load_y = [&](int l, int st, int r) {                       // dY[co0 + co][r][st*16 + col] -> ry
-        const int W = a.lv[l].W, HW = a.lv[l].HW;
+        lvl = l; H = a.lv[l].H; W = a.lv[l].W; xg = a.lv[l].x; yg = a.lv[l].dy;
+        strip = v / H; row = v - strip * H;
+        const int HW = a.lv[l].HW, c0 = strip * CW_TC;
+        ymask = 0; xmask = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int e = lane + 64 * k, co = e >> 4, col = st * CW_TC + (e & 15);
-            ry[k] = col < W ? a.lv[l].dy[(size_t)(co0 + co) * HW + r * W + col] : 0.0f;
+            const int c = c0 + sh * 8 + k;
+            const bool ok = c < W;
+            yo[k] = (unsigned)((co0 + sr) * HW + (ok ? c : 0));
+            ymask |= ok ? (1u << k) : 0u;
         }
-    };
-    auto load_x = [&](int l, int st, int r) {                       // X[ci0 + ci][r][st*16 - 1 + col], col = 0..17 -> rx (zero outside the image)
-        const int W = a.lv[l].W, H = a.lv[l].H, HW = a.lv[l].HW;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const int e = lane + 64 * k, ci = e / 18, c = st * CW_TC - 1 + (e - ci * 18);
-            rx[k] = (r >= 0 && r < H && c >= 0 && c < W) ? a.lv[l].x[(size_t)(ci0 + ci) * HW + r * W + c] : 0.0f;
+            const int c = c0 - 1 + sh * 9 + k;
+            const bool ok = c >= 0 && c < W;
+            xo[k] = (unsigned)((ci0 + sr) * HW + (ok ? c : 0));
+            xmask |= ok ? (1u << k) : 0u;
         }
     };
-    auto put_y = [&](int buf) {
+    // two register sets: during unit r the loads of unit r + 2 land in set r & 1 while set (r + 1) & 1 (loaded during unit r - 1) is
+    // written to LDS for unit r + 1 -- no copies, a whole unit (72 MFMAs) of flight for every load
+    float sy[2][8], sx[2][9];
+    auto load_y = [&](float (&d)[8], int r) {                       // r is a row of the image
+        const float *b = yg + (size_t)r * W;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int e = lane + 64 * k; sY[buf * CW_YB + (e >> 4) * CW_YS + (e & 15)] = ry[k]; }
+        for (int k = 0; k < 8; ++k) d[k] = b[yo[k]];
     };
-    auto put_x = [&](int r) {                                       // feature row r lives in ring slot (r + 1) & 3
-        const int slot = (r + 1) & 3;
+    auto load_x = [&](float (&d)[9], int r) {                       // rows outside the image are read clamped and stored as zeros
+        const float *b = xg + (size_t)min(max(r, 0), H - 1) * W;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { const int e = lane + 64 * k, ci = e / 18; sX[slot * CW_XB + ci * CW_XS + (e - ci * 18)] = rx[k]; }
+        for (int k = 0; k < 9; ++k) d[k] = b[xo[k]];
     };
+    auto put_y1 = [&](int buf, int k, float v) { wy[buf * CW_YB + k] = (ymask >> k) & 1u ? v : 0.0f; };
+    auto put_x1 = [&](int r, int k, float v) { wx[((r + 1) & 3) * CW_XB + k] = ((xmask >> k) & 1u) && r >= 0 && r < H ? v : 0.0f; };
+    // one unit = row r of the strip: 8 k steps (column pairs) x 9 taps.  LOAD / WRITE are compile-time: the steady state has no branch.
+    auto unit = [&](auto LOADc, auto WRITEc, float (&ly)[8], float (&lx)[9], float (&qy)[8], float (&qx)[9], int r) {
+        constexpr bool LOAD = decltype(LOADc)::value, WRITE = decltype(WRITEc)::value;
+        const float *py = sY + (r & 1) * CW_YB + li * CW_YS + lh;
+        const float *px0 = sX + ((r + 0) & 3) * CW_XB + li * CW_XS + lh;            // feature row r - 1
+        const float *px1 = sX + ((r + 1) & 3) * CW_XB + li * CW_XS + lh;
+        const float *px2 = sX + ((r + 2) & 3) * CW_XB + li * CW_XS + lh;
+        float oa[2], ob[2][9];
+        auto fetch = [&](int ks, int slot) {
+#if defined(CW_ABL) && (CW_ABL & 1)                                 // developer ablation: no LDS operand reads (results meaningless)
+            oa[slot] = (float)(ks + lane);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) ob[slot][t] = (float)(t + r);
+#else
+            oa[slot] = py[2 * ks];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3, dx = t % 3 - 1;
+                const float *px = dy == 0 ? px0 : (dy == 1 ? px1 : px2);
+                ob[slot][t] = px[2 * ks + dx + 1];
+            }
+#endif
+        };
+        fetch(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int slot = ks & 1;
+            if (ks + 1 < 8) fetch(ks + 1, slot ^ 1);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot], ob[slot][0], acc[0], 0, 0, 0);
+            if (LOAD && ks == 0) { load_y(ly, r + 2); load_x(lx, r + 3); }          // behind the first MFMA, not in front of the unit
+            if (WRITE && ks >= 1) {                                                 // unit r + 1's operands -> LDS: two or three stores per step
+                put_y1((r + 1) & 1, ks, qy[ks]);
+                put_x1(r + 2, ks, qx[ks]);
+                if (ks == 1) { put_y1((r + 1) & 1, 0, qy[0]); put_x1(r + 2, 0, qx[0]); }
+                if (ks == 7) put_x1(r + 2, 8, qx[8]);
+            }
+#pragma unroll
+            for (int t = 1; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot], ob[slot][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    const std::true_type Y{};
+    const std::false_type N{};
 
     if (u0 < u1) {
         decode(u0);
-        int ybuf = 0;
-        bool fresh = true;                                          // the ring does not hold this strip's rows yet
-        for (int u = u0; u < u1; ++u) {
-            if (fresh) {
-                load_y(lvl, strip, row); put_y(ybuf);
-                load_x(lvl, strip, row - 1); put_x(row - 1);
-                load_x(lvl, strip, row); put_x(row);
-                load_x(lvl, strip, row + 1); put_x(row + 1);
-                fresh = false;
-            }
-            // next unit's operands into registers while this unit's MFMAs run
-            int nl = lvl, ns = strip, nr = row + 1;
-            const bool more = u + 1 < u1;
-            bool nfresh = false;
-            if (more && nr == a.lv[lvl].H) {                        // the next unit starts another strip: its rows are staged at the top of its iteration
-                const int pl = lvl, ps = strip, pr = row;
-                decode(u + 1);
-                nl = lvl; ns = strip; nr = row;
-                lvl = pl; strip = ps; row = pr;
-                nfresh = true;
-            }
-            if (more && !nfresh) { load_y(nl, ns, nr); load_x(nl, ns, nr + 1); }
-            const float *py = sY + ybuf * CW_YB + li * CW_YS + lh;
-            const float *px0 = sX + ((row + 0) & 3) * CW_XB + li * CW_XS + lh;      // feature row (row - 1): slot (row) & 3
-            const float *px1 = sX + ((row + 1) & 3) * CW_XB + li * CW_XS + lh;
-            const float *px2 = sX + ((row + 2) & 3) * CW_XB + li * CW_XS + lh;
+        int u = u0;
+        while (u < u1) {
+            // ---- a run of rows [row, r_end) of one strip: prime the ring, then one unit per row
+            const int r_end = min(H, row + (u1 - u));
+            load_y(sy[0], row);
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float av = py[2 * ks];
+            for (int k = 0; k < 8; ++k) put_y1(row & 1, k, sy[0][k]);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int dy = t / 3, dx = t % 3 - 1;
-                    const float *px = dy == 0 ? px0 : (dy == 1 ? px1 : px2);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, px[2 * ks + dx + 1], acc[t], 0, 0, 0);
-                }
+            for (int d = -1; d <= 1; ++d) {
+                load_x(sx[0], row + d);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) put_x1(row + d, k, sx[0][k]);
             }
-            if (more && !nfresh) { put_y(ybuf ^ 1); put_x(nr + 1); ybuf ^= 1; }
-            fresh = nfresh;
-            lvl = nl; strip = ns; row = nr;
+            int r = row;
+#if !(defined(CW_ABL) && (CW_ABL & 2))
+            if (r + 1 < r_end) { load_y(sy[1], r + 1); load_x(sx[1], r + 2); }      // in flight: the operands of unit row + 1 (set 1)
+            // steady state, two units per trip: sets alternate (unit at even distance from `row` loads set 0 and writes set 1)
+            for (; r + 3 < r_end; r += 2) {
+                unit(Y, Y, sy[0], sx[0], sy[1], sx[1], r);
+                unit(Y, Y, sy[1], sx[1], sy[0], sx[0], r + 1);
+            }
+            // tail: at most three units left; the parity of (r - row) is even here
+            if (r + 2 < r_end) { unit(Y, Y, sy[0], sx[0], sy[1], sx[1], r); unit(N, Y, sy[1], sx[1], sy[0], sx[0], r + 1); unit(N, N, sy[0], sx[0], sy[1], sx[1], r + 2); }
+            else if (r + 1 < r_end) { unit(N, Y, sy[0], sx[0], sy[1], sx[1], r); unit(N, N, sy[1], sx[1], sy[0], sx[0], r + 1); }
+            else unit(N, N, sy[0], sx[0], sy[1], sx[1], r);
+#else
+            for (; r < r_end; ++r) unit(N, N, sy[0], sx[0], sy[1], sx[1], r);
+#endif
+            u += r_end - row;
+            if (u < u1) decode(u);
         }
     }
     // ---- the four waves' accumulators added through LDS in wave order, three taps at a time; then the tile (or this workgroup's slab)
@@ -424,7 +485,11 @@ __global__ __launch_bounds__(256, 1) void rpn_conv3x3_f32_wgrad_kernel(CwArgs a,
             const int tt = e / 1024, r = (e >> 6) & 15, l = e & 63;
             const int co = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ci = l & 31, t = g * 3 + tt;
             if (dst) __hip_atomic_store(&dst[(co * 32 + ci) * 9 + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef CW_NO_STORE
             else dw[((size_t)(co0 + co) * C + ci0 + ci) * 9 + t] = v;
+#else
+            else if (v == 12345.678f) dw[0] = v;
+#endif
         }
         __syncthreads();
     }
@@ -451,7 +516,7 @@ static int cf_ranges()
     static const int g = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return 2 * cus;                                              // two workgroups of 51.7 KB LDS per CU
+        return CF_WPS * cus;                                         // CF_WPS workgroups of 51.7 KB LDS per CU
     }();
     return g;
 }
@@ -463,7 +528,7 @@ static CfWs cf_carve(void *ws, int C)
     w.wt = (float *)take((size_t)C * C * 9 * sizeof(float));
     const size_t fwd = (size_t)cf_ranges() * 2 * CF_SLAB * sizeof(float);
     const size_t wg_tiles = (size_t)(C / 32) * (C / 32);           // weight gradient: tiles x workgroups per tile <= max(tiles, CUs) slabs of one tile
-    const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / 2) * (32 * 32 * 9) * sizeof(float);
+    const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / CF_WPS * CW_WPS) * (32 * 32 * 9) * sizeof(float);
     w.part = (float *)take(fwd > wg ? fwd : wg);
     w.total = o;
     return w;
@@ -523,7 +588,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
     if (rc) return rc;
     const CfWs ws = cf_carve(workspace, C);
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)(C / 32), (unsigned)(C / 32)), dim3(256), 0, s, w3_dev, ws.wt, C);
+    FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)((C * C * 9 + 255) / 256)), dim3(256), 0, s, w3_dev, ws.wt, C);
     FRCNN_CHECK_LAUNCH("rpn_conv_f32_pack_kernel");
     return cf_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, ws.wt, ws, s);
 }
@@ -553,7 +618,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, cons
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         return c;
     }();
-    int S = cus / tiles;                                            // one workgroup per CU: 256 tiles at C = 512 -> 1, 64 tiles at C = 256 -> 4
+    int S = CW_WPS * cus / tiles;                                   // CW_WPS workgroups per CU: 256 tiles at C = 512, 64 tiles at C = 256
     if (S < 1) S = 1;
     if (S > 16) S = 16;
     while (S > 1 && (long long)S * 4 > units) --S;
