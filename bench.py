@@ -83,7 +83,8 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "roi_align_fwd77_kernel": "hbm", "roi_align_fwd_nhwc_kernel": "hbm", "roi_align_bwd_tile_kernel": "hbm", "roi_align_bwd_nhwc_kernel": "hbm",
          "roi_align_bwd_combine_kernel": "hbm", "rpn_conv3x3_head_kernel": "mfma", "rpn_conv3x3_bwd_data_kernel": "mfma",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
-         "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma"}
+         "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
+         "rpn_conv_f32_pack_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel")
 
 
@@ -120,6 +121,7 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "roi_align_bwd_tile_kernel": 4 * pooled + feat_bytes,             # grad_out in + every gradient pixel written once
         "roi_align_bwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
+        "rpn_conv_f32_pack_kernel": 2 * 4 * 9 * C * C,                    # the 3x3 weights in, transposed + flipped out
     }.get(kernel)
 
 

@@ -51,13 +51,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct CfLevel { const float *x; float *y; int H, W, HW, tile0; };
 struct CfArgs {
     CfLevel lv[FRCNN_MAX_LEVELS];
-    int n_levels, C, n_co_tiles, n_pos_tiles, Kc, n_units, G;
+    int n_levels, C, n_co_tiles, n_pos_tiles, Kc, n_units, G, pos_major;
 };
 struct CfTile { const float *x; float *y; int W, HW, p0, co0, tile; };
 
 __device__ __forceinline__ CfTile cf_tile(const CfArgs &a, int t)
 {
-    const int ct = t / a.n_pos_tiles, pt = t - ct * a.n_pos_tiles;
+    // tile order: co-major (small maps: the positions of one co tile are neighbours, a weight slice stays in L2) or position-major
+    // (large maps: the co tiles of one position tile are neighbours, the activations are re-read while they are still cached)
+    int ct, pt;
+    if (a.pos_major) { pt = t / a.n_co_tiles; ct = t - pt * a.n_co_tiles; }
+    else { ct = t / a.n_pos_tiles; pt = t - ct * a.n_pos_tiles; }
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && pt >= a.lv[q].tile0) ? 1 : 0;
@@ -171,6 +175,10 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_conv3x3_f32_kernel(CfArgs a, 
     };
     auto finish_segment = [&](const CfTile &T, int first_chunk, int n_chunks) {
         if (n_chunks == Kc) { store_tile(T); return; }
+#if defined(CF_ABL) && (CF_ABL & 1)                                 // developer ablation: no slabs, no tickets, no reduction (results meaningless)
+        if (first_chunk == 0) store_tile(T);
+        return;
+#endif
         float *slab = part + ((size_t)sigma * 2 + (first_chunk == 0 ? 1 : 0)) * CF_SLAB;
         // register order [wave][mi][ni][r][lane]: 256 contiguous bytes per store, one address per accumulator tile + immediates, write-through
 #pragma unroll
@@ -261,20 +269,29 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_conv3x3_f32_kernel(CfArgs a, 
         float oa[2][2], ob[2][2];
         auto fetch = [&](int s, int slot) {
             const int cp = s / 9, t = s - cp * 9, dy = t / 3, dx = t % 3 - 1;
+#if defined(CF_ABL) && (CF_ABL & 2)                                 // developer ablation: no LDS operand reads
+            oa[slot][0] = (float)(s + lane); oa[slot][1] = (float)(s - lane); ob[slot][0] = (float)(t + lane); ob[slot][1] = (float)(dy * lane + dx);
+#else
             oa[slot][0] = pa[cp * 9 + t]; oa[slot][1] = pa[32 * CF_AS + cp * 9 + t];
             ob[slot][0] = pb[(cp * 3 + dy) * CF_RS + 1 + dx]; ob[slot][1] = pb[(cp * 3 + dy) * CF_RS + 1 + dx + 32];
+#endif
         };
         fetch(0, 0);
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             const int slot = s & 1, dx = (s % 9) % 3 - 1;
             if (s + 1 < 18) fetch(s + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);                      // the next step's LDS reads go out BEFORE this step's MFMAs
             float b0 = ob[slot][0], b1 = ob[slot][1];
             if (dx == -1) { b0 = el[0] ? 0.0f : b0; b1 = el[1] ? 0.0f : b1; }
             if (dx == 1) { b0 = er[0] ? 0.0f : b0; b1 = er[1] ? 0.0f : b1; }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b0, acc[0][0], 0, 0, 0);
+#if !(defined(CF_ABL) && (CF_ABL & 32))                             // developer ablations 16 / 32: no LDS stores / no global loads of the next chunk
             if (s == 0 && more) issue_loads(Tn, nchunk);
+#endif
+#if !(defined(CF_ABL) && (CF_ABL & 16))
             if (s >= 13 && more) store_part(buf ^ 1, s - 13);
+#endif
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], b1, acc[1][1], 0, 0, 0);
@@ -296,15 +313,24 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_conv3x3_f32_kernel(CfArgs a, 
     }
 }
 
-// Wt[ci][co][e] = W[co][ci][8 - e]: the data gradient dX = conv(dY, Wt) runs on the forward kernel.  One output element per thread,
-// written coalesced; the reads are 36-byte pieces 9 C floats apart that the L2 serves (the tensor is 2.4 / 9.4 MB).  (A 32 x 32 block
-// transpose through LDS with 256 workgroups took 13.7 us; this form has 9216 workgroups in flight.)
+// Wt[ci][co][e] = W[co][ci][8 - e]: the data gradient dX = conv(dY, Wt) runs on the forward kernel.  16 x 16 (co, ci) blocks through LDS:
+// 576-byte contiguous runs on both sides, C * C / 256 workgroups (1024 at C = 512).
 __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__restrict__ w, float *__restrict__ wt, int C)
 {
-    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C * 9u;
-    if (o >= n) return;
-    const unsigned pair = o / 9u, e = o - pair * 9u, ci = pair / (unsigned)C, co = pair - ci * (unsigned)C;
-    wt[o] = w[(co * (unsigned)C + ci) * 9u + (8u - e)];
+    __shared__ float s[16][16 * 9 + 1];
+    const unsigned nb = (unsigned)C / 16u, co0 = (blockIdx.x / nb) * 16u, ci0 = (blockIdx.x % nb) * 16u, row = (unsigned)C * 9u;
+#pragma unroll
+    for (unsigned k = 0; k < 9; ++k) {
+        const unsigned e = threadIdx.x + 256u * k, r = e / 144u, q = e - r * 144u;       // r = co, q = ci * 9 + tap
+        s[r][q] = w[(co0 + r) * row + ci0 * 9u + q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < 9; ++k) {
+        const unsigned e = threadIdx.x + 256u * k, r = e / 144u, q = e - r * 144u;       // r = ci, q = co * 9 + tap
+        const unsigned co = q / 9u, t = q - co * 9u;
+        wt[(ci0 + r) * row + co0 * 9u + q] = s[co][r * 9u + 8u - t];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
@@ -548,6 +574,7 @@ static int cf_run(const float *const *in, float *const *out, const int *H, const
         } else a.lv[l] = {nullptr, nullptr, 1, 1, 1, 1 << 30};
     }
     a.n_pos_tiles = tiles;
+    a.pos_major = (long long)tiles * CF_NT * C > 2ll * C * C * 9 ? 1 : 0;      // activations larger than twice the weights
     const long long n_tiles = (long long)tiles * a.n_co_tiles, units = n_tiles * a.Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     a.n_units = (int)units;
@@ -588,7 +615,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
     if (rc) return rc;
     const CfWs ws = cf_carve(workspace, C);
     hipStream_t s = (hipStream_t)stream;
-    FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)((C * C * 9 + 255) / 256)), dim3(256), 0, s, w3_dev, ws.wt, C);
+    FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)((C / 16) * (C / 16))), dim3(256), 0, s, w3_dev, ws.wt, C);
     FRCNN_CHECK_LAUNCH("rpn_conv_f32_pack_kernel");
     return cf_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, ws.wt, ws, s);
 }
