@@ -52,7 +52,8 @@ SIGNATURES = {
     "frcnn_roi_pool_fwd_a16": (_i, [_vp, _i, _i, _i, _vp, _i64, _f, _vp, _vp, _vp]),
     "frcnn_roi_pool_bwd_a16": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "frcnn_roi_level_map": (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp]),
-    "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "frcnn_roi_scale_order": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "frcnn_ms_roi_align_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "frcnn_ms_roi_align_bwd_workspace": (_sz, [_vp, _vp, _i, _i, _i64]),
     "frcnn_detection_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -183,11 +183,12 @@ __device__ __forceinline__ void tile_of_block(int b, int R, int n_cg, int *cg, i
 #endif
 //                 // floats of footprint staging per workgroup (25 KB -> 6 workgroups / CU)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVES, 8))) void roi_align_fwd77_kernel(MsLevels L, int C, const float4 *__restrict__ rois, int R, int aligned, int k_min,
-                                                              float s0, int k0, float *__restrict__ out, int32_t *__restrict__ out_level, int n_cg)
+                                                              float s0, int k0, float *__restrict__ out, int32_t *__restrict__ out_level, int n_cg, const int32_t *__restrict__ order)
 {
     __shared__ float s_f[RA_FWD_LDS];
     int cg, r;
     tile_of_block(blockIdx.x, R, n_cg, &cg, &r);
+    if (order) r = order[r];                            // dispatch slot -> RoI: largest footprint first (roi_scale_order_kernel); the output row is the RoI's own
     const int t = threadIdx.x, grp = t / 49, bin = t - grp * 49;
     const float4 b = rois[r];
     const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
@@ -878,9 +879,68 @@ static int fill_levels(MsLevels *L, const float *const *feats, float *const *gra
     return FRCNN_OK;
 }
 
+// ---- dispatch order of the forward: RoIs by decreasing staging cost ----------------------------------------------------------------
+// roi_align_fwd77's workgroup (RoI, 32 channels) stages the RoI's footprint in one to four passes, or gathers from global memory when
+// the footprint does not fit at all: its time is set by the footprint, and with the RoIs in list order the launch ends on whichever
+// long workgroups happen to come last (a host-side sort of the list gave 42-54 us against 55-63, profiles/README.md).  This kernel
+// replaces the `roi * (w, h, w, h)` elementwise launch of FastRCNNHead.forward (models/new_model.py:136-140): ONE workgroup writes the
+// scaled boxes (the same fp32 products) and the permutation `order` = RoI indices by (passes, footprint pixels) descending, index
+// ascending -- the forward kernel maps dispatch slot -> order[slot] and still writes every RoI's rows at its own index.
+#define RO_MAX 4096
+__global__ __launch_bounds__(1024) void roi_scale_order_kernel(const float4 *__restrict__ rois, int R, float4 mul, MsLevels L, int aligned, int k_min, float s0,
+                                                               int k0, float4 *__restrict__ out_rois, int32_t *__restrict__ out_order, uint32_t *__restrict__ out_cost)
+{
+    __shared__ uint32_t s_key[RO_MAX];
+    for (int i = threadIdx.x; i < R; i += 1024) {
+        float4 b = rois[i];
+        b.x = b.x * mul.x; b.y = b.y * mul.y; b.z = b.z * mul.z; b.w = b.w * mul.w;
+        if (out_rois) out_rois[i] = b;
+        const int l = L.n_levels > 1 ? level_of(b, k_min, k_min + L.n_levels - 1, s0, k0, 1e-6f) : 0;
+        const int H = L.H[l], W = L.W[l];
+        const AlignGeom g = align_geom(b, L.scale[l], 7, 7, 2, aligned != 0);
+        const Lin ya = lin_setup(H, g.sh + 0.5f * g.bh / 2.0f), yb = lin_setup(H, g.sh + 6.0f * g.bh + 1.5f * g.bh / 2.0f);
+        const Lin xa = lin_setup(W, g.sw + 0.5f * g.bw / 2.0f), xb = lin_setup(W, g.sw + 6.0f * g.bw + 1.5f * g.bw / 2.0f);
+        const int fh = yb.hi - ya.lo + 1, fw = xb.hi - xa.lo + 1;
+        const long long fp = (long long)fh * (fw | 1);
+        uint32_t key;
+        if (!(fh >= 1 && fw >= 1) || fp > RA_FWD_LDS) key = (31u << 20) | (uint32_t)(fp > 0xFFFFF ? 0xFFFFF : (fp < 0 ? 0 : fp));   // gathers from global: the longest
+        else {
+            const int cb = min(RA_FWD_LDS / (int)fp, RA_FWD_CG);
+            key = ((uint32_t)((RA_FWD_CG + cb - 1) / cb) << 20) | (uint32_t)fp;
+        }
+        s_key[i] = key;
+        if (out_cost) out_cost[i] = key;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R; i += 1024) {
+        const uint32_t k = s_key[i];
+        int rank = 0;
+        for (int j = 0; j < R; ++j) { const uint32_t q = s_key[j]; rank += (q > k) || (q == k && j < i); }   // broadcast LDS reads
+        out_order[rank] = i;
+    }
+}
+
+FRCNN_EXPORT int frcnn_roi_scale_order(const float *rois, int64_t R, const float *mul4_host, const int *H, const int *W, const float *scales, int n_levels,
+                                       int aligned, int k_min, float s0, int k0, float *out_rois, int32_t *out_order, uint32_t *out_cost, void *stream)
+{
+    FRCNN_REQUIRE(R >= 0 && s0 > 0.f && mul4_host, "roi_scale_order: bad argument");
+    if (R == 0) return FRCNN_OK;
+    if (R > RO_MAX) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "roi_scale_order: R=%lld above limit %d", (long long)R, RO_MAX);
+    FRCNN_REQUIRE(rois && out_order, "roi_scale_order: NULL pointer");
+    MsLevels L;
+    static const float *dummy[FRCNN_MAX_LEVELS] = {(const float *)16, (const float *)16, (const float *)16, (const float *)16,
+                                                  (const float *)16, (const float *)16, (const float *)16, (const float *)16};   // geometry only: never dereferenced
+    int rc = fill_levels(&L, dummy, nullptr, H, W, scales, n_levels);
+    if (rc) return rc;
+    FRCNN_LAUNCH(roi_scale_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float4 *)rois, (int)R,
+                 make_float4(mul4_host[0], mul4_host[1], mul4_host[2], mul4_host[3]), L, aligned, k_min, s0, k0, (float4 *)out_rois, out_order, out_cost);
+    FRCNN_CHECK_LAUNCH("roi_scale_order_kernel");
+    return FRCNN_OK;
+}
+
 FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H, const int *W, const float *scales, int n_levels, int C,
                                         const float *rois, int64_t R, int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0,
-                                        int k0, float *out, int32_t *out_level, void *stream)
+                                        int k0, float *out, int32_t *out_level, const int32_t *order, void *stream)
 {
     FRCNN_REQUIRE(C > 0 && PH > 0 && PW > 0 && R >= 0 && sampling_ratio >= 0 && s0 > 0.f, "ms_roi_align_fwd: bad argument");
     if (R == 0) return FRCNN_OK;
@@ -896,7 +956,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
     if (PH == 7 && PW == 7 && sampling_ratio == 2 && R < (1 << 24) && small_planes) {
         const int n_cg = (C + RA_FWD_CG - 1) / RA_FWD_CG;
         FRCNN_LAUNCH(roi_align_fwd77_kernel, dim3((unsigned)(n_cg * R)), dim3(256), 0, s, L, C, (const float4 *)rois, (int)R,
-                     aligned, k_min, s0, k0, out, out_level, n_cg);
+                     aligned, k_min, s0, k0, out, out_level, n_cg, order);
         FRCNN_CHECK_LAUNCH("roi_align_fwd77_kernel");
         return FRCNN_OK;
     }

@@ -274,9 +274,14 @@ class FRCNNHead(nn.Module):
 
     def forward(self, features, roi, img_shape):
         h, w = img_shape
-        scale = ops.const_tensor((w, h, w, h), roi.device)                         # cached: torch.tensor(list, device=cuda) is a blocking copy
-        scaled_roi = roi * scale                                                   # new_model.py:136-140: image pixels
-        pool = self.roi_pool(features, [scaled_roi], [(w, h)])
+        feats = [features[k] for k in self.roi_pool.featmap_names]
+        if roi.is_cuda and roi.dtype == torch.float32 and self.roi_pool.scales != "reference" and roi.shape[0] <= 4096 and not roi.requires_grad:
+            # new_model.py:136-140 (roi * (w, h, w, h): image pixels) and, in the same launch, the order that dispatches the pooling's
+            # workgroups largest footprint first (the pooled rows do not depend on it)
+            scaled_roi, order = ops.roi_scale_order(roi, (w, h, w, h), [tuple(f.shape[-2:]) for f in feats], self.roi_pool.scales)
+        else:
+            scaled_roi, order = roi * ops.const_tensor((w, h, w, h), roi.device), None
+        pool = self.roi_pool(features, [scaled_roi], [(w, h)], order=order)
         x = self.classifier(pool.view(pool.size(0), -1))
         return self.cls_head(x), self.reg_head(x)
 

@@ -886,7 +886,7 @@ def _level_tables(feats, scales):
 
 class _MsRoIAlignFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rois, PH, PW, sampling_ratio, aligned, scales, k_min, s0, k0, *feats):
+    def forward(ctx, rois, PH, PW, sampling_ratio, aligned, scales, k_min, s0, k0, order, *feats):
         feats = [_req(f, name="feature map") for f in feats]
         rois = _req(rois, name="rois").reshape(-1, 4)
         Cc = feats[0].shape[1]
@@ -894,11 +894,15 @@ class _MsRoIAlignFn(torch.autograd.Function):
             if f.dim() != 4 or f.shape[0] != 1 or f.shape[1] != Cc:
                 raise ValueError("MultiScaleRoIAlign: feature maps must be [1,C,H,W] with a common C")
         R = rois.shape[0]
+        if order is not None:
+            order = _req(order, torch.int32, "order").reshape(-1)
+            if order.shape[0] != R:
+                raise ValueError("MultiScaleRoIAlign: order must hold one entry per RoI")
         out = torch.empty((R, Cc, PH, PW), dtype=torch.float32, device=rois.device)
         ptrs, H, W, sc = _level_tables(feats, scales)
         with torch.cuda.device(rois.device):
             check(lib.frcnn_ms_roi_align_fwd(ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(feats), Cc, _ptr(rois), R, PH, PW,
-                                             sampling_ratio, int(aligned), k_min, float(s0), k0, _ptr(out), None, _stream()), "ms_roi_align_fwd")
+                                             sampling_ratio, int(aligned), k_min, float(s0), k0, _ptr(out), None, _ptr(order), _stream()), "ms_roi_align_fwd")
         ctx.save_for_backward(rois)
         ctx.meta = (PH, PW, sampling_ratio, aligned, tuple(scales), k_min, s0, k0, [tuple(f.shape) for f in feats])
         return out
@@ -916,17 +920,41 @@ class _MsRoIAlignFn(torch.autograd.Function):
             check(lib.frcnn_ms_roi_align_bwd(_ptr(grad_out), ptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(grads), shapes[0][1], _ptr(rois),
                                              rois.shape[0], PH, PW, sampling_ratio, int(aligned), k_min, float(s0), k0, _ptr(ws), ws.numel(),
                                              _stream()), "ms_roi_align_bwd")
-        return (None,) * 9 + tuple(grads)
+        return (None,) * 10 + tuple(grads)
+
+
+def roi_scale_order(rois, mul, feat_shapes, scales=(0.25, 0.125, 0.0625, 0.03125), aligned=False, canonical_scale=224.0, canonical_level=4,
+                    want_cost=False):
+    """(rois * mul, order[, cost]) in one launch: the `roi * (w, h, w, h)` of FastRCNNHead.forward (models/new_model.py:136-140) and the
+    dispatch order (largest footprint first) that ms_roi_align(..., order=order) hands to the forward kernel.  feat_shapes = the (h, w) of
+    the pyramid levels the pooler reads; results of the pooling do not depend on `order`."""
+    rois = _req(rois, name="rois").reshape(-1, 4)
+    R = rois.shape[0]
+    dev = rois.device
+    out = torch.empty_like(rois)
+    order = torch.empty((R,), dtype=torch.int32, device=dev)
+    cost = torch.empty((R,), dtype=torch.int32, device=dev) if want_cost else None
+    H = _host_i32([s[0] for s in feat_shapes])
+    W = _host_i32([s[1] for s in feat_shapes])
+    sc = np.ascontiguousarray(scales, dtype=np.float32)
+    m = np.ascontiguousarray(mul, dtype=np.float32)
+    if m.shape != (4,):
+        raise ValueError("roi_scale_order: mul must have four entries")
+    k_min = int(round(-np.log2(scales[0])))
+    with torch.cuda.device(dev):
+        check(lib.frcnn_roi_scale_order(_ptr(rois), R, _np_ptr(m), _np_ptr(H), _np_ptr(W), _np_ptr(sc), len(feat_shapes), int(aligned), k_min,
+                                        float(canonical_scale), int(canonical_level), _ptr(out), _ptr(order), _ptr(cost), _stream()), "roi_scale_order")
+    return (out, order, cost) if want_cost else (out, order)
 
 
 def ms_roi_align(feats, rois, output_size=7, sampling_ratio=2, scales=(0.25, 0.125, 0.0625, 0.03125), aligned=False,
-                 canonical_scale=224.0, canonical_level=4):
+                 canonical_scale=224.0, canonical_level=4, order=None):
     k_min = int(round(-np.log2(scales[0])))
     PH, PW = (output_size, output_size) if isinstance(output_size, int) else output_size
     feats = [f if f.dtype == torch.float32 else f.float() for f in feats]      # under autocast: pooling runs in fp32 (as torchvision's does)
     rois = rois.float()
     return _MsRoIAlignFn.apply(rois, int(PH), int(PW), int(sampling_ratio), bool(aligned), tuple(float(s) for s in scales), k_min,
-                               float(canonical_scale), int(canonical_level), *feats)
+                               float(canonical_scale), int(canonical_level), order, *feats)
 
 
 def infer_scales_like_torchvision(feat_shapes, image_shapes):
@@ -969,7 +997,7 @@ class MultiScaleRoIAlign(torch.nn.Module):
         else:
             self.scales = tuple(scales) if scales is not None else tuple(2.0 ** -(2 + i) for i in range(len(self.featmap_names)))
 
-    def forward(self, x, boxes, image_shapes=None):
+    def forward(self, x, boxes, image_shapes=None, order=None):
         if isinstance(boxes, (list, tuple)):
             if len(boxes) != 1:
                 raise ValueError("MultiScaleRoIAlign: one image per call (batch 1 per GPU)")
@@ -980,7 +1008,7 @@ class MultiScaleRoIAlign(torch.nn.Module):
             if not image_shapes:
                 raise ValueError("MultiScaleRoIAlign(scales='reference') needs image_shapes (as passed at new_model.py:143)")
             scales = infer_scales_like_torchvision([tuple(f.shape[-2:]) for f in feats], image_shapes)
-        return ms_roi_align(feats, boxes, self.output_size, self.sampling_ratio, scales)
+        return ms_roi_align(feats, boxes, self.output_size, self.sampling_ratio, scales, order=order)
 
 
 # --------------------------------------------------------------------------------------------

@@ -280,7 +280,16 @@ int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, int k_max, floa
 int frcnn_ms_roi_align_fwd(const float *const *feats_host /*[n_levels] device ptrs*/, const int *H_host, const int *W_host,
                            const float *scales_host, int n_levels, int C, const float *rois, int64_t R,
                            int PH, int PW, int sampling_ratio, int aligned, int k_min, float s0, int k0,
-                           float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/, void *stream);
+                           float *out /*[R,C,PH,PW]*/, int32_t *out_level /*[R] or NULL*/,
+                           const int32_t *order /*[R] or NULL: dispatch order of the RoIs (frcnn_roi_scale_order); results do not depend on it*/,
+                           void *stream);
+/* The `roi * (w, h, w, h)` of FastRCNNHead.forward (models/new_model.py:136-140) and, in the same launch, the permutation that
+ * dispatches the 7x7 / sampling-ratio-2 forward's workgroups largest footprint first: out_rois[i] = rois[i] * mul4 (fp32 products, as
+ * torch computes them), out_order = RoI indices by decreasing (staging passes, footprint pixels) of frcnn_ms_roi_align_fwd, ties by
+ * index; out_cost (optional, [R]) = the keys.  R <= 4096.  Level table as in frcnn_ms_roi_align_fwd (no feature pointers needed).  */
+int frcnn_roi_scale_order(const float *rois, int64_t R, const float *mul4_host, const int *H_host, const int *W_host, const float *scales_host,
+                          int n_levels, int aligned, int k_min, float s0, int k0, float *out_rois /*[R,4] or NULL*/, int32_t *out_order /*[R]*/,
+                          uint32_t *out_cost /*[R] or NULL*/, void *stream);
 /* grad_feats[l] [C,H_l,W_l] are OVERWRITTEN with the gradient of every level (zero where no RoI reaches); the caller does
  * not clear them.  7x7 / sampling_ratio 2: tile-owner gather (per-tile RoI lists, long lists summed by segments in a fixed
  * order), no atomics, bit-reproducible; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists, weight-table records of

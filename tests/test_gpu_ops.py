@@ -1530,3 +1530,44 @@ def test_rpn_conv3x3_f32_autograd_matches_torch_conv(ops):
         assert float((o - r).abs().max()) < 1e-4 * max(1.0, float(r.abs().max()))
     for a, b in zip(got, [f.grad for f in feats] + [wt.grad]):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------ RoIAlign forward dispatch order (round 4)
+def test_roi_scale_order_and_ordered_forward_are_bit_identical(ops):
+    """frcnn_roi_scale_order replaces the `roi * (w, h, w, h)` launch of FastRCNNHead.forward (models/new_model.py:136-140) and also hands
+    out the order in which the pooling's workgroups are dispatched (largest footprint first).  The scaled boxes must be torch's own
+    products bit for bit, `order` a permutation along which the cost keys do not increase (ties by index), and the pooled output must
+    not depend on the order: bit-identical to the unordered call and to the oracle-checked path, for the library's order, a random
+    permutation and the reversed order."""
+    rng = np.random.RandomState(41)
+    H, W = 800, 1344
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    R = 512
+    b = rand_boxes(rng, R, 0.01, 0.9)                                          # normalised boxes of every size: all four levels, 1-4 staging passes
+    b[:7] = np.array([[0, 0, 1, 1], [0.1, 0.1, 0.1001, 0.1001], [0, 0, 1, 0.02], [0.3, 0, 0.31, 1], [0.5, 0.5, 0.5, 0.5], [0, 0, 0.99, 0.99], [0.2, 0.2, 0.8, 0.8]], np.float32)
+    mul = np.array([W, H, W, H], np.float32)
+    tb = T(b)
+    scaled, order, cost = ops.roi_scale_order(tb, mul, shapes, scales, want_cost=True)
+    assert torch.equal(scaled, tb * T(mul))                                     # the same fp32 products as the elementwise launch it replaces
+    o = order.cpu().numpy().astype(np.int64)
+    c = cost.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    assert sorted(o.tolist()) == list(range(R))
+    ck = c[o]
+    assert (np.diff(ck) <= 0).all()
+    assert all(o[i] < o[i + 1] for i in range(R - 1) if ck[i] == ck[i + 1])      # ties by index
+    passes, fp = ck >> 20, ck & 0xFFFFF
+    assert passes.max() > passes.min() and passes.min() >= 1                     # the test frame really mixes short and long workgroups
+    # footprint of the key = the oracle-independent geometry: pixels of the level-scaled box, give or take the sampling border
+    lv = ops.roi_level_map(scaled).cpu().numpy()
+    sc = np.asarray(scales)[lv]
+    approx = (np.clip((b[:, 2] - b[:, 0]) * W * sc, 1, None) + 2) * (np.clip((b[:, 3] - b[:, 1]) * H * sc, 1, None) + 2)
+    rel = np.abs(np.log((c & 0xFFFFF)[: R].clip(1) / approx.clip(1)))
+    assert np.median(rel) < 0.7
+    feats = [torch.randn(1, 256, h, w, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)) for h, w in shapes]
+    base = ops.ms_roi_align(feats, scaled, 7, 2, scales)
+    for perm in (order, T(rng.permutation(R).astype(np.int32)), torch.flip(order, [0]).contiguous()):
+        got = ops.ms_roi_align(feats, scaled, 7, 2, scales, order=perm)
+        assert torch.equal(got, base)
+    ref, _ = orc.ms_roi_align([f[0].cpu().numpy() for f in feats], scaled.cpu().numpy(), scales=scales)
+    assert np.abs(base.cpu().numpy() - ref).max() < 1e-5

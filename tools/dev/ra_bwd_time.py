@@ -77,8 +77,11 @@ for key in os.environ.get("KEYS", "rois0,rois15,rois29").split(","):
         fa = (w * sc_np) * (h * sc_np) if False else None
         area = ((r[:, 2] - r[:, 0]) * np.asarray(scales)[k]) * ((r[:, 3] - r[:, 1]) * np.asarray(scales)[k])
         frois = torch.from_numpy(r[np.argsort(-area)].copy()).to(dev)
+    order = None
+    if os.environ.get('ORDER'):                              # the library's own device-side order (round 4): rois are already in pixels -> mul = 1
+        _, order = ops.roi_scale_order(rois, (1.0, 1.0, 1.0, 1.0), [s[-2:] for s in shapes], scales)
     def fwd():
-        check(lib.frcnn_ms_roi_align_fwd(fptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), 4, 256, _ptr(frois), len(r), 7, 7, 2, 0, 2, 224.0, 4, _ptr(out), None, _stream()), "fwd")
+        check(lib.frcnn_ms_roi_align_fwd(fptrs, _np_ptr(H), _np_ptr(W), _np_ptr(sc), 4, 256, _ptr(frois), len(r), 7, 7, 2, 0, 2, 224.0, 4, _ptr(out), None, _ptr(order), _stream()), "fwd")
     for _ in range(5): fwd()
     torch.cuda.synchronize()
     tf = []
