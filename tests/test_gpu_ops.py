@@ -1571,3 +1571,32 @@ def test_roi_scale_order_and_ordered_forward_are_bit_identical(ops):
         assert torch.equal(got, base)
     ref, _ = orc.ms_roi_align([f[0].cpu().numpy() for f in feats], scaled.cpu().numpy(), scales=scales)
     assert np.abs(base.cpu().numpy() - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ["vgg600x1000", "fpn_small"])
+def test_rpn_conv3x3_f32_matches_the_references_cpu_path_golden(ops, golden, name):
+    """north_star: tensors within 1e-4 of the reference's CPU path on identical inputs.  `inter_layer` on the CPU is torch's fp32
+    conv2d + autograd (tests/golden/make_golden_rpn_conv.py restates the layer and its init: models/model.py:68-77); the committed
+    fixture holds strided samples of its forward output and of both gradients; the inputs are regenerated from the seed and their
+    sha256 checked."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk_rpn_conv", os.path.join(ROOT, "tests", "golden", "make_golden_rpn_conv.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = golden("rpn_conv")
+    C, shapes, w, feats, gouts = mk.inputs(name)
+    if mk.sha([w] + feats + gouts) != str(g[name + "_inputs_sha256"]):
+        pytest.skip("this torch build draws other random inputs than the one that made the fixture")
+    wd, fd, gd = w.to(DEV), [f.to(DEV) for f in feats], [t.to(DEV) for t in gouts]
+    outs = ops.rpn_conv3x3_fwd(fd, wd)
+    dxs = ops.rpn_conv3x3_bwd_data(gd, wd)
+    dw = ops.rpn_conv3x3_wgrad(fd, gd)
+
+    def close(got, want):
+        got = got.reshape(-1)[::mk.STRIDE].cpu().numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-4 * max(1.0, float(np.abs(want).max())), np.abs(got - want).max()
+    for k in range(len(shapes)):
+        close(outs[k], g["%s_out%d" % (name, k)])
+        close(dxs[k], g["%s_dx%d" % (name, k)])
+    close(dw, g[name + "_dw"])

@@ -151,3 +151,20 @@ def test_loss_matches_reference(golden):
     out = orc.frcnn_loss((g["p_rpn_cls"], g["p_rpn_reg"], g["p_head_cls"], g["p_head_reg"]),
                          (g["t_rpn_cls"], g["t_rpn_reg"], g["t_head_cls"], g["t_head_reg"]))
     assert np.allclose(out, g["losses"], rtol=2e-6, atol=1e-6)
+
+
+def test_rpn_conv_golden_inputs_are_reproducible_here(golden):
+    """tests/golden/rpn_conv.npz stores outputs only; its inputs are regenerated from the seed.  The -m gpu test skips itself when this
+    torch build draws other numbers than the one that made the fixture: say so here, where every round runs."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_rpn_conv.py")
+    spec = importlib.util.spec_from_file_location("mk_rpn_conv", path)
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = golden("rpn_conv")
+    for name in mk.CASES:
+        C, shapes, w, feats, gouts = mk.inputs(name)
+        assert mk.sha([w] + feats + gouts) == str(g[name + "_inputs_sha256"]), name
+        n_out = sum(C * h * ww for h, ww in shapes)
+        assert sum(len(g["%s_out%d" % (name, k)]) for k in range(len(shapes))) >= n_out // mk.STRIDE
