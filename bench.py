@@ -63,14 +63,14 @@ MFMA_PEAK_F32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 / 16x16x4_f32: th
 
 CONFIGS = {
     "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
-                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62),
+                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62, Tw=640),
                 metric="train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)",
                 workload="VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
                          "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)"),
     "fpn": dict(H=800, W=1344, num_classes=91, label_lo=1, label_hi=91,          # raw COCO ids 1..90
                 shape=dict(N=268569, K=4000, P=1000, R=512, C=256, G=8,
                            feat_bytes=4 * 256 * (200 * 336 + 100 * 168 + 50 * 84 + 25 * 42), A=3,
-                           P_head=200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21),
+                           P_head=200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21, Tw=22784),       # Tw: 2x2 output tiles of the RPN conv, padded to 128 per level
                 metric="train images/sec (ResNet-50-FPN Faster R-CNN, 800x1344, bs=1/GPU)",
                 workload="ResNet-50-FPN Faster R-CNN train step, synthetic 800x1344 frames (COCO 800x1333 padded to /32), bs=1/GPU, "
                          "HIP proposal/RoI path (N=268569 anchors over 5 levels, pre/post NMS 4000/1000, 512 RoIs, "
@@ -84,8 +84,10 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "roi_align_bwd_combine_kernel": "hbm", "rpn_conv3x3_head_kernel": "mfma", "rpn_conv3x3_bwd_data_kernel": "mfma",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
-         "rpn_conv_f32_pack_kernel": "hbm"}
-F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel")
+         "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
+         "rpn_wino_weight_kernel": "hbm"}
+F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
+WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel")
 
 
 def synth_frame(cfg, rank, step):
@@ -100,7 +102,7 @@ def synth_frame(cfg, rank, step):
     return x, boxes, labels
 
 
-def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
+def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
     """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels'); None where the figure would say nothing."""
     nblk = (K + 63) // 64
     pooled = R * C * 49
@@ -122,15 +124,21 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "roi_align_bwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
         "rpn_conv_f32_pack_kernel": 2 * 4 * 9 * C * C,                    # the 3x3 weights in, transposed + flipped out
+        "rpn_wino_weight_kernel": 4 * (9 + 16) * C * C,                   # Winograd F(2x2,3x3): W in, G g G^T out
+        "rpn_wino_input_kernel": 4 * C * P_head + 4 * 16 * C * Tw,        # activations in, B^T d B (16 planes over the padded tiles) out
+        "rpn_wino_output_kernel": 4 * 16 * C * Tw + 4 * C * P_head,       # 16 product planes in, A^T M A out
     }.get(kernel)
 
 
-def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
+def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
     """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
     conv = 2 * C * 9 * C * P_head                                         # C -> C 3x3 on every RPN position (model.py:68-70, new_model.py:96-98)
     return {"rpn_conv3x3_head_kernel": conv + 2 * C * 6 * A * P_head,     # raw = conv3x3 + both 1x1 heads
             "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv,
-            "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv}.get(kernel)
+            "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv,
+            # the Winograd GEMM is priced on the convolution's OWN flop count over the time of the whole four-launch stage (build_record);
+            # what its MFMAs really execute is 32 C^2 Tw, 2.25 x less
+            "rpn_wino_gemm_kernel": conv}.get(kernel)
 
 
 def percentiles(v):
@@ -382,6 +390,21 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
             per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
             per_kernel[name]["mfma_peak_TFLOP_s"] = MFMA_PEAK_F32_TFLOPS if name in F32_MFMA_KERNELS else MFMA_PEAK_BF16_TFLOPS
             per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / per_kernel[name]["mfma_peak_TFLOP_s"], 5)
+    # Winograd convolution = a stage of four launches (weight / input transforms, the GEMM, the output transform): the convolution's flop
+    # count is priced over the time of ALL FOUR per call, reported under the GEMM's name; the GEMM's own MFMA utilisation beside it
+    if "rpn_wino_gemm_kernel" in per_kernel:
+        d = per_kernel["rpn_wino_gemm_kernel"]
+        calls = max(d["launches"], 1)
+        stage_us = sum(sum(samples[k]) for k in WINO_STAGE if k in samples) * 1e3 / calls
+        own = 32 * shape["C"] * shape["C"] * shape.get("Tw", 0)
+        d["stage_us_per_call"] = round(stage_us, 2)
+        d["stage_kernels"] = [k for k in WINO_STAGE if k in samples]
+        d["TFLOP_s"] = round(d["algorithmic_flops"] / stage_us * 1e-6, 2)
+        d["mfma_frac"] = round(d["algorithmic_flops"] / stage_us * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5)
+        d["gemm_executed_flops"] = own
+        d["gemm_mfma_utilisation"] = round(own / d["avg_us"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5) if own else None
+        d["note"] = ("Winograd F(2x2,3x3): achieved = the direct convolution's flops / the time of the stage's four launches; the GEMM itself "
+                     "executes 2.25x fewer flops (gemm_mfma_utilisation)")
     # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
     nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
     if "nms_kernel" in per_kernel and nms_us > 0:
@@ -404,9 +427,13 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
                     "algorithmic_bytes": d["algorithmic_bytes"], "GB_s": d["GB_s"], "hbm_frac": d["hbm_frac"],
                     "note": "all NMS launches of one image over the full K(K-1)/2 pair count x 16 VALU (the checked form; 11 issued on the packed path)"}
         if d["bound"] == "mfma" and d.get("algorithmic_flops"):
-            return {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": d["mfma_peak_TFLOP_s"], "unit": "TFLOP/s",
-                    "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
-                    "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
+            r = {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": d["mfma_peak_TFLOP_s"], "unit": "TFLOP/s",
+                 "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
+                 "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
+            for k in ("stage_us_per_call", "stage_kernels", "gemm_mfma_utilisation", "note"):
+                if k in d:
+                    r[k] = d[k]
+            return r
         return {"kernel": name, "bound": d["bound"], "achieved": d["GB_s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": d["hbm_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
                 "median_launch_us": d["median_us"], "algorithmic_bytes": d["algorithmic_bytes"]}
@@ -478,7 +505,7 @@ def compact_record(full, also=()):
                        "vs_baseline", "dtype", "data"))
     out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission"))
     rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
-    roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions",))
+    roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions", "stage_us_per_call", "gemm_mfma_utilisation"))
     if roof is not None and full["roofline"].get("hbm_kernel"):
         roof["hbm_kernel"] = _pick(full["roofline"]["hbm_kernel"], rk)
     out["roofline"] = roof

@@ -33,6 +33,7 @@
 #include "frcnn_internal.h"
 #include "frcnn_layout.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 FRCNN_LAYOUT_STAMP(rpn_conv_f32);
 
@@ -333,6 +334,291 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3)
+// Forward and data gradient as Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A: 16 independent [C x C] . [C x T] products over the 2 x 2
+// output tiles (T = ceil(H/2) ceil(W/2) per level) instead of one with K = 9 C -- 2.25 x fewer MFMAs for the same result (in exact
+// arithmetic; fp32: ~1e-6 of the output scale, tests).  Four launches, all levels each:
+//   rpn_wino_weight_kernel   U[xi][m][k] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
+//   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded 4 x 4 input patch of tile t; rows padded to a multiple of 128 tiles
+//   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][m][k] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
+//                            v_mfma_f32_32x32x2_f32, the forward kernel's skeleton without taps: both operands are plain aligned
+//                            float4 row pieces, no edge selects, 16 k steps per chunk
+//   rpn_wino_output_kernel   Y[m][2ty + i][2tx + j] = (A^T M A)_ij
+// The transformed operands travel through the workspace (16 C Ttot floats each way: 21 MB at 600x1000, 373 MB at FPN size).
+#define WN_KC 32                       // input channels per K chunk
+#define WN_AS 33                       // LDS row stride of the U tile [128][32]
+#define WN_BS 160                      // LDS row stride of the V tile [32][128]: 160 = 32 (mod 64), the two k halves hit disjoint banks
+struct WnLevel { const float *x; float *y; int H, W, tw, T, off; };
+struct WnArgs {
+    WnLevel lv[FRCNN_MAX_LEVELS];
+    int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;
+};
+
+template <bool TR>
+__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C)
+{
+    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C;
+    if (o >= n) return;
+    const unsigned m = o / (unsigned)C, k = o - m * (unsigned)C;
+    float g[9];
+    if (!TR) {
+#pragma unroll
+        for (int e = 0; e < 9; ++e) g[e] = w[(size_t)o * 9 + e];
+    } else {                                                         // data gradient: g'[m = ci][k = co] = W[co][ci] rotated by 180 degrees
+#pragma unroll
+        for (int e = 0; e < 9; ++e) g[e] = w[((size_t)k * C + m) * 9 + (8 - e)];
+    }
+    float t[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        t[0][c] = g[c];
+        t[1][c] = (g[c] + g[3 + c] + g[6 + c]) * 0.5f;
+        t[2][c] = (g[c] - g[3 + c] + g[6 + c]) * 0.5f;
+        t[3][c] = g[6 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float u0 = t[r][0], u1 = (t[r][0] + t[r][1] + t[r][2]) * 0.5f, u2 = (t[r][0] - t[r][1] + t[r][2]) * 0.5f, u3 = t[r][2];
+        U[(size_t)(r * 4 + 0) * n + o] = u0; U[(size_t)(r * 4 + 1) * n + o] = u1;
+        U[(size_t)(r * 4 + 2) * n + o] = u2; U[(size_t)(r * 4 + 3) * n + o] = u3;
+    }
+}
+
+__global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, float *__restrict__ V)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;     // padded tile column, channel
+    if (t >= a.Ttot) return;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
+    const int tl = t - a.lv[l].off;
+    float d[4][4];
+    if (tl < a.lv[l].T) {
+        const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
+        const float *x = a.lv[l].x + (size_t)c * H * W;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
+                d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[r][q] = 0.0f;            // padding columns: zeros, so that the product's columns are zeros too
+    }
+    float wv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        wv[0][q] = d[0][q] - d[2][q]; wv[1][q] = d[1][q] + d[2][q]; wv[2][q] = d[2][q] - d[1][q]; wv[3][q] = d[1][q] - d[3][q];
+    }
+    const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        V[(size_t)(r * 4 + 0) * plane + at] = wv[r][0] - wv[r][2];
+        V[(size_t)(r * 4 + 1) * plane + at] = wv[r][1] + wv[r][2];
+        V[(size_t)(r * 4 + 2) * plane + at] = wv[r][2] - wv[r][1];
+        V[(size_t)(r * 4 + 3) * plane + at] = wv[r][1] - wv[r][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ M)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= a.Ttot) return;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
+    const int tl = t - a.lv[l].off;
+    if (tl >= a.lv[l].T) return;
+    const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
+    float m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[r][q] = M[(size_t)(r * 4 + q) * plane + at];
+    float s0[4], s1[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s0[q] = m[0][q] + m[1][q] + m[2][q]; s1[q] = m[1][q] - m[2][q] - m[3][q]; }
+    const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3], y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+    const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
+    float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(2 * ty) * W + 2 * tx;
+    const bool x1 = 2 * tx + 1 < W, r1 = 2 * ty + 1 < H;
+    y[0] = y00;
+    if (x1) y[1] = y01;
+    if (r1) { y[W] = y10; if (x1) y[W + 1] = y11; }
+}
+
+__global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ Mo,
+                                                                    float *__restrict__ part, int *__restrict__ cnt)
+{
+    __shared__ float sA[2][CF_MT * WN_AS];
+    __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * WN_BS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    const int G = a.G, U_ = a.n_units, Kc = a.Kc, C = a.C, Ttot = a.Ttot;
+    const int sigma = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int u0 = (int)cf_start(sigma, U_, G), u1 = (int)cf_start(sigma + 1, U_, G);
+    if (u0 >= u1) return;
+    // tile -> (xi, t tile, m tile): the m tiles of one (xi, t tile) are neighbours (they share the V rows)
+    struct Tl { const float *u, *v; float *o; int tile; };
+    auto tile_of = [&](int t) {
+        const int mt = t % a.n_m_tiles, r = t / a.n_m_tiles, tt = r % a.n_t_tiles, xi = r / a.n_t_tiles;
+        Tl T;
+        T.u = U + ((size_t)xi * C + (size_t)mt * CF_MT) * C;
+        T.v = V + (size_t)xi * C * Ttot + (size_t)tt * CF_NT;
+        T.o = Mo + ((size_t)xi * C + (size_t)mt * CF_MT) * Ttot + (size_t)tt * CF_NT;
+        T.tile = t;
+        return T;
+    };
+    // staging slots: four 16-byte pieces of the U tile (128 rows x 8) and four of the V tile (32 rows x 32) per thread
+    // (piece q of a thread = piece 0 plus q * 32 rows of U / q * 8 rows of V: one offset each, the rest are uniform increments)
+    const unsigned a_off0 = (unsigned)((tid >> 3) * C + (tid & 7) * 4), b_off0 = (unsigned)((tid >> 5) * Ttot + (tid & 31) * 4);
+    const int a_lds0 = (tid >> 3) * WN_AS + (tid & 7) * 4, b_lds0 = (tid >> 5) * WN_BS + (tid & 31) * 4;
+    float4 ra[4], rb[4];
+    auto issue_loads = [&](const Tl &T, int chunk) {
+        const float *ub = T.u + chunk * WN_KC, *vb = T.v + (size_t)chunk * WN_KC * Ttot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = *(const float4 *)(ub + (size_t)q * 32 * C + a_off0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rb[q] = *(const float4 *)(vb + (size_t)q * 8 * Ttot + b_off0);
+    };
+    auto store_part = [&](int buf, int q) {
+        float *d = &sA[buf][a_lds0 + q * 32 * WN_AS];
+        d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
+        *(float4 *)&sB[buf][b_lds0 + q * 8 * WN_BS] = rb[q];
+    };
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    };
+    zero_acc();
+    auto store_tile = [&](const Tl &T) {                             // padded columns: no bounds
+        int tt = Ttot;
+        asm volatile("" : "+s"(tt));                                 // opaque here: otherwise the 64 store offsets are hoisted out of the unit loop
+                                                                     // and live in 64 registers through it (the staging registers went to scratch)
+        float *o = T.o + (size_t)(wm * 64 + 4 * lh) * tt + wn * 64 + li;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    o[(size_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * tt + ni * 32] = acc[mi][ni][r];
+    };
+    auto finish_segment = [&](const Tl &T, int first_chunk, int n_chunks) {       // as in rpn_conv3x3_f32_kernel
+#if defined(WN_ABL) && (WN_ABL & 1)                                 // developer ablation: no output at all
+        return;
+#endif
+        if (n_chunks == Kc) { store_tile(T); return; }
+        float *slab = part + ((size_t)sigma * 2 + (first_chunk == 0 ? 1 : 0)) * CF_SLAB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float *dst = &slab[(wave * 4 + g) * 16 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                asm volatile("global_store_dword %0, %1, off offset:%2 sc1" :: "v"(dst), "v"(acc[g >> 1][g & 1][r]), "n"(r * 256) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = (__hip_atomic_fetch_add(&cnt[T.tile], n_chunks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_chunks == Kc) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;
+        const long long lo = (long long)T.tile * Kc, hi = lo + Kc - 1;
+        int s_first = (int)((lo * G) / U_), s_end = (int)((hi * G) / U_);
+        while (cf_start(s_first + 1, U_, G) <= lo) ++s_first;
+        while (cf_start(s_first, U_, G) > lo) --s_first;
+        while (cf_start(s_end + 1, U_, G) <= hi) ++s_end;
+        while (cf_start(s_end, U_, G) > hi) --s_end;
+        zero_acc();
+        for (int s = s_first; s <= s_end; ++s) {
+            const long long st = cf_start(s, U_, G);
+            const float *sl = part + ((size_t)s * 2 + (st <= lo ? 1 : 0)) * CF_SLAB;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {                         // two accumulator tiles (32 loads in flight) at a time: the reducer must not
+                float t[2][16];                                      // push the main loop's staging registers out to scratch
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float *src = &sl[(wave * 4 + hf * 2 + g) * 16 * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(t[g][r]) : "v"(src), "n"(r * 256) : "memory");
+                }
+#define WN_WAIT(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]), "+v"(t[g][4]), "+v"(t[g][5]), "+v"(t[g][6]), \
+                                   "+v"(t[g][7]), "+v"(t[g][8]), "+v"(t[g][9]), "+v"(t[g][10]), "+v"(t[g][11]), "+v"(t[g][12]), "+v"(t[g][13]), "+v"(t[g][14]), "+v"(t[g][15]) :: "memory")
+                WN_WAIT(16, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[hf][0][r] += t[0][r];
+                WN_WAIT(0, 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[hf][1][r] += t[1][r];
+            }
+#undef WN_WAIT
+        }
+        store_tile(T);
+        if (tid == 0) __hip_atomic_store(&cnt[T.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    int tile = u0 / Kc, chunk = u0 - tile * Kc;
+    Tl T = tile_of(tile);
+    int seg_first = chunk;
+    issue_loads(T, chunk);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store_part(0, q);
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int buf = (u - u0) & 1;
+        int ntile = tile, nchunk = chunk + 1;
+        if (nchunk == Kc) { nchunk = 0; ++ntile; }
+        Tl Tn = T;
+        const bool more = u + 1 < u1;
+        if (more && ntile != tile) Tn = tile_of(ntile);
+        const float *pa = &sA[buf][(wm * 64 + li) * WN_AS + lh];
+        const float *pb = &sB[buf][lh * WN_BS + wn * 64 + li];
+        float oa[2][2], ob[2][2];
+        auto fetch = [&](int s, int slot) {
+#if defined(WN_ABL) && (WN_ABL & 2)                                 // developer ablation 2: no LDS operand reads
+            oa[slot][0] = (float)(s + lane); oa[slot][1] = (float)(s - lane); ob[slot][0] = (float)(s * lane); ob[slot][1] = (float)(lane - 3 * s);
+#else
+            oa[slot][0] = pa[2 * s]; oa[slot][1] = pa[32 * WN_AS + 2 * s];
+            ob[slot][0] = pb[2 * s * WN_BS]; ob[slot][1] = pb[2 * s * WN_BS + 32];
+#endif
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int slot = s & 1;
+            if (s + 1 < 16) fetch(s + 1, slot ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][0], acc[0][0], 0, 0, 0);
+#if !(defined(WN_ABL) && (WN_ABL & 4))                              // developer ablation 4: no staging of the next chunk
+            if (s == 0 && more) issue_loads(Tn, nchunk);
+            if (s >= 12 && more) store_part(buf ^ 1, s - 12);
+#endif
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!more || ntile != tile) {
+            finish_segment(T, seg_first, chunk + 1 - seg_first);
+            zero_acc();
+            seg_first = 0;
+            if (more) T = Tn;
+        }
+        tile = ntile; chunk = nchunk;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
 #define CW_TC 16                       // columns per row segment (8 MFMA k steps)
 #define CW_YS 17                       // LDS row stride of the dY segment [32 co][16]
@@ -536,7 +822,7 @@ __global__ __launch_bounds__(256, CW_WPS) void rpn_conv3x3_f32_wgrad_kernel(CwAr
 
 // ---------------------------------------------------------------------------------------------------------------- host side
 // workspace (dedicated, ZERO before the first call, left zero by every call): [ticket words | transposed weights | slabs]
-struct CfWs { int *cnt; float *wt, *part; size_t total; };
+struct CfWs { int *cnt; float *wt, *part, *U, *V, *M; size_t total; };
 static int cf_ranges()
 {
     static const int g = [] {
@@ -546,7 +832,7 @@ static int cf_ranges()
     }();
     return g;
 }
-static CfWs cf_carve(void *ws, int C)
+static CfWs cf_carve(void *ws, int C, long long Ttot = 0)
 {
     CfWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
@@ -556,6 +842,9 @@ static CfWs cf_carve(void *ws, int C)
     const size_t wg_tiles = (size_t)(C / 32) * (C / 32);           // weight gradient: tiles x workgroups per tile <= max(tiles, CUs) slabs of one tile
     const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / CF_WPS * CW_WPS) * (32 * 32 * 9) * sizeof(float);
     w.part = (float *)take(fwd > wg ? fwd : wg);
+    w.U = Ttot ? (float *)take((size_t)16 * C * C * sizeof(float)) : nullptr;             // Winograd: transformed weights, inputs, products
+    w.V = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;
+    w.M = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;
     w.total = o;
     return w;
 }
@@ -584,6 +873,62 @@ static int cf_run(const float *const *in, float *const *out, const int *H, const
     return FRCNN_OK;
 }
 
+// development A/B: FRCNN_CONV_F32_DIRECT=1 keeps the direct (9 C deep) kernel for forward / data gradient
+static bool cf_use_direct()
+{
+    static const bool d = [] { const char *e = getenv("FRCNN_CONV_F32_DIRECT"); return e && atoi(e) != 0; }();
+    return d;
+}
+
+static long long wn_fill(WnArgs *a, const float *const *in, float *const *out, const int *H, const int *W, int n_levels, int C)
+{
+    long long off = 0;
+    for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+        if (l < n_levels) {
+            const int tw = (W[l] + 1) / 2, th = (H[l] + 1) / 2;
+            a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
+            off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
+        } else a->lv[l] = {nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
+    }
+    a->n_levels = n_levels; a->C = C; a->Ttot = (int)off;
+    a->n_m_tiles = C / CF_MT; a->n_t_tiles = (int)(off / CF_NT); a->Kc = C / WN_KC;
+    return off;
+}
+
+FRCNN_EXPORT size_t frcnn_rpn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int C)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || C <= 0 || C % CF_MT != 0 || C > 4096) return 0;
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, nullptr, nullptr, H_host, W_host, n_levels, C);
+    return cf_carve(nullptr, C, Ttot).total;
+}
+
+// forward (transposed = false) or data gradient (true) through the Winograd domain: four launches for all levels
+static int wn_run(const float *const *in, float *const *out, const int *H, const int *W, int n_levels, int C, const float *w, bool transposed,
+                  void *workspace, hipStream_t s)
+{
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, in, out, H, W, n_levels, C);
+    FRCNN_REQUIRE(Ttot < (1ll << 24) && 16ll * C * Ttot < (1ll << 31) * 4, "rpn_conv3x3_f32: %lld output tiles are too many", Ttot);
+    const CfWs ws = cf_carve(workspace, C, Ttot);
+    const long long n_tiles = 16ll * a.n_m_tiles * a.n_t_tiles, units = n_tiles * a.Kc;
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    a.n_units = (int)units;
+    a.G = (int)std::min<long long>(cf_ranges(), units);
+    const unsigned wb = (unsigned)((C * C + 255) / 256);
+    if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
+    else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
+    FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
+    const dim3 tg((unsigned)((Ttot + 255) / 256), (unsigned)C);
+    FRCNN_LAUNCH(rpn_wino_input_kernel, tg, dim3(256), 0, s, a, ws.V);
+    FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)a.G), dim3(256), 0, s, a, ws.U, ws.V, ws.M, ws.part, ws.cnt);
+    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
+    FRCNN_LAUNCH(rpn_wino_output_kernel, tg, dim3(256), 0, s, a, ws.M);
+    FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
+    return FRCNN_OK;
+}
+
 static int cf_check(const void *const *p0, const void *const *p1, const int *H, const int *W, int n_levels, int C, const void *w, void *ws, size_t ws_bytes,
                     const char *what)
 {
@@ -594,7 +939,8 @@ static int cf_check(const void *const *p0, const void *const *p1, const int *H, 
         FRCNN_REQUIRE(p0[l] && p1[l] && H[l] > 0 && W[l] > 0, "%s: bad level %d", what, l);
         FRCNN_REQUIRE((long long)H[l] * W[l] * C < (1ll << 31), "%s: level %d too large", what, l);
     }
-    if (ws_bytes < frcnn_ws_rpn_conv_f32(C)) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, frcnn_ws_rpn_conv_f32(C));
+    const size_t need = frcnn_rpn_conv3x3_f32_workspace(H, W, n_levels, C);
+    if (ws_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     return FRCNN_OK;
 }
 
@@ -604,7 +950,8 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float 
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_fwd");
     if (rc) return rc;
-    return cf_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, cf_carve(workspace, C), (hipStream_t)stream);
+    if (cf_use_direct()) return cf_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, cf_carve(workspace, C), (hipStream_t)stream);
+    return wn_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, false, workspace, (hipStream_t)stream);
 }
 
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, float *const *d_feats_dev, const int *H_host, const int *W_host, int n_levels,
@@ -613,6 +960,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
     int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_bwd_data");
     if (rc) return rc;
+    if (!cf_use_direct()) return wn_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, w3_dev, true, workspace, (hipStream_t)stream);
     const CfWs ws = cf_carve(workspace, C);
     hipStream_t s = (hipStream_t)stream;
     FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)((C / 16) * (C / 16))), dim3(256), 0, s, w3_dev, ws.wt, C);

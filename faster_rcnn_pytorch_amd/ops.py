@@ -539,7 +539,7 @@ def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
     W = _host_i32([t.shape[3] for t in ins])
     ip = (C.c_void_p * len(ins))(*[t.data_ptr() for t in ins])
     op = (C.c_void_p * len(outs))(*[t.data_ptr() for t in outs])
-    nb = _lib.workspace_bytes(_lib.OP_RPN_CONV_F32, C_)
+    nb = int(lib.frcnn_rpn_conv3x3_f32_workspace(_np_ptr(H), _np_ptr(W), len(ins), C_))
     if nb == 0:
         raise _lib.FrcnnError("%s: C = %d is outside what the fp32 conv kernels are built for (a multiple of 128)" % (what, C_))
     ws = _ctrl_workspace(dev, "rpn_conv_f32", nb)     # ticket words zero on first use, left zero by every call; slabs + transposed weights behind them

@@ -203,11 +203,12 @@ int frcnn_rpn_conv_wgrad(const void *const *feat_levels_bf16, const void *const 
  * v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate, sums in a fixed order (bit-reproducible; a k-ordered fmaf chain per
  * output inside a K range, K ranges added in range order).  feat_levels / out_levels: [C, H_l, W_l] fp32 NCHW, batch 1; w3 [C, C, 3, 3]
  * in the reference's layout; C a multiple of 128.
- * The three calls share ONE workspace of frcnn_workspace_bytes(FRCNN_OP_RPN_CONV_F32, C, 0) bytes that is DEDICATED to them and ZERO
+ * The three calls share ONE workspace of frcnn_rpn_conv3x3_f32_workspace(H, W, n_levels, C) bytes that is DEDICATED to them and ZERO
  * before the first call (its ticket words are left zero by every call); calls on one workspace must be stream-ordered.
  *   _fwd      : out[co] = sum_ci conv3x3(feat[ci], w3[co][ci]), padding 1.
  *   _bwd_data : d_feat[ci] = sum_co conv3x3(d_out[co], w3[co][ci] flipped): what autograd derives for the input.
  *   _wgrad    : dw3[co][ci][ky][kx] = sum over levels and positions of d_out[co](y, x) * feat[ci](y + ky - 1, x + kx - 1) (fully overwritten). */
+size_t frcnn_rpn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int C);
 int frcnn_rpn_conv3x3_f32_fwd(const float *const *feat_levels, float *const *out_levels, const int *H_host, const int *W_host, int n_levels, int C,
                               const float *w3, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_out_levels, float *const *d_feat_levels, const int *H_host, const int *W_host, int n_levels,

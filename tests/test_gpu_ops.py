@@ -1485,7 +1485,11 @@ def test_rpn_conv3x3_f32_forward_backward_vs_float64(ops, name, C, shapes):
     gd = [t.to(DEV) for t in gouts]
     wd = wt.to(DEV)
     ref = _conv_ref64(feats, wt)
+    from faster_rcnn_pytorch_amd import _lib
+    _lib.prof_reset(); _lib.prof_enable(True)
     out = ops.rpn_conv3x3_fwd(fd, wd)
+    _lib.prof_enable(False)
+    assert "rpn_wino_gemm_kernel" in _lib.prof_report()                          # default form: Winograd F(2x2, 3x3), four launches
     for o, r in zip(out, ref):
         scale = float(r.abs().max())
         assert o.shape == r.shape and float((o.double().cpu() - r).abs().max()) < 1e-4 * max(1.0, scale)
@@ -1600,3 +1604,36 @@ def test_rpn_conv3x3_f32_matches_the_references_cpu_path_golden(ops, golden, nam
         close(outs[k], g["%s_out%d" % (name, k)])
         close(dxs[k], g["%s_dx%d" % (name, k)])
     close(dw, g[name + "_dw"])
+
+
+def test_rpn_conv3x3_f32_direct_form_in_a_child_process():
+    """Forward / data gradient run through the Winograd domain (four launches); the direct K = 9 C stream-K kernel (+ pack kernel for
+    the data gradient) stays in the library behind FRCNN_CONV_F32_DIRECT=1 (read once per process).  A child process runs it at the
+    600x1000 shape, three small FPN levels and an odd shape against float64, like the default form above."""
+    import subprocess
+    code = r'''
+import torch, torch.nn.functional as F
+from faster_rcnn_pytorch_amd import ops, _lib
+dev = "cuda:0"
+for C, shapes in ((512, [(37, 62)]), (256, [(50, 84), (25, 42), (13, 21)]), (128, [(5, 7), (1, 1), (3, 130), (17, 2)])):
+    g = torch.Generator().manual_seed(C)
+    feats = [torch.randn(1, C, h, w, generator=g) for h, w in shapes]
+    wt = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    gouts = [torch.randn(1, C, h, w, generator=g) for h, w in shapes]
+    _lib.prof_reset(); _lib.prof_enable(True)
+    out = ops.rpn_conv3x3_fwd([f.to(dev) for f in feats], wt.to(dev))
+    dx = ops.rpn_conv3x3_bwd_data([t.to(dev) for t in gouts], wt.to(dev))
+    _lib.prof_enable(False)
+    names = set(_lib.prof_report())
+    assert "rpn_conv3x3_f32_kernel" in names and "rpn_conv_f32_pack_kernel" in names and not any("wino" in n for n in names), names
+    for o, f in zip(out, feats):
+        r = F.conv2d(f.double(), wt.double(), None, padding=1)
+        assert float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
+    for o, t in zip(dx, gouts):
+        r = F.conv_transpose2d(t.double(), wt.double(), None, padding=1)
+        assert float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
+print("direct form OK")
+'''
+    e = dict(os.environ, FRCNN_CONV_F32_DIRECT="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "direct form OK" in r.stdout, r.stdout + r.stderr
