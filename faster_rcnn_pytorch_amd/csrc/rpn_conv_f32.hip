@@ -354,20 +354,23 @@ struct WnArgs {
     int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;
 };
 
+// 16 x 16 (m, k) blocks: the data gradient reads W[k][m] (m contiguous) and writes U[m][k] (k contiguous), so its block goes through LDS
+// (the plain one-thread-per-element form read 36-byte pieces 18 KB apart: 15 us at C = 512)
 template <bool TR>
 __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C)
 {
-    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C;
-    if (o >= n) return;
-    const unsigned m = o / (unsigned)C, k = o - m * (unsigned)C;
-    float g[9];
-    if (!TR) {
+    __shared__ float s[16][16 * 9 + 1];
+    const unsigned nb = (unsigned)C / 16u, m0 = (blockIdx.x / nb) * 16u, k0 = (blockIdx.x % nb) * 16u, row = (unsigned)C * 9u;
 #pragma unroll
-        for (int e = 0; e < 9; ++e) g[e] = w[(size_t)o * 9 + e];
-    } else {                                                         // data gradient: g'[m = ci][k = co] = W[co][ci] rotated by 180 degrees
-#pragma unroll
-        for (int e = 0; e < 9; ++e) g[e] = w[((size_t)k * C + m) * 9 + (8 - e)];
+    for (unsigned q = 0; q < 9; ++q) {
+        const unsigned e = threadIdx.x + 256u * q, r = e / 144u, c = e - r * 144u;
+        s[r][c] = TR ? w[(k0 + r) * row + m0 * 9u + c] : w[(m0 + r) * row + k0 * 9u + c];     // rows: k (TR) or m
     }
+    __syncthreads();
+    const unsigned mi = threadIdx.x >> 4, ki = threadIdx.x & 15u;
+    float g[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) g[e] = TR ? s[ki][mi * 9 + (8 - e)] : s[mi][ki * 9 + e];       // data gradient: W[k][m] rotated by 180 degrees
     float t[4][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
         t[2][c] = (g[c] - g[3 + c] + g[6 + c]) * 0.5f;
         t[3][c] = g[6 + c];
     }
+    const size_t n = (size_t)C * C, o = (size_t)(m0 + mi) * C + k0 + ki;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float u0 = t[r][0], u1 = (t[r][0] + t[r][1] + t[r][2]) * 0.5f, u2 = (t[r][0] - t[r][1] + t[r][2]) * 0.5f, u3 = t[r][2];
@@ -601,12 +605,15 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][0], acc[0][0], 0, 0, 0);
 #if !(defined(WN_ABL) && (WN_ABL & 4))                              // developer ablation 4: no staging of the next chunk
             if (s == 0 && more) issue_loads(Tn, nchunk);
-            if (s >= 12 && more) store_part(buf ^ 1, s - 12);
 #endif
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][0], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][1], acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {                                                  // the staged chunk -> LDS behind the sixteenth step (riding in steps 12-15 it
+#pragma unroll                                                       // left the loads four steps less to land: 554 against 533 us at FPN size)
+            for (int q = 0; q < 4; ++q) store_part(buf ^ 1, q);
         }
         if (!more || ntile != tile) {
             finish_segment(T, seg_first, chunk + 1 - seg_first);
@@ -915,7 +922,7 @@ static int wn_run(const float *const *in, float *const *out, const int *H, const
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     a.n_units = (int)units;
     a.G = (int)std::min<long long>(cf_ranges(), units);
-    const unsigned wb = (unsigned)((C * C + 255) / 256);
+    const unsigned wb = (unsigned)((C / 16) * (C / 16));
     if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
     else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
     FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
