@@ -93,3 +93,9 @@ for key in os.environ.get("KEYS", "rois0,rois15,rois29").split(","):
     print("   forward: median %.1f us  min %.1f us   sha1 %s" % (float(np.median(tf)), min(tf), hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]))
     h = hashlib.sha1(b"".join(x.cpu().numpy().tobytes() for x in grads)).hexdigest()[:12]
     print("   backward (4 launches back to back): median %.1f us  min %.1f us   sha1 %s" % (float(np.median(ts)), min(ts), h))
+# the ordering kernel itself (round 4)
+for _ in range(3): ops.roi_scale_order(rois, (1.0, 1.0, 1.0, 1.0), [s[-2:] for s in shapes], scales)
+torch.cuda.synchronize(); e0.record()
+for _ in range(50): ops.roi_scale_order(rois, (1.0, 1.0, 1.0, 1.0), [s[-2:] for s in shapes], scales)
+e1.record(); torch.cuda.synchronize()
+print("roi_scale_order: %.1f us per call (host-bound loop, includes the launch)" % (e0.elapsed_time(e1) * 1e3 / 50))
