@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
         s[r][c] = TR ? w[(k0 + r) * row + m0 * 9u + c] : w[(m0 + r) * row + k0 * 9u + c];     // rows: k (TR) or m
     }
     __syncthreads();
-    const unsigned mi = threadIdx.x >> 4, ki = threadIdx.x & 15u;
+    const unsigned ki = threadIdx.x >> 4, mi = threadIdx.x & 15u;    // m fastest: U is stored [xi][k][m] (the GEMM's A tile = 32 k rows x 128 m)
     float g[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) g[e] = TR ? s[ki][mi * 9 + (8 - e)] : s[mi][ki * 9 + e];       // data gradient: W[k][m] rotated by 180 degrees
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
         t[2][c] = (g[c] - g[3 + c] + g[6 + c]) * 0.5f;
         t[3][c] = g[6 + c];
     }
-    const size_t n = (size_t)C * C, o = (size_t)(m0 + mi) * C + k0 + ki;
+    const size_t n = (size_t)C * C, o = (size_t)(k0 + ki) * C + m0 + mi;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float u0 = t[r][0], u1 = (t[r][0] + t[r][1] + t[r][2]) * 0.5f, u2 = (t[r][0] - t[r][1] + t[r][2]) * 0.5f, u3 = t[r][2];
@@ -458,8 +458,9 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ Mo,
                                                                     float *__restrict__ part, int *__restrict__ cnt)
 {
-    __shared__ float sA[2][CF_MT * WN_AS];
-    __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * WN_BS];
+    // both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
+    __shared__ __attribute__((aligned(16))) float sA[2][WN_KC * CF_MT];
+    __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * CF_NT];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -472,28 +473,29 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
     auto tile_of = [&](int t) {
         const int mt = t % a.n_m_tiles, r = t / a.n_m_tiles, tt = r % a.n_t_tiles, xi = r / a.n_t_tiles;
         Tl T;
-        T.u = U + ((size_t)xi * C + (size_t)mt * CF_MT) * C;
+        T.u = U + (size_t)xi * C * C + (size_t)mt * CF_MT;         // U[xi][k][m]: rows k, this tile's 128 columns
         T.v = V + (size_t)xi * C * Ttot + (size_t)tt * CF_NT;
         T.o = Mo + ((size_t)xi * C + (size_t)mt * CF_MT) * Ttot + (size_t)tt * CF_NT;
         T.tile = t;
         return T;
     };
-    // staging slots: four 16-byte pieces of the U tile (128 rows x 8) and four of the V tile (32 rows x 32) per thread
-    // (piece q of a thread = piece 0 plus q * 32 rows of U / q * 8 rows of V: one offset each, the rest are uniform increments)
-    const unsigned a_off0 = (unsigned)((tid >> 3) * C + (tid & 7) * 4), b_off0 = (unsigned)((tid >> 5) * Ttot + (tid & 31) * 4);
-    const int a_lds0 = (tid >> 3) * WN_AS + (tid & 7) * 4, b_lds0 = (tid >> 5) * WN_BS + (tid & 31) * 4;
-    float4 ra[4], rb[4];
-    auto issue_loads = [&](const Tl &T, int chunk) {
-        const float *ub = T.u + chunk * WN_KC, *vb = T.v + (size_t)chunk * WN_KC * Ttot;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = *(const float4 *)(ub + (size_t)q * 32 * C + a_off0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rb[q] = *(const float4 *)(vb + (size_t)q * 8 * Ttot + b_off0);
+    // staging by LDS-DMA: a chunk = 16 + 16 wave transfers of 1 KB (two k rows x 512 B each), four + four per wave; no staging registers,
+    // no ds_write, and the transfers of chunk u + 1 are in flight during all sixteen k steps of chunk u.  (With the chunk staged through
+    // registers -- 8 x 16 bytes per thread, written to LDS behind the last step -- the GEMM took 533 us at FPN size and 70 at 600x1000;
+    // without any staging the same loop takes 366.)
+    const unsigned dma_row = (unsigned)(lane >> 5), dma_col = (unsigned)(lane & 31) * 4u;
+    auto dma16 = [&](const float *g, const float *lds) {
+        const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
     };
-    auto store_part = [&](int buf, int q) {
-        float *d = &sA[buf][a_lds0 + q * 32 * WN_AS];
-        d[0] = ra[q].x; d[1] = ra[q].y; d[2] = ra[q].z; d[3] = ra[q].w;
-        *(float4 *)&sB[buf][b_lds0 + q * 8 * WN_BS] = rb[q];
+    auto issue_dma = [&](const Tl &T, int chunk, int buf) {
+        const float *ub = T.u + (size_t)chunk * WN_KC * C, *vb = T.v + (size_t)chunk * WN_KC * Ttot;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = wave * 4 + q;                              // transfer d = k rows 2d, 2d + 1
+            dma16(ub + (size_t)(2 * d + dma_row) * C + dma_col, &sA[buf][d * 256]);
+            dma16(vb + (size_t)(2 * d + dma_row) * Ttot + dma_col, &sB[buf][d * 256]);
+        }
     };
     f32x16 acc[2][2];
     auto zero_acc = [&]() {
@@ -574,9 +576,8 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
     int tile = u0 / Kc, chunk = u0 - tile * Kc;
     Tl T = tile_of(tile);
     int seg_first = chunk;
-    issue_loads(T, chunk);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) store_part(0, q);
+    issue_dma(T, chunk, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int u = u0; u < u1; ++u) {
         const int buf = (u - u0) & 1;
@@ -585,16 +586,13 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
         Tl Tn = T;
         const bool more = u + 1 < u1;
         if (more && ntile != tile) Tn = tile_of(ntile);
-        const float *pa = &sA[buf][(wm * 64 + li) * WN_AS + lh];
-        const float *pb = &sB[buf][lh * WN_BS + wn * 64 + li];
+        if (more) issue_dma(Tn, nchunk, buf ^ 1);                   // every wave is past the barrier that ended the last reads of that buffer
+        const float *pa = &sA[buf][lh * CF_MT + wm * 64 + li];
+        const float *pb = &sB[buf][lh * CF_NT + wn * 64 + li];
         float oa[2][2], ob[2][2];
         auto fetch = [&](int s, int slot) {
-#if defined(WN_ABL) && (WN_ABL & 2)                                 // developer ablation 2: no LDS operand reads
-            oa[slot][0] = (float)(s + lane); oa[slot][1] = (float)(s - lane); ob[slot][0] = (float)(s * lane); ob[slot][1] = (float)(lane - 3 * s);
-#else
-            oa[slot][0] = pa[2 * s]; oa[slot][1] = pa[32 * WN_AS + 2 * s];
-            ob[slot][0] = pb[2 * s * WN_BS]; ob[slot][1] = pb[2 * s * WN_BS + 32];
-#endif
+            oa[slot][0] = pa[2 * s * CF_MT]; oa[slot][1] = pa[2 * s * CF_MT + 32];
+            ob[slot][0] = pb[2 * s * CF_NT]; ob[slot][1] = pb[2 * s * CF_NT + 32];
         };
         fetch(0, 0);
 #pragma unroll
@@ -603,17 +601,10 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
             if (s + 1 < 16) fetch(s + 1, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][0], acc[0][0], 0, 0, 0);
-#if !(defined(WN_ABL) && (WN_ABL & 4))                              // developer ablation 4: no staging of the next chunk
-            if (s == 0 && more) issue_loads(Tn, nchunk);
-#endif
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][1], acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][0], acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][1], acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) {                                                  // the staged chunk -> LDS behind the sixteenth step (riding in steps 12-15 it
-#pragma unroll                                                       // left the loads four steps less to land: 554 against 533 us at FPN size)
-            for (int q = 0; q < 4; ++q) store_part(buf ^ 1, q);
         }
         if (!more || ntile != tile) {
             finish_segment(T, seg_first, chunk + 1 - seg_first);
@@ -622,6 +613,7 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
             if (more) T = Tn;
         }
         tile = ntile; chunk = nchunk;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk's transfers have landed (this wave's; the barrier covers the others')
         __syncthreads();
     }
 }
