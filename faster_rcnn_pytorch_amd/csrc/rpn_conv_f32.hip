@@ -353,6 +353,14 @@ struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
     int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;
 };
+// the batched product of the stage: O[xi][m][n] = sum_k A[xi][k][m] B[xi][k][n], both operands K-major (rows k, 128 columns per tile)
+//   forward / data gradient: A = U [k = ci][m = co], B = V [ci][t], O = M [co][t], K = C
+//   weight gradient:         A = dMt [k = t][m = co], B = Vt [t][ci], O = dU [co][ci], K = Ttot
+struct WgArgs {
+    const float *A, *B; float *O;
+    long long sA, sB, sO;              // xi strides (floats)
+    int lda, ldb, ldo, n_m_tiles, n_t_tiles, Kc, n_units, G;
+};
 
 // 16 x 16 (m, k) blocks: the data gradient reads W[k][m] (m contiguous) and writes U[m][k] (k contiguous), so its block goes through LDS
 // (the plain one-thread-per-element form read 36-byte pieces 18 KB apart: 15 us at C = 512)
@@ -455,8 +463,90 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     if (r1) { y[W] = y10; if (x1) y[W + 1] = y11; }
 }
 
-__global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, const float *__restrict__ U, const float *__restrict__ V, float *__restrict__ Mo,
-                                                                    float *__restrict__ part, int *__restrict__ cnt)
+// ---- weight gradient through the same domain: dU[xi][co][ci] = sum_t (A dY A^T)_xi[co][t] (B^T d B)_xi[ci][t], dW = G^T dU G.
+// The product sums over the TILES, so both operands must be K-major with K = t: the two transforms below write [xi][t][channel]
+// (channel contiguous) through an LDS transpose -- block = 8 tiles x 32 channels: patches are read with the lanes along the tiles, the
+// 16 planes written with the lanes along the channels (128-byte runs).
+// MODE 0: V^T of the activations (4 x 4 input patch, B^T d B);  MODE 1: dM^T of the output gradient (2 x 2 tile, A y A^T).
+template <int MODE>
+__global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__restrict__ out)
+{
+    __shared__ float s[16][8][33];
+    const int tl = threadIdx.x & 7, cl = threadIdx.x >> 3;
+    const int t = blockIdx.x * 8 + tl, c = blockIdx.y * 32 + cl;
+    int l = 0;
+#pragma unroll
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
+    const int ti = t - a.lv[l].off;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.0f;                        // padding tiles: zero rows of the product
+    if (ti < a.lv[l].T) {
+        const int H = a.lv[l].H, W = a.lv[l].W, ty = ti / a.lv[l].tw, tx = ti - ty * a.lv[l].tw;
+        const float *x = (MODE == 0 ? a.lv[l].x : (const float *)a.lv[l].y) + (size_t)c * H * W;
+        if (MODE == 0) {
+            float d[4][4], w[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
+                    d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { w[0][q] = d[0][q] - d[2][q]; w[1][q] = d[1][q] + d[2][q]; w[2][q] = d[2][q] - d[1][q]; w[3][q] = d[1][q] - d[3][q]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0] - w[r][2]; v[r * 4 + 1] = w[r][1] + w[r][2]; v[r * 4 + 2] = w[r][2] - w[r][1]; v[r * 4 + 3] = w[r][1] - w[r][3]; }
+        } else {
+            float y[2][2], w[4][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int yy = 2 * ty + r, xx = 2 * tx + q;
+                    y[r][q] = (yy < H && xx < W) ? x[yy * W + xx] : 0.0f;
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { w[0][q] = y[0][q]; w[1][q] = y[0][q] + y[1][q]; w[2][q] = y[0][q] - y[1][q]; w[3][q] = -y[1][q]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0]; v[r * 4 + 1] = w[r][0] + w[r][1]; v[r * 4 + 2] = w[r][0] - w[r][1]; v[r * 4 + 3] = -w[r][1]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e][tl][cl] = v[e];
+    __syncthreads();
+    const int c2 = threadIdx.x & 31, t2 = threadIdx.x >> 5;
+    const size_t plane = (size_t)a.Ttot * a.C, at = (size_t)(blockIdx.x * 8 + t2) * a.C + blockIdx.y * 32 + c2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[(size_t)e * plane + at] = s[e][t2][c2];
+}
+
+// dW[co][ci] = G^T dU G: 4 x 4 -> 3 x 3, thread = (co, ci)
+__global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, int C)
+{
+    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C;
+    if (o >= n) return;
+    float u[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[r][q] = dU[(size_t)(r * 4 + q) * n + o];
+    float t[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        t[0][q] = u[0][q] + (u[1][q] + u[2][q]) * 0.5f;
+        t[1][q] = (u[1][q] - u[2][q]) * 0.5f;
+        t[2][q] = (u[1][q] + u[2][q]) * 0.5f + u[3][q];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        dw[(size_t)o * 9 + r * 3 + 0] = t[r][0] + (t[r][1] + t[r][2]) * 0.5f;
+        dw[(size_t)o * 9 + r * 3 + 1] = (t[r][1] - t[r][2]) * 0.5f;
+        dw[(size_t)o * 9 + r * 3 + 2] = (t[r][1] + t[r][2]) * 0.5f + t[r][3];
+    }
+}
+
+__global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
 {
     // both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
     __shared__ __attribute__((aligned(16))) float sA[2][WN_KC * CF_MT];
@@ -464,7 +554,7 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-    const int G = a.G, U_ = a.n_units, Kc = a.Kc, C = a.C, Ttot = a.Ttot;
+    const int G = a.G, U_ = a.n_units, Kc = a.Kc, lda = a.lda, ldb = a.ldb, ldo = a.ldo;
     const int sigma = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int u0 = (int)cf_start(sigma, U_, G), u1 = (int)cf_start(sigma + 1, U_, G);
     if (u0 >= u1) return;
@@ -473,9 +563,9 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
     auto tile_of = [&](int t) {
         const int mt = t % a.n_m_tiles, r = t / a.n_m_tiles, tt = r % a.n_t_tiles, xi = r / a.n_t_tiles;
         Tl T;
-        T.u = U + (size_t)xi * C * C + (size_t)mt * CF_MT;         // U[xi][k][m]: rows k, this tile's 128 columns
-        T.v = V + (size_t)xi * C * Ttot + (size_t)tt * CF_NT;
-        T.o = Mo + ((size_t)xi * C + (size_t)mt * CF_MT) * Ttot + (size_t)tt * CF_NT;
+        T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT;          // rows k, this tile's 128 columns
+        T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT;
+        T.o = a.O + (size_t)xi * a.sO + (size_t)mt * CF_MT * ldo + (size_t)tt * CF_NT;
         T.tile = t;
         return T;
     };
@@ -489,12 +579,12 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
     };
     auto issue_dma = [&](const Tl &T, int chunk, int buf) {
-        const float *ub = T.u + (size_t)chunk * WN_KC * C, *vb = T.v + (size_t)chunk * WN_KC * Ttot;
+        const float *ub = T.u + (size_t)chunk * WN_KC * lda, *vb = T.v + (size_t)chunk * WN_KC * ldb;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int d = wave * 4 + q;                              // transfer d = k rows 2d, 2d + 1
-            dma16(ub + (size_t)(2 * d + dma_row) * C + dma_col, &sA[buf][d * 256]);
-            dma16(vb + (size_t)(2 * d + dma_row) * Ttot + dma_col, &sB[buf][d * 256]);
+            dma16(ub + (size_t)(2 * d + dma_row) * lda + dma_col, &sA[buf][d * 256]);
+            dma16(vb + (size_t)(2 * d + dma_row) * ldb + dma_col, &sB[buf][d * 256]);
         }
     };
     f32x16 acc[2][2];
@@ -508,7 +598,7 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WnArgs a, co
     };
     zero_acc();
     auto store_tile = [&](const Tl &T) {                             // padded columns: no bounds
-        int tt = Ttot;
+        int tt = ldo;
         asm volatile("" : "+s"(tt));                                 // opaque here: otherwise the 64 store offsets are hoisted out of the unit loop
                                                                      // and live in 64 registers through it (the staging registers went to scratch)
         float *o = T.o + (size_t)(wm * 64 + 4 * lh) * tt + wn * 64 + li;
@@ -912,8 +1002,6 @@ static int wn_run(const float *const *in, float *const *out, const int *H, const
     const CfWs ws = cf_carve(workspace, C, Ttot);
     const long long n_tiles = 16ll * a.n_m_tiles * a.n_t_tiles, units = n_tiles * a.Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    a.n_units = (int)units;
-    a.G = (int)std::min<long long>(cf_ranges(), units);
     const unsigned wb = (unsigned)((C / 16) * (C / 16));
     if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
     else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
@@ -921,7 +1009,9 @@ static int wn_run(const float *const *in, float *const *out, const int *H, const
     const dim3 tg((unsigned)((Ttot + 255) / 256), (unsigned)C);
     FRCNN_LAUNCH(rpn_wino_input_kernel, tg, dim3(256), 0, s, a, ws.V);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)a.G), dim3(256), 0, s, a, ws.U, ws.V, ws.M, ws.part, ws.cnt);
+    WgArgs g = {ws.U, ws.V, ws.M, (long long)C * C, (long long)C * Ttot, (long long)C * Ttot, C, (int)Ttot, (int)Ttot,
+                a.n_m_tiles, a.n_t_tiles, a.Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
     FRCNN_LAUNCH(rpn_wino_output_kernel, tg, dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
@@ -967,12 +1057,38 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
     return cf_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, ws.wt, ws, s);
 }
 
+// weight gradient through the Winograd domain: V^T of the features, dM^T of the output gradient, dU = sum over the tiles (the stage's GEMM
+// with K = Ttot), dW = G^T dU G: four launches for all levels
+static int wn_wgrad(const float *const *feats, const float *const *d_outs, const int *H, const int *W, int n_levels, int C, float *dw, void *workspace,
+                    hipStream_t s)
+{
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, feats, (float *const *)d_outs, H, W, n_levels, C);      // lv[l].y = the output gradient (read only)
+    FRCNN_REQUIRE(Ttot < (1ll << 24), "rpn_conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
+    const CfWs ws = cf_carve(workspace, C, Ttot);
+    const int nt = C / CF_MT;
+    const long long n_tiles = 16ll * nt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    const dim3 tg((unsigned)(Ttot / 8), (unsigned)(C / 32));
+    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<0>, tg, dim3(256), 0, s, a, ws.V);
+    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
+    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<1>, tg, dim3(256), 0, s, a, ws.M);
+    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
+    WgArgs g = {ws.M, ws.V, ws.U, Ttot * C, Ttot * C, (long long)C * C, C, C, C, nt, nt, (int)Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
+    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
+    FRCNN_LAUNCH(rpn_wino_dw_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, s, ws.U, dw, C);
+    FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
+    return FRCNN_OK;
+}
+
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, const float *const *d_outs_dev, const int *H_host, const int *W_host, int n_levels,
                                              int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, dw_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_wgrad");
     if (rc) return rc;
+    if (!cf_use_direct()) return wn_wgrad(feats_dev, d_outs_dev, H_host, W_host, n_levels, C, dw_dev, workspace, (hipStream_t)stream);
     const CfWs ws = cf_carve(workspace, C);
     CwArgs a;
     a.n_levels = n_levels; a.C = C;
