@@ -85,9 +85,10 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm"}
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_tr_t_kernel": "hbm", "rpn_wino_dw_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
-WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel")
+WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel", "rpn_wino_tr_t_kernel",
+              "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: tr_t x 2, gemm, dw
 
 
 def synth_frame(cfg, rank, step):
@@ -127,6 +128,8 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
         "rpn_wino_weight_kernel": 4 * (9 + 16) * C * C,                   # Winograd F(2x2,3x3): W in, G g G^T out
         "rpn_wino_input_kernel": 4 * C * P_head + 4 * 16 * C * Tw,        # activations in, B^T d B (16 planes over the padded tiles) out
         "rpn_wino_output_kernel": 4 * 16 * C * Tw + 4 * C * P_head,       # 16 product planes in, A^T M A out
+        "rpn_wino_tr_t_kernel": 4 * C * P_head + 4 * 16 * C * Tw,         # weight gradient: features or output gradient in, 16 transposed planes out
+        "rpn_wino_dw_kernel": 4 * (16 + 9) * C * C,                       # dU in, G^T dU G out
     }.get(kernel)
 
 
@@ -390,8 +393,9 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
             per_kernel[name]["TFLOP_s"] = round(af / us * 1e-6, 2)
             per_kernel[name]["mfma_peak_TFLOP_s"] = MFMA_PEAK_F32_TFLOPS if name in F32_MFMA_KERNELS else MFMA_PEAK_BF16_TFLOPS
             per_kernel[name]["mfma_frac"] = round(af / us * 1e-6 / per_kernel[name]["mfma_peak_TFLOP_s"], 5)
-    # Winograd convolution = a stage of four launches (weight / input transforms, the GEMM, the output transform): the convolution's flop
-    # count is priced over the time of ALL FOUR per call, reported under the GEMM's name; the GEMM's own MFMA utilisation beside it
+    # Winograd convolution = a stage of four launches per call (forward / data gradient: weight and input transforms, the GEMM, the output
+    # transform; weight gradient: two transposed transforms, the GEMM, G^T dU G): the convolution's flop count is priced over the time of
+    # ALL the stage's launches per call, reported under the GEMM's name; the GEMM's own MFMA utilisation beside it
     if "rpn_wino_gemm_kernel" in per_kernel:
         d = per_kernel["rpn_wino_gemm_kernel"]
         calls = max(d["launches"], 1)
@@ -403,7 +407,7 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         d["mfma_frac"] = round(d["algorithmic_flops"] / stage_us * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5)
         d["gemm_executed_flops"] = own
         d["gemm_mfma_utilisation"] = round(own / d["avg_us"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5) if own else None
-        d["note"] = ("Winograd F(2x2,3x3): achieved = the direct convolution's flops / the time of the stage's four launches; the GEMM itself "
+        d["note"] = ("Winograd F(2x2,3x3): achieved = the direct convolution's flops / the time of the stage's four launches per call; the GEMM itself "
                      "executes 2.25x fewer flops (gemm_mfma_utilisation)")
     # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
     nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))

@@ -465,60 +465,68 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
 
 // ---- weight gradient through the same domain: dU[xi][co][ci] = sum_t (A dY A^T)_xi[co][t] (B^T d B)_xi[ci][t], dW = G^T dU G.
 // The product sums over the TILES, so both operands must be K-major with K = t: the two transforms below write [xi][t][channel]
-// (channel contiguous) through an LDS transpose -- block = 8 tiles x 32 channels: patches are read with the lanes along the tiles, the
+// (channel contiguous) through an LDS transpose -- block = 16 tiles x 32 channels: patches are read with the lanes along the tiles, the
 // 16 planes written with the lanes along the channels (128-byte runs).
 // MODE 0: V^T of the activations (4 x 4 input patch, B^T d B);  MODE 1: dM^T of the output gradient (2 x 2 tile, A y A^T).
 template <int MODE>
 __global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__restrict__ out)
 {
-    __shared__ float s[16][8][33];
-    const int tl = threadIdx.x & 7, cl = threadIdx.x >> 3;
-    const int t = blockIdx.x * 8 + tl, c = blockIdx.y * 32 + cl;
-    int l = 0;
+    __shared__ float s[16][16][33];                                  // [xi][tile][channel]: block = 16 tiles x 32 channels, two tiles per thread
+    const int tq = threadIdx.x & 7, cl = threadIdx.x >> 3;
+    const int c = blockIdx.y * 32 + cl;
 #pragma unroll
-    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
-    const int ti = t - a.lv[l].off;
-    float v[16];
+    for (int half = 0; half < 2; ++half) {
+        const int tl = tq + 8 * half, t = blockIdx.x * 16 + tl;
+        int l = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = 0.0f;                        // padding tiles: zero rows of the product
-    if (ti < a.lv[l].T) {
-        const int H = a.lv[l].H, W = a.lv[l].W, ty = ti / a.lv[l].tw, tx = ti - ty * a.lv[l].tw;
-        const float *x = (MODE == 0 ? a.lv[l].x : (const float *)a.lv[l].y) + (size_t)c * H * W;
-        if (MODE == 0) {
-            float d[4][4], w[4][4];
+        for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
+        const int ti = t - a.lv[l].off;
+        float v[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int e = 0; e < 16; ++e) v[e] = 0.0f;                    // padding tiles: zero rows of the product
+        if (ti < a.lv[l].T) {
+            const int H = a.lv[l].H, W = a.lv[l].W, ty = ti / a.lv[l].tw, tx = ti - ty * a.lv[l].tw;
+            const float *x = (MODE == 0 ? a.lv[l].x : (const float *)a.lv[l].y) + (size_t)c * H * W;
+            if (MODE == 0) {
+                float d[4][4], w[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
-                    d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
-                }
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { w[0][q] = d[0][q] - d[2][q]; w[1][q] = d[1][q] + d[2][q]; w[2][q] = d[2][q] - d[1][q]; w[3][q] = d[1][q] - d[3][q]; }
+                    for (int q = 0; q < 4; ++q) {
+                        const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
+                        d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
+                    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0] - w[r][2]; v[r * 4 + 1] = w[r][1] + w[r][2]; v[r * 4 + 2] = w[r][2] - w[r][1]; v[r * 4 + 3] = w[r][1] - w[r][3]; }
-        } else {
-            float y[2][2], w[4][2];
+                for (int q = 0; q < 4; ++q) { w[0][q] = d[0][q] - d[2][q]; w[1][q] = d[1][q] + d[2][q]; w[2][q] = d[2][q] - d[1][q]; w[3][q] = d[1][q] - d[3][q]; }
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+                for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0] - w[r][2]; v[r * 4 + 1] = w[r][1] + w[r][2]; v[r * 4 + 2] = w[r][2] - w[r][1]; v[r * 4 + 3] = w[r][1] - w[r][3]; }
+            } else {
+                float y[2][2], w[4][2];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int yy = 2 * ty + r, xx = 2 * tx + q;
-                    y[r][q] = (yy < H && xx < W) ? x[yy * W + xx] : 0.0f;
-                }
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) { w[0][q] = y[0][q]; w[1][q] = y[0][q] + y[1][q]; w[2][q] = y[0][q] - y[1][q]; w[3][q] = -y[1][q]; }
+                    for (int q = 0; q < 2; ++q) {
+                        const int yy = 2 * ty + r, xx = 2 * tx + q;
+                        y[r][q] = (yy < H && xx < W) ? x[yy * W + xx] : 0.0f;
+                    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0]; v[r * 4 + 1] = w[r][0] + w[r][1]; v[r * 4 + 2] = w[r][0] - w[r][1]; v[r * 4 + 3] = -w[r][1]; }
+                for (int q = 0; q < 2; ++q) { w[0][q] = y[0][q]; w[1][q] = y[0][q] + y[1][q]; w[2][q] = y[0][q] - y[1][q]; w[3][q] = -y[1][q]; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0]; v[r * 4 + 1] = w[r][0] + w[r][1]; v[r * 4 + 2] = w[r][0] - w[r][1]; v[r * 4 + 3] = -w[r][1]; }
+            }
         }
-    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) s[e][tl][cl] = v[e];
+        for (int e = 0; e < 16; ++e) s[e][tl][cl] = v[e];
+    }
     __syncthreads();
     const int c2 = threadIdx.x & 31, t2 = threadIdx.x >> 5;
-    const size_t plane = (size_t)a.Ttot * a.C, at = (size_t)(blockIdx.x * 8 + t2) * a.C + blockIdx.y * 32 + c2;
+    const size_t plane = (size_t)a.Ttot * a.C;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) out[(size_t)e * plane + at] = s[e][t2][c2];
+    for (int half = 0; half < 2; ++half) {
+        const size_t at = (size_t)(blockIdx.x * 16 + t2 + 8 * half) * a.C + blockIdx.y * 32 + c2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[(size_t)e * plane + at] = s[e][t2 + 8 * half][c2];
+    }
 }
 
 // dW[co][ci] = G^T dU G: 4 x 4 -> 3 x 3, thread = (co, ci)
@@ -1069,7 +1077,7 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     const int nt = C / CF_MT;
     const long long n_tiles = 16ll * nt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    const dim3 tg((unsigned)(Ttot / 8), (unsigned)(C / 32));
+    const dim3 tg((unsigned)(Ttot / 16), (unsigned)(C / 32));
     FRCNN_LAUNCH(rpn_wino_tr_t_kernel<0>, tg, dim3(256), 0, s, a, ws.V);
     FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
     FRCNN_LAUNCH(rpn_wino_tr_t_kernel<1>, tg, dim3(256), 0, s, a, ws.M);

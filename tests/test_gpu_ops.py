@@ -1607,8 +1607,9 @@ def test_rpn_conv3x3_f32_matches_the_references_cpu_path_golden(ops, golden, nam
 
 
 def test_rpn_conv3x3_f32_direct_form_in_a_child_process():
-    """Forward / data gradient run through the Winograd domain (four launches); the direct K = 9 C stream-K kernel (+ pack kernel for
-    the data gradient) stays in the library behind FRCNN_CONV_F32_DIRECT=1 (read once per process).  A child process runs it at the
+    """Forward, data gradient and weight gradient run through the Winograd domain (four launches each); the direct kernels (K = 9 C
+    stream-K kernel, + pack kernel for the data gradient; per-wave K-range weight gradient) stay in the library behind
+    FRCNN_CONV_F32_DIRECT=1 (read once per process).  A child process runs it at the
     600x1000 shape, three small FPN levels and an odd shape against float64, like the default form above."""
     import subprocess
     code = r'''
@@ -1623,9 +1624,12 @@ for C, shapes in ((512, [(37, 62)]), (256, [(50, 84), (25, 42), (13, 21)]), (128
     _lib.prof_reset(); _lib.prof_enable(True)
     out = ops.rpn_conv3x3_fwd([f.to(dev) for f in feats], wt.to(dev))
     dx = ops.rpn_conv3x3_bwd_data([t.to(dev) for t in gouts], wt.to(dev))
+    dw = ops.rpn_conv3x3_wgrad([f.to(dev) for f in feats], [t.to(dev) for t in gouts])
     _lib.prof_enable(False)
     names = set(_lib.prof_report())
-    assert "rpn_conv3x3_f32_kernel" in names and "rpn_conv_f32_pack_kernel" in names and not any("wino" in n for n in names), names
+    assert {"rpn_conv3x3_f32_kernel", "rpn_conv_f32_pack_kernel", "rpn_conv3x3_f32_wgrad_kernel"} <= names and not any("wino" in n for n in names), names
+    wref = sum(torch.nn.grad.conv2d_weight(f.double(), (C, C, 3, 3), t.double(), padding=1) for f, t in zip(feats, gouts))
+    assert float((dw.double().cpu() - wref).abs().max()) < 1e-4 * max(1.0, float(wref.abs().max()))
     for o, f in zip(out, feats):
         r = F.conv2d(f.double(), wt.double(), None, padding=1)
         assert float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
