@@ -139,8 +139,8 @@ def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
     return {"rpn_conv3x3_head_kernel": conv + 2 * C * 6 * A * P_head,     # raw = conv3x3 + both 1x1 heads
             "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv,
             "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv,
-            # the Winograd GEMM is priced on the convolution's OWN flop count over the time of the whole four-launch stage (build_record);
-            # what its MFMAs really execute is 32 C^2 Tw, 2.25 x less
+            # placeholder = the convolution's flops: build_record replaces it by what the GEMM executes (32 C^2 Tw, 2.25 x less) and keeps
+            # the convolution's count beside it for the stage-level figure
             "rpn_wino_gemm_kernel": conv}.get(kernel)
 
 
@@ -400,15 +400,17 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         d = per_kernel["rpn_wino_gemm_kernel"]
         calls = max(d["launches"], 1)
         stage_us = sum(sum(samples[k]) for k in WINO_STAGE if k in samples) * 1e3 / calls
-        own = 32 * shape["C"] * shape["C"] * shape.get("Tw", 0)
-        d["stage_us_per_call"] = round(stage_us, 2)
+        conv = d["algorithmic_flops"]                               # the convolution the stage replaces (18 C^2 per position)
+        own = 32 * shape["C"] * shape["C"] * shape.get("Tw", 0)     # what the GEMM executes: 16 products [C x C] . [C x Tw]
+        d["algorithmic_flops"] = own                                # the roofline prices the kernel on ITS OWN contraction ...
+        d["TFLOP_s"] = round(own / d["avg_us"] * 1e-6, 2)
+        d["mfma_frac"] = round(own / d["avg_us"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5)
+        d["stage_us_per_call"] = round(stage_us, 2)                 # ... and the stage it belongs to on the convolution's flop count
         d["stage_kernels"] = [k for k in WINO_STAGE if k in samples]
-        d["TFLOP_s"] = round(d["algorithmic_flops"] / stage_us * 1e-6, 2)
-        d["mfma_frac"] = round(d["algorithmic_flops"] / stage_us * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5)
-        d["gemm_executed_flops"] = own
-        d["gemm_mfma_utilisation"] = round(own / d["avg_us"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5) if own else None
-        d["note"] = ("Winograd F(2x2,3x3): achieved = the direct convolution's flops / the time of the stage's four launches per call; the GEMM itself "
-                     "executes 2.25x fewer flops (gemm_mfma_utilisation)")
+        d["conv_flops_per_call"] = conv
+        d["conv_equivalent_TFLOP_s"] = round(conv / stage_us * 1e-6, 2)
+        d["note"] = ("Winograd F(2x2,3x3): this GEMM executes 2.25x fewer flops than the convolution it serves; conv_equivalent_TFLOP_s = the "
+                     "convolution's own flop count over the time of the stage's four launches per call (may exceed the MFMA peak)")
     # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
     nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
     if "nms_kernel" in per_kernel and nms_us > 0:
@@ -434,7 +436,7 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
             r = {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": d["mfma_peak_TFLOP_s"], "unit": "TFLOP/s",
                  "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
                  "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
-            for k in ("stage_us_per_call", "stage_kernels", "gemm_mfma_utilisation", "note"):
+            for k in ("stage_us_per_call", "stage_kernels", "conv_equivalent_TFLOP_s", "conv_flops_per_call", "note"):
                 if k in d:
                     r[k] = d[k]
             return r
@@ -509,7 +511,7 @@ def compact_record(full, also=()):
                        "vs_baseline", "dtype", "data"))
     out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission"))
     rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
-    roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions", "stage_us_per_call", "gemm_mfma_utilisation"))
+    roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions", "stage_us_per_call", "conv_equivalent_TFLOP_s"))
     if roof is not None and full["roofline"].get("hbm_kernel"):
         roof["hbm_kernel"] = _pick(full["roofline"]["hbm_kernel"], rk)
     out["roofline"] = roof

@@ -147,3 +147,26 @@ def test_bench_timing_rule_and_record_assembly_world2_gloo():
     assert rec["distributed"]["backend"] == "gloo" and rec["distributed"]["per_rank_ms_per_step"] == pr0
     assert rec["distributed"]["ddp"]["num_parameter_tensors"] == 2
     assert len(json.dumps(rec)) < 4096
+
+
+def test_winograd_stage_accounting_in_the_roofline():
+    """The fp32 RPN conv runs as a Winograd stage: the GEMM kernel is priced on the flops IT executes (32 C^2 Tw: a fraction of the fp32
+    MFMA peak, never above it), and the convolution's own flop count over the time of the stage's launches per call rides beside it."""
+    import bench
+    us = {"rpn_wino_gemm_kernel": 0.060, "rpn_wino_input_kernel": 0.010, "rpn_wino_output_kernel": 0.008, "rpn_wino_weight_kernel": 0.008,
+          "rpn_wino_tr_t_kernel": 0.011, "rpn_wino_dw_kernel": 0.008, "nms_kernel": 0.070}
+    n = {"rpn_wino_gemm_kernel": 3, "rpn_wino_input_kernel": 2, "rpn_wino_output_kernel": 2, "rpn_wino_weight_kernel": 2, "rpn_wino_tr_t_kernel": 2,
+         "rpn_wino_dw_kernel": 1, "nms_kernel": 1}
+    samples = {k: [us[k]] * (n[k] * 5) for k in us}                          # five bracketed steps
+    rec = bench.build_record("vgg", "none", world=1, steps=20, warmup=4, dt=0.284, per_rank_ms=[14.2], step_ms=[14.2] * 20, samples=samples,
+                             n_sampled=5, n_props=[780], graph=False, pmc={}, pmc_src=None, cpu=None, allocator={}, ddp=None, backend=None,
+                             world_seen=1, final_loss=1.0)
+    r = rec["roofline"]
+    assert r["kernel"] == "rpn_wino_gemm_kernel" and r["bound"] == "mfma" and r["peak"] == 157.3
+    own = 32 * 512 * 512 * 640
+    assert abs(r["achieved"] - own / 60.0 * 1e-6) < 0.05 and 0 < r["frac"] < 1
+    stage = (3 * 60 + 2 * 10 + 2 * 8 + 2 * 8 + 2 * 11 + 8) / 3
+    assert abs(r["stage_us_per_call"] - stage) < 0.05
+    assert abs(r["conv_equivalent_TFLOP_s"] - 2 * 512 * 9 * 512 * 37 * 62 / stage * 1e-6) < 0.05
+    c = bench.compact_record(rec)["roofline"]
+    assert c["conv_equivalent_TFLOP_s"] == r["conv_equivalent_TFLOP_s"] and c["frac"] == r["frac"]
