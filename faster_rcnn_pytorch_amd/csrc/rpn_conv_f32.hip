@@ -6,6 +6,11 @@
 // convolution was the one MIOpen call left on the hot path (igemm_fwd_gtcx35_nhwc_fp32 at 67 % of that peak, Winograd / igemm_wrw
 // for its backward).  The bias, the ReLU and both 1x1 heads stay in rpn_head.hip, which reads the bias-free output written here.
 //
+// TWO forms live in this file.  The DEFAULT one for all three directions is the Winograd F(2x2, 3x3) stage (section "Winograd" below:
+// rpn_wino_weight / _input / _gemm / _output, and rpn_wino_tr_t x 2 / _gemm / _dw for the weight gradient): 2.25 x fewer MFMAs.
+// The DIRECT form (9 C deep implicit GEMM, described next) is kept behind FRCNN_CONV_F32_DIRECT=1 as the A/B partner and the
+// independent check of the stage (tests/test_gpu_ops.py runs it in a child process); the stage's GEMM reuses its stream-K skeleton.
+//
 // rpn_conv3x3_f32_kernel (forward; data gradient = the same kernel on the weights transposed and flipped by rpn_conv_f32_pack_kernel):
 //   implicit GEMM  Y[co][p] = sum_{ci, tap} Wt[co][ci * 9 + tap] * X[ci][p + off(tap)],  M = co, N = flat positions p of one level, K = 9 C.
 //   Workgroup tile 128 co x 128 consecutive flat positions, 4 waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulators per lane).
@@ -341,8 +346,9 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 //   rpn_wino_weight_kernel   U[xi][m][k] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
 //   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded 4 x 4 input patch of tile t; rows padded to a multiple of 128 tiles
 //   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][m][k] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
-//                            v_mfma_f32_32x32x2_f32, the forward kernel's skeleton without taps: both operands are plain aligned
-//                            float4 row pieces, no edge selects, 16 k steps per chunk
+//                            v_mfma_f32_32x32x2_f32, the direct kernel's skeleton without taps: both operand tiles (32 K rows x 128
+//                            floats) are staged by LDS-DMA (global_load_lds_dwordx4, no staging registers), no edge selects,
+//                            16 k steps per chunk; the weight gradient runs the same kernel with K = the tiles (below)
 //   rpn_wino_output_kernel   Y[m][2ty + i][2tx + j] = (A^T M A)_ij
 // The transformed operands travel through the workspace (16 C Ttot floats each way: 21 MB at 600x1000, 373 MB at FPN size).
 #define WN_KC 32                       // input channels per K chunk
