@@ -354,10 +354,14 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 #define WN_KC 32                       // input channels per K chunk
 #define WN_AS 33                       // LDS row stride of the U tile [128][32]
 #define WN_BS 160                      // LDS row stride of the V tile [32][128]: 160 = 32 (mod 64), the two k halves hit disjoint banks
-struct WnLevel { const float *x; float *y; int H, W, tw, T, off; };
+// m (optional): the forward's ReLU output of the level whose gradient x (input transform) / y (transposed transform, bias gradient) is: the
+// gradient counts where m > 0 -- what autograd's threshold_backward computes in a launch of its own
+struct WnLevel { const float *x; float *y; const float *m; int H, W, tw, T, off; };
 struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
-    int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;
+    const float *bias;                 // output transform: + bias[c] (or NULL), then ReLU if relu != 0
+    int relu;
+    int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;       // C = channels of the side the launch touches
 };
 // the batched product of the stage: O[xi][m][n] = sum_k A[xi][k][m] B[xi][k][n], both operands K-major (rows k, 128 columns per tile)
 //   forward / data gradient: A = U [k = ci][m = co], B = V [ci][t], O = M [co][t], K = C
@@ -371,10 +375,11 @@ struct WgArgs {
 // 16 x 16 (m, k) blocks: the data gradient reads W[k][m] (m contiguous) and writes U[m][k] (k contiguous), so its block goes through LDS
 // (the plain one-thread-per-element form read 36-byte pieces 18 KB apart: 15 us at C = 512)
 template <bool TR>
-__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int C)
+__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int M, int K, int Cin)
 {
+    // w [Cout][Cin][9].  forward: m = co, k = ci;  data gradient (TR): m = ci, k = co
     __shared__ float s[16][16 * 9 + 1];
-    const unsigned nb = (unsigned)C / 16u, m0 = (blockIdx.x / nb) * 16u, k0 = (blockIdx.x % nb) * 16u, row = (unsigned)C * 9u;
+    const unsigned nb = (unsigned)K / 16u, m0 = (blockIdx.x / nb) * 16u, k0 = (blockIdx.x % nb) * 16u, row = (unsigned)Cin * 9u;
 #pragma unroll
     for (unsigned q = 0; q < 9; ++q) {
         const unsigned e = threadIdx.x + 256u * q, r = e / 144u, c = e - r * 144u;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
         t[2][c] = (g[c] - g[3 + c] + g[6 + c]) * 0.5f;
         t[3][c] = g[6 + c];
     }
-    const size_t n = (size_t)C * C, o = (size_t)(k0 + ki) * C + m0 + mi;
+    const size_t n = (size_t)M * K, o = (size_t)(k0 + ki) * M + m0 + mi;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float u0 = t[r][0], u1 = (t[r][0] + t[r][1] + t[r][2]) * 0.5f, u2 = (t[r][0] - t[r][1] + t[r][2]) * 0.5f, u3 = t[r][2];
@@ -414,12 +419,16 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, float *__
     if (tl < a.lv[l].T) {
         const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
         const float *x = a.lv[l].x + (size_t)c * H * W;
+        const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
-                d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                float v = in ? x[yy * W + xx] : 0.0f;
+                if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
+                d[r][q] = v;
             }
     } else {
 #pragma unroll
@@ -460,7 +469,9 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     float s0[4], s1[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s0[q] = m[0][q] + m[1][q] + m[2][q]; s1[q] = m[1][q] - m[2][q] - m[3][q]; }
-    const float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3], y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+    float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3], y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
+    if (a.bias) { const float b = a.bias[c]; y00 += b; y01 += b; y10 += b; y11 += b; }
+    if (a.relu) { y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f); y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f); }
     const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
     float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(2 * ty) * W + 2 * tx;
     const bool x1 = 2 * tx + 1 < W, r1 = 2 * ty + 1 < H;
@@ -493,6 +504,7 @@ __global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__r
         if (ti < a.lv[l].T) {
             const int H = a.lv[l].H, W = a.lv[l].W, ty = ti / a.lv[l].tw, tx = ti - ty * a.lv[l].tw;
             const float *x = (MODE == 0 ? a.lv[l].x : (const float *)a.lv[l].y) + (size_t)c * H * W;
+            const float *mk = (MODE == 1 && a.lv[l].m) ? a.lv[l].m + (size_t)c * H * W : nullptr;
             if (MODE == 0) {
                 float d[4][4], w[4][4];
 #pragma unroll
@@ -513,7 +525,10 @@ __global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__r
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
                         const int yy = 2 * ty + r, xx = 2 * tx + q;
-                        y[r][q] = (yy < H && xx < W) ? x[yy * W + xx] : 0.0f;
+                        const bool in = yy < H && xx < W;
+                        float v = in ? x[yy * W + xx] : 0.0f;
+                        if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
+                        y[r][q] = v;
                     }
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { w[0][q] = y[0][q]; w[1][q] = y[0][q] + y[1][q]; w[2][q] = y[0][q] - y[1][q]; w[3][q] = -y[1][q]; }
@@ -536,9 +551,9 @@ __global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__r
 }
 
 // dW[co][ci] = G^T dU G: 4 x 4 -> 3 x 3, thread = (co, ci)
-__global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, int C)
+__global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, unsigned n)
 {
-    const unsigned o = blockIdx.x * 256u + threadIdx.x, n = (unsigned)C * (unsigned)C;
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;                // (co, ci) of dW [Cout][Cin][9]; n = Cout * Cin
     if (o >= n) return;
     float u[4][4];
 #pragma unroll
@@ -558,6 +573,32 @@ __global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restric
         dw[(size_t)o * 9 + r * 3 + 1] = (t[r][1] - t[r][2]) * 0.5f;
         dw[(size_t)o * 9 + r * 3 + 2] = (t[r][1] + t[r][2]) * 0.5f + t[r][3];
     }
+}
+
+// db[c] = sum over levels and positions of the (masked) output gradient: one workgroup per channel, fixed-order sums
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__restrict__ db)
+{
+    __shared__ float red[256];
+    const int c = blockIdx.x;
+    float acc = 0.0f;
+    for (int l = 0; l < a.n_levels; ++l) {
+        const int HW = a.lv[l].H * a.lv[l].W;
+        const float *g = (const float *)a.lv[l].y + (size_t)c * HW;
+        const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * HW : nullptr;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v = g[i];
+            if (mk) v = mk[i] > 0.0f ? v : 0.0f;
+            acc += v;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] = red[0];
 }
 
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
@@ -935,8 +976,11 @@ static int cf_ranges()
     }();
     return g;
 }
-static CfWs cf_carve(void *ws, int C, long long Ttot = 0)
+static CfWs cf_carve(void *ws, int C, long long Ttot = 0, int Cin = 0, int Cout = 0)
 {
+    // C = max(Cin, Cout): the direct kernels' share (Cin = Cout there); Ttot != 0 adds the Winograd stage's operand buffers
+    if (!Cin) Cin = C;
+    if (!Cout) Cout = C;
     CfWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
     w.cnt = (int *)take(CF_MAX_TILES * sizeof(int));
@@ -945,8 +989,8 @@ static CfWs cf_carve(void *ws, int C, long long Ttot = 0)
     const size_t wg_tiles = (size_t)(C / 32) * (C / 32);           // weight gradient: tiles x workgroups per tile <= max(tiles, CUs) slabs of one tile
     const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / CF_WPS * CW_WPS) * (32 * 32 * 9) * sizeof(float);
     w.part = (float *)take(fwd > wg ? fwd : wg);
-    w.U = Ttot ? (float *)take((size_t)16 * C * C * sizeof(float)) : nullptr;             // Winograd: transformed weights, inputs, products
-    w.V = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;
+    w.U = Ttot ? (float *)take((size_t)16 * Cin * Cout * sizeof(float)) : nullptr;        // Winograd: transformed weights, inputs, products
+    w.V = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;          // (either side may be the wider one: forward / data gradient)
     w.M = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;
     w.total = o;
     return w;
@@ -983,87 +1027,173 @@ static bool cf_use_direct()
     return d;
 }
 
-static long long wn_fill(WnArgs *a, const float *const *in, float *const *out, const int *H, const int *W, int n_levels, int C)
+static long long wn_fill(WnArgs *a, const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels)
 {
     long long off = 0;
     for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
         if (l < n_levels) {
             const int tw = (W[l] + 1) / 2, th = (H[l] + 1) / 2;
-            a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
+            a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, mask ? mask[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
             off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
-        } else a->lv[l] = {nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
+        } else a->lv[l] = {nullptr, nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
-    a->n_levels = n_levels; a->C = C; a->Ttot = (int)off;
-    a->n_m_tiles = C / CF_MT; a->n_t_tiles = (int)(off / CF_NT); a->Kc = C / WN_KC;
+    a->bias = nullptr; a->relu = 0;
+    a->n_levels = n_levels; a->C = 0; a->Ttot = (int)off;
+    a->n_m_tiles = 0; a->n_t_tiles = (int)(off / CF_NT); a->Kc = 0; a->n_units = 0; a->G = 0;
     return off;
 }
 
+static bool wn_dims_ok(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % WN_KC == 0 && Cout % WN_KC == 0 && Cin <= 4096 && Cout <= 4096; }
+
+FRCNN_EXPORT size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || !wn_dims_ok(Cin, Cout)) return 0;
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
+    const int C = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;
+    return cf_carve(nullptr, C, Ttot, Cin, Cout).total;
+}
 FRCNN_EXPORT size_t frcnn_rpn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int C)
 {
-    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || C <= 0 || C % CF_MT != 0 || C > 4096) return 0;
-    WnArgs a;
-    const long long Ttot = wn_fill(&a, nullptr, nullptr, H_host, W_host, n_levels, C);
-    return cf_carve(nullptr, C, Ttot).total;
+    if (C <= 0 || C % CF_MT != 0) return 0;
+    return frcnn_conv3x3_f32_workspace(H_host, W_host, n_levels, C, C);
+}
+static CfWs wn_carve(void *workspace, int Cin, int Cout, long long Ttot)
+{
+    return cf_carve(workspace, ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT, Ttot, Cin, Cout);
 }
 
-// forward (transposed = false) or data gradient (true) through the Winograd domain: four launches for all levels
-static int wn_run(const float *const *in, float *const *out, const int *H, const int *W, int n_levels, int C, const float *w, bool transposed,
-                  void *workspace, hipStream_t s)
+// forward (transposed = false) or data gradient (true) of the convolution with w [Cout][Cin][3][3] through the Winograd domain: four
+// launches for all levels.  forward: K = Cin, M = Cout (+ bias, ReLU in the output transform);  data gradient: K = Cout, M = Cin, the
+// incoming gradient optionally masked by the forward's ReLU output
+static int wn_run(const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
+                  const float *w, bool transposed, const float *bias, int relu, void *workspace, hipStream_t s)
 {
+    const int K = transposed ? Cout : Cin, M = transposed ? Cin : Cout;
     WnArgs a;
-    const long long Ttot = wn_fill(&a, in, out, H, W, n_levels, C);
-    FRCNN_REQUIRE(Ttot < (1ll << 24) && 16ll * C * Ttot < (1ll << 31) * 4, "rpn_conv3x3_f32: %lld output tiles are too many", Ttot);
-    const CfWs ws = cf_carve(workspace, C, Ttot);
+    const long long Ttot = wn_fill(&a, in, out, mask, H, W, n_levels);
+    FRCNN_REQUIRE(Ttot < (1ll << 24) && 16ll * std::max(K, M) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
+    const CfWs ws = wn_carve(workspace, Cin, Cout, Ttot);
+    a.n_m_tiles = M / CF_MT; a.Kc = K / WN_KC;
     const long long n_tiles = 16ll * a.n_m_tiles * a.n_t_tiles, units = n_tiles * a.Kc;
-    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    const unsigned wb = (unsigned)((C / 16) * (C / 16));
-    if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
-    else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, C);
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    const unsigned wb = (unsigned)((M / 16) * (K / 16));
+    if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, M, K, Cin);
+    else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, M, K, Cin);
     FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
-    const dim3 tg((unsigned)((Ttot + 255) / 256), (unsigned)C);
-    FRCNN_LAUNCH(rpn_wino_input_kernel, tg, dim3(256), 0, s, a, ws.V);
+    a.C = K;
+    FRCNN_LAUNCH(rpn_wino_input_kernel, dim3((unsigned)((Ttot + 255) / 256), (unsigned)K), dim3(256), 0, s, a, ws.V);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.U, ws.V, ws.M, (long long)C * C, (long long)C * Ttot, (long long)C * Ttot, C, (int)Ttot, (int)Ttot,
+    WgArgs g = {ws.U, ws.V, ws.M, (long long)M * K, (long long)K * Ttot, (long long)M * Ttot, M, (int)Ttot, (int)Ttot,
                 a.n_m_tiles, a.n_t_tiles, a.Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
     FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
-    FRCNN_LAUNCH(rpn_wino_output_kernel, tg, dim3(256), 0, s, a, ws.M);
+    a.C = M; a.bias = bias; a.relu = relu;
+    FRCNN_LAUNCH(rpn_wino_output_kernel, dim3((unsigned)((Ttot + 255) / 256), (unsigned)M), dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
     return FRCNN_OK;
 }
 
-static int cf_check(const void *const *p0, const void *const *p1, const int *H, const int *W, int n_levels, int C, const void *w, void *ws, size_t ws_bytes,
-                    const char *what)
+// m_mult / k_mult: what the GEMM of the call needs of the two channel counts (its M side in 128-wide tiles, its K side in 32-deep chunks)
+static int cf_check(const void *const *p0, const void *const *p1, const int *H, const int *W, int n_levels, int Cin, int Cout, int in_mult, int out_mult,
+                    const void *w, void *ws, size_t ws_bytes, const char *what)
 {
     FRCNN_REQUIRE(p0 && p1 && H && W && w && ws, "%s: NULL pointer", what);
     FRCNN_REQUIRE(n_levels >= 1 && n_levels <= FRCNN_MAX_LEVELS, "%s: 1 <= n_levels <= %d", what, FRCNN_MAX_LEVELS);
-    if (C <= 0 || C % CF_MT != 0 || C > 4096) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "%s: C=%d must be a multiple of %d", what, C, CF_MT);
+    if (!wn_dims_ok(Cin, Cout) || Cin % in_mult != 0 || Cout % out_mult != 0)
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "%s: Cin=%d / Cout=%d must be multiples of %d / %d", what, Cin, Cout, in_mult, out_mult);
     for (int l = 0; l < n_levels; ++l) {
         FRCNN_REQUIRE(p0[l] && p1[l] && H[l] > 0 && W[l] > 0, "%s: bad level %d", what, l);
-        FRCNN_REQUIRE((long long)H[l] * W[l] * C < (1ll << 31), "%s: level %d too large", what, l);
+        FRCNN_REQUIRE((long long)H[l] * W[l] * std::max(Cin, Cout) < (1ll << 31), "%s: level %d too large", what, l);
     }
-    const size_t need = frcnn_rpn_conv3x3_f32_workspace(H, W, n_levels, C);
+    const size_t need = frcnn_conv3x3_f32_workspace(H, W, n_levels, Cin, Cout);
     if (ws_bytes < need) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", what, ws_bytes, need);
     return FRCNN_OK;
 }
 
+FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *y_dev, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
+                                       const float *w_dev, const float *bias_dev, int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, CF_MT, w_dev, workspace, workspace_bytes,
+                      "conv3x3_f32_fwd");
+    if (rc) return rc;
+    return wn_run(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
+}
+
+FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const float *const *y_mask_dev, float *const *dx_dev, const int *H_host, const int *W_host,
+                                            int n_levels, int Cin, int Cout, const float *w_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, CF_MT, WN_KC, w_dev, workspace, workspace_bytes,
+                      "conv3x3_f32_bwd_data");
+    if (rc) return rc;
+    if (y_mask_dev)
+        for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_bwd_data: NULL mask level %d", l);
+    return wn_run(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
+}
+
+// weight gradient through the Winograd domain: V^T of the features, dM^T of the output gradient, dU = sum over the tiles (the stage's GEMM
+// with K = Ttot), dW = G^T dU G: four launches for all levels (+ one for the bias gradient)
+static int wn_wgrad(const float *const *feats, const float *const *d_outs, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
+                    float *dw, float *dbias, void *workspace, hipStream_t s)
+{
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, feats, (float *const *)d_outs, mask, H, W, n_levels);   // lv[l].y = the output gradient (read only)
+    FRCNN_REQUIRE(Ttot < (1ll << 24), "conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
+    const CfWs ws = wn_carve(workspace, Cin, Cout, Ttot);
+    const int mt = Cout / CF_MT, nt = Cin / CF_NT;
+    const long long n_tiles = 16ll * mt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    a.C = Cin;
+    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<0>, dim3((unsigned)(Ttot / 16), (unsigned)(Cin / 32)), dim3(256), 0, s, a, ws.V);
+    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
+    a.C = Cout;
+    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<1>, dim3((unsigned)(Ttot / 16), (unsigned)(Cout / 32)), dim3(256), 0, s, a, ws.M);
+    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
+    WgArgs g = {ws.M, ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, Cout, Cin, Cin, mt, nt, (int)Kc, (int)units,
+                (int)std::min<long long>(cf_ranges(), units)};
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
+    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
+    const unsigned n = (unsigned)Cout * (unsigned)Cin;
+    FRCNN_LAUNCH(rpn_wino_dw_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ws.U, dw, n);
+    FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
+    if (dbias) {
+        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout), dim3(256), 0, s, a, dbias);
+        FRCNN_CHECK_LAUNCH("conv_bias_grad_kernel");
+    }
+    return FRCNN_OK;
+}
+
+FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const float *const *y_mask_dev, const int *H_host, const int *W_host,
+                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, CF_NT, CF_MT, dw_dev, workspace, workspace_bytes,
+                      "conv3x3_f32_wgrad");
+    if (rc) return rc;
+    if (y_mask_dev)
+        for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_wgrad: NULL mask level %d", l);
+    return wn_wgrad(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
+}
+
+// ---- the RPN head's entry points: Cin = Cout = C, no bias (rpn_head.hip adds it), no mask; FRCNN_CONV_F32_DIRECT=1 routes them to the direct kernels
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float *const *outs_dev, const int *H_host, const int *W_host, int n_levels, int C,
                                            const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
+    if (!cf_use_direct())
+        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, workspace, workspace_bytes, stream);
+    int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_fwd");
     if (rc) return rc;
-    if (cf_use_direct()) return cf_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, cf_carve(workspace, C), (hipStream_t)stream);
-    return wn_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, false, workspace, (hipStream_t)stream);
+    return cf_run(feats_dev, outs_dev, H_host, W_host, n_levels, C, w3_dev, cf_carve(workspace, C), (hipStream_t)stream);
 }
 
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, float *const *d_feats_dev, const int *H_host, const int *W_host, int n_levels,
                                                 int C, const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, w3_dev, workspace, workspace_bytes,
-                      "rpn_conv3x3_f32_bwd_data");
+    if (!cf_use_direct())
+        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, workspace, workspace_bytes, stream);
+    int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace,
+                      workspace_bytes, "rpn_conv3x3_f32_bwd_data");
     if (rc) return rc;
-    if (!cf_use_direct()) return wn_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, w3_dev, true, workspace, (hipStream_t)stream);
     const CfWs ws = cf_carve(workspace, C);
     hipStream_t s = (hipStream_t)stream;
     FRCNN_LAUNCH(rpn_conv_f32_pack_kernel, dim3((unsigned)((C / 16) * (C / 16))), dim3(256), 0, s, w3_dev, ws.wt, C);
@@ -1071,38 +1201,14 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
     return cf_run(d_outs_dev, d_feats_dev, H_host, W_host, n_levels, C, ws.wt, ws, s);
 }
 
-// weight gradient through the Winograd domain: V^T of the features, dM^T of the output gradient, dU = sum over the tiles (the stage's GEMM
-// with K = Ttot), dW = G^T dU G: four launches for all levels
-static int wn_wgrad(const float *const *feats, const float *const *d_outs, const int *H, const int *W, int n_levels, int C, float *dw, void *workspace,
-                    hipStream_t s)
-{
-    WnArgs a;
-    const long long Ttot = wn_fill(&a, feats, (float *const *)d_outs, H, W, n_levels, C);      // lv[l].y = the output gradient (read only)
-    FRCNN_REQUIRE(Ttot < (1ll << 24), "rpn_conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
-    const CfWs ws = cf_carve(workspace, C, Ttot);
-    const int nt = C / CF_MT;
-    const long long n_tiles = 16ll * nt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
-    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "rpn_conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    const dim3 tg((unsigned)(Ttot / 16), (unsigned)(C / 32));
-    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<0>, tg, dim3(256), 0, s, a, ws.V);
-    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
-    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<1>, tg, dim3(256), 0, s, a, ws.M);
-    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
-    WgArgs g = {ws.M, ws.V, ws.U, Ttot * C, Ttot * C, (long long)C * C, C, C, C, nt, nt, (int)Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
-    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
-    FRCNN_LAUNCH(rpn_wino_dw_kernel, dim3((unsigned)((C * C + 255) / 256)), dim3(256), 0, s, ws.U, dw, C);
-    FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
-    return FRCNN_OK;
-}
-
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, const float *const *d_outs_dev, const int *H_host, const int *W_host, int n_levels,
                                              int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, dw_dev, workspace, workspace_bytes,
+    if (!cf_use_direct())
+        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, workspace, workspace_bytes, stream);
+    int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, dw_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_wgrad");
     if (rc) return rc;
-    if (!cf_use_direct()) return wn_wgrad(feats_dev, d_outs_dev, H_host, W_host, n_levels, C, dw_dev, workspace, (hipStream_t)stream);
     const CfWs ws = cf_carve(workspace, C);
     CwArgs a;
     a.n_levels = n_levels; a.C = C;

@@ -54,6 +54,29 @@ def vgg16_features():
     return layers
 
 
+class VGGExtractor(nn.Sequential):
+    """`nn.Sequential(*list(vgg16.features)[:-1])` (models/model.py:279-281) with the same children, indices and state_dict keys.  Its forward walks
+    the children like nn.Sequential does, except that a 3x3 convolution the fp32 Winograd stage takes (ops.conv3x3_supported: 128-multiples of
+    channels, batch 1, fp32 on the device) runs there TOGETHER with the ReLU behind it -- bias and ReLU in the output transform, the ReLU's
+    backward in the gradient kernels' transforms -- instead of three vendor / elementwise launches forward and four backward.  Every other
+    child (conv1_x, conv2_1, the pools; any layer under autocast or with batch > 1) runs as it is."""
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1) and m.dilation == (1, 1)
+                    and m.groups == 1 and m.bias is not None and not torch.is_autocast_enabled() and ops.conv3x3_supported(x, m.weight)):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = ops.conv3x3(x, m.weight, m.bias, relu=fuse)
+                i += 2 if fuse else 1
+                continue
+            x = m(x)
+            i += 1
+        return x
+
+
 class RegionProposal(nn.Module):
     """models/model.py:12-58."""
 
@@ -216,7 +239,7 @@ class FRCNN(nn.Module):
         if pretrained:
             raise RuntimeError("pretrained weights need the network (gdown / torchvision hub); load a state_dict instead")
         self.num_classes = num_classes
-        self.extractor = nn.Sequential(*vgg16_features()[:-1])                 # model.py:279-281: drop the last max-pool
+        self.extractor = VGGExtractor(*vgg16_features()[:-1])                  # model.py:279-281: drop the last max-pool
         self.classifier = nn.Sequential(nn.Linear(in_features=25088, out_features=4096), nn.ReLU(inplace=True),
                                         nn.Linear(in_features=4096, out_features=4096), nn.ReLU(inplace=True))
         self.sampler = _Sampler(sampling, seed)

@@ -613,6 +613,133 @@ def rpn_conv3x3(feats, w3):
     return list(_RPNConv3x3F32Fn.apply(w3, *feats))
 
 
+# ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of):
+    Hh, Wh = _host_i32(H), _host_i32(W)
+    nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
+    if nb == 0:
+        raise _lib.FrcnnError("%s: Cin = %d / Cout = %d is outside what the fp32 conv stage is built for (multiples of 32)" % (what, Cin, Cout))
+    ws = _ctrl_workspace(dev, "rpn_conv_f32", nb)     # ONE block for every fp32 3x3 of the step, sized by the largest layer seen
+    with torch.cuda.device(dev):
+        check(fn(*args_of(_np_ptr(Hh), _np_ptr(Wh), _ptr(ws), ws.numel(), _stream())), what)
+
+
+def _ptr_list(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+
+def _conv3x3_levels(ts, Cc, name):
+    ts = [_req(t, torch.float32, name) for t in ts]
+    if not ts:
+        raise ValueError("conv3x3: no level")
+    for t in ts:
+        if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != Cc:
+            raise ValueError("conv3x3: every %s level must be [1,%d,h,w] (batch 1 per GPU)" % (name, Cc))
+    return ts
+
+
+def conv3x3_fwd(xs, w, bias=None, relu=False):
+    """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd)."""
+    w = _req(w, name="w")
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
+        raise ValueError("conv3x3: weight must be [Cout,Cin,3,3]")
+    xs = _conv3x3_levels(xs, Cin, "input")
+    if bias is not None:
+        bias = _req(bias, name="bias")
+        if tuple(bias.shape) != (Cout,):
+            raise ValueError("conv3x3: bias must be [Cout]")
+    ys = [torch.empty((1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
+    xp, yp = _ptr_list(xs), _ptr_list(ys)
+    _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, ws, nws, st))
+    return ys
+
+
+def conv3x3_bwd_data(dys, w, y_masks=None):
+    """Input gradient of conv3x3_fwd; y_masks = the forward's ReLU outputs (the gradient counts where they are > 0) or None."""
+    w = _req(w, name="w")
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    dys = _conv3x3_levels(dys, Cout, "d_out")
+    if y_masks is not None:
+        y_masks = _conv3x3_levels(y_masks, Cout, "mask")
+        if len(y_masks) != len(dys) or any(a.shape != b.shape for a, b in zip(dys, y_masks)):
+            raise ValueError("conv3x3_bwd_data: d_out and mask differ in shape")
+    dxs = [torch.empty((1, Cin, d.shape[2], d.shape[3]), dtype=torch.float32, device=d.device) for d in dys]
+    gp, xp = _ptr_list(dys), _ptr_list(dxs)
+    mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
+    _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [d.shape[2] for d in dys], [d.shape[3] for d in dys], len(dys), Cin, Cout,
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, mp, xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st))
+    return dxs
+
+
+def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False):
+    """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels."""
+    Cin, Cout = int(xs[0].shape[1]), int(dys[0].shape[1])
+    xs = _conv3x3_levels(xs, Cin, "input")
+    dys = _conv3x3_levels(dys, Cout, "d_out")
+    if len(xs) != len(dys) or any(a.shape[2:] != b.shape[2:] for a, b in zip(xs, dys)):
+        raise ValueError("conv3x3_wgrad: inputs and d_out differ in shape")
+    if y_masks is not None:
+        y_masks = _conv3x3_levels(y_masks, Cout, "mask")
+        if len(y_masks) != len(dys) or any(a.shape != b.shape for a, b in zip(dys, y_masks)):
+            raise ValueError("conv3x3_wgrad: d_out and mask differ in shape")
+    dev = xs[0].device
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+    db = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_bias else None
+    xp, gp = _ptr_list(xs), _ptr_list(dys)
+    mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
+    _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
+                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), ws, nws, st))
+    return dw, db
+
+
+CONV3X3_MIN_POSITIONS = 2048      # below this the stage's fixed costs (four launches, partial-tile reduction) lose to the vendor kernel (tools/dev/conv_layers_time.py)
+
+
+def conv3x3_supported(x, weight, need_input_grad=None):
+    """Whether `conv3x3` takes this layer: fp32 on a HIP device, batch 1, [Cout,Cin,3,3] with the multiples the stage's GEMMs need (forward
+    Cin % 32, Cout % 128; the gradients Cin % 128 as well).  Everything else stays with torch's own convolution (the backbone is PyTorch code
+    in the north-star's own words; this stage takes the layers where it wins)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
+        return False
+    Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
+    if tuple(weight.shape[2:]) != (3, 3) or Cout % 128 != 0 or Cin % 32 != 0 or x.shape[2] * x.shape[3] < CONV3X3_MIN_POSITIONS:
+        return False
+    grads = torch.is_grad_enabled() and (weight.requires_grad or (x.requires_grad if need_input_grad is None else need_input_grad))
+    return (not grads) or Cin % 128 == 0
+
+
+class _Conv3x3F32Fn(torch.autograd.Function):
+    """args: (relu, w, bias | None, x) -> act(bias + conv3x3(x, w)); the ReLU's backward rides in the gradient kernels' transforms."""
+
+    @staticmethod
+    def forward(ctx, relu, w, bias, x):
+        y = conv3x3_fwd([x], w, bias, relu)[0]
+        ctx.relu = bool(relu)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(w, x, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x, y = ctx.saved_tensors
+        g = g.contiguous()
+        mask = [y] if ctx.relu else None
+        dx = conv3x3_bwd_data([g], w, mask)[0] if ctx.needs_input_grad[3] else None
+        dw = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            if not ctx.needs_input_grad[1]:
+                dw = None
+        return None, dw, db, dx
+
+
+def conv3x3(x, weight, bias=None, relu=False):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) [+ nn.ReLU] on one fp32 [1,Cin,h,w] map through the hand-written Winograd stage; differentiable."""
+    return _Conv3x3F32Fn.apply(bool(relu), weight, bias, x)
+
+
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):
     """(pred_cls [1, sum P_l * A, 2], pred_reg [1, sum P_l * A, 4]) of the shared FPN RPN head on bf16 feature maps (models/new_model.py:37-44,
     89-114): one launch for conv3x3 + ReLU + both heads on the bf16 matrix cores; box regression outputs stay fp32."""

@@ -1536,6 +1536,93 @@ def test_rpn_conv3x3_f32_autograd_matches_torch_conv(ops):
         assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
 
 
+# ------------------------------------------------------------------------------------------ the same stage on the backbone's 3x3 convolutions
+CONV3X3_CASES = [   # name, Cin, Cout, level shapes, bias, relu, gradients
+    ("vgg_conv3_1", 128, 256, [(150, 250)], True, True, True),               # vgg16.features[10] + [11] behind models/model.py:279-281 at 600x1000
+    ("vgg_conv4_1", 256, 512, [(75, 125)], True, True, True),                 # features[17] + [18]: odd rows and columns
+    ("narrow_in", 64, 128, [(33, 47)], True, True, False),                    # Cin = 64 (features[5]): forward only
+    ("wide_in", 384, 128, [(20, 31)], True, False, True),                     # Cin > Cout, bias without ReLU (the FPN's layer blocks)
+    ("levels", 128, 128, [(9, 14), (30, 5), (1, 1)], False, True, True),      # several levels sharing the weight, no bias
+]
+
+
+@pytest.mark.parametrize("name,Cin,Cout,shapes,use_bias,relu,grads", CONV3X3_CASES, ids=[c[0] for c in CONV3X3_CASES])
+def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, relu, grads):
+    """frcnn_conv3x3_f32_fwd / _bwd_data / _wgrad (Cin != Cout, bias + ReLU in the output transform, the ReLU's backward in the gradient
+    kernels' transforms, bias gradient) against float64 on the CPU.  The ReLU mask of the float64 gradients is taken from the DEVICE output:
+    where the exact pre-activation is within rounding of zero the two forwards may legitimately disagree about the sign, and one such
+    element moves a gradient by a whole dy * x; that the masks differ only there is asserted separately."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(len(name) * 7 + Cin)
+    xs = [torch.randn(1, Cin, h, w, generator=g) for h, w in shapes]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.2 if use_bias else None
+    dys = [torch.randn(1, Cout, h, w, generator=g) for h, w in shapes]
+    xd, dyd, wd = [x.to(DEV) for x in xs], [t.to(DEV) for t in dys], wt.to(DEV)
+    bd = b.to(DEV) if use_bias else None
+    pre = [F.conv2d(x.double(), wt.double(), b.double() if use_bias else None, padding=1) for x in xs]
+    ys = ops.conv3x3_fwd(xd, wd, bd, relu)
+    for y, p in zip(ys, pre):
+        r = p.clamp_min(0) if relu else p
+        assert y.shape == r.shape and float((y.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(p.abs().max()))
+    assert all(torch.equal(a, c) for a, c in zip(ys, ops.conv3x3_fwd(xd, wd, bd, relu)))          # bit-reproducible
+    if not grads:
+        return
+    masks = [(y.cpu() > 0) for y in ys] if relu else [torch.ones_like(p, dtype=torch.bool) for p in pre]
+    for m, p in zip(masks if relu else [], pre):
+        flips = m != (p > 0)
+        assert int(flips.sum()) == 0 or float(p[flips].abs().max()) < 1e-5                          # sign disagreements only at rounding-level zeros
+    gs = [t.double() * m for t, m in zip(dys, masks)]
+    dx_ref = [F.conv_transpose2d(t, wt.double(), None, padding=1) for t in gs]
+    dx = ops.conv3x3_bwd_data(dyd, wd, ys if relu else None)
+    for o, r in zip(dx, dx_ref):
+        assert o.shape == r.shape and float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
+    assert all(torch.equal(a, c) for a, c in zip(dx, ops.conv3x3_bwd_data(dyd, wd, ys if relu else None)))
+    w_ref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64)
+    b_ref = torch.zeros(Cout, dtype=torch.float64)
+    for x, t in zip(xs, gs):
+        w_ref += torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), t, padding=1)
+        b_ref += t.sum(dim=(0, 2, 3))
+    dw, db = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True)
+    assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
+    assert float((db.double().cpu() - b_ref).abs().max()) < 1e-4 * max(1.0, float(b_ref.abs().max()))
+    dw2, db2 = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_conv3x3_f32_autograd_and_argument_checks(ops):
+    """ops.conv3x3 (what VGGExtractor calls) under autograd against torch's conv2d + relu on the device, with the reference's own mask
+    tolerance handled by a bias that keeps pre-activations away from zero; and the entry points refuse what the stage is not built for."""
+    import torch.nn.functional as F
+    from faster_rcnn_pytorch_amd._lib import FrcnnError
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 128, 40, 52, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(256, 128, 3, 3, generator=g) * 0.03).to(DEV).requires_grad_(True)
+    b = (torch.randn(256, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    dy = torch.randn(1, 256, 40, 52, generator=g).to(DEV)
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    keep = ((ref > 1e-4) | (F.conv2d(x, w, b, padding=1) < -1e-4)).float()                       # gradient only where the sign is beyond rounding
+    (ref * dy * keep).sum().backward()
+    want = [t.grad.clone() for t in (x, w, b)]
+    for t in (x, w, b):
+        t.grad = None
+    got_y = ops.conv3x3(x, w, b, relu=True)
+    (got_y * dy * keep).sum().backward()
+    assert float((got_y - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    for a, c in zip([x.grad, w.grad, b.grad], want):
+        assert float((a - c).abs().max()) < 1e-4 * max(1.0, float(c.abs().max()))
+    assert ops.conv3x3_supported(x, w) and not ops.conv3x3_supported(x.half(), w) and not ops.conv3x3_supported(x[:, :, :8, :8], w)
+    w64 = torch.zeros(128, 64, 3, 3, device=DEV, requires_grad=True)
+    x64 = torch.zeros(1, 64, 64, 64, device=DEV)
+    assert not ops.conv3x3_supported(x64, w64)                                                   # training needs Cin % 128 == 0
+    with torch.no_grad():
+        assert ops.conv3x3_supported(x64, w64)                                                   # forward only: Cin % 32 == 0
+    with pytest.raises(FrcnnError):
+        ops.conv3x3_wgrad([x64], [torch.zeros(1, 128, 64, 64, device=DEV)])
+    with pytest.raises(FrcnnError):
+        ops.conv3x3_fwd([x64], torch.zeros(64, 64, 3, 3, device=DEV))                            # Cout = 64
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign forward dispatch order (round 4)
 def test_roi_scale_order_and_ordered_forward_are_bit_identical(ops):
     """frcnn_roi_scale_order replaces the `roi * (w, h, w, h)` launch of FastRCNNHead.forward (models/new_model.py:136-140) and also hands
