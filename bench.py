@@ -85,7 +85,7 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm", "rpn_wino_tr_t_kernel": "hbm", "rpn_wino_dw_kernel": "hbm"}
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_tr_t_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv_bias_grad_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel", "rpn_wino_tr_t_kernel",
               "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: tr_t x 2, gemm, dw
@@ -142,6 +142,36 @@ def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
             # placeholder = the convolution's flops: build_record replaces it by what the GEMM executes (32 C^2 Tw, 2.25 x less) and keeps
             # the convolution's count beside it for the stage-level figure
             "rpn_wino_gemm_kernel": conv}.get(kernel)
+
+
+def wino_work(calls):
+    """Per-image algorithmic totals of the fp32 Winograd stage's kernels from the calls ONE training step makes (ops.CONV_TRACE: the RPN
+    convolution and every backbone layer the stage takes, each forward / data gradient / weight gradient): kernel -> launches, bytes,
+    flops; plus the flop count of the convolutions served (18 Cin Cout per position and direction).  Tiles are padded to 128 per level
+    (that padding is executed, so the GEMM is priced on it); transforms move the activations once and the 16 planes once."""
+    tot = {k: {"launches": 0, "bytes": 0, "flops": 0} for k in WINO_STAGE + ("conv_bias_grad_kernel",)}
+    conv_flops = 0
+
+    def add(k, b=0, f=0):
+        tot[k]["launches"] += 1; tot[k]["bytes"] += b; tot[k]["flops"] += f
+    for c in calls:
+        Cin, Cout, mask = c["Cin"], c["Cout"], 2 if c.get("mask") else 1
+        HW = sum(h * w for h, w in c["shapes"])
+        Tp = sum(-(-(((h + 1) // 2) * ((w + 1) // 2)) // 128) * 128 for h, w in c["shapes"])
+        conv_flops += 18 * Cin * Cout * HW
+        add("rpn_wino_gemm_kernel", 0, 32 * Cin * Cout * Tp)
+        if c["kind"] == "wgrad":
+            add("rpn_wino_tr_t_kernel", 4 * Cin * HW + 64 * Cin * Tp)
+            add("rpn_wino_tr_t_kernel", 4 * Cout * HW * mask + 64 * Cout * Tp)
+            add("rpn_wino_dw_kernel", 4 * 25 * Cin * Cout)
+            if c.get("bias"):
+                add("conv_bias_grad_kernel", 4 * Cout * HW * mask)
+        else:
+            K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
+            add("rpn_wino_weight_kernel", 4 * 25 * Cin * Cout)
+            add("rpn_wino_input_kernel", 4 * K * HW * (mask if c["kind"] == "bwd_data" else 1) + 64 * K * Tp)
+            add("rpn_wino_output_kernel", 64 * M * Tp + 4 * M * HW)
+    return tot, conv_flops
 
 
 def percentiles(v):
@@ -209,7 +239,7 @@ def timed_region(step, steps, warmup, device, armed=None, before_step=None):
 
 def run_config(args, config, amp, steps, warmup, graph, rank, world, device, with_cpu):
     """One bench record (the JSON object described in the module docstring) for one configuration."""
-    from faster_rcnn_pytorch_amd import _lib, parallel
+    from faster_rcnn_pytorch_amd import _lib, ops, parallel
     from faster_rcnn_pytorch_amd.loss import FRCNNLoss
     cfg = CONFIGS[config]
 
@@ -265,6 +295,10 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     log("model + %d frames resident; initialisation pass" % len(frames))
     for i in range(3):
         eager_step(i)
+    torch.cuda.synchronize()
+    ops.CONV_TRACE = []                              # which calls the fp32 conv stage gets in one step (shapes only; for the roofline's flop / byte totals)
+    eager_step(3)
+    conv_calls, ops.CONV_TRACE = ops.CONV_TRACE, None
     torch.cuda.synchronize()
     step = eager_step
     graphs = None
@@ -355,11 +389,11 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     cpu = cpu_baseline(config, cfg, args.cpu_steps, args.lr) if with_cpu else None
     return build_record(config, amp, world=world, steps=steps, warmup=warmup, dt=dt, per_rank_ms=per_rank_ms, step_ms=step_ms,
                         samples=samples, n_sampled=n_sampled, n_props=n_props, graph=graph, pmc=pmc, pmc_src=pmc_src, cpu=cpu,
-                        allocator=allocator, ddp=ddp, backend=backend, world_seen=world_seen, final_loss=final_loss, gc_on=args.gc_on)
+                        allocator=allocator, ddp=ddp, backend=backend, world_seen=world_seen, final_loss=final_loss, gc_on=args.gc_on, conv_calls=conv_calls)
 
 
 def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms, samples, n_sampled, n_props, graph, pmc, pmc_src, cpu,
-                 allocator, ddp, backend, world_seen, final_loss, gc_on=False):
+                 allocator, ddp, backend, world_seen, final_loss, gc_on=False, conv_calls=None):
     """The FULL bench record (written to bench_detail.json) from plain measured values: no GPU, no torch.  `samples` = kernel name ->
     list of launch times in ms (frcnn_prof_samples), `dt` = max-over-ranks seconds of the timed region, `n_props` = device-side
     proposal counts of the timed steps.  compact_record() cuts it down to the line the driver parses."""
@@ -396,7 +430,42 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
     # Winograd convolution = a stage of four launches per call (forward / data gradient: weight and input transforms, the GEMM, the output
     # transform; weight gradient: two transposed transforms, the GEMM, G^T dU G): the convolution's flop count is priced over the time of
     # ALL the stage's launches per call, reported under the GEMM's name; the GEMM's own MFMA utilisation beside it
-    if "rpn_wino_gemm_kernel" in per_kernel:
+    if "rpn_wino_gemm_kernel" in per_kernel and conv_calls:
+        # the stage serves several layers per image (round 4: the backbone's 3x3 convolutions too), so every figure is a PER-IMAGE total
+        # from the traced calls of one step over the per-image time of the kernel's launches; "per launch" = that total / launches
+        tot, conv_flops = wino_work(conv_calls)
+        matched = True
+        for k, t in tot.items():
+            if k not in per_kernel:
+                continue
+            d = per_kernel[k]
+            if t["launches"] == 0 or abs(d["launches_per_img"] - t["launches"]) > 0.01:
+                matched = False                                      # the sampled steps did not make the traced calls: no figure rather than a wrong one
+                d["algorithmic_bytes"] = d["GB_s"] = d["hbm_frac"] = None
+                continue
+            if t["bytes"]:
+                d["algorithmic_bytes"] = round(t["bytes"] / t["launches"])
+                d["algorithmic_bytes_per_img"] = t["bytes"]
+                d["GB_s"] = round(t["bytes"] / d["us_per_img"] * 1e-3, 2)
+                d["hbm_frac"] = round(t["bytes"] / d["us_per_img"] * 1e-3 / HBM_PEAK_GBS, 5)
+        d = per_kernel["rpn_wino_gemm_kernel"]
+        stage_us = sum(per_kernel[k]["us_per_img"] for k in tot if k in per_kernel)
+        own = tot["rpn_wino_gemm_kernel"]["flops"]
+        d["algorithmic_flops_per_img"] = own
+        d["algorithmic_flops"] = round(own / max(tot["rpn_wino_gemm_kernel"]["launches"], 1))
+        d["TFLOP_s"] = round(own / d["us_per_img"] * 1e-6, 2) if matched else None
+        d["mfma_frac"] = round(own / d["us_per_img"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5) if matched else None
+        d["stage_calls_per_img"] = len(conv_calls)
+        d["stage_us_per_img"] = round(stage_us, 2)
+        d["stage_us_per_call"] = round(stage_us / len(conv_calls), 2)
+        d["stage_kernels"] = [k for k in tot if k in per_kernel]
+        d["conv_flops_per_img"] = conv_flops
+        d["conv_equivalent_TFLOP_s"] = round(conv_flops / stage_us * 1e-6, 2) if matched else None
+        d["layers"] = sorted({"%dx%d %s" % (c["Cin"], c["Cout"], "+".join("%dx%d" % s for s in c["shapes"])) for c in conv_calls})
+        d["note"] = ("Winograd F(2x2,3x3), all launches of one image (the RPN convolution and the backbone layers in `layers`, forward + data gradient "
+                     "+ weight gradient): the GEMM is priced on the flops it executes (32 Cin Cout per padded 2x2 tile, 2.25x fewer than the "
+                     "convolutions it serves); conv_equivalent_TFLOP_s = the convolutions' own flop count over the time of ALL the stage's launches")
+    elif "rpn_wino_gemm_kernel" in per_kernel:
         d = per_kernel["rpn_wino_gemm_kernel"]
         calls = max(d["launches"], 1)
         stage_us = sum(sum(samples[k]) for k in WINO_STAGE if k in samples) * 1e3 / calls
@@ -436,7 +505,8 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
             r = {"kernel": name, "bound": "mfma", "achieved": d["TFLOP_s"], "peak": d["mfma_peak_TFLOP_s"], "unit": "TFLOP/s",
                  "frac": d["mfma_frac"], "traffic": d["pmc_traffic_bytes"], "avg_launch_us": d["avg_us"],
                  "median_launch_us": d["median_us"], "algorithmic_flops": d["algorithmic_flops"]}
-            for k in ("stage_us_per_call", "stage_kernels", "conv_equivalent_TFLOP_s", "conv_flops_per_call", "note"):
+            for k in ("stage_us_per_call", "stage_us_per_img", "stage_calls_per_img", "stage_kernels", "conv_equivalent_TFLOP_s", "conv_flops_per_call",
+                      "conv_flops_per_img", "algorithmic_flops_per_img", "layers", "note"):
                 if k in d:
                     r[k] = d[k]
             return r

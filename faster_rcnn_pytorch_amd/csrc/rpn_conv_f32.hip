@@ -575,20 +575,30 @@ __global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restric
     }
 }
 
-// db[c] = sum over levels and positions of the (masked) output gradient: one workgroup per channel, fixed-order sums
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__restrict__ db)
+// db[c] = sum over levels and positions of the (masked) output gradient.  Grid (channels, S): slice s of a channel's positions -> partial
+// [c][s] (write-through), a ticket per channel, and the slice that arrives last adds the S partials in slice order: one launch, fixed-order
+// sums, ticket words left zero.  (One workgroup per channel read 150 000 floats in sequence at 600x1000: 60 us per call.)
+#define CB_MAX_S 64
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__restrict__ db, float *__restrict__ part, int *__restrict__ cnt)
 {
     __shared__ float red[256];
-    const int c = blockIdx.x;
+    __shared__ int s_last;
+    const int c = blockIdx.x, S = gridDim.y, sl = blockIdx.y;
     float acc = 0.0f;
     for (int l = 0; l < a.n_levels; ++l) {
-        const int HW = a.lv[l].H * a.lv[l].W;
+        const int HW = a.lv[l].H * a.lv[l].W, per = (HW + S - 1) / S, i0 = sl * per, i1 = min(HW, i0 + per);
         const float *g = (const float *)a.lv[l].y + (size_t)c * HW;
         const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * HW : nullptr;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float v = g[i];
-            if (mk) v = mk[i] > 0.0f ? v : 0.0f;
-            acc += v;
+        for (int base = i0 + (int)threadIdx.x; base < i1; base += 256 * 8) {      // eight (+ eight) loads in flight per thread, added in index order
+            float v[8], mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256;
+                v[u] = i < i1 ? g[i] : 0.0f;
+                mv[u] = (mk && i < i1) ? mk[i] : 1.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += mv[u] > 0.0f ? v[u] : 0.0f;
         }
     }
     red[threadIdx.x] = acc;
@@ -598,7 +608,23 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[c] = red[0];
+    if (S == 1) { if (threadIdx.x == 0) db[c] = red[0]; return; }
+    if (threadIdx.x == 0) {
+        // the hand-off of the GEMM's slabs: write-through store, counted wait, relaxed ticket (a release FENCE would write back every dirty
+        // line of the XCD's L2 -- behind the transforms' hundreds of MB that took 130 us per call)
+        asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(&part[(size_t)c * CB_MAX_S + sl]), "v"(red[0]) : "memory");
+        s_last = (__hip_atomic_fetch_add(&cnt[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    float sum = 0.0f;
+    for (int s = 0; s < S; ++s) {
+        float v;
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&part[(size_t)c * CB_MAX_S + s]) : "memory");
+        sum += v;
+    }
+    db[c] = sum;
+    __hip_atomic_store(&cnt[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
@@ -1157,7 +1183,11 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     FRCNN_LAUNCH(rpn_wino_dw_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ws.U, dw, n);
     FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
     if (dbias) {
-        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout), dim3(256), 0, s, a, dbias);
+        long long hw_max = 0;
+        for (int l = 0; l < n_levels; ++l) hw_max = std::max<long long>(hw_max, (long long)H[l] * W[l]);
+        int S = (int)std::min<long long>(CB_MAX_S, std::max<long long>(1, std::min<long long>(hw_max / 2048, (16 * 256 + Cout - 1) / Cout)));
+        static_assert(4096 <= CF_MAX_TILES, "one ticket word per channel");
+        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout, (unsigned)S), dim3(256), 0, s, a, dbias, ws.part, ws.cnt);
         FRCNN_CHECK_LAUNCH("conv_bias_grad_kernel");
     }
     return FRCNN_OK;

@@ -86,7 +86,14 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         idt = x
         out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
+        if self.conv2.stride == (1, 1) and not torch.is_autocast_enabled() and ops.conv3x3_supported(out, self.conv2.weight):
+            # conv2 + bn2 + ReLU in one stage call: the frozen norm's scale folded into the weight (s * conv(x, w) = conv(x, s w): one small
+            # elementwise launch, differentiable), its shift as the bias, the ReLU in the output transform and its backward in the gradient
+            # kernels -- instead of the vendor convolution + two norm passes + the ReLU, forward and backward
+            scale, shift = self.bn2.affine()
+            out = ops.conv3x3(out, self.conv2.weight * scale.reshape(-1, 1, 1, 1), shift.reshape(-1), relu=True)
+        else:
+            out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
         if self.downsample is not None:
             idt = self.downsample(x)
@@ -144,12 +151,17 @@ class FeaturePyramidNetwork(nn.Module):
 
     def forward(self, x):
         names, xs = list(x.keys()), list(x.values())
+        def layer(idx, t):
+            conv = self.layer_blocks[idx][0]
+            if not torch.is_autocast_enabled() and ops.conv3x3_supported(t, conv.weight):
+                return ops.conv3x3(t, conv.weight, conv.bias)            # the 256 -> 256 output convolution on the fp32 Winograd stage
+            return self.layer_blocks[idx](t)
         last = self.inner_blocks[-1](xs[-1])
-        results = [self.layer_blocks[-1](last)]
+        results = [layer(-1, last)]
         for idx in range(len(xs) - 2, -1, -1):
             lat = self.inner_blocks[idx](xs[idx])
             last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
-            results.insert(0, self.layer_blocks[idx](last))
+            results.insert(0, layer(idx, last))
         names.append("pool")
         results.append(F.max_pool2d(results[-1], 1, 2, 0))           # LastLevelMaxPool
         return OrderedDict(zip(names, results))

@@ -533,6 +533,16 @@ def rpn_conv_wgrad(feats, d_raws):
 # --------------------------------------------------------------------------------------------
 # the RPN head's 3x3 convolution in fp32 (models/model.py:68-70,79; models/new_model.py:96-98,109) on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------
+CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
+
+
+def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False):
+    if CONV_TRACE is not None:
+        kind = "wgrad" if what.endswith("wgrad") else ("bwd_data" if what.endswith("bwd_data") else "fwd")
+        CONV_TRACE.append({"kind": kind, "Cin": int(Cin), "Cout": int(Cout), "shapes": [(int(h), int(w)) for h, w in zip(H, W)], "mask": bool(mask),
+                           "bias": bool(bias)})
+
+
 def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
     dev = ins[0].device
     H = _host_i32([t.shape[2] for t in ins])
@@ -545,6 +555,7 @@ def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
     ws = _ctrl_workspace(dev, "rpn_conv_f32", nb)     # ticket words zero on first use, left zero by every call; slabs + transposed weights behind them
     with torch.cuda.device(dev):
         check(fn(ip, op, _np_ptr(H), _np_ptr(W), len(ins), C_, _ptr(w_or_dw), _ptr(ws), ws.numel(), _stream()), what)
+    _conv_trace(what, C_, C_, H, W)
 
 
 def _conv_f32_levels(ts, name):
@@ -614,7 +625,8 @@ def rpn_conv3x3(feats, w3):
 
 
 # ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
-def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of):
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False):
+    _conv_trace(what, Cin, Cout, H, W, mask, bias)
     Hh, Wh = _host_i32(H), _host_i32(W)
     nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
     if nb == 0:
@@ -652,7 +664,7 @@ def conv3x3_fwd(xs, w, bias=None, relu=False):
     ys = [torch.empty((1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
     xp, yp = _ptr_list(xs), _ptr_list(ys)
     _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
-                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, ws, nws, st))
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, ws, nws, st), bias=bias is not None)
     return ys
 
 
@@ -669,7 +681,7 @@ def conv3x3_bwd_data(dys, w, y_masks=None):
     gp, xp = _ptr_list(dys), _ptr_list(dxs)
     mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
     _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [d.shape[2] for d in dys], [d.shape[3] for d in dys], len(dys), Cin, Cout,
-                  dys[0].device, lambda H, W, ws, nws, st: (gp, mp, xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st))
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, mp, xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st), mask=y_masks is not None)
     return dxs
 
 
@@ -690,11 +702,12 @@ def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False):
     xp, gp = _ptr_list(xs), _ptr_list(dys)
     mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
     _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
-                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), ws, nws, st))
+                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), ws, nws, st), mask=y_masks is not None, bias=want_bias)
     return dw, db
 
 
-CONV3X3_MIN_POSITIONS = 2048      # below this the stage's fixed costs (four launches, partial-tile reduction) lose to the vendor kernel (tools/dev/conv_layers_time.py)
+CONV3X3_MIN_WORK = 1 << 27         # Cin * Cout * positions: below this the stage's fixed costs (four launches per direction, partial-tile reduction) lose to
+                                   # the vendor kernel (tools/dev/conv_layers_time.py: 256 -> 256 on 25 x 42 loses, on 50 x 84 and 512 -> 512 on 25 x 42 win)
 
 
 def conv3x3_supported(x, weight, need_input_grad=None):
@@ -704,7 +717,7 @@ def conv3x3_supported(x, weight, need_input_grad=None):
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
         return False
     Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
-    if tuple(weight.shape[2:]) != (3, 3) or Cout % 128 != 0 or Cin % 32 != 0 or x.shape[2] * x.shape[3] < CONV3X3_MIN_POSITIONS:
+    if tuple(weight.shape[2:]) != (3, 3) or Cout % 128 != 0 or Cin % 32 != 0 or Cin * Cout * x.shape[2] * x.shape[3] < CONV3X3_MIN_WORK:
         return False
     grads = torch.is_grad_enabled() and (weight.requires_grad or (x.requires_grad if need_input_grad is None else need_input_grad))
     return (not grads) or Cin % 128 == 0

@@ -1596,10 +1596,10 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
     import torch.nn.functional as F
     from faster_rcnn_pytorch_amd._lib import FrcnnError
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(1, 128, 40, 52, generator=g).to(DEV).requires_grad_(True)
+    x = torch.randn(1, 128, 64, 80, generator=g).to(DEV).requires_grad_(True)
     w = (torch.randn(256, 128, 3, 3, generator=g) * 0.03).to(DEV).requires_grad_(True)
     b = (torch.randn(256, generator=g) * 0.1).to(DEV).requires_grad_(True)
-    dy = torch.randn(1, 256, 40, 52, generator=g).to(DEV)
+    dy = torch.randn(1, 256, 64, 80, generator=g).to(DEV)
     ref = torch.relu(F.conv2d(x, w, b, padding=1))
     keep = ((ref > 1e-4) | (F.conv2d(x, w, b, padding=1) < -1e-4)).float()                       # gradient only where the sign is beyond rounding
     (ref * dy * keep).sum().backward()
@@ -1613,12 +1613,12 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
         assert float((a - c).abs().max()) < 1e-4 * max(1.0, float(c.abs().max()))
     assert ops.conv3x3_supported(x, w) and not ops.conv3x3_supported(x.half(), w) and not ops.conv3x3_supported(x[:, :, :8, :8], w)
     w64 = torch.zeros(128, 64, 3, 3, device=DEV, requires_grad=True)
-    x64 = torch.zeros(1, 64, 64, 64, device=DEV)
+    x64 = torch.zeros(1, 64, 160, 160, device=DEV)
     assert not ops.conv3x3_supported(x64, w64)                                                   # training needs Cin % 128 == 0
     with torch.no_grad():
         assert ops.conv3x3_supported(x64, w64)                                                   # forward only: Cin % 32 == 0
     with pytest.raises(FrcnnError):
-        ops.conv3x3_wgrad([x64], [torch.zeros(1, 128, 64, 64, device=DEV)])
+        ops.conv3x3_wgrad([x64], [torch.zeros(1, 128, 160, 160, device=DEV)])
     with pytest.raises(FrcnnError):
         ops.conv3x3_fwd([x64], torch.zeros(64, 64, 3, 3, device=DEV))                            # Cout = 64
 
