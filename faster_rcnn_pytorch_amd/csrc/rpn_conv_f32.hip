@@ -407,47 +407,69 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, float *__restrict__ V)
+// Block = (channel, strip): 256 consecutive tiles of ONE tile row.  The four input rows of the strip (514 columns with the halo) are staged in
+// LDS by coalesced loads -- every input element is fetched once; read straight from global memory each 4 x 4 patch cost 16 loads of a
+// stride-2 pattern that touched every line four times, and the transform ran at 2.9 TB/s (load-path bound: more loads in flight per thread
+// made it slower) -- and each thread then reads its patch as eight 8-byte LDS reads.  The ReLU mask of the data gradient is applied while
+// staging.  Padding columns of V (tiles past a level's last) are NOT written: a column of the product depends on the same column of V only,
+// and the output transform never reads those.
+// A strip = up to 1024 tiles (four per thread): tile rows x a piece of at most 256 tile columns, as many whole rows as fit -- the more
+// rows, the smaller the share of the two halo rows that neighbouring strips fetch again (1.25 x at four rows, 2 x at one).
+struct WnStrips { int first[FRCNN_MAX_LEVELS + 1]; int segs[FRCNN_MAX_LEVELS]; int rows[FRCNN_MAX_LEVELS]; };   // first strip, strips per tile row, tile rows per strip
+#define WN_IN_LDS 5632
+#define WN_IN_TILES 1024
+__global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips st, float *__restrict__ V)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;     // padded tile column, channel
-    if (t >= a.Ttot) return;
+    __shared__ __attribute__((aligned(8))) float s[WN_IN_LDS];
+    const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int l = 0;
 #pragma unroll
-    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
-    const int tl = t - a.lv[l].off;
-    float d[4][4];
-    if (tl < a.lv[l].T) {
-        const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
-        const float *x = a.lv[l].x + (size_t)c * H * W;
-        const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
-                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
-                float v = in ? x[yy * W + xx] : 0.0f;
-                if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
-                d[r][q] = v;
-            }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) d[r][q] = 0.0f;            // padding columns: zeros, so that the product's columns are zeros too
+    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && (int)blockIdx.x >= st.first[q]) ? 1 : 0;
+    const int strip = blockIdx.x - st.first[l], segs = st.segs[l], R = st.rows[l];
+    const int H = a.lv[l].H, W = a.lv[l].W, tw = a.lv[l].tw, th = (H + 1) / 2;
+    const int ty0 = (strip / segs) * R, tx0 = (strip % segs) * 256, wt = min(256, tw - tx0), nr = min(R, th - ty0);
+    const float *x = a.lv[l].x + (size_t)c * H * W;
+    const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
+    const int x0 = 2 * tx0 - 1, y0 = 2 * ty0 - 1, ncol = 2 * wt + 2, nrow = 2 * nr + 2;      // the strip's input window with its halo
+    for (int r = wave; r < nrow; r += 4) {
+        const int yy = y0 + r;
+        const bool row_in = yy >= 0 && yy < H;
+        for (int q = lane; q < ncol; q += 64) {
+            const int xx = x0 + q;
+            const bool in = row_in && xx >= 0 && xx < W;
+            float v = in ? x[yy * W + xx] : 0.0f;
+            if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
+            s[r * ncol + q] = v;
+        }
     }
-    float wv[4][4];
+    __syncthreads();
+    const size_t plane = (size_t)a.C * a.Ttot, at0 = (size_t)c * a.Ttot + a.lv[l].off + (size_t)ty0 * tw + tx0;
+    const int n_tiles = nr * wt;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        wv[0][q] = d[0][q] - d[2][q]; wv[1][q] = d[1][q] + d[2][q]; wv[2][q] = d[2][q] - d[1][q]; wv[3][q] = d[1][q] - d[3][q];
-    }
-    const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
+    for (int u = 0; u < WN_IN_TILES / 256; ++u) {
+        const int e = u * 256 + (int)threadIdx.x;
+        if (e >= n_tiles) break;
+        const int rr = e / wt, txl = e - rr * wt;
+        float d[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        V[(size_t)(r * 4 + 0) * plane + at] = wv[r][0] - wv[r][2];
-        V[(size_t)(r * 4 + 1) * plane + at] = wv[r][1] + wv[r][2];
-        V[(size_t)(r * 4 + 2) * plane + at] = wv[r][2] - wv[r][1];
-        V[(size_t)(r * 4 + 3) * plane + at] = wv[r][1] - wv[r][3];
+        for (int r = 0; r < 4; ++r) {
+            const float *row = &s[(2 * rr + r) * ncol + 2 * txl];
+            const float2 p0 = *(const float2 *)row, p1 = *(const float2 *)(row + 2);
+            d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
+        }
+        float wv[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wv[0][q] = d[0][q] - d[2][q]; wv[1][q] = d[1][q] + d[2][q]; wv[2][q] = d[2][q] - d[1][q]; wv[3][q] = d[1][q] - d[3][q];
+        }
+        const size_t at = at0 + (size_t)rr * tw + txl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            V[(size_t)(r * 4 + 0) * plane + at] = wv[r][0] - wv[r][2];
+            V[(size_t)(r * 4 + 1) * plane + at] = wv[r][1] + wv[r][2];
+            V[(size_t)(r * 4 + 2) * plane + at] = wv[r][2] - wv[r][1];
+            V[(size_t)(r * 4 + 3) * plane + at] = wv[r][1] - wv[r][3];
+        }
     }
 }
 
@@ -1108,7 +1130,21 @@ static int wn_run(const float *const *in, float *const *out, const float *const 
     else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, M, K, Cin);
     FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
     a.C = K;
-    FRCNN_LAUNCH(rpn_wino_input_kernel, dim3((unsigned)((Ttot + 255) / 256), (unsigned)K), dim3(256), 0, s, a, ws.V);
+    WnStrips st;
+    int n_strips = 0;
+    for (int per_block = WN_IN_TILES; per_block >= 256; per_block /= 2) {       // the largest strips that still give the chip >= 4096 workgroups
+        n_strips = 0;
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+            st.first[l] = n_strips;
+            const int tw = l < n_levels ? a.lv[l].tw : 1, th = l < n_levels ? (H[l] + 1) / 2 : 1;
+            st.segs[l] = (tw + 255) / 256;
+            st.rows[l] = std::min(128, std::max(1, per_block / std::min(tw, 256)));     // (2 R + 2)(2 wt + 2) <= WN_IN_LDS for every wt <= 256
+            if (l < n_levels) n_strips += st.segs[l] * ((th + st.rows[l] - 1) / st.rows[l]);
+        }
+        st.first[FRCNN_MAX_LEVELS] = n_strips;
+        if ((long long)n_strips * K >= 4096) break;
+    }
+    FRCNN_LAUNCH(rpn_wino_input_kernel, dim3((unsigned)n_strips, (unsigned)K), dim3(256), 0, s, a, st, ws.V);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.U, ws.V, ws.M, (long long)M * K, (long long)K * Ttot, (long long)M * Ttot, M, (int)Ttot, (int)Ttot,
                 a.n_m_tiles, a.n_t_tiles, a.Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
