@@ -87,8 +87,8 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
          "rpn_wino_weight_kernel": "hbm", "rpn_wino_tr_t_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv_bias_grad_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
-WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel", "rpn_wino_tr_t_kernel",
-              "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: tr_t x 2, gemm, dw
+WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
+              "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: input x 2, gemm, dw
 
 
 def synth_frame(cfg, rank, step):
@@ -157,20 +157,23 @@ def wino_work(calls):
     for c in calls:
         Cin, Cout, mask = c["Cin"], c["Cout"], 2 if c.get("mask") else 1
         HW = sum(h * w for h, w in c["shapes"])
-        Tp = sum(-(-(((h + 1) // 2) * ((w + 1) // 2)) // 128) * 128 for h, w in c["shapes"])
+        # the library's choice of the output tile (csrc/rpn_conv_f32.hip wn_pick_m): 4 x 4 from 512 such tiles on, else 2 x 2
+        m = 4 if sum(((h + 3) // 4) * ((w + 3) // 4) for h, w in c["shapes"]) >= 512 else 2
+        P = (m + 2) ** 2
+        Tp = sum(-(-(((h + m - 1) // m) * ((w + m - 1) // m)) // 128) * 128 for h, w in c["shapes"])
         conv_flops += 18 * Cin * Cout * HW
-        add("rpn_wino_gemm_kernel", 0, 32 * Cin * Cout * Tp)
+        add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
         if c["kind"] == "wgrad":
-            add("rpn_wino_tr_t_kernel", 4 * Cin * HW + 64 * Cin * Tp)
-            add("rpn_wino_tr_t_kernel", 4 * Cout * HW * mask + 64 * Cout * Tp)
-            add("rpn_wino_dw_kernel", 4 * 25 * Cin * Cout)
+            add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)                 # B^T d B of the activations
+            add("rpn_wino_input_kernel", 4 * Cout * HW * mask + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
+            add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)
             if c.get("bias"):
                 add("conv_bias_grad_kernel", 4 * Cout * HW * mask)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
-            add("rpn_wino_weight_kernel", 4 * 25 * Cin * Cout)
-            add("rpn_wino_input_kernel", 4 * K * HW * (mask if c["kind"] == "bwd_data" else 1) + 64 * K * Tp)
-            add("rpn_wino_output_kernel", 64 * M * Tp + 4 * M * HW)
+            add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
+            add("rpn_wino_input_kernel", 4 * K * HW * (mask if c["kind"] == "bwd_data" else 1) + 4 * P * K * Tp)
+            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * HW)
     return tot, conv_flops
 
 

@@ -339,45 +339,122 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- Winograd F(2x2, 3x3)
-// Forward and data gradient as Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A: 16 independent [C x C] . [C x T] products over the 2 x 2
-// output tiles (T = ceil(H/2) ceil(W/2) per level) instead of one with K = 9 C -- 2.25 x fewer MFMAs for the same result (in exact
-// arithmetic; fp32: ~1e-6 of the output scale, tests).  Four launches, all levels each:
-//   rpn_wino_weight_kernel   U[xi][m][k] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
-//   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded 4 x 4 input patch of tile t; rows padded to a multiple of 128 tiles
-//   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][m][k] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
+// ---------------------------------------------------------------------------------------------------------------- Winograd F(m x m, 3x3)
+// Forward and data gradient as Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A: P = (m + 2)^2 independent [Cout x Cin] . [Cin x T] products over
+// the m x m output tiles (T = ceil(H/m) ceil(W/m) per level) instead of one with K = 9 Cin.  m = 2: 16 products, 2.25 x fewer MFMAs
+// (fp32: ~3e-7 of the output scale, as good as the direct sum); m = 4: 36 products over a quarter of the tiles, 4 x fewer MFMAs and 0.56 x
+// the transformed bytes (fp32: ~5e-6 of the scale -- the 1/24 .. 8 range of its transform constants -- inside the path's 1e-4; maps with fewer
+// than WN_M4_MIN_TILES 4 x 4 tiles stay with m = 2, where the 128-tile padding would eat the gain).  Four launches, all levels each:
+//   rpn_wino_weight_kernel   U[xi][k][m] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
+//   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded (m + 2)^2 input patch of tile t; rows padded to a multiple of 128 tiles
+//   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][k][m] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
 //                            v_mfma_f32_32x32x2_f32, the direct kernel's skeleton without taps: both operand tiles (32 K rows x 128
 //                            floats) are staged by LDS-DMA (global_load_lds_dwordx4, no staging registers), no edge selects,
-//                            16 k steps per chunk; the weight gradient runs the same kernel with K = the tiles (below)
-//   rpn_wino_output_kernel   Y[m][2ty + i][2tx + j] = (A^T M A)_ij
-// The transformed operands travel through the workspace (16 C Ttot floats each way: 21 MB at 600x1000, 373 MB at FPN size).
-#define WN_KC 32                       // input channels per K chunk
-#define WN_AS 33                       // LDS row stride of the U tile [128][32]
-#define WN_BS 160                      // LDS row stride of the V tile [32][128]: 160 = 32 (mod 64), the two k halves hit disjoint banks
-// m (optional): the forward's ReLU output of the level whose gradient x (input transform) / y (transposed transform, bias gradient) is: the
-// gradient counts where m > 0 -- what autograd's threshold_backward computes in a launch of its own
+//                            16 k steps per chunk
+//   rpn_wino_output_kernel   Y[m][m ty + i][m tx + j] = (A^T M A)_ij (+ bias, ReLU)
+// Weight gradient: dU[xi][co][ci] = sum_t (A dY A^T)_xi[co][t] (B^T d B)_xi[ci][t], dW = G^T dU G: the SAME input transform (of the
+// activations) and its sibling for the output gradient write [xi][channel][t] with the tiles contiguous, and the product -- which sums over
+// the tiles -- runs on the k-contiguous form of the GEMM (rpn_wino_gemm_kernel<true>: both operand tiles 128 rows x 32 k, 16-byte pieces
+// XOR-swizzled at the source side of the LDS-DMA, fragments by ds_read_b128); no transposing pass.
+// The transformed operands travel through the workspace (P C Ttot floats each way).
+#define WN_KC 32                       // K values per chunk
+#define WN_M4_MIN_TILES 512            // 4 x 4 tiles (all levels) from which m = 4 is used
+// m (optional): the forward's ReLU output of the level whose gradient x is: the gradient counts where m > 0 -- what autograd's
+// threshold_backward computes in a launch of its own
 struct WnLevel { const float *x; float *y; const float *m; int H, W, tw, T, off; };
 struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
     const float *bias;                 // output transform: + bias[c] (or NULL), then ReLU if relu != 0
-    int relu;
-    int n_levels, C, Ttot, n_m_tiles, n_t_tiles, Kc, n_units, G;       // C = channels of the side the launch touches
+    int relu, zero_pad;                // zero_pad: the input transforms also write zeros into the padding columns (weight gradient: the product sums over them)
+    int n_levels, C, Ttot;             // C = channels of the side the launch touches
 };
-// the batched product of the stage: O[xi][m][n] = sum_k A[xi][k][m] B[xi][k][n], both operands K-major (rows k, 128 columns per tile)
-//   forward / data gradient: A = U [k = ci][m = co], B = V [ci][t], O = M [co][t], K = C
-//   weight gradient:         A = dMt [k = t][m = co], B = Vt [t][ci], O = dU [co][ci], K = Ttot
+// the batched product of the stage, both forms:
+//   <false>  O[xi][m][n] = sum_k A[xi][k][m] B[xi][k][n], operands K-major (rows k, 128 columns per tile): forward / data gradient,
+//            A = U [k = ci][m = co], B = V [ci][t], O = M [co][t], K = Cin (Cout for the data gradient)
+//   <true>   O[xi][m][n] = sum_k A[xi][m][k] B[xi][n][k], operands k-contiguous (128 rows per tile, 32 k per chunk): weight gradient,
+//            A = dM [co][t], B = V [ci][t], O = dU [co][ci], K = Ttot
 struct WgArgs {
     const float *A, *B; float *O;
     long long sA, sB, sO;              // xi strides (floats)
     int lda, ldb, ldo, n_m_tiles, n_t_tiles, Kc, n_units, G;
 };
 
+template <int M> struct Wn;
+template <> struct Wn<2> { static constexpr int A = 4, P = 16, WT = 256, TPB = 1024, LDS = 5632; };
+template <> struct Wn<4> { static constexpr int A = 6, P = 36, WT = 128, TPB = 512, LDS = 9472; };
+
+// ---- the 1-D transforms (Lavin & Gray's matrices; points 0, +-1, inf for m = 2 and 0, +-1, +-2, inf for m = 4)
+template <int M> __device__ __forceinline__ void wn_bt(const float *d, float *v);       // B^T d: (m + 2) -> (m + 2)
+template <> __device__ __forceinline__ void wn_bt<2>(const float *d, float *v)
+{
+    v[0] = d[0] - d[2]; v[1] = d[1] + d[2]; v[2] = d[2] - d[1]; v[3] = d[1] - d[3];
+}
+template <> __device__ __forceinline__ void wn_bt<4>(const float *d, float *v)
+{
+    v[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+    v[1] = (d[3] + d[4]) - 4.0f * (d[1] + d[2]);
+    v[2] = 4.0f * (d[1] - d[2]) + (d[4] - d[3]);
+    v[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+    v[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+    v[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+template <int M> __device__ __forceinline__ void wn_g(const float *g, float *u);        // G g: 3 -> (m + 2)
+template <> __device__ __forceinline__ void wn_g<2>(const float *g, float *u)
+{
+    u[0] = g[0]; u[1] = (g[0] + g[1] + g[2]) * 0.5f; u[2] = (g[0] - g[1] + g[2]) * 0.5f; u[3] = g[2];
+}
+template <> __device__ __forceinline__ void wn_g<4>(const float *g, float *u)
+{
+    u[0] = g[0] * 0.25f;
+    u[1] = (g[0] + g[1] + g[2]) * (-1.0f / 6.0f);
+    u[2] = (g[0] - g[1] + g[2]) * (-1.0f / 6.0f);
+    u[3] = g[0] * (1.0f / 24.0f) + g[1] * (1.0f / 12.0f) + g[2] * (1.0f / 6.0f);
+    u[4] = g[0] * (1.0f / 24.0f) - g[1] * (1.0f / 12.0f) + g[2] * (1.0f / 6.0f);
+    u[5] = g[2];
+}
+template <int M> __device__ __forceinline__ void wn_at(const float *m, float *y);       // A^T m: (m + 2) -> m
+template <> __device__ __forceinline__ void wn_at<2>(const float *m, float *y)
+{
+    y[0] = m[0] + m[1] + m[2]; y[1] = m[1] - m[2] - m[3];
+}
+template <> __device__ __forceinline__ void wn_at<4>(const float *m, float *y)
+{
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.0f * d34;
+    y[2] = s12 + 4.0f * s34;
+    y[3] = d12 + 8.0f * d34 + m[5];
+}
+template <int M> __device__ __forceinline__ void wn_a(const float *y, float *r);        // A y: m -> (m + 2)   (the transpose of A^T: weight gradient)
+template <> __device__ __forceinline__ void wn_a<2>(const float *y, float *r)
+{
+    r[0] = y[0]; r[1] = y[0] + y[1]; r[2] = y[0] - y[1]; r[3] = -y[1];
+}
+template <> __device__ __forceinline__ void wn_a<4>(const float *y, float *r)
+{
+    const float e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.0f * y[2], o4 = 2.0f * y[1] + 8.0f * y[3];
+    r[0] = y[0]; r[1] = e + o; r[2] = e - o; r[3] = e4 + o4; r[4] = e4 - o4; r[5] = y[3];
+}
+template <int M> __device__ __forceinline__ void wn_gt(const float *u, float *w);       // G^T u: (m + 2) -> 3
+template <> __device__ __forceinline__ void wn_gt<2>(const float *u, float *w)
+{
+    w[0] = u[0] + (u[1] + u[2]) * 0.5f; w[1] = (u[1] - u[2]) * 0.5f; w[2] = (u[1] + u[2]) * 0.5f + u[3];
+}
+template <> __device__ __forceinline__ void wn_gt<4>(const float *u, float *w)
+{
+    const float s12 = u[1] + u[2], d12 = u[2] - u[1], s34 = u[3] + u[4], d34 = u[3] - u[4];
+    w[0] = u[0] * 0.25f - s12 * (1.0f / 6.0f) + s34 * (1.0f / 24.0f);
+    w[1] = d12 * (1.0f / 6.0f) + d34 * (1.0f / 12.0f);
+    w[2] = s34 * (1.0f / 6.0f) - s12 * (1.0f / 6.0f) + u[5];
+}
+
 // 16 x 16 (m, k) blocks: the data gradient reads W[k][m] (m contiguous) and writes U[m][k] (k contiguous), so its block goes through LDS
 // (the plain one-thread-per-element form read 36-byte pieces 18 KB apart: 15 us at C = 512)
-template <bool TR>
-__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int M, int K, int Cin)
+template <int M, bool TR>
+__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int Mo, int K, int Cin)
 {
     // w [Cout][Cin][9].  forward: m = co, k = ci;  data gradient (TR): m = ci, k = co
+    constexpr int A = Wn<M>::A;
     __shared__ float s[16][16 * 9 + 1];
     const unsigned nb = (unsigned)K / 16u, m0 = (blockIdx.x / nb) * 16u, k0 = (blockIdx.x % nb) * 16u, row = (unsigned)Cin * 9u;
 #pragma unroll
@@ -390,47 +467,50 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
     float g[9];
 #pragma unroll
     for (int e = 0; e < 9; ++e) g[e] = TR ? s[ki][mi * 9 + (8 - e)] : s[mi][ki * 9 + e];       // data gradient: W[k][m] rotated by 180 degrees
-    float t[4][3];
+    float t[A][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        t[0][c] = g[c];
-        t[1][c] = (g[c] + g[3 + c] + g[6 + c]) * 0.5f;
-        t[2][c] = (g[c] - g[3 + c] + g[6 + c]) * 0.5f;
-        t[3][c] = g[6 + c];
-    }
-    const size_t n = (size_t)M * K, o = (size_t)(k0 + ki) * M + m0 + mi;
+        const float col[3] = {g[c], g[3 + c], g[6 + c]};
+        float u[A];
+        wn_g<M>(col, u);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float u0 = t[r][0], u1 = (t[r][0] + t[r][1] + t[r][2]) * 0.5f, u2 = (t[r][0] - t[r][1] + t[r][2]) * 0.5f, u3 = t[r][2];
-        U[(size_t)(r * 4 + 0) * n + o] = u0; U[(size_t)(r * 4 + 1) * n + o] = u1;
-        U[(size_t)(r * 4 + 2) * n + o] = u2; U[(size_t)(r * 4 + 3) * n + o] = u3;
+        for (int r = 0; r < A; ++r) t[r][c] = u[r];
+    }
+    const size_t n = (size_t)Mo * K, o = (size_t)(k0 + ki) * Mo + m0 + mi;
+#pragma unroll
+    for (int r = 0; r < A; ++r) {
+        float u[A];
+        wn_g<M>(t[r], u);
+#pragma unroll
+        for (int q = 0; q < A; ++q) U[(size_t)(r * A + q) * n + o] = u[q];
     }
 }
 
-// Block = (channel, strip): 256 consecutive tiles of ONE tile row.  The four input rows of the strip (514 columns with the halo) are staged in
-// LDS by coalesced loads -- every input element is fetched once; read straight from global memory each 4 x 4 patch cost 16 loads of a
-// stride-2 pattern that touched every line four times, and the transform ran at 2.9 TB/s (load-path bound: more loads in flight per thread
-// made it slower) -- and each thread then reads its patch as eight 8-byte LDS reads.  The ReLU mask of the data gradient is applied while
-// staging.  Padding columns of V (tiles past a level's last) are NOT written: a column of the product depends on the same column of V only,
-// and the output transform never reads those.
-// A strip = up to 1024 tiles (four per thread): tile rows x a piece of at most 256 tile columns, as many whole rows as fit -- the more
-// rows, the smaller the share of the two halo rows that neighbouring strips fetch again (1.25 x at four rows, 2 x at one).
+// The input-side transforms.  Block = (channel, strip); a strip = up to TPB tiles: tile rows x a piece of at most WT tile columns, as many
+// whole rows as fit.  The strip's input window is staged in LDS by coalesced loads -- every element is fetched once (plus the halo rows
+// that neighbouring strips share); read straight from global memory each patch cost (m + 2)^2 loads of a stride-m pattern that touched
+// every line several times, and the transform ran at 2.9 TB/s (load-path bound: more loads in flight per thread made it slower) -- and
+// each thread then reads its patches as 8-byte LDS reads.  The ReLU mask of a gradient is applied while staging.
+//   MODE 0: V  = B^T d B of the (m + 2)^2 patch with its one-pixel halo (activations; the masked output gradient for the data gradient)
+//   MODE 1: dM = A g A^T of the m x m tile of the (masked) output gradient (weight gradient)
+// Padding columns of a level (tiles past its last) are written as zeros only when a.zero_pad is set (weight gradient: the product sums
+// over the tiles); forward / data gradient never read the product's columns there, and a column depends on the same column of V only.
 struct WnStrips { int first[FRCNN_MAX_LEVELS + 1]; int segs[FRCNN_MAX_LEVELS]; int rows[FRCNN_MAX_LEVELS]; };   // first strip, strips per tile row, tile rows per strip
-#define WN_IN_LDS 5632
-#define WN_IN_TILES 1024
+template <int M, int MODE>
 __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips st, float *__restrict__ V)
 {
-    __shared__ __attribute__((aligned(8))) float s[WN_IN_LDS];
+    constexpr int A = Wn<M>::A, P = Wn<M>::P, WT = Wn<M>::WT, HALO = MODE == 0 ? 1 : 0, IN = MODE == 0 ? A : M;
+    extern __shared__ __attribute__((aligned(8))) float s[];          // the largest window of the launch's levels (wn_strips): <= Wn<M>::LDS floats
     const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && (int)blockIdx.x >= st.first[q]) ? 1 : 0;
     const int strip = blockIdx.x - st.first[l], segs = st.segs[l], R = st.rows[l];
-    const int H = a.lv[l].H, W = a.lv[l].W, tw = a.lv[l].tw, th = (H + 1) / 2;
-    const int ty0 = (strip / segs) * R, tx0 = (strip % segs) * 256, wt = min(256, tw - tx0), nr = min(R, th - ty0);
+    const int H = a.lv[l].H, W = a.lv[l].W, tw = a.lv[l].tw, th = (H + M - 1) / M;
+    const int ty0 = (strip / segs) * R, tx0 = (strip % segs) * WT, wt = min(WT, tw - tx0), nr = min(R, th - ty0);
     const float *x = a.lv[l].x + (size_t)c * H * W;
     const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
-    const int x0 = 2 * tx0 - 1, y0 = 2 * ty0 - 1, ncol = 2 * wt + 2, nrow = 2 * nr + 2;      // the strip's input window with its halo
+    const int x0 = M * tx0 - HALO, y0 = M * ty0 - HALO, ncol = M * wt + 2 * HALO, nrow = M * nr + 2 * HALO;      // the strip's input window
     for (int r = wave; r < nrow; r += 4) {
         const int yy = y0 + r;
         const bool row_in = yy >= 0 && yy < H;
@@ -443,38 +523,55 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         }
     }
     __syncthreads();
-    const size_t plane = (size_t)a.C * a.Ttot, at0 = (size_t)c * a.Ttot + a.lv[l].off + (size_t)ty0 * tw + tx0;
+    const size_t plane = (size_t)a.C * a.Ttot, col0 = (size_t)c * a.Ttot + a.lv[l].off;
     const int n_tiles = nr * wt;
-#pragma unroll
-    for (int u = 0; u < WN_IN_TILES / 256; ++u) {
+#pragma unroll 1
+    for (int u = 0; u < Wn<M>::TPB / 256; ++u) {
         const int e = u * 256 + (int)threadIdx.x;
         if (e >= n_tiles) break;
         const int rr = e / wt, txl = e - rr * wt;
-        float d[4][4];
+        float d[IN][IN];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float *row = &s[(2 * rr + r) * ncol + 2 * txl];
-            const float2 p0 = *(const float2 *)row, p1 = *(const float2 *)(row + 2);
-            d[r][0] = p0.x; d[r][1] = p0.y; d[r][2] = p1.x; d[r][3] = p1.y;
+        for (int r = 0; r < IN; ++r) {
+            const float *row = &s[(M * rr + r) * ncol + M * txl];          // even offset: ncol and M are even
+#pragma unroll
+            for (int q = 0; q < IN; q += 2) {
+                const float2 p = *(const float2 *)(row + q);
+                d[r][q] = p.x; d[r][q + 1] = p.y;
+            }
         }
-        float wv[4][4];
+        float wv[A][IN];                                                  // columns first: wv[.][q] = T d[.][q]
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            wv[0][q] = d[0][q] - d[2][q]; wv[1][q] = d[1][q] + d[2][q]; wv[2][q] = d[2][q] - d[1][q]; wv[3][q] = d[1][q] - d[3][q];
+        for (int q = 0; q < IN; ++q) {
+            float col[IN], o[A];
+#pragma unroll
+            for (int r = 0; r < IN; ++r) col[r] = d[r][q];
+            if (MODE == 0) wn_bt<M>(col, o); else wn_a<M>(col, o);
+#pragma unroll
+            for (int r = 0; r < A; ++r) wv[r][q] = o[r];
         }
-        const size_t at = at0 + (size_t)rr * tw + txl;
+        const size_t at = col0 + (size_t)(ty0 + rr) * tw + tx0 + txl;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            V[(size_t)(r * 4 + 0) * plane + at] = wv[r][0] - wv[r][2];
-            V[(size_t)(r * 4 + 1) * plane + at] = wv[r][1] + wv[r][2];
-            V[(size_t)(r * 4 + 2) * plane + at] = wv[r][2] - wv[r][1];
-            V[(size_t)(r * 4 + 3) * plane + at] = wv[r][1] - wv[r][3];
+        for (int r = 0; r < A; ++r) {
+            float o[A];
+            if (MODE == 0) wn_bt<M>(wv[r], o); else wn_a<M>(wv[r], o);
+#pragma unroll
+            for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];
+        }
+    }
+    if (a.zero_pad && strip == 0) {                                       // this level's padding columns of channel c, all planes
+        const int T = a.lv[l].T, Tp = (T + CF_NT - 1) / CF_NT * CF_NT, np = Tp - T;
+        for (int e = threadIdx.x; e < P * np; e += 256) {
+            const int xi = e / np, q = e - xi * np;
+            V[(size_t)xi * plane + col0 + T + q] = 0.0f;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ M)
+template <int M>
+__global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ Mp)
 {
+    constexpr int A = Wn<M>::A;
     const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (t >= a.Ttot) return;
     int l = 0;
@@ -483,117 +580,57 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     const int tl = t - a.lv[l].off;
     if (tl >= a.lv[l].T) return;
     const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
-    float m[4][4];
+    float s[M][A];                                                        // rows first: s[i][q] = (A^T m[.][q])_i
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < A; ++q) {
+        float col[A], o[M];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) m[r][q] = M[(size_t)(r * 4 + q) * plane + at];
-    float s0[4], s1[4];
+        for (int r = 0; r < A; ++r) col[r] = Mp[(size_t)(r * A + q) * plane + at];
+        wn_at<M>(col, o);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { s0[q] = m[0][q] + m[1][q] + m[2][q]; s1[q] = m[1][q] - m[2][q] - m[3][q]; }
-    float y00 = s0[0] + s0[1] + s0[2], y01 = s0[1] - s0[2] - s0[3], y10 = s1[0] + s1[1] + s1[2], y11 = s1[1] - s1[2] - s1[3];
-    if (a.bias) { const float b = a.bias[c]; y00 += b; y01 += b; y10 += b; y11 += b; }
-    if (a.relu) { y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f); y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f); }
+        for (int i = 0; i < M; ++i) s[i][q] = o[i];
+    }
+    const float b = a.bias ? a.bias[c] : 0.0f;
     const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
-    float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(2 * ty) * W + 2 * tx;
-    const bool x1 = 2 * tx + 1 < W, r1 = 2 * ty + 1 < H;
-    y[0] = y00;
-    if (x1) y[1] = y01;
-    if (r1) { y[W] = y10; if (x1) y[W + 1] = y11; }
-}
-
-// ---- weight gradient through the same domain: dU[xi][co][ci] = sum_t (A dY A^T)_xi[co][t] (B^T d B)_xi[ci][t], dW = G^T dU G.
-// The product sums over the TILES, so both operands must be K-major with K = t: the two transforms below write [xi][t][channel]
-// (channel contiguous) through an LDS transpose -- block = 16 tiles x 32 channels: patches are read with the lanes along the tiles, the
-// 16 planes written with the lanes along the channels (128-byte runs).
-// MODE 0: V^T of the activations (4 x 4 input patch, B^T d B);  MODE 1: dM^T of the output gradient (2 x 2 tile, A y A^T).
-template <int MODE>
-__global__ __launch_bounds__(256) void rpn_wino_tr_t_kernel(WnArgs a, float *__restrict__ out)
-{
-    __shared__ float s[16][16][33];                                  // [xi][tile][channel]: block = 16 tiles x 32 channels, two tiles per thread
-    const int tq = threadIdx.x & 7, cl = threadIdx.x >> 3;
-    const int c = blockIdx.y * 32 + cl;
+    float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(M * ty) * W + M * tx;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int tl = tq + 8 * half, t = blockIdx.x * 16 + tl;
-        int l = 0;
+    for (int i = 0; i < M; ++i) {
+        float o[M];
+        wn_at<M>(s[i], o);
+        if (M * ty + i < H) {
 #pragma unroll
-        for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
-        const int ti = t - a.lv[l].off;
-        float v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = 0.0f;                    // padding tiles: zero rows of the product
-        if (ti < a.lv[l].T) {
-            const int H = a.lv[l].H, W = a.lv[l].W, ty = ti / a.lv[l].tw, tx = ti - ty * a.lv[l].tw;
-            const float *x = (MODE == 0 ? a.lv[l].x : (const float *)a.lv[l].y) + (size_t)c * H * W;
-            const float *mk = (MODE == 1 && a.lv[l].m) ? a.lv[l].m + (size_t)c * H * W : nullptr;
-            if (MODE == 0) {
-                float d[4][4], w[4][4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int yy = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
-                        d[r][q] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
-                    }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { w[0][q] = d[0][q] - d[2][q]; w[1][q] = d[1][q] + d[2][q]; w[2][q] = d[2][q] - d[1][q]; w[3][q] = d[1][q] - d[3][q]; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0] - w[r][2]; v[r * 4 + 1] = w[r][1] + w[r][2]; v[r * 4 + 2] = w[r][2] - w[r][1]; v[r * 4 + 3] = w[r][1] - w[r][3]; }
-            } else {
-                float y[2][2], w[4][2];
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int yy = 2 * ty + r, xx = 2 * tx + q;
-                        const bool in = yy < H && xx < W;
-                        float v = in ? x[yy * W + xx] : 0.0f;
-                        if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
-                        y[r][q] = v;
-                    }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { w[0][q] = y[0][q]; w[1][q] = y[0][q] + y[1][q]; w[2][q] = y[0][q] - y[1][q]; w[3][q] = -y[1][q]; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r * 4] = w[r][0]; v[r * 4 + 1] = w[r][0] + w[r][1]; v[r * 4 + 2] = w[r][0] - w[r][1]; v[r * 4 + 3] = -w[r][1]; }
+            for (int j = 0; j < M; ++j) {
+                float v = o[j] + b;
+                if (a.relu) v = fmaxf(v, 0.0f);
+                if (M * tx + j < W) y[(size_t)i * W + j] = v;
             }
         }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[e][tl][cl] = v[e];
-    }
-    __syncthreads();
-    const int c2 = threadIdx.x & 31, t2 = threadIdx.x >> 5;
-    const size_t plane = (size_t)a.Ttot * a.C;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const size_t at = (size_t)(blockIdx.x * 16 + t2 + 8 * half) * a.C + blockIdx.y * 32 + c2;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[(size_t)e * plane + at] = s[e][t2 + 8 * half][c2];
     }
 }
 
-// dW[co][ci] = G^T dU G: 4 x 4 -> 3 x 3, thread = (co, ci)
+// dW[co][ci] = G^T dU G: (m + 2)^2 -> 3 x 3, thread = (co, ci); n = Cout * Cin
+template <int M>
 __global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, unsigned n)
 {
-    const unsigned o = blockIdx.x * 256u + threadIdx.x;                // (co, ci) of dW [Cout][Cin][9]; n = Cout * Cin
+    constexpr int A = Wn<M>::A;
+    const unsigned o = blockIdx.x * 256u + threadIdx.x;
     if (o >= n) return;
-    float u[4][4];
+    float t[3][A];                                                        // t[i][q] = (G^T u[.][q])_i
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int q = 0; q < A; ++q) {
+        float col[A], w3[3];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) u[r][q] = dU[(size_t)(r * 4 + q) * n + o];
-    float t[3][4];
+        for (int r = 0; r < A; ++r) col[r] = dU[(size_t)(r * A + q) * n + o];
+        wn_gt<M>(col, w3);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        t[0][q] = u[0][q] + (u[1][q] + u[2][q]) * 0.5f;
-        t[1][q] = (u[1][q] - u[2][q]) * 0.5f;
-        t[2][q] = (u[1][q] + u[2][q]) * 0.5f + u[3][q];
+        for (int i = 0; i < 3; ++i) t[i][q] = w3[i];
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        dw[(size_t)o * 9 + r * 3 + 0] = t[r][0] + (t[r][1] + t[r][2]) * 0.5f;
-        dw[(size_t)o * 9 + r * 3 + 1] = (t[r][1] - t[r][2]) * 0.5f;
-        dw[(size_t)o * 9 + r * 3 + 2] = (t[r][1] + t[r][2]) * 0.5f + t[r][3];
+    for (int i = 0; i < 3; ++i) {
+        float w3[3];
+        wn_gt<M>(t[i], w3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dw[(size_t)o * 9 + i * 3 + j] = w3[j];
     }
 }
 
@@ -649,9 +686,13 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__
     __hip_atomic_store(&cnt[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
 {
-    // both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
+    // <false>: both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
+    // <true>:  128 rows x 32 k (k contiguous in memory): row r's eight 16-byte pieces sit at slots p ^ ((r >> 1) & 7) of its 128 LDS bytes -- the
+    //          DMA's LDS image is lane-linear, but which global piece a lane fetches is free -- so that the ds_read_b128 of 16 different rows
+    //          (one lane group) hit 16 different bank quads
     __shared__ __attribute__((aligned(16))) float sA[2][WN_KC * CF_MT];
     __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * CF_NT];
     __shared__ int s_last;
@@ -666,8 +707,13 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
     auto tile_of = [&](int t) {
         const int mt = t % a.n_m_tiles, r = t / a.n_m_tiles, tt = r % a.n_t_tiles, xi = r / a.n_t_tiles;
         Tl T;
-        T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT;          // rows k, this tile's 128 columns
-        T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT;
+        if (NT) {
+            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT * lda;    // this tile's 128 rows, k from 0
+            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT * ldb;
+        } else {
+            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT;      // rows k, this tile's 128 columns
+            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT;
+        }
         T.o = a.O + (size_t)xi * a.sO + (size_t)mt * CF_MT * ldo + (size_t)tt * CF_NT;
         T.tile = t;
         return T;
@@ -682,6 +728,17 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
     };
     auto issue_dma = [&](const Tl &T, int chunk, int buf) {
+        if (NT) {
+            const float *ub = T.u + (size_t)chunk * WN_KC, *vb = T.v + (size_t)chunk * WN_KC;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = wave * 4 + q;                          // transfer d = rows 8d .. 8d + 7, 128 bytes each
+                const unsigned r = (unsigned)(8 * d) + (unsigned)(lane >> 3), p = ((unsigned)lane & 7u) ^ ((r >> 1) & 7u);
+                dma16(ub + (size_t)r * lda + 4u * p, &sA[buf][d * 256]);
+                dma16(vb + (size_t)r * ldb + 4u * p, &sB[buf][d * 256]);
+            }
+            return;
+        }
         const float *ub = T.u + (size_t)chunk * WN_KC * lda, *vb = T.v + (size_t)chunk * WN_KC * ldb;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -780,6 +837,34 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         const bool more = u + 1 < u1;
         if (more && ntile != tile) Tn = tile_of(ntile);
         if (more) issue_dma(Tn, nchunk, buf ^ 1);                   // every wave is past the barrier that ended the last reads of that buffer
+        if (NT) {
+            // lane (i = li, half lh) takes k = 16 lh + s at step s: sixteen consecutive floats of its row = four ds_read_b128 per operand row
+            // and chunk (the contraction does not care which k goes to which step as long as both operands agree)
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const float *ra = &sA[buf][(wm * 64 + li) * WN_KC], *rb = &sB[buf][(wn * 64 + li) * WN_KC];
+            const int fsw = (li >> 1) & 7;
+            f32x4 fa[2][2], fb[2][2];                                // [slot][row half]
+            auto fetch4 = [&](int j, int slot) {
+                const int o = (((4 * lh + j) ^ fsw) << 2);
+                fa[slot][0] = *(const f32x4 *)(ra + o); fa[slot][1] = *(const f32x4 *)(ra + 32 * WN_KC + o);
+                fb[slot][0] = *(const f32x4 *)(rb + o); fb[slot][1] = *(const f32x4 *)(rb + 32 * WN_KC + o);
+            };
+            fetch4(0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = j & 1;
+                if (j + 1 < 4) fetch4(j + 1, slot ^ 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][e], fb[slot][0][e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][e], fb[slot][1][e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1][e], fb[slot][0][e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1][e], fb[slot][1][e], acc[1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         const float *pa = &sA[buf][lh * CF_MT + wm * 64 + li];
         const float *pb = &sB[buf][lh * CF_NT + wn * 64 + li];
         float oa[2][2], ob[2][2];
@@ -787,9 +872,9 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
             oa[slot][0] = pa[2 * s * CF_MT]; oa[slot][1] = pa[2 * s * CF_MT + 32];
             ob[slot][0] = pb[2 * s * CF_NT]; ob[slot][1] = pb[2 * s * CF_NT + 32];
         };
-        fetch(0, 0);
+        if (!NT) fetch(0, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < (NT ? 0 : 16); ++s) {
             const int slot = s & 1;
             if (s + 1 < 16) fetch(s + 1, slot ^ 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -1024,11 +1109,10 @@ static int cf_ranges()
     }();
     return g;
 }
-static CfWs cf_carve(void *ws, int C, long long Ttot = 0, int Cin = 0, int Cout = 0)
+static CfWs cf_carve(void *ws, int C, size_t u_floats = 0, size_t vm_floats = 0)
 {
-    // C = max(Cin, Cout): the direct kernels' share (Cin = Cout there); Ttot != 0 adds the Winograd stage's operand buffers
-    if (!Cin) Cin = C;
-    if (!Cout) Cout = C;
+    // C = max(Cin, Cout) rounded up to 128: the direct kernels' share (Cin = Cout there); u_floats / vm_floats != 0 add the Winograd stage's
+    // operand buffers (transformed weights; transformed inputs and products, either of which may be the wider side)
     CfWs w; char *p = (char *)ws; size_t o = 0;
     auto take = [&](size_t b) { void *r = p ? p + o : nullptr; o += align_up(b, 256); return r; };
     w.cnt = (int *)take(CF_MAX_TILES * sizeof(int));
@@ -1037,9 +1121,9 @@ static CfWs cf_carve(void *ws, int C, long long Ttot = 0, int Cin = 0, int Cout 
     const size_t wg_tiles = (size_t)(C / 32) * (C / 32);           // weight gradient: tiles x workgroups per tile <= max(tiles, CUs) slabs of one tile
     const size_t wg = std::max<size_t>(wg_tiles, (size_t)cf_ranges() / CF_WPS * CW_WPS) * (32 * 32 * 9) * sizeof(float);
     w.part = (float *)take(fwd > wg ? fwd : wg);
-    w.U = Ttot ? (float *)take((size_t)16 * Cin * Cout * sizeof(float)) : nullptr;        // Winograd: transformed weights, inputs, products
-    w.V = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;          // (either side may be the wider one: forward / data gradient)
-    w.M = Ttot ? (float *)take((size_t)16 * C * Ttot * sizeof(float)) : nullptr;
+    w.U = u_floats ? (float *)take(u_floats * sizeof(float)) : nullptr;
+    w.V = vm_floats ? (float *)take(vm_floats * sizeof(float)) : nullptr;
+    w.M = vm_floats ? (float *)take(vm_floats * sizeof(float)) : nullptr;
     w.total = o;
     return w;
 }
@@ -1075,88 +1159,119 @@ static bool cf_use_direct()
     return d;
 }
 
-static long long wn_fill(WnArgs *a, const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels)
+static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels)
 {
     long long off = 0;
     for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
         if (l < n_levels) {
-            const int tw = (W[l] + 1) / 2, th = (H[l] + 1) / 2;
+            const int tw = (W[l] + M - 1) / M, th = (H[l] + M - 1) / M;
             a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, mask ? mask[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
             off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
         } else a->lv[l] = {nullptr, nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
-    a->bias = nullptr; a->relu = 0;
+    a->bias = nullptr; a->relu = 0; a->zero_pad = 0;
     a->n_levels = n_levels; a->C = 0; a->Ttot = (int)off;
-    a->n_m_tiles = 0; a->n_t_tiles = (int)(off / CF_NT); a->Kc = 0; a->n_units = 0; a->G = 0;
     return off;
+}
+
+// m = 4 from WN_M4_MIN_TILES 4 x 4 tiles on (below that the padding to 128 tiles eats what the larger tile saves); FRCNN_WINO_M=2|4 forces one
+// (development A/B and the tests' second form)
+static int wn_pick_m(const int *H, const int *W, int n_levels)
+{
+    static const int forced = [] { const char *e = getenv("FRCNN_WINO_M"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 0; }();
+    if (forced) return forced;
+    long long t4 = 0;
+    for (int l = 0; l < n_levels; ++l) t4 += (long long)((H[l] + 3) / 4) * ((W[l] + 3) / 4);
+    return t4 >= WN_M4_MIN_TILES ? 4 : 2;
 }
 
 static bool wn_dims_ok(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % WN_KC == 0 && Cout % WN_KC == 0 && Cin <= 4096 && Cout <= 4096; }
 
+static CfWs wn_carve(void *workspace, int Cin, int Cout, int M, long long Ttot)
+{
+    const int C = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT, P = (M + 2) * (M + 2);
+    return cf_carve(workspace, C, (size_t)P * Cin * Cout, (size_t)P * std::max(Cin, Cout) * Ttot);
+}
+
 FRCNN_EXPORT size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout)
 {
     if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || !wn_dims_ok(Cin, Cout)) return 0;
-    WnArgs a;
-    const long long Ttot = wn_fill(&a, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
-    const int C = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;
-    return cf_carve(nullptr, C, Ttot, Cin, Cout).total;
+    size_t need = 0;
+    for (int M = 2; M <= 4; M += 2) {                                // whichever tile size a call picks (the choice may be forced by the environment)
+        WnArgs a;
+        const long long Ttot = wn_fill(&a, M, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
+        need = std::max(need, wn_carve(nullptr, Cin, Cout, M, Ttot).total);
+    }
+    return need;
 }
 FRCNN_EXPORT size_t frcnn_rpn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int C)
 {
     if (C <= 0 || C % CF_MT != 0) return 0;
     return frcnn_conv3x3_f32_workspace(H_host, W_host, n_levels, C, C);
 }
-static CfWs wn_carve(void *workspace, int Cin, int Cout, long long Ttot)
+
+template <int M>
+static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, long long channels, int halo, size_t *lds_bytes)
 {
-    return cf_carve(workspace, ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT, Ttot, Cin, Cout);
+    int n_strips = 0;
+    for (int per_block = Wn<M>::TPB; per_block >= 256; per_block /= 2) {       // the largest strips that still give the chip >= 4096 workgroups
+        n_strips = 0;
+        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
+            st->first[l] = n_strips;
+            const int tw = l < n_levels ? a.lv[l].tw : 1, th = l < n_levels ? (H[l] + M - 1) / M : 1;
+            st->segs[l] = (tw + Wn<M>::WT - 1) / Wn<M>::WT;
+            st->rows[l] = std::min(128, std::max(1, per_block / std::min(tw, Wn<M>::WT)));   // (M R + 2)(M wt + 2) <= Wn<M>::LDS for every wt <= WT
+            if (l < n_levels) n_strips += st->segs[l] * ((th + st->rows[l] - 1) / st->rows[l]);
+        }
+        st->first[FRCNN_MAX_LEVELS] = n_strips;
+        if ((long long)n_strips * channels >= 4096) break;
+    }
+    size_t fl = 0;                                                   // LDS: the largest (M R + 2 halo)(M wt + 2 halo) window of the levels
+    for (int l = 0; l < n_levels; ++l) {
+        const int wt = std::min(a.lv[l].tw, Wn<M>::WT), th = (H[l] + M - 1) / M, nr = std::min(st->rows[l], th);
+        fl = std::max(fl, (size_t)(M * nr + 2 * halo) * (size_t)(M * wt + 2 * halo));
+    }
+    *lds_bytes = fl * sizeof(float);
+    return n_strips;
 }
 
 // forward (transposed = false) or data gradient (true) of the convolution with w [Cout][Cin][3][3] through the Winograd domain: four
 // launches for all levels.  forward: K = Cin, M = Cout (+ bias, ReLU in the output transform);  data gradient: K = Cout, M = Cin, the
 // incoming gradient optionally masked by the forward's ReLU output
+template <int M>
 static int wn_run(const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
                   const float *w, bool transposed, const float *bias, int relu, void *workspace, hipStream_t s)
 {
-    const int K = transposed ? Cout : Cin, M = transposed ? Cin : Cout;
+    constexpr int P = Wn<M>::P;
+    const int K = transposed ? Cout : Cin, Mo = transposed ? Cin : Cout;
     WnArgs a;
-    const long long Ttot = wn_fill(&a, in, out, mask, H, W, n_levels);
-    FRCNN_REQUIRE(Ttot < (1ll << 24) && 16ll * std::max(K, M) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
-    const CfWs ws = wn_carve(workspace, Cin, Cout, Ttot);
-    a.n_m_tiles = M / CF_MT; a.Kc = K / WN_KC;
-    const long long n_tiles = 16ll * a.n_m_tiles * a.n_t_tiles, units = n_tiles * a.Kc;
+    const long long Ttot = wn_fill(&a, M, in, out, mask, H, W, n_levels);
+    FRCNN_REQUIRE(Ttot < (1ll << 24) && (long long)P * std::max(K, Mo) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
+    const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
+    const int n_m_tiles = Mo / CF_MT, n_t_tiles = (int)(Ttot / CF_NT), Kc = K / WN_KC;
+    const long long n_tiles = (long long)P * n_m_tiles * n_t_tiles, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    const unsigned wb = (unsigned)((M / 16) * (K / 16));
-    if (transposed) FRCNN_LAUNCH(rpn_wino_weight_kernel<true>, dim3(wb), dim3(256), 0, s, w, ws.U, M, K, Cin);
-    else FRCNN_LAUNCH(rpn_wino_weight_kernel<false>, dim3(wb), dim3(256), 0, s, w, ws.U, M, K, Cin);
+    const unsigned wb = (unsigned)((Mo / 16) * (K / 16));
+    if (transposed) FRCNN_LAUNCH((rpn_wino_weight_kernel<M, true>), dim3(wb), dim3(256), 0, s, w, ws.U, Mo, K, Cin);
+    else FRCNN_LAUNCH((rpn_wino_weight_kernel<M, false>), dim3(wb), dim3(256), 0, s, w, ws.U, Mo, K, Cin);
     FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
     a.C = K;
     WnStrips st;
-    int n_strips = 0;
-    for (int per_block = WN_IN_TILES; per_block >= 256; per_block /= 2) {       // the largest strips that still give the chip >= 4096 workgroups
-        n_strips = 0;
-        for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
-            st.first[l] = n_strips;
-            const int tw = l < n_levels ? a.lv[l].tw : 1, th = l < n_levels ? (H[l] + 1) / 2 : 1;
-            st.segs[l] = (tw + 255) / 256;
-            st.rows[l] = std::min(128, std::max(1, per_block / std::min(tw, 256)));     // (2 R + 2)(2 wt + 2) <= WN_IN_LDS for every wt <= 256
-            if (l < n_levels) n_strips += st.segs[l] * ((th + st.rows[l] - 1) / st.rows[l]);
-        }
-        st.first[FRCNN_MAX_LEVELS] = n_strips;
-        if ((long long)n_strips * K >= 4096) break;
-    }
-    FRCNN_LAUNCH(rpn_wino_input_kernel, dim3((unsigned)n_strips, (unsigned)K), dim3(256), 0, s, a, st, ws.V);
+    size_t lds = 0;
+    const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds);
+    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, ws.V);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.U, ws.V, ws.M, (long long)M * K, (long long)K * Ttot, (long long)M * Ttot, M, (int)Ttot, (int)Ttot,
-                a.n_m_tiles, a.n_t_tiles, a.Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
+    WgArgs g = {ws.U, ws.V, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
+                n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel<false>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
-    a.C = M; a.bias = bias; a.relu = relu;
-    FRCNN_LAUNCH(rpn_wino_output_kernel, dim3((unsigned)((Ttot + 255) / 256), (unsigned)M), dim3(256), 0, s, a, ws.M);
+    a.C = Mo; a.bias = bias; a.relu = relu;
+    FRCNN_LAUNCH(rpn_wino_output_kernel<M>, dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
     return FRCNN_OK;
 }
 
-// m_mult / k_mult: what the GEMM of the call needs of the two channel counts (its M side in 128-wide tiles, its K side in 32-deep chunks)
+// in_mult / out_mult: what the GEMM of the call needs of the two channel counts (a side that is tiled by 128, or only chunked by 32)
 static int cf_check(const void *const *p0, const void *const *p1, const int *H, const int *W, int n_levels, int Cin, int Cout, int in_mult, int out_mult,
                     const void *w, void *ws, size_t ws_bytes, const char *what)
 {
@@ -1179,7 +1294,9 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *
     int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, CF_MT, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
     if (rc) return rc;
-    return wn_run(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
+    if (wn_pick_m(H_host, W_host, n_levels) == 4)
+        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
+    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const float *const *y_mask_dev, float *const *dx_dev, const int *H_host, const int *W_host,
@@ -1190,40 +1307,53 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const fl
     if (rc) return rc;
     if (y_mask_dev)
         for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_bwd_data: NULL mask level %d", l);
-    return wn_run(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
+    if (wn_pick_m(H_host, W_host, n_levels) == 4)
+        return wn_run<4>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
+    return wn_run<2>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
 }
 
-// weight gradient through the Winograd domain: V^T of the features, dM^T of the output gradient, dU = sum over the tiles (the stage's GEMM
-// with K = Ttot), dW = G^T dU G: four launches for all levels (+ one for the bias gradient)
+// weight gradient through the Winograd domain: V = B^T d B of the features and dM = A g A^T of the (masked) output gradient, both [xi][channel][t];
+// dU = sum over the tiles on the k-contiguous form of the stage's GEMM (K = Ttot); dW = G^T dU G: four launches for all levels (+ one for the
+// bias gradient)
+template <int M>
 static int wn_wgrad(const float *const *feats, const float *const *d_outs, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
                     float *dw, float *dbias, void *workspace, hipStream_t s)
 {
+    constexpr int P = Wn<M>::P;
     WnArgs a;
-    const long long Ttot = wn_fill(&a, feats, (float *const *)d_outs, mask, H, W, n_levels);   // lv[l].y = the output gradient (read only)
+    const long long Ttot = wn_fill(&a, M, feats, nullptr, nullptr, H, W, n_levels);
     FRCNN_REQUIRE(Ttot < (1ll << 24), "conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
-    const CfWs ws = wn_carve(workspace, Cin, Cout, Ttot);
+    const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
     const int mt = Cout / CF_MT, nt = Cin / CF_NT;
-    const long long n_tiles = 16ll * mt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
+    const long long n_tiles = (long long)P * mt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    a.C = Cin;
-    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<0>, dim3((unsigned)(Ttot / 16), (unsigned)(Cin / 32)), dim3(256), 0, s, a, ws.V);
-    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
-    a.C = Cout;
-    FRCNN_LAUNCH(rpn_wino_tr_t_kernel<1>, dim3((unsigned)(Ttot / 16), (unsigned)(Cout / 32)), dim3(256), 0, s, a, ws.M);
-    FRCNN_CHECK_LAUNCH("rpn_wino_tr_t_kernel");
-    WgArgs g = {ws.M, ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, Cout, Cin, Cin, mt, nt, (int)Kc, (int)units,
+    WnStrips st;
+    a.C = Cin; a.zero_pad = 1;
+    size_t lds = 0;
+    int n_strips = wn_strips<M>(&st, a, H, n_levels, Cin, 1, &lds);
+    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)Cin), dim3(256), lds, s, a, st, ws.V);
+    FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    WnArgs g1 = a;                                                   // the output gradient (and its mask) as the transform's input
+    for (int l = 0; l < n_levels; ++l) { g1.lv[l].x = d_outs[l]; g1.lv[l].m = mask ? mask[l] : nullptr; }
+    g1.C = Cout;
+    n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds);
+    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
+    FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    WgArgs g = {ws.M, ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
                 (int)std::min<long long>(cf_ranges(), units)};
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
+    FRCNN_LAUNCH(rpn_wino_gemm_kernel<true>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
-    FRCNN_LAUNCH(rpn_wino_dw_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, ws.U, dw, n);
+    FRCNN_LAUNCH(rpn_wino_dw_kernel<M>, dim3((n + 255u) / 256u), dim3(256), 0, s, ws.U, dw, n);
     FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
     if (dbias) {
+        WnArgs b = g1;
+        for (int l = 0; l < n_levels; ++l) b.lv[l].y = (float *)d_outs[l];
         long long hw_max = 0;
         for (int l = 0; l < n_levels; ++l) hw_max = std::max<long long>(hw_max, (long long)H[l] * W[l]);
         int S = (int)std::min<long long>(CB_MAX_S, std::max<long long>(1, std::min<long long>(hw_max / 2048, (16 * 256 + Cout - 1) / Cout)));
         static_assert(4096 <= CF_MAX_TILES, "one ticket word per channel");
-        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout, (unsigned)S), dim3(256), 0, s, a, dbias, ws.part, ws.cnt);
+        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout, (unsigned)S), dim3(256), 0, s, b, dbias, ws.part, ws.cnt);
         FRCNN_CHECK_LAUNCH("conv_bias_grad_kernel");
     }
     return FRCNN_OK;
@@ -1237,7 +1367,9 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float 
     if (rc) return rc;
     if (y_mask_dev)
         for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_wgrad: NULL mask level %d", l);
-    return wn_wgrad(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
+    if (wn_pick_m(H_host, W_host, n_levels) == 4)
+        return wn_wgrad<4>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
+    return wn_wgrad<2>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
 }
 
 // ---- the RPN head's entry points: Cin = Cout = C, no bias (rpn_head.hip adds it), no mask; FRCNN_CONV_F32_DIRECT=1 routes them to the direct kernels
