@@ -164,7 +164,8 @@ def wino_work(calls):
         conv_flops += 18 * Cin * Cout * HW
         add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
         if c["kind"] == "wgrad":
-            add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)                 # B^T d B of the activations
+            if not c.get("cached"):
+                add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
             add("rpn_wino_input_kernel", 4 * Cout * HW * mask + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
             add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)
             if c.get("bias"):

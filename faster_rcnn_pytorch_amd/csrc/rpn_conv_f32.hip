@@ -377,6 +377,7 @@ struct WgArgs {
     const float *A, *B; float *O;
     long long sA, sB, sO;              // xi strides (floats)
     int lda, ldb, ldo, n_m_tiles, n_t_tiles, Kc, n_units, G;
+    int whole;                         // ranges cut at tile boundaries (no partial tiles, no slabs): when every workgroup gets several tiles
 };
 
 template <int M> struct Wn;
@@ -700,7 +701,8 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     const int G = a.G, U_ = a.n_units, Kc = a.Kc, lda = a.lda, ldb = a.ldb, ldo = a.ldo;
     const int sigma = (G % 8 == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int u0 = (int)cf_start(sigma, U_, G), u1 = (int)cf_start(sigma + 1, U_, G);
+    const int u0 = a.whole ? (int)cf_start(sigma, U_ / Kc, G) * Kc : (int)cf_start(sigma, U_, G);
+    const int u1 = a.whole ? (int)cf_start(sigma + 1, U_ / Kc, G) * Kc : (int)cf_start(sigma + 1, U_, G);
     if (u0 >= u1) return;
     // tile -> (xi, t tile, m tile): the m tiles of one (xi, t tile) are neighbours (they share the V rows)
     struct Tl { const float *u, *v; float *o; int tile; };
@@ -1240,7 +1242,7 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
 // incoming gradient optionally masked by the forward's ReLU output
 template <int M>
 static int wn_run(const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                  const float *w, bool transposed, const float *bias, int relu, void *workspace, hipStream_t s)
+                  const float *w, bool transposed, const float *bias, int relu, float *xt, void *workspace, hipStream_t s)
 {
     constexpr int P = Wn<M>::P;
     const int K = transposed ? Cout : Cin, Mo = transposed ? Cin : Cout;
@@ -1256,13 +1258,21 @@ static int wn_run(const float *const *in, float *const *out, const float *const 
     else FRCNN_LAUNCH((rpn_wino_weight_kernel<M, false>), dim3(wb), dim3(256), 0, s, w, ws.U, Mo, K, Cin);
     FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
     a.C = K;
+    float *Vb = xt ? xt : ws.V;                                      // kept for the weight gradient (zero padding columns included) or scratch
+    a.zero_pad = xt ? 1 : 0;
     WnStrips st;
     size_t lds = 0;
     const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds);
-    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, ws.V);
+    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.U, ws.V, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
-                n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units)};
+    WgArgs g = {ws.U, Vb, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
+                n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
+    {
+        // several tiles per workgroup: cut the ranges at tile boundaries (no partial tiles, no slabs, no tickets) when the rounding costs less
+        // than 16 % (128 -> 128 on 300 x 500: 5.2 tiles per workgroup, 132 -> 124 us; 256 -> 256 on 150 x 250: 2.7, 121 -> 118)
+        const long long per = (n_tiles + g.G - 1) / g.G;
+        if (n_tiles >= 2ll * g.G && per * g.G * 100 <= n_tiles * 116) g.whole = 1;
+    }
     FRCNN_LAUNCH(rpn_wino_gemm_kernel<false>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
     a.C = Mo; a.bias = bias; a.relu = relu;
@@ -1289,14 +1299,23 @@ static int cf_check(const void *const *p0, const void *const *p1, const int *H, 
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *y_dev, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
-                                       const float *w_dev, const float *bias_dev, int relu, void *workspace, size_t workspace_bytes, void *stream)
+                                       const float *w_dev, const float *bias_dev, int relu, float *x_transformed_dev, void *workspace, size_t workspace_bytes,
+                                       void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, CF_MT, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
-    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, workspace, (hipStream_t)stream);
+        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, x_transformed_dev, workspace, (hipStream_t)stream);
+    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, x_transformed_dev, workspace, (hipStream_t)stream);
+}
+
+FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || Cin <= 0) return 0;
+    const int M = wn_pick_m(H_host, W_host, n_levels);
+    WnArgs a;
+    return (size_t)((M + 2) * (M + 2)) * (size_t)Cin * (size_t)wn_fill(&a, M, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const float *const *y_mask_dev, float *const *dx_dev, const int *H_host, const int *W_host,
@@ -1308,8 +1327,8 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const fl
     if (y_mask_dev)
         for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_bwd_data: NULL mask level %d", l);
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
-    return wn_run<2>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, workspace, (hipStream_t)stream);
+        return wn_run<4>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, workspace, (hipStream_t)stream);
+    return wn_run<2>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, workspace, (hipStream_t)stream);
 }
 
 // weight gradient through the Winograd domain: V = B^T d B of the features and dM = A g A^T of the (masked) output gradient, both [xi][channel][t];
@@ -1317,7 +1336,7 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const fl
 // bias gradient)
 template <int M>
 static int wn_wgrad(const float *const *feats, const float *const *d_outs, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                    float *dw, float *dbias, void *workspace, hipStream_t s)
+                    float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s)
 {
     constexpr int P = Wn<M>::P;
     WnArgs a;
@@ -1330,17 +1349,20 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     WnStrips st;
     a.C = Cin; a.zero_pad = 1;
     size_t lds = 0;
-    int n_strips = wn_strips<M>(&st, a, H, n_levels, Cin, 1, &lds);
-    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)Cin), dim3(256), lds, s, a, st, ws.V);
-    FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    int n_strips = 0;
+    if (!xt) {                                                       // the forward did not keep B^T d B of the activations: transform them again
+        n_strips = wn_strips<M>(&st, a, H, n_levels, Cin, 1, &lds);
+        FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)Cin), dim3(256), lds, s, a, st, ws.V);
+        FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    }
     WnArgs g1 = a;                                                   // the output gradient (and its mask) as the transform's input
     for (int l = 0; l < n_levels; ++l) { g1.lv[l].x = d_outs[l]; g1.lv[l].m = mask ? mask[l] : nullptr; }
     g1.C = Cout;
     n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds);
     FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.M, ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
-                (int)std::min<long long>(cf_ranges(), units)};
+    WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
+                (int)std::min<long long>(cf_ranges(), units), 0};
     FRCNN_LAUNCH(rpn_wino_gemm_kernel<true>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
@@ -1360,7 +1382,8 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const float *const *y_mask_dev, const int *H_host, const int *W_host,
-                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, void *workspace, size_t workspace_bytes, void *stream)
+                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, void *workspace,
+                                         size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, CF_NT, CF_MT, dw_dev, workspace, workspace_bytes,
                       "conv3x3_f32_wgrad");
@@ -1368,8 +1391,8 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float 
     if (y_mask_dev)
         for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_wgrad: NULL mask level %d", l);
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_wgrad<4>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
-    return wn_wgrad<2>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, workspace, (hipStream_t)stream);
+        return wn_wgrad<4>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+    return wn_wgrad<2>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
 }
 
 // ---- the RPN head's entry points: Cin = Cout = C, no bias (rpn_head.hip adds it), no mask; FRCNN_CONV_F32_DIRECT=1 routes them to the direct kernels
@@ -1377,7 +1400,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float 
                                            const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_fwd");
     if (rc) return rc;
@@ -1403,7 +1426,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, cons
                                              int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, nullptr, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, dw_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_wgrad");
     if (rc) return rc;

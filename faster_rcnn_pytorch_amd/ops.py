@@ -536,11 +536,11 @@ def rpn_conv_wgrad(feats, d_raws):
 CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
 
 
-def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False):
+def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False):
     if CONV_TRACE is not None:
         kind = "wgrad" if what.endswith("wgrad") else ("bwd_data" if what.endswith("bwd_data") else "fwd")
         CONV_TRACE.append({"kind": kind, "Cin": int(Cin), "Cout": int(Cout), "shapes": [(int(h), int(w)) for h, w in zip(H, W)], "mask": bool(mask),
-                           "bias": bool(bias)})
+                           "bias": bool(bias), "cached": bool(cached)})
 
 
 def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
@@ -625,8 +625,8 @@ def rpn_conv3x3(feats, w3):
 
 
 # ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
-def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False):
-    _conv_trace(what, Cin, Cout, H, W, mask, bias)
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False):
+    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached)
     Hh, Wh = _host_i32(H), _host_i32(W)
     nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
     if nb == 0:
@@ -650,8 +650,9 @@ def _conv3x3_levels(ts, Cc, name):
     return ts
 
 
-def conv3x3_fwd(xs, w, bias=None, relu=False):
-    """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd)."""
+def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False):
+    """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd).
+    keep_transformed: also return the transformed activations (a flat fp32 tensor) for conv3x3_wgrad(..., x_transformed=)."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
@@ -663,9 +664,14 @@ def conv3x3_fwd(xs, w, bias=None, relu=False):
             raise ValueError("conv3x3: bias must be [Cout]")
     ys = [torch.empty((1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
     xp, yp = _ptr_list(xs), _ptr_list(ys)
+    xt = None
+    if keep_transformed:
+        Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
+        xt = torch.empty((int(lib.frcnn_conv3x3_f32_xt_floats(_np_ptr(Hh), _np_ptr(Wh), len(xs), Cin)),), dtype=torch.float32, device=xs[0].device)
     _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
-                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, ws, nws, st), bias=bias is not None)
-    return ys
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, _ptr(xt), ws, nws, st),
+                  bias=bias is not None)
+    return (ys, xt) if keep_transformed else ys
 
 
 def conv3x3_bwd_data(dys, w, y_masks=None):
@@ -685,8 +691,9 @@ def conv3x3_bwd_data(dys, w, y_masks=None):
     return dxs
 
 
-def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False):
-    """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels."""
+def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False, x_transformed=None):
+    """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels.  x_transformed: what conv3x3_fwd(..., keep_transformed=True)
+    returned for the same xs (the activations are then not transformed again)."""
     Cin, Cout = int(xs[0].shape[1]), int(dys[0].shape[1])
     xs = _conv3x3_levels(xs, Cin, "input")
     dys = _conv3x3_levels(dys, Cout, "d_out")
@@ -702,7 +709,8 @@ def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False):
     xp, gp = _ptr_list(xs), _ptr_list(dys)
     mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
     _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
-                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), ws, nws, st), mask=y_masks is not None, bias=want_bias)
+                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), ws, nws, st),
+                  mask=y_masks is not None, bias=want_bias, cached=x_transformed is not None)
     return dw, db
 
 
@@ -728,21 +736,27 @@ class _Conv3x3F32Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, relu, w, bias, x):
-        y = conv3x3_fwd([x], w, bias, relu)[0]
+        # the transformed activations are kept for the weight gradient when there will be one (0.6 GB per VGG16 step; HBM is 288 GB)
+        keep = ctx.needs_input_grad[1] and int(w.shape[1]) % 128 == 0
+        if keep:
+            ys, xt = conv3x3_fwd([x], w, bias, relu, keep_transformed=True)
+        else:
+            ys, xt = conv3x3_fwd([x], w, bias, relu), None
+        y = ys[0]
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(w, x, y if relu else None)
+        ctx.save_for_backward(w, x, y if relu else None, xt)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        w, x, y = ctx.saved_tensors
+        w, x, y, xt = ctx.saved_tensors
         g = g.contiguous()
         mask = [y] if ctx.relu else None
         dx = conv3x3_bwd_data([g], w, mask)[0] if ctx.needs_input_grad[3] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2], x_transformed=xt)
             if not ctx.needs_input_grad[1]:
                 dw = None
         return None, dw, db, dx

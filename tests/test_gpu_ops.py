@@ -1588,6 +1588,15 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     assert float((db.double().cpu() - b_ref).abs().max()) < 1e-4 * max(1.0, float(b_ref.abs().max()))
     dw2, db2 = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # the forward can keep its transformed activations for the weight gradient: same outputs, same gradient, one launch less
+    ys_k, xt = ops.conv3x3_fwd(xd, wd, bd, relu, keep_transformed=True)
+    assert all(torch.equal(a, c) for a, c in zip(ys, ys_k))
+    from faster_rcnn_pytorch_amd import _lib
+    _lib.prof_reset(); _lib.prof_enable(True)
+    dw3, db3 = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True, x_transformed=xt)
+    _lib.prof_enable(False)
+    assert torch.equal(dw, dw3) and torch.equal(db, db3)
+    assert _lib.prof_report()["rpn_wino_input_kernel"][1] == 1                                     # only the output gradient was transformed
 
 
 def test_conv3x3_f32_autograd_and_argument_checks(ops):
