@@ -63,14 +63,14 @@ MFMA_PEAK_F32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 / 16x16x4_f32: th
 
 CONFIGS = {
     "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
-                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62, Tw=640),
+                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62),
                 metric="train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)",
                 workload="VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
                          "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)"),
     "fpn": dict(H=800, W=1344, num_classes=91, label_lo=1, label_hi=91,          # raw COCO ids 1..90
                 shape=dict(N=268569, K=4000, P=1000, R=512, C=256, G=8,
                            feat_bytes=4 * 256 * (200 * 336 + 100 * 168 + 50 * 84 + 25 * 42), A=3,
-                           P_head=200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21, Tw=22784),       # Tw: 2x2 output tiles of the RPN conv, padded to 128 per level
+                           P_head=200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21),
                 metric="train images/sec (ResNet-50-FPN Faster R-CNN, 800x1344, bs=1/GPU)",
                 workload="ResNet-50-FPN Faster R-CNN train step, synthetic 800x1344 frames (COCO 800x1333 padded to /32), bs=1/GPU, "
                          "HIP proposal/RoI path (N=268569 anchors over 5 levels, pre/post NMS 4000/1000, 512 RoIs, "
@@ -85,7 +85,7 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm", "rpn_wino_tr_t_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv_bias_grad_kernel": "hbm"}
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv_bias_grad_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
               "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: input x 2, gemm, dw
@@ -103,7 +103,7 @@ def synth_frame(cfg, rank, step):
     return x, boxes, labels
 
 
-def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
+def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels'); None where the figure would say nothing."""
     nblk = (K + 63) // 64
     pooled = R * C * 49
@@ -125,23 +125,16 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
         "roi_align_bwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
         "rpn_conv_f32_pack_kernel": 2 * 4 * 9 * C * C,                    # the 3x3 weights in, transposed + flipped out
-        "rpn_wino_weight_kernel": 4 * (9 + 16) * C * C,                   # Winograd F(2x2,3x3): W in, G g G^T out
-        "rpn_wino_input_kernel": 4 * C * P_head + 4 * 16 * C * Tw,        # activations in, B^T d B (16 planes over the padded tiles) out
-        "rpn_wino_output_kernel": 4 * 16 * C * Tw + 4 * C * P_head,       # 16 product planes in, A^T M A out
-        "rpn_wino_tr_t_kernel": 4 * C * P_head + 4 * 16 * C * Tw,         # weight gradient: features or output gradient in, 16 transposed planes out
-        "rpn_wino_dw_kernel": 4 * (16 + 9) * C * C,                       # dU in, G^T dU G out
     }.get(kernel)
 
 
-def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, Tw=0):
+def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
     """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
     conv = 2 * C * 9 * C * P_head                                         # C -> C 3x3 on every RPN position (model.py:68-70, new_model.py:96-98)
     return {"rpn_conv3x3_head_kernel": conv + 2 * C * 6 * A * P_head,     # raw = conv3x3 + both 1x1 heads
             "rpn_conv3x3_bwd_data_kernel": conv, "rpn_conv3x3_wgrad_kernel": conv,
-            "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv,
-            # placeholder = the convolution's flops: build_record replaces it by what the GEMM executes (32 C^2 Tw, 2.25 x less) and keeps
-            # the convolution's count beside it for the stage-level figure
-            "rpn_wino_gemm_kernel": conv}.get(kernel)
+            "rpn_conv3x3_f32_kernel": conv, "rpn_conv3x3_f32_bwd_data_kernel": conv, "rpn_conv3x3_f32_wgrad_kernel": conv}.get(kernel)
+    # (rpn_wino_gemm_kernel serves several layers per image: build_record prices it from the traced calls of one step, wino_work)
 
 
 def wino_work(calls):
@@ -457,6 +450,7 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         own = tot["rpn_wino_gemm_kernel"]["flops"]
         d["algorithmic_flops_per_img"] = own
         d["algorithmic_flops"] = round(own / max(tot["rpn_wino_gemm_kernel"]["launches"], 1))
+        d["mfma_peak_TFLOP_s"] = MFMA_PEAK_F32_TFLOPS
         d["TFLOP_s"] = round(own / d["us_per_img"] * 1e-6, 2) if matched else None
         d["mfma_frac"] = round(own / d["us_per_img"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5) if matched else None
         d["stage_calls_per_img"] = len(conv_calls)
@@ -469,21 +463,6 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         d["note"] = ("Winograd F(2x2,3x3), all launches of one image (the RPN convolution and the backbone layers in `layers`, forward + data gradient "
                      "+ weight gradient): the GEMM is priced on the flops it executes (32 Cin Cout per padded 2x2 tile, 2.25x fewer than the "
                      "convolutions it serves); conv_equivalent_TFLOP_s = the convolutions' own flop count over the time of ALL the stage's launches")
-    elif "rpn_wino_gemm_kernel" in per_kernel:
-        d = per_kernel["rpn_wino_gemm_kernel"]
-        calls = max(d["launches"], 1)
-        stage_us = sum(sum(samples[k]) for k in WINO_STAGE if k in samples) * 1e3 / calls
-        conv = d["algorithmic_flops"]                               # the convolution the stage replaces (18 C^2 per position)
-        own = 32 * shape["C"] * shape["C"] * shape.get("Tw", 0)     # what the GEMM executes: 16 products [C x C] . [C x Tw]
-        d["algorithmic_flops"] = own                                # the roofline prices the kernel on ITS OWN contraction ...
-        d["TFLOP_s"] = round(own / d["avg_us"] * 1e-6, 2)
-        d["mfma_frac"] = round(own / d["avg_us"] * 1e-6 / MFMA_PEAK_F32_TFLOPS, 5)
-        d["stage_us_per_call"] = round(stage_us, 2)                 # ... and the stage it belongs to on the convolution's flop count
-        d["stage_kernels"] = [k for k in WINO_STAGE if k in samples]
-        d["conv_flops_per_call"] = conv
-        d["conv_equivalent_TFLOP_s"] = round(conv / stage_us * 1e-6, 2)
-        d["note"] = ("Winograd F(2x2,3x3): this GEMM executes 2.25x fewer flops than the convolution it serves; conv_equivalent_TFLOP_s = the "
-                     "convolution's own flop count over the time of the stage's four launches per call (may exceed the MFMA peak)")
     # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
     nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
     if "nms_kernel" in per_kernel and nms_us > 0:

@@ -150,23 +150,38 @@ def test_bench_timing_rule_and_record_assembly_world2_gloo():
 
 
 def test_winograd_stage_accounting_in_the_roofline():
-    """The fp32 RPN conv runs as a Winograd stage: the GEMM kernel is priced on the flops IT executes (32 C^2 Tw: a fraction of the fp32
-    MFMA peak, never above it), and the convolution's own flop count over the time of the stage's launches per call rides beside it."""
+    """The fp32 3x3 convolutions (the RPN's and the backbone layers the stage takes) run as Winograd stages of several launches: the GEMM
+    kernel is priced on the flops IT executes per image -- 2 (m + 2)^2 Cin Cout per padded m x m tile, summed over the calls one step
+    makes (ops.CONV_TRACE) -- over the per-image time of its launches: a fraction of the fp32 MFMA peak, never above it; the convolutions'
+    own flop count over the time of ALL the stage's launches rides beside it."""
     import bench
-    us = {"rpn_wino_gemm_kernel": 0.060, "rpn_wino_input_kernel": 0.010, "rpn_wino_output_kernel": 0.008, "rpn_wino_weight_kernel": 0.008,
-          "rpn_wino_tr_t_kernel": 0.011, "rpn_wino_dw_kernel": 0.008, "nms_kernel": 0.070}
-    n = {"rpn_wino_gemm_kernel": 3, "rpn_wino_input_kernel": 2, "rpn_wino_output_kernel": 2, "rpn_wino_weight_kernel": 2, "rpn_wino_tr_t_kernel": 2,
-         "rpn_wino_dw_kernel": 1, "nms_kernel": 1}
+    rpn = {"Cin": 512, "Cout": 512, "shapes": [(37, 62)], "mask": False, "bias": False, "cached": False}          # 10 x 16 tiles of 4 x 4 < 512: m = 2
+    c4 = {"Cin": 512, "Cout": 512, "shapes": [(75, 125)], "mask": True, "bias": True, "cached": True}            # 19 x 32 = 608 tiles: m = 4
+    calls = [dict(rpn, kind=k) for k in ("fwd", "bwd_data", "wgrad")] + [dict(c4, kind="fwd", mask=False), dict(c4, kind="bwd_data"), dict(c4, kind="wgrad")]
+    tot, conv = bench.wino_work(calls)
+    assert tot["rpn_wino_gemm_kernel"]["launches"] == 6 and tot["rpn_wino_input_kernel"]["launches"] == 4 + 2 + 1     # rpn wgrad transforms x, the cached one does not
+    own = 3 * 2 * 16 * 512 * 512 * 640 + 3 * 2 * 36 * 512 * 512 * 640                                            # 589 -> 640 and 608 -> 640 padded tiles
+    assert tot["rpn_wino_gemm_kernel"]["flops"] == own and conv == 3 * 18 * 512 * 512 * (37 * 62 + 75 * 125)
+    assert tot["conv_bias_grad_kernel"] == {"launches": 1, "bytes": 2 * 4 * 512 * 75 * 125, "flops": 0}
+    us = {"rpn_wino_gemm_kernel": 0.090, "rpn_wino_input_kernel": 0.020, "rpn_wino_output_kernel": 0.012, "rpn_wino_weight_kernel": 0.008,
+          "rpn_wino_dw_kernel": 0.008, "conv_bias_grad_kernel": 0.012, "nms_kernel": 0.070}
+    n = {k: tot[k]["launches"] for k in tot}
+    n["nms_kernel"] = 1
     samples = {k: [us[k]] * (n[k] * 5) for k in us}                          # five bracketed steps
-    rec = bench.build_record("vgg", "none", world=1, steps=20, warmup=4, dt=0.284, per_rank_ms=[14.2], step_ms=[14.2] * 20, samples=samples,
-                             n_sampled=5, n_props=[780], graph=False, pmc={}, pmc_src=None, cpu=None, allocator={}, ddp=None, backend=None,
-                             world_seen=1, final_loss=1.0)
+    kw = dict(world=1, steps=20, warmup=4, dt=0.2, per_rank_ms=[10.0], step_ms=[10.0] * 20, n_sampled=5, n_props=[780], graph=False, pmc={},
+              pmc_src=None, cpu=None, allocator={}, ddp=None, backend=None, world_seen=1, final_loss=1.0)
+    rec = bench.build_record("vgg", "none", samples=samples, conv_calls=calls, **kw)
     r = rec["roofline"]
     assert r["kernel"] == "rpn_wino_gemm_kernel" and r["bound"] == "mfma" and r["peak"] == 157.3
-    own = 32 * 512 * 512 * 640
-    assert abs(r["achieved"] - own / 60.0 * 1e-6) < 0.05 and 0 < r["frac"] < 1
-    stage = (3 * 60 + 2 * 10 + 2 * 8 + 2 * 8 + 2 * 11 + 8) / 3
-    assert abs(r["stage_us_per_call"] - stage) < 0.05
-    assert abs(r["conv_equivalent_TFLOP_s"] - 2 * 512 * 9 * 512 * 37 * 62 / stage * 1e-6) < 0.05
+    assert abs(r["achieved"] - own / (6 * 90.0) * 1e-6) < 0.05 and 0 < r["frac"] < 1
+    stage = 6 * 90 + 7 * 20 + 4 * 12 + 4 * 8 + 2 * 8 + 12
+    assert abs(r["stage_us_per_img"] - stage) < 0.05 and r["stage_calls_per_img"] == 6
+    assert abs(r["conv_equivalent_TFLOP_s"] - conv / stage * 1e-6) < 0.05
+    hk = r["hbm_kernel"]
+    assert hk["kernel"] == "rpn_wino_input_kernel" and abs(hk["achieved"] - tot["rpn_wino_input_kernel"]["bytes"] / (7 * 20.0) * 1e-3) < 0.5
     c = bench.compact_record(rec)["roofline"]
     assert c["conv_equivalent_TFLOP_s"] == r["conv_equivalent_TFLOP_s"] and c["frac"] == r["frac"]
+    # a step that did not make the traced calls gets no figure rather than a wrong one
+    short = dict(samples, rpn_wino_gemm_kernel=[0.09] * 25)
+    r2 = bench.build_record("vgg", "none", samples=short, conv_calls=calls, **kw)["roofline"]
+    assert r2["kernel"] != "rpn_wino_gemm_kernel" or r2.get("frac") is None
