@@ -778,12 +778,18 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
 #endif
         if (n_chunks == Kc) { store_tile(T); return; }
         float *slab = part + ((size_t)sigma * 2 + (first_chunk == 0 ? 1 : 0)) * CF_SLAB;
+        // 16-byte write-through stores, [wave][tile][quad][lane][4]: a dword sc1 store is one fabric write per lane-dword (about six times the
+        // time per byte of the 16-byte form, MI355X_MICROARCH.md): 64 of them per lane held a workgroup ~10 us per partial segment, two
+        // segments per launch -- most of the ~25 us that every launch of this kernel cost beyond its MFMA time
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float *dst = &slab[(wave * 4 + g) * 16 * 64 + lane];
+            float *dst = &slab[(wave * 4 + g) * 16 * 64 + lane * 4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                asm volatile("global_store_dword %0, %1, off offset:%2 sc1" :: "v"(dst), "v"(acc[g >> 1][g & 1][r]), "n"(r * 256) : "memory");
+            for (int q = 0; q < 4; ++q) {
+                const f32x4s v = {acc[g >> 1][g & 1][4 * q], acc[g >> 1][g & 1][4 * q + 1], acc[g >> 1][g & 1][4 * q + 2], acc[g >> 1][g & 1][4 * q + 3]};
+                asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" :: "v"(dst), "v"(v), "n"(q * 1024) : "memory");
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -801,23 +807,22 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
             const long long st = cf_start(s, U_, G);
             const float *sl = part + ((size_t)s * 2 + (st <= lo ? 1 : 0)) * CF_SLAB;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {                         // two accumulator tiles (32 loads in flight) at a time: the reducer must not
-                float t[2][16];                                      // push the main loop's staging registers out to scratch
+            for (int hf = 0; hf < 2; ++hf) {                         // two accumulator tiles (eight 16-byte loads in flight) at a time: the reducer
+                f32x4s t[2][4];                                      // must not push the main loop's registers out to scratch
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const float *src = &sl[(wave * 4 + hf * 2 + g) * 16 * 64 + lane];
+                    const float *src = &sl[(wave * 4 + hf * 2 + g) * 16 * 64 + lane * 4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        asm volatile("global_load_dword %0, %1, off offset:%2 sc1" : "=v"(t[g][r]) : "v"(src), "n"(r * 256) : "memory");
+                    for (int q = 0; q < 4; ++q)
+                        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(t[g][q]) : "v"(src), "n"(q * 1024) : "memory");
                 }
-#define WN_WAIT(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]), "+v"(t[g][4]), "+v"(t[g][5]), "+v"(t[g][6]), \
-                                   "+v"(t[g][7]), "+v"(t[g][8]), "+v"(t[g][9]), "+v"(t[g][10]), "+v"(t[g][11]), "+v"(t[g][12]), "+v"(t[g][13]), "+v"(t[g][14]), "+v"(t[g][15]) :: "memory")
-                WN_WAIT(16, 0);
+#define WN_WAIT(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]) :: "memory")
+                WN_WAIT(4, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[hf][0][r] += t[0][r];
+                for (int r = 0; r < 16; ++r) acc[hf][0][r] += t[0][r >> 2][r & 3];
                 WN_WAIT(0, 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[hf][1][r] += t[1][r];
+                for (int r = 0; r < 16; ++r) acc[hf][1][r] += t[1][r >> 2][r & 3];
             }
 #undef WN_WAIT
         }
