@@ -85,7 +85,7 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv_bias_grad_kernel": "hbm"}
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
               "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: input x 2, gemm, dw
@@ -142,7 +142,7 @@ def wino_work(calls):
     convolution and every backbone layer the stage takes, each forward / data gradient / weight gradient): kernel -> launches, bytes,
     flops; plus the flop count of the convolutions served (18 Cin Cout per position and direction).  Tiles are padded to 128 per level
     (that padding is executed, so the GEMM is priced on it); transforms move the activations once and the 16 planes once."""
-    tot = {k: {"launches": 0, "bytes": 0, "flops": 0} for k in WINO_STAGE + ("conv_bias_grad_kernel",)}
+    tot = {k: {"launches": 0, "bytes": 0, "flops": 0} for k in WINO_STAGE}
     conv_flops = 0
 
     def add(k, b=0, f=0):
@@ -160,9 +160,7 @@ def wino_work(calls):
             if not c.get("cached"):
                 add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
             add("rpn_wino_input_kernel", 4 * Cout * HW * mask + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
-            add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)
-            if c.get("bias"):
-                add("conv_bias_grad_kernel", 4 * Cout * HW * mask)
+            add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)                           # (the bias gradient rides in the output gradient's transform)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
             add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)

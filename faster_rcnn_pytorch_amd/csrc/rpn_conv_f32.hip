@@ -52,7 +52,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CF_RS 144                      // LDS row stride of one (ci, dy) activation copy: 130 used; 6 * 144 = 32 (mod 64): the two k halves hit disjoint banks
 #define CF_ROWS (CF_CI * 3)
 #define CF_SLAB (CF_MT * CF_NT)        // floats per partial slab
-#define CF_MAX_TILES 8192              // ticket words in the control block
+#define CF_MAX_TILES 32768             // ticket words in the control block
 
 struct CfLevel { const float *x; float *y; int H, W, HW, tile0; };
 struct CfArgs {
@@ -366,6 +366,7 @@ struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
     const float *bias;                 // output transform: + bias[c] (or NULL), then ReLU if relu != 0
     int relu, zero_pad;                // zero_pad: the input transforms also write zeros into the padding columns (weight gradient: the product sums over them)
+    float *db_part;                    // MODE 1 of the input transform also leaves per-strip sums of its (masked) gradient: the bias gradient's partials (NULL: not wanted)
     int n_levels, C, Ttot;             // C = channels of the side the launch touches
 };
 // the batched product of the stage, both forms:
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 {
     constexpr int A = Wn<M>::A, P = Wn<M>::P, WT = Wn<M>::WT, HALO = MODE == 0 ? 1 : 0, IN = MODE == 0 ? A : M;
     extern __shared__ __attribute__((aligned(8))) float s[];          // the largest window of the launch's levels (wn_strips): <= Wn<M>::LDS floats
-    const int c = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && (int)blockIdx.x >= st.first[q]) ? 1 : 0;
@@ -512,18 +513,69 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
     const float *x = a.lv[l].x + (size_t)c * H * W;
     const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
     const int x0 = M * tx0 - HALO, y0 = M * ty0 - HALO, ncol = M * wt + 2 * HALO, nrow = M * nr + 2 * HALO;      // the strip's input window
-    for (int r = wave; r < nrow; r += 4) {
-        const int yy = y0 + r;
-        const bool row_in = yy >= 0 && yy < H;
-        for (int q = lane; q < ncol; q += 64) {
-            const int xx = x0 + q;
-            const bool in = row_in && xx >= 0 && xx < W;
-            float v = in ? x[yy * W + xx] : 0.0f;
-            if (mk) v = (in && mk[yy * W + xx] > 0.0f) ? v : 0.0f;
-            s[r * ncol + q] = v;
+    float bsum = 0.0f;                                                    // this thread's share of the strip's gradient sum (MODE 1 with a.db)
+    // eight (+ eight mask) loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE
+    // load in flight per wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
+    // eight (+ eight mask) loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE
+    // load in flight per wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
+    if (ncol >= 192) {                                                    // wide windows: a wave per row, eight column pieces per lane
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int r = wave; r < nrow; r += 4) {
+            const int yy = y0 + r;
+            const bool row_in = yy >= 0 && yy < H;
+            const float *xr = x + (size_t)yy * W + x0, *mr = mk ? mk + (size_t)yy * W + x0 : nullptr;
+            for (int qb = lane; qb < ncol; qb += 64 * 8) {
+                float v[8], mv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = qb + 64 * j, xx = x0 + q;
+                    const bool in = row_in && q < ncol && xx >= 0 && xx < W;
+                    v[j] = in ? xr[q] : 0.0f;
+                    mv[j] = (mr && in) ? mr[q] : 1.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = qb + 64 * j;
+                    const float g = mv[j] > 0.0f ? v[j] : 0.0f;
+                    if (q < ncol) { s[r * ncol + q] = g; bsum += g; }
+                }
+            }
+        }
+    } else {                                                              // narrow windows flattened: any shape keeps the eight loads busy
+        const int n_el = nrow * ncol;
+        const float inv_ncol = 1.0f / (float)ncol;
+        for (int base = threadIdx.x; base < n_el; base += 256 * 8) {
+            float v[8], mv[8];
+            int at[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = base + 256 * j;
+                int r = (int)((float)e * inv_ncol);                           // e / ncol, fixed up below (e < 2^14: the estimate is off by one at most)
+                r -= (r * ncol > e) ? 1 : 0;
+                r += ((r + 1) * ncol <= e) ? 1 : 0;
+                const int q = e - r * ncol, yy = y0 + r, xx = x0 + q;
+                const bool in = e < n_el && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                at[j] = e < n_el ? e : -1;
+                v[j] = in ? x[yy * W + xx] : 0.0f;
+                mv[j] = (mk && in) ? mk[yy * W + xx] : 1.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (at[j] >= 0) { const float g = mv[j] > 0.0f ? v[j] : 0.0f; s[at[j]] = g; bsum += g; }
         }
     }
     __syncthreads();
+    // bias gradient (MODE 1 with a.db): the windows have no halo, so the strips of a channel partition its positions: strip sums -> partials
+    // [channel][strip], which the last launch of the weight gradient (rpn_wino_dw_kernel) adds in strip order.  (A ticket + last-arriver
+    // sum inside this launch held every block's resources for the round trips of its thread 0: +30 % on the whole transform.)
+    if (MODE == 1 && a.db_part) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int h = 32; h > 0; h >>= 1) bsum += __shfl_down(bsum, h, 64);   // wave sums by lane shuffles (fixed tree), then four values through LDS
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bsum;
+        __syncthreads();
+        if (threadIdx.x == 0) a.db_part[(size_t)c * st.first[FRCNN_MAX_LEVELS] + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
     const size_t plane = (size_t)a.C * a.Ttot, col0 = (size_t)c * a.Ttot + a.lv[l].off;
     const int n_tiles = nr * wt;
 #pragma unroll 1
@@ -610,10 +662,28 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
 }
 
 // dW[co][ci] = G^T dU G: (m + 2)^2 -> 3 x 3, thread = (co, ci); n = Cout * Cin
+// blocks past the (co, ci) range: the bias gradient, one block per channel adds the output-gradient transform's strip partials in strip order
 template <int M>
-__global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, unsigned n)
+__global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restrict__ dU, float *__restrict__ dw, unsigned n, float *__restrict__ db,
+                                                          const float *__restrict__ db_part, int n_strips)
 {
     constexpr int A = Wn<M>::A;
+    const unsigned dw_blocks = (n + 255u) / 256u;
+    if (blockIdx.x >= dw_blocks) {
+        __shared__ float red[256];
+        const unsigned c = blockIdx.x - dw_blocks;
+        float t = 0.0f;
+        for (int i = threadIdx.x; i < n_strips; i += 256) t += db_part[(size_t)c * n_strips + i];      // fixed assignment and order: bit-reproducible
+        red[threadIdx.x] = t;
+        __syncthreads();
+#pragma unroll
+        for (int h = 128; h > 0; h >>= 1) {
+            if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) db[c] = red[0];
+        return;
+    }
     const unsigned o = blockIdx.x * 256u + threadIdx.x;
     if (o >= n) return;
     float t[3][A];                                                        // t[i][q] = (G^T u[.][q])_i
@@ -633,58 +703,6 @@ __global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restric
 #pragma unroll
         for (int j = 0; j < 3; ++j) dw[(size_t)o * 9 + i * 3 + j] = w3[j];
     }
-}
-
-// db[c] = sum over levels and positions of the (masked) output gradient.  Grid (channels, S): slice s of a channel's positions -> partial
-// [c][s] (write-through), a ticket per channel, and the slice that arrives last adds the S partials in slice order: one launch, fixed-order
-// sums, ticket words left zero.  (One workgroup per channel read 150 000 floats in sequence at 600x1000: 60 us per call.)
-#define CB_MAX_S 64
-__global__ __launch_bounds__(256) void conv_bias_grad_kernel(WnArgs a, float *__restrict__ db, float *__restrict__ part, int *__restrict__ cnt)
-{
-    __shared__ float red[256];
-    __shared__ int s_last;
-    const int c = blockIdx.x, S = gridDim.y, sl = blockIdx.y;
-    float acc = 0.0f;
-    for (int l = 0; l < a.n_levels; ++l) {
-        const int HW = a.lv[l].H * a.lv[l].W, per = (HW + S - 1) / S, i0 = sl * per, i1 = min(HW, i0 + per);
-        const float *g = (const float *)a.lv[l].y + (size_t)c * HW;
-        const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * HW : nullptr;
-        for (int base = i0 + (int)threadIdx.x; base < i1; base += 256 * 8) {      // eight (+ eight) loads in flight per thread, added in index order
-            float v[8], mv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = base + u * 256;
-                v[u] = i < i1 ? g[i] : 0.0f;
-                mv[u] = (mk && i < i1) ? mk[i] : 1.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += mv[u] > 0.0f ? v[u] : 0.0f;
-        }
-    }
-    red[threadIdx.x] = acc;
-    __syncthreads();
-#pragma unroll
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (S == 1) { if (threadIdx.x == 0) db[c] = red[0]; return; }
-    if (threadIdx.x == 0) {
-        // the hand-off of the GEMM's slabs: write-through store, counted wait, relaxed ticket (a release FENCE would write back every dirty
-        // line of the XCD's L2 -- behind the transforms' hundreds of MB that took 130 us per call)
-        asm volatile("global_store_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(&part[(size_t)c * CB_MAX_S + sl]), "v"(red[0]) : "memory");
-        s_last = (__hip_atomic_fetch_add(&cnt[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last || threadIdx.x != 0) return;
-    float sum = 0.0f;
-    for (int s = 0; s < S; ++s) {
-        float v;
-        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(&part[(size_t)c * CB_MAX_S + s]) : "memory");
-        sum += v;
-    }
-    db[c] = sum;
-    __hip_atomic_store(&cnt[c], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <bool NT>
@@ -1176,7 +1194,7 @@ static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const 
             off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
         } else a->lv[l] = {nullptr, nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
-    a->bias = nullptr; a->relu = 0; a->zero_pad = 0;
+    a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr;
     a->n_levels = n_levels; a->C = 0; a->Ttot = (int)off;
     return off;
 }
@@ -1348,7 +1366,7 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     const long long Ttot = wn_fill(&a, M, feats, nullptr, nullptr, H, W, n_levels);
     FRCNN_REQUIRE(Ttot < (1ll << 24), "conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
-    const int mt = Cout / CF_MT, nt = Cin / CF_NT;
+    const int mt = Cout / CF_MT, nt = Cin / CF_NT, C9 = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;     // ws.wt holds C9^2 * 9 floats
     const long long n_tiles = (long long)P * mt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     WnStrips st;
@@ -1364,6 +1382,10 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     for (int l = 0; l < n_levels; ++l) { g1.lv[l].x = d_outs[l]; g1.lv[l].m = mask ? mask[l] : nullptr; }
     g1.C = Cout;
     n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds);
+    const int n_strips_dy = n_strips;
+    FRCNN_REQUIRE(!dbias || (size_t)Cout * n_strips_dy <= (size_t)C9 * C9 * 9, "conv3x3_f32_wgrad: %d strips are too many for the bias partials", n_strips_dy);
+    if (dbias) g1.db_part = ws.wt;                                   // the bias gradient's strip partials ride in this launch (in the direct form's weight
+                                                                     // buffer, idle in this form) and are added up by the last launch
     FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
@@ -1371,18 +1393,8 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     FRCNN_LAUNCH(rpn_wino_gemm_kernel<true>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
     FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
-    FRCNN_LAUNCH(rpn_wino_dw_kernel<M>, dim3((n + 255u) / 256u), dim3(256), 0, s, ws.U, dw, n);
+    FRCNN_LAUNCH(rpn_wino_dw_kernel<M>, dim3((n + 255u) / 256u + (dbias ? (unsigned)Cout : 0u)), dim3(256), 0, s, ws.U, dw, n, dbias, ws.wt, n_strips_dy);
     FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
-    if (dbias) {
-        WnArgs b = g1;
-        for (int l = 0; l < n_levels; ++l) b.lv[l].y = (float *)d_outs[l];
-        long long hw_max = 0;
-        for (int l = 0; l < n_levels; ++l) hw_max = std::max<long long>(hw_max, (long long)H[l] * W[l]);
-        int S = (int)std::min<long long>(CB_MAX_S, std::max<long long>(1, std::min<long long>(hw_max / 2048, (16 * 256 + Cout - 1) / Cout)));
-        static_assert(4096 <= CF_MAX_TILES, "one ticket word per channel");
-        FRCNN_LAUNCH(conv_bias_grad_kernel, dim3((unsigned)Cout, (unsigned)S), dim3(256), 0, s, b, dbias, ws.part, ws.cnt);
-        FRCNN_CHECK_LAUNCH("conv_bias_grad_kernel");
-    }
     return FRCNN_OK;
 }
 
