@@ -705,9 +705,20 @@ __global__ __launch_bounds__(256) void rpn_wino_dw_kernel(const float *__restric
     }
 }
 
+#ifdef WN_STAMP                                                      // developer build (tools/dev/wn_stamps.py): wall-clock stamps (100 MHz) of every workgroup of the last launch
+__device__ unsigned long long wn_stamps[4 * 1024];
+extern "C" __attribute__((visibility("default"))) int frcnn_debug_wn_stamps(unsigned long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wn_stamps), sizeof(wn_stamps));
+}
+#define WN_STAMP_AT(i) do { if (threadIdx.x == 0) wn_stamps[blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define WN_STAMP_AT(i) do { } while (0)
+#endif
 template <bool NT>
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
 {
+    WN_STAMP_AT(0);
     // <false>: both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
     // <true>:  128 rows x 32 k (k contiguous in memory): row r's eight 16-byte pieces sit at slots p ^ ((r >> 1) & 7) of its 128 LDS bytes -- the
     //          DMA's LDS image is lane-linear, but which global piece a lane fetches is free -- so that the ds_read_b128 of 16 different rows
@@ -854,6 +865,7 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
     issue_dma(T, chunk, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    WN_STAMP_AT(1);
     for (int u = u0; u < u1; ++u) {
         const int buf = (u - u0) & 1;
         int ntile = tile, nchunk = chunk + 1;
@@ -910,7 +922,9 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!more || ntile != tile) {
+            if (!more) WN_STAMP_AT(2);
             finish_segment(T, seg_first, chunk + 1 - seg_first);
+            if (!more) WN_STAMP_AT(3);
             zero_acc();
             seg_first = 0;
             if (more) T = Tn;
