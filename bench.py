@@ -519,6 +519,7 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
                    "submission": "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)"},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "conv_calls": conv_calls,           # every call of the fp32 conv stage in one step (ops.CONV_TRACE): what wino_work() prices
         "step_ms": ({"median": round(smed, 3), "p10": round(sp10, 3), "p90": round(sp90, 3), "max": round(max(step_ms), 3),
                      "slowest_steps": sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3],
                      "source": "HIP events at the step boundaries on the main stream (rank 0)"} if step_ms else None),

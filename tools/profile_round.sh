@@ -29,6 +29,10 @@ echo "pmc done"
 mkdir -p profiles
 for c in vgg fpn fpn_bf16; do cp gpurun_out/${TAG}_pmc_traffic_$c.json profiles/${TAG}_pmc_traffic_$c.json; done
 python3 bench.py --no-also > gpurun_out/${TAG}_bench_vgg.json 2> gpurun_out/${TAG}_bench_vgg.err
+cp bench_detail.json gpurun_out/${TAG}_bench_detail_vgg.json
 python3 bench.py --config fpn > gpurun_out/${TAG}_bench_fpn.json 2> gpurun_out/${TAG}_bench_fpn.err
+cp bench_detail.json gpurun_out/${TAG}_bench_detail_fpn.json
 python3 bench.py --config fpn --amp bf16 > gpurun_out/${TAG}_bench_fpn_bf16.json 2> gpurun_out/${TAG}_bench_fpn_bf16.err
+cp bench_detail.json gpurun_out/${TAG}_bench_detail_fpn_bf16.json
+python3 bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err     # the driver's command: headline + the two FPN figures in `also`
 echo "bench done"
