@@ -1632,6 +1632,45 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
         ops.conv3x3_fwd([x64], torch.zeros(64, 64, 3, 3, device=DEV))                            # Cout = 64
 
 
+@pytest.mark.parametrize("m", ["2", "4"])
+def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
+    """The stage picks F(4x4, 3x3) from 512 tiles per call on and F(2x2, 3x3) below; FRCNN_WINO_M (read once per process) forces one.  A child process
+    runs a large map with the small tile and small / odd maps with the large one (what the default choice never does) against float64: forward with
+    bias + ReLU, masked data gradient, weight + bias gradient; 2e-5 of the scale for m = 2, 5e-5 for m = 4 (its transform constants span 1/24 .. 8)."""
+    import subprocess
+    code = r"""
+import os, torch, torch.nn.functional as F
+from faster_rcnn_pytorch_amd import ops
+dev = "cuda:0"
+tol = 2e-5 if os.environ["FRCNN_WINO_M"] == "2" else 5e-5
+for Cin, Cout, shapes in ((128, 256, [(96, 130)]), (256, 128, [(9, 14), (30, 5), (1, 1), (4, 4)]), (128, 128, [(37, 62)])):
+    g = torch.Generator().manual_seed(Cin + len(shapes))
+    xs = [torch.randn(1, Cin, h, w, generator=g) for h, w in shapes]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.2
+    dys = [torch.randn(1, Cout, h, w, generator=g) for h, w in shapes]
+    xd, dyd, wd, bd = [x.to(dev) for x in xs], [t.to(dev) for t in dys], wt.to(dev), b.to(dev)
+    ys = ops.conv3x3_fwd(xd, wd, bd, True)
+    pre = [F.conv2d(x.double(), wt.double(), b.double(), padding=1) for x in xs]
+    for y, p in zip(ys, pre):
+        assert float((y.double().cpu() - p.clamp_min(0)).abs().max()) < tol * max(1.0, float(p.abs().max()))
+    gs = [t.double() * (y.cpu() > 0) for t, y in zip(dys, ys)]
+    dx = ops.conv3x3_bwd_data(dyd, wd, ys)
+    for o, t in zip(dx, gs):
+        r = F.conv_transpose2d(t, wt.double(), None, padding=1)
+        assert float((o.double().cpu() - r).abs().max()) < tol * max(1.0, float(r.abs().max()))
+    dw, db = ops.conv3x3_wgrad(xd, dyd, ys, want_bias=True)
+    w_ref = sum(torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), t, padding=1) for x, t in zip(xs, gs))
+    b_ref = sum(t.sum(dim=(0, 2, 3)) for t in gs)
+    assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
+    assert float((db.double().cpu() - b_ref).abs().max()) < 1e-4 * max(1.0, float(b_ref.abs().max()))
+print("forced tile OK")
+"""
+    e = dict(os.environ, FRCNN_WINO_M=m, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "forced tile OK" in r.stdout, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------------------------------ RoIAlign forward dispatch order (round 4)
 def test_roi_scale_order_and_ordered_forward_are_bit_identical(ops):
     """frcnn_roi_scale_order replaces the `roi * (w, h, w, h)` launch of FastRCNNHead.forward (models/new_model.py:136-140) and also hands
