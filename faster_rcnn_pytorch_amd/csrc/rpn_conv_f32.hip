@@ -715,16 +715,20 @@ extern "C" __attribute__((visibility("default"))) int frcnn_debug_wn_stamps(unsi
 #else
 #define WN_STAMP_AT(i) do { } while (0)
 #endif
-template <bool NT>
+// MT x NW = the workgroup's output tile (128 or 64 each way: the 64-channel layers of a backbone have a 64-wide side); its four waves sit
+// 2 x 2, a wave owns (MT / 2) x (NW / 2) = MI x NI MFMA tiles of 32 x 32.
+template <bool NT, int MT, int NW>
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
 {
     WN_STAMP_AT(0);
-    // <false>: both operand tiles are 32 k rows x 128 floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
-    // <true>:  128 rows x 32 k (k contiguous in memory): row r's eight 16-byte pieces sit at slots p ^ ((r >> 1) & 7) of its 128 LDS bytes -- the
+    constexpr int MI = MT / 64, NI = NW / 64, NG = MI * NI;          // MFMA tiles per wave
+    constexpr int TA = MT / 8, TB = NW / 8;                          // 1-KB DMA transfers per chunk and operand (32 x MT x 4 bytes)
+    // <false>: both operand tiles are 32 k rows x MT (NW) floats, row-contiguous: the image global_load_lds_dwordx4 writes (wave base + lane x 16 bytes)
+    // <true>:  MT (NW) rows x 32 k (k contiguous in memory): row r's eight 16-byte pieces sit at slots p ^ ((r >> 1) & 7) of its 128 LDS bytes -- the
     //          DMA's LDS image is lane-linear, but which global piece a lane fetches is free -- so that the ds_read_b128 of 16 different rows
     //          (one lane group) hit 16 different bank quads
-    __shared__ __attribute__((aligned(16))) float sA[2][WN_KC * CF_MT];
-    __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * CF_NT];
+    __shared__ __attribute__((aligned(16))) float sA[2][WN_KC * MT];
+    __shared__ __attribute__((aligned(16))) float sB[2][WN_KC * NW];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -739,21 +743,20 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         const int mt = t % a.n_m_tiles, r = t / a.n_m_tiles, tt = r % a.n_t_tiles, xi = r / a.n_t_tiles;
         Tl T;
         if (NT) {
-            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT * lda;    // this tile's 128 rows, k from 0
-            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT * ldb;
+            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * MT * lda;   // this tile's MT rows, k from 0
+            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * NW * ldb;
         } else {
-            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * CF_MT;      // rows k, this tile's 128 columns
-            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * CF_NT;
+            T.u = a.A + (size_t)xi * a.sA + (size_t)mt * MT;         // rows k, this tile's MT columns
+            T.v = a.B + (size_t)xi * a.sB + (size_t)tt * NW;
         }
-        T.o = a.O + (size_t)xi * a.sO + (size_t)mt * CF_MT * ldo + (size_t)tt * CF_NT;
+        T.o = a.O + (size_t)xi * a.sO + (size_t)mt * MT * ldo + (size_t)tt * NW;
         T.tile = t;
         return T;
     };
-    // staging by LDS-DMA: a chunk = 16 + 16 wave transfers of 1 KB (two k rows x 512 B each), four + four per wave; no staging registers,
-    // no ds_write, and the transfers of chunk u + 1 are in flight during all sixteen k steps of chunk u.  (With the chunk staged through
-    // registers -- 8 x 16 bytes per thread, written to LDS behind the last step -- the GEMM took 533 us at FPN size and 70 at 600x1000;
-    // without any staging the same loop takes 366.)
-    const unsigned dma_row = (unsigned)(lane >> 5), dma_col = (unsigned)(lane & 31) * 4u;
+    // staging by LDS-DMA: a chunk = TA + TB wave transfers of 1 KB, a quarter of them per wave; no staging registers, no ds_write, and the
+    // transfers of chunk u + 1 are in flight during all sixteen k steps of chunk u.  (With the chunk staged through registers -- 8 x 16
+    // bytes per thread, written to LDS behind the last step -- the GEMM took 533 us at FPN size and 70 at 600x1000; without any staging
+    // the same loop takes 366.)
     auto dma16 = [&](const float *g, const float *lds) {
         const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
@@ -761,29 +764,40 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
     auto issue_dma = [&](const Tl &T, int chunk, int buf) {
         if (NT) {
             const float *ub = T.u + (size_t)chunk * WN_KC, *vb = T.v + (size_t)chunk * WN_KC;
+            const unsigned rl = (unsigned)(lane >> 3), sl = (unsigned)lane & 7u;     // transfer d = rows 8d .. 8d + 7, 128 bytes each
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = wave * 4 + q;                          // transfer d = rows 8d .. 8d + 7, 128 bytes each
-                const unsigned r = (unsigned)(8 * d) + (unsigned)(lane >> 3), p = ((unsigned)lane & 7u) ^ ((r >> 1) & 7u);
+            for (int q = 0; q < TA / 4; ++q) {
+                const int d = wave * (TA / 4) + q;
+                const unsigned r = (unsigned)(8 * d) + rl, p = sl ^ ((r >> 1) & 7u);
                 dma16(ub + (size_t)r * lda + 4u * p, &sA[buf][d * 256]);
+            }
+#pragma unroll
+            for (int q = 0; q < TB / 4; ++q) {
+                const int d = wave * (TB / 4) + q;
+                const unsigned r = (unsigned)(8 * d) + rl, p = sl ^ ((r >> 1) & 7u);
                 dma16(vb + (size_t)r * ldb + 4u * p, &sB[buf][d * 256]);
             }
             return;
         }
         const float *ub = T.u + (size_t)chunk * WN_KC * lda, *vb = T.v + (size_t)chunk * WN_KC * ldb;
+        constexpr int RA = 256 / MT, RB = 256 / NW;                  // k rows per transfer: 2 (128-wide tile) or 4 (64-wide)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int d = wave * 4 + q;                              // transfer d = k rows 2d, 2d + 1
-            dma16(ub + (size_t)(2 * d + dma_row) * lda + dma_col, &sA[buf][d * 256]);
-            dma16(vb + (size_t)(2 * d + dma_row) * ldb + dma_col, &sB[buf][d * 256]);
+        for (int q = 0; q < TA / 4; ++q) {
+            const int d = wave * (TA / 4) + q;
+            dma16(ub + (size_t)(RA * d + lane / (MT / 4)) * lda + (unsigned)(lane % (MT / 4)) * 4u, &sA[buf][d * 256]);
+        }
+#pragma unroll
+        for (int q = 0; q < TB / 4; ++q) {
+            const int d = wave * (TB / 4) + q;
+            dma16(vb + (size_t)(RB * d + lane / (NW / 4)) * ldb + (unsigned)(lane % (NW / 4)) * 4u, &sB[buf][d * 256]);
         }
     };
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
     };
@@ -792,11 +806,11 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         int tt = ldo;
         asm volatile("" : "+s"(tt));                                 // opaque here: otherwise the 64 store offsets are hoisted out of the unit loop
                                                                      // and live in 64 registers through it (the staging registers went to scratch)
-        float *o = T.o + (size_t)(wm * 64 + 4 * lh) * tt + wn * 64 + li;
+        float *o = T.o + (size_t)(wm * (MT / 2) + 4 * lh) * tt + wn * (NW / 2) + li;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     o[(size_t)(mi * 32 + (r & 3) + 8 * (r >> 2)) * tt + ni * 32] = acc[mi][ni][r];
@@ -807,16 +821,15 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
 #endif
         if (n_chunks == Kc) { store_tile(T); return; }
         float *slab = part + ((size_t)sigma * 2 + (first_chunk == 0 ? 1 : 0)) * CF_SLAB;
-        // 16-byte write-through stores, [wave][tile][quad][lane][4]: a dword sc1 store is one fabric write per lane-dword (about six times the
-        // time per byte of the 16-byte form, MI355X_MICROARCH.md): 64 of them per lane held a workgroup ~10 us per partial segment, two
-        // segments per launch -- most of the ~25 us that every launch of this kernel cost beyond its MFMA time
+        // 16-byte write-through stores, [wave][tile][quad][lane][4] (a dword sc1 store is one fabric write per lane-dword: about six times
+        // the time per byte of the 16-byte form, MI355X_MICROARCH.md)
         typedef float f32x4s __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float *dst = &slab[(wave * 4 + g) * 16 * 64 + lane * 4];
+        for (int g = 0; g < NG; ++g) {
+            float *dst = &slab[(wave * NG + g) * 16 * 64 + lane * 4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4s v = {acc[g >> 1][g & 1][4 * q], acc[g >> 1][g & 1][4 * q + 1], acc[g >> 1][g & 1][4 * q + 2], acc[g >> 1][g & 1][4 * q + 3]};
+                const f32x4s v = {acc[g / NI][g % NI][4 * q], acc[g / NI][g % NI][4 * q + 1], acc[g / NI][g % NI][4 * q + 2], acc[g / NI][g % NI][4 * q + 3]};
                 asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc1" :: "v"(dst), "v"(v), "n"(q * 1024) : "memory");
             }
         }
@@ -832,28 +845,37 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         while (cf_start(s_end + 1, U_, G) <= hi) ++s_end;
         while (cf_start(s_end, U_, G) > hi) --s_end;
         zero_acc();
+        constexpr int PER = NG >= 2 ? 2 : 1;                         // accumulator tiles per batch of loads (at most eight 16-byte loads in flight: the
+                                                                     // reducer must not push the main loop's registers out to scratch)
         for (int s = s_first; s <= s_end; ++s) {
             const long long st = cf_start(s, U_, G);
             const float *sl = part + ((size_t)s * 2 + (st <= lo ? 1 : 0)) * CF_SLAB;
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {                         // two accumulator tiles (eight 16-byte loads in flight) at a time: the reducer
-                f32x4s t[2][4];                                      // must not push the main loop's registers out to scratch
+            for (int hf = 0; hf < NG / PER; ++hf) {
+                f32x4s t[PER][4];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const float *src = &sl[(wave * 4 + hf * 2 + g) * 16 * 64 + lane * 4];
+                for (int g = 0; g < PER; ++g) {
+                    const float *src = &sl[(wave * NG + hf * PER + g) * 16 * 64 + lane * 4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(t[g][q]) : "v"(src), "n"(q * 1024) : "memory");
                 }
 #define WN_WAIT(N, g) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(t[g][0]), "+v"(t[g][1]), "+v"(t[g][2]), "+v"(t[g][3]) :: "memory")
-                WN_WAIT(4, 0);
+                if (PER == 2) WN_WAIT(4, 0); else WN_WAIT(0, 0);
+                {
+                    constexpr int g0 = 0;
+                    const int gg = hf * PER + g0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[hf][0][r] += t[0][r >> 2][r & 3];
-                WN_WAIT(0, 1);
+                    for (int r = 0; r < 16; ++r) acc[gg / NI][gg % NI][r] += t[g0][r >> 2][r & 3];
+                }
+                if (PER == 2) {
+                    WN_WAIT(0, PER - 1);
+                    const int gg = hf * PER + 1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[hf][1][r] += t[1][r >> 2][r & 3];
-            }
+                    for (int r = 0; r < 16; ++r) acc[gg / NI][gg % NI][r] += t[PER - 1][r >> 2][r & 3];
+                }
 #undef WN_WAIT
+            }
         }
         store_tile(T);
         if (tid == 0) __hip_atomic_store(&cnt[T.tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -878,13 +900,15 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
             // lane (i = li, half lh) takes k = 16 lh + s at step s: sixteen consecutive floats of its row = four ds_read_b128 per operand row
             // and chunk (the contraction does not care which k goes to which step as long as both operands agree)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const float *ra = &sA[buf][(wm * 64 + li) * WN_KC], *rb = &sB[buf][(wn * 64 + li) * WN_KC];
+            const float *ra = &sA[buf][(wm * (MT / 2) + li) * WN_KC], *rb = &sB[buf][(wn * (NW / 2) + li) * WN_KC];
             const int fsw = (li >> 1) & 7;
-            f32x4 fa[2][2], fb[2][2];                                // [slot][row half]
+            f32x4 fa[2][MI], fb[2][NI];                              // [slot][tile]
             auto fetch4 = [&](int j, int slot) {
                 const int o = (((4 * lh + j) ^ fsw) << 2);
-                fa[slot][0] = *(const f32x4 *)(ra + o); fa[slot][1] = *(const f32x4 *)(ra + 32 * WN_KC + o);
-                fb[slot][0] = *(const f32x4 *)(rb + o); fb[slot][1] = *(const f32x4 *)(rb + 32 * WN_KC + o);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[slot][mi] = *(const f32x4 *)(ra + mi * 32 * WN_KC + o);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[slot][ni] = *(const f32x4 *)(rb + ni * 32 * WN_KC + o);
             };
             fetch4(0, 0);
 #pragma unroll
@@ -894,32 +918,37 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     __builtin_amdgcn_sched_barrier(0);
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][e], fb[slot][0][e], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][0][e], fb[slot][1][e], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1][e], fb[slot][0][e], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][1][e], fb[slot][1][e], acc[1][1], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][e], fb[slot][ni][e], acc[mi][ni], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        const float *pa = &sA[buf][lh * CF_MT + wm * 64 + li];
-        const float *pb = &sB[buf][lh * CF_NT + wn * 64 + li];
-        float oa[2][2], ob[2][2];
-        auto fetch = [&](int s, int slot) {
-            oa[slot][0] = pa[2 * s * CF_MT]; oa[slot][1] = pa[2 * s * CF_MT + 32];
-            ob[slot][0] = pb[2 * s * CF_NT]; ob[slot][1] = pb[2 * s * CF_NT + 32];
-        };
-        if (!NT) fetch(0, 0);
+        } else {
+            const float *pa = &sA[buf][lh * MT + wm * (MT / 2) + li];
+            const float *pb = &sB[buf][lh * NW + wn * (NW / 2) + li];
+            float oa[2][MI], ob[2][NI];
+            auto fetch = [&](int s, int slot) {
 #pragma unroll
-        for (int s = 0; s < (NT ? 0 : 16); ++s) {
-            const int slot = s & 1;
-            if (s + 1 < 16) fetch(s + 1, slot ^ 1);
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][0], ob[slot][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][1], ob[slot][1], acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int mi = 0; mi < MI; ++mi) oa[slot][mi] = pa[2 * s * MT + 32 * mi];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) ob[slot][ni] = pb[2 * s * NW + 32 * ni];
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int slot = s & 1;
+                if (s + 1 < 16) fetch(s + 1, slot ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][mi], ob[slot][ni], acc[mi][ni], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (!more || ntile != tile) {
             if (!more) WN_STAMP_AT(2);
@@ -933,6 +962,25 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk's transfers have landed (this wave's; the barrier covers the others')
         __syncthreads();
     }
+}
+
+// the instantiation a product's tile widths need (host side)
+static int wn_launch_gemm(bool nt, int MT, int NW, const WgArgs &g, float *part, int *cnt, hipStream_t s)
+{
+#define WN_GEMM_CASE(NTv, MTv, NWv)                                                                                          \
+    if (nt == NTv && MT == MTv && NW == NWv) {                                                                               \
+        FRCNN_LAUNCH((rpn_wino_gemm_kernel<NTv, MTv, NWv>), dim3((unsigned)g.G), dim3(256), 0, s, g, part, cnt);             \
+        FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");                                                                          \
+        return FRCNN_OK;                                                                                                     \
+    }
+    WN_GEMM_CASE(false, 128, 128)
+    WN_GEMM_CASE(false, 64, 128)
+    WN_GEMM_CASE(true, 128, 128)
+    WN_GEMM_CASE(true, 128, 64)
+    WN_GEMM_CASE(true, 64, 128)
+    WN_GEMM_CASE(true, 64, 64)
+#undef WN_GEMM_CASE
+    return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32: no GEMM for a %d x %d tile", MT, NW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight gradient
@@ -1287,7 +1335,8 @@ static int wn_run(const float *const *in, float *const *out, const float *const 
     const long long Ttot = wn_fill(&a, M, in, out, mask, H, W, n_levels);
     FRCNN_REQUIRE(Ttot < (1ll << 24) && (long long)P * std::max(K, Mo) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
-    const int n_m_tiles = Mo / CF_MT, n_t_tiles = (int)(Ttot / CF_NT), Kc = K / WN_KC;
+    const int MT = Mo % CF_MT == 0 ? CF_MT : 64;                     // a 64-channel output side (conv1_2, the data gradient of conv2_1): 64-row tiles
+    const int n_m_tiles = Mo / MT, n_t_tiles = (int)(Ttot / CF_NT), Kc = K / WN_KC;
     const long long n_tiles = (long long)P * n_m_tiles * n_t_tiles, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     const unsigned wb = (unsigned)((Mo / 16) * (K / 16));
@@ -1310,8 +1359,7 @@ static int wn_run(const float *const *in, float *const *out, const float *const 
         const long long per = (n_tiles + g.G - 1) / g.G;
         if (n_tiles >= 2ll * g.G && per * g.G * 100 <= n_tiles * 116) g.whole = 1;
     }
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel<false>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
-    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
+    { const int rc = wn_launch_gemm(false, MT, CF_NT, g, ws.part, ws.cnt, s); if (rc) return rc; }
     a.C = Mo; a.bias = bias; a.relu = relu;
     FRCNN_LAUNCH(rpn_wino_output_kernel<M>, dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
@@ -1339,7 +1387,7 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *
                                        const float *w_dev, const float *bias_dev, int relu, float *x_transformed_dev, void *workspace, size_t workspace_bytes,
                                        void *stream)
 {
-    int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, CF_MT, w_dev, workspace, workspace_bytes,
+    int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, 64, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
@@ -1358,7 +1406,7 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const float *const *y_mask_dev, float *const *dx_dev, const int *H_host, const int *W_host,
                                             int n_levels, int Cin, int Cout, const float *w_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
-    int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, CF_MT, WN_KC, w_dev, workspace, workspace_bytes,
+    int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
     if (rc) return rc;
     if (y_mask_dev)
@@ -1380,7 +1428,8 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     const long long Ttot = wn_fill(&a, M, feats, nullptr, nullptr, H, W, n_levels);
     FRCNN_REQUIRE(Ttot < (1ll << 24), "conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
-    const int mt = Cout / CF_MT, nt = Cin / CF_NT, C9 = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;     // ws.wt holds C9^2 * 9 floats
+    const int MT = Cout % CF_MT == 0 ? CF_MT : 64, NW = Cin % CF_NT == 0 ? CF_NT : 64;
+    const int mt = Cout / MT, nt = Cin / NW, C9 = ((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;     // ws.wt holds C9^2 * 9 floats
     const long long n_tiles = (long long)P * mt * nt, Kc = Ttot / WN_KC, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32_wgrad: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     WnStrips st;
@@ -1404,8 +1453,7 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
                 (int)std::min<long long>(cf_ranges(), units), 0};
-    FRCNN_LAUNCH(rpn_wino_gemm_kernel<true>, dim3((unsigned)g.G), dim3(256), 0, s, g, ws.part, ws.cnt);
-    FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");
+    { const int rc = wn_launch_gemm(true, MT, NW, g, ws.part, ws.cnt, s); if (rc) return rc; }
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
     FRCNN_LAUNCH(rpn_wino_dw_kernel<M>, dim3((n + 255u) / 256u + (dbias ? (unsigned)Cout : 0u)), dim3(256), 0, s, ws.U, dw, n, dbias, ws.wt, n_strips_dy);
     FRCNN_CHECK_LAUNCH("rpn_wino_dw_kernel");
@@ -1416,7 +1464,7 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float 
                                          int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, void *workspace,
                                          size_t workspace_bytes, void *stream)
 {
-    int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, CF_NT, CF_MT, dw_dev, workspace, workspace_bytes,
+    int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, 64, 64, dw_dev, workspace, workspace_bytes,
                       "conv3x3_f32_wgrad");
     if (rc) return rc;
     if (y_mask_dev)

@@ -720,15 +720,15 @@ CONV3X3_MIN_WORK = 1 << 27         # Cin * Cout * positions: below this the stag
 
 def conv3x3_supported(x, weight, need_input_grad=None):
     """Whether `conv3x3` takes this layer: fp32 on a HIP device, batch 1, [Cout,Cin,3,3] with the multiples the stage's GEMMs need (forward
-    Cin % 32, Cout % 128; the gradients Cin % 128 as well).  Everything else stays with torch's own convolution (the backbone is PyTorch code
+    Cin % 32, Cout % 64; the gradients Cin % 64 as well).  Everything else stays with torch's own convolution (the backbone is PyTorch code
     in the north-star's own words; this stage takes the layers where it wins)."""
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1):
         return False
     Cout, Cin = int(weight.shape[0]), int(weight.shape[1])
-    if tuple(weight.shape[2:]) != (3, 3) or Cout % 128 != 0 or Cin % 32 != 0 or Cin * Cout * x.shape[2] * x.shape[3] < CONV3X3_MIN_WORK:
+    if tuple(weight.shape[2:]) != (3, 3) or Cout % 64 != 0 or Cin % 32 != 0 or Cin * Cout * x.shape[2] * x.shape[3] < CONV3X3_MIN_WORK:
         return False
     grads = torch.is_grad_enabled() and (weight.requires_grad or (x.requires_grad if need_input_grad is None else need_input_grad))
-    return (not grads) or Cin % 128 == 0
+    return (not grads) or Cin % 64 == 0
 
 
 class _Conv3x3F32Fn(torch.autograd.Function):
@@ -737,7 +737,7 @@ class _Conv3x3F32Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, relu, w, bias, x):
         # the transformed activations are kept for the weight gradient when there will be one (0.6 GB per VGG16 step; HBM is 288 GB)
-        keep = ctx.needs_input_grad[1] and int(w.shape[1]) % 128 == 0
+        keep = ctx.needs_input_grad[1] and int(w.shape[1]) % 64 == 0
         if keep:
             ys, xt = conv3x3_fwd([x], w, bias, relu, keep_transformed=True)
         else:

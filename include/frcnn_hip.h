@@ -221,11 +221,11 @@ int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feat_levels, const float *co
  * channels on 75 x 125 / 37 x 62 at 600 x 1000) and the FPN's output convolutions behind models/new_model.py:372 (256 -> 256 on P2..P5) -- which
  * are 2/3 of the training step's GPU time through the vendor library.  w [Cout, Cin, 3, 3] in the reference's layout.
  *   _fwd      : y[co] = act(bias[co] + sum_ci conv3x3(x[ci], w[co][ci])); bias may be NULL; act = ReLU when relu != 0 (the Conv2d + ReLU(inplace)
- *               pair of vgg16.features in one pass).  Cin a multiple of 32, Cout a multiple of 128.
+ *               pair of vgg16.features in one pass).  Cin a multiple of 32, Cout a multiple of 64 (64-row GEMM tiles where a side is not a multiple of 128).
  *   _bwd_data : dx[ci] = sum_co conv3x3(g[co], w[co][ci] flipped), g = dy where y_mask > 0 (y_mask_levels = the forward's ReLU outputs: autograd's
- *               threshold_backward folded into the input transform), or g = dy when y_mask_levels is NULL.  Cin a multiple of 128, Cout of 32.
+ *               threshold_backward folded into the input transform), or g = dy when y_mask_levels is NULL.  Cin a multiple of 64, Cout of 32.
  *   _wgrad    : dw[co][ci][ky][kx] = sum over levels and positions of g[co](y, x) * x[ci](y + ky - 1, x + kx - 1) (fully overwritten); dbias[co] =
- *               sum of g[co] (NULL: not wanted).  Cin and Cout multiples of 128.
+ *               sum of g[co] (NULL: not wanted).  Cin and Cout multiples of 64.
  * Workspace: frcnn_conv3x3_f32_workspace(H, W, n_levels, Cin, Cout) bytes, the same DEDICATED zero-before-first-use block as the RPN calls
  * above (one block sized for the largest layer serves all of them; calls on it must be stream-ordered).  Bit-reproducible.                  */
 size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout);

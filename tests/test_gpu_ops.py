@@ -1543,6 +1543,10 @@ CONV3X3_CASES = [   # name, Cin, Cout, level shapes, bias, relu, gradients
     ("narrow_in", 64, 128, [(33, 47)], True, True, False),                    # Cin = 64 (features[5]): forward only
     ("wide_in", 384, 128, [(20, 31)], True, False, True),                     # Cin > Cout, bias without ReLU (the FPN's layer blocks)
     ("levels", 128, 128, [(9, 14), (30, 5), (1, 1)], False, True, True),      # several levels sharing the weight, no bias
+    ("vgg_conv1_2", 64, 64, [(120, 200)], True, True, True),                  # features[2] + [3]: 64-wide tiles on both sides (F(4x4): 1500 tiles)
+    ("vgg_conv2_1", 64, 128, [(100, 160)], True, True, True),                 # features[5] + [6]: a 64-channel input side
+    ("narrow_both", 64, 64, [(20, 30), (7, 9)], True, True, True),            # the same with F(2x2)
+    ("wide_out_64", 256, 64, [(25, 33)], True, False, True),                  # 64 outputs of a wide input
 ]
 
 
@@ -1621,15 +1625,15 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
     for a, c in zip([x.grad, w.grad, b.grad], want):
         assert float((a - c).abs().max()) < 1e-4 * max(1.0, float(c.abs().max()))
     assert ops.conv3x3_supported(x, w) and not ops.conv3x3_supported(x.half(), w) and not ops.conv3x3_supported(x[:, :, :8, :8], w)
-    w64 = torch.zeros(128, 64, 3, 3, device=DEV, requires_grad=True)
-    x64 = torch.zeros(1, 64, 160, 160, device=DEV)
-    assert not ops.conv3x3_supported(x64, w64)                                                   # training needs Cin % 128 == 0
+    w32 = torch.zeros(128, 32, 3, 3, device=DEV, requires_grad=True)
+    x32 = torch.zeros(1, 32, 256, 256, device=DEV)
+    assert not ops.conv3x3_supported(x32, w32)                                                   # training needs Cin % 64 == 0
     with torch.no_grad():
-        assert ops.conv3x3_supported(x64, w64)                                                   # forward only: Cin % 32 == 0
+        assert ops.conv3x3_supported(x32, w32)                                                   # forward only: Cin % 32 == 0
     with pytest.raises(FrcnnError):
-        ops.conv3x3_wgrad([x64], [torch.zeros(1, 128, 160, 160, device=DEV)])
+        ops.conv3x3_wgrad([x32], [torch.zeros(1, 128, 256, 256, device=DEV)])
     with pytest.raises(FrcnnError):
-        ops.conv3x3_fwd([x64], torch.zeros(64, 64, 3, 3, device=DEV))                            # Cout = 64
+        ops.conv3x3_fwd([x32], torch.zeros(32, 32, 3, 3, device=DEV))                            # Cout = 32
 
 
 @pytest.mark.parametrize("m", ["2", "4"])
