@@ -148,24 +148,25 @@ def wino_work(calls):
     def add(k, b=0, f=0):
         tot[k]["launches"] += 1; tot[k]["bytes"] += b; tot[k]["flops"] += f
     for c in calls:
-        Cin, Cout, mask = c["Cin"], c["Cout"], 2 if c.get("mask") else 1
+        Cin, Cout = c["Cin"], c["Cout"]
         HW = sum(h * w for h, w in c["shapes"])
         # the library's choice of the output tile (csrc/rpn_conv_f32.hip wn_pick_m): 4 x 4 from 512 such tiles on, else 2 x 2
         m = 4 if sum(((h + 3) // 4) * ((w + 3) // 4) for h, w in c["shapes"]) >= 512 else 2
         P = (m + 2) ** 2
         Tp = sum(-(-(((h + m - 1) // m) * ((w + m - 1) // m)) // 128) * 128 for h, w in c["shapes"])
+        bits = 2 * Cout * Tp if c.get("mask") else 0                    # the ReLU's sign words: one uint16 per (channel, tile)
         conv_flops += 18 * Cin * Cout * HW
         add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
         if c["kind"] == "wgrad":
             if not c.get("cached"):
                 add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
-            add("rpn_wino_input_kernel", 4 * Cout * HW * mask + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
+            add("rpn_wino_input_kernel", 4 * Cout * HW + bits + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
             add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)                           # (the bias gradient rides in the output gradient's transform)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
             add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
-            add("rpn_wino_input_kernel", 4 * K * HW * (mask if c["kind"] == "bwd_data" else 1) + 4 * P * K * Tp)
-            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * HW)
+            add("rpn_wino_input_kernel", 4 * K * HW + (bits if c["kind"] == "bwd_data" else 0) + 4 * P * K * Tp)
+            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * HW + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
     return tot, conv_flops
 
 

@@ -359,12 +359,14 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // The transformed operands travel through the workspace (P C Ttot floats each way).
 #define WN_KC 32                       // K values per chunk
 #define WN_M4_MIN_TILES 512            // 4 x 4 tiles (all levels) from which m = 4 is used
-// m (optional): the forward's ReLU output of the level whose gradient x is: the gradient counts where m > 0 -- what autograd's
-// threshold_backward computes in a launch of its own
-struct WnLevel { const float *x; float *y; const float *m; int H, W, tw, T, off; };
+struct WnLevel { const float *x; float *y; int H, W, tw, T, off; };
 struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
     const float *bias;                 // output transform: + bias[c] (or NULL), then ReLU if relu != 0
+    // the ReLU's sign pattern as ONE 16-bit word per (channel, output tile): bit i * m + j = output (m ty + i, m tx + j) > 0.  Written by the output
+    // transform (bits_out), read by the gradient kernels' input transforms (bits: the gradient counts where the bit is set -- what autograd's
+    // threshold_backward computes in a launch of its own, from 1/32 of the bytes of the activations)
+    unsigned short *bits_out; const unsigned short *bits;
     int relu, zero_pad;                // zero_pad: the input transforms also write zeros into the padding columns (weight gradient: the product sums over them)
     float *db_part;                    // MODE 1 of the input transform also leaves per-strip sums of its (masked) gradient: the bias gradient's partials (NULL: not wanted)
     int n_levels, C, Ttot;             // C = channels of the side the launch touches
@@ -511,33 +513,38 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
     const int H = a.lv[l].H, W = a.lv[l].W, tw = a.lv[l].tw, th = (H + M - 1) / M;
     const int ty0 = (strip / segs) * R, tx0 = (strip % segs) * WT, wt = min(WT, tw - tx0), nr = min(R, th - ty0);
     const float *x = a.lv[l].x + (size_t)c * H * W;
-    const float *mk = a.lv[l].m ? a.lv[l].m + (size_t)c * H * W : nullptr;
+    const unsigned short *mk = a.bits ? a.bits + (size_t)c * a.Ttot + a.lv[l].off : nullptr;    // this channel's sign words of the level, [ty * tw + tx]
     const int x0 = M * tx0 - HALO, y0 = M * ty0 - HALO, ncol = M * wt + 2 * HALO, nrow = M * nr + 2 * HALO;      // the strip's input window
-    float bsum = 0.0f;                                                    // this thread's share of the strip's gradient sum (MODE 1 with a.db)
-    // eight (+ eight mask) loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE
-    // load in flight per wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
-    // eight (+ eight mask) loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE
-    // load in flight per wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
+    // the sign words of the strip's tiles and of the ring of tiles around it (MODE 0's halo pixels belong to those): (nr + 2) x (wt + 2) words in
+    // LDS; a thread then masks its patch with nine (MODE 0) or one (MODE 1) of them at compile-time bit positions.  (Looked up per staged
+    // element -- one 2-byte load each -- the mask cost as much as the 4-byte float mask it replaced: the staging is load-instruction bound.)
+    __shared__ unsigned short wb[1664];
+    if (mk) {
+        const int nwc = wt + 2;
+        for (int e = threadIdx.x; e < (nr + 2) * nwc; e += 256) {
+            const int i = e / nwc, j = e - i * nwc, ty = ty0 - 1 + i, tx = tx0 - 1 + j;
+            wb[e] = (ty >= 0 && ty < th && tx >= 0 && tx < tw) ? mk[ty * tw + tx] : (unsigned short)0;
+        }
+    }
+    // eight loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE load in flight per
+    // wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
     if (ncol >= 192) {                                                    // wide windows: a wave per row, eight column pieces per lane
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int r = wave; r < nrow; r += 4) {
             const int yy = y0 + r;
             const bool row_in = yy >= 0 && yy < H;
-            const float *xr = x + (size_t)yy * W + x0, *mr = mk ? mk + (size_t)yy * W + x0 : nullptr;
+            const float *xr = x + (size_t)yy * W + x0;
             for (int qb = lane; qb < ncol; qb += 64 * 8) {
-                float v[8], mv[8];
+                float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = qb + 64 * j, xx = x0 + q;
-                    const bool in = row_in && q < ncol && xx >= 0 && xx < W;
-                    v[j] = in ? xr[q] : 0.0f;
-                    mv[j] = (mr && in) ? mr[q] : 1.0f;
+                    v[j] = (row_in && q < ncol && xx >= 0 && xx < W) ? xr[q] : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = qb + 64 * j;
-                    const float g = mv[j] > 0.0f ? v[j] : 0.0f;
-                    if (q < ncol) { s[r * ncol + q] = g; bsum += g; }
+                    if (q < ncol) s[r * ncol + q] = v[j];
                 }
             }
         }
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         const int n_el = nrow * ncol;
         const float inv_ncol = 1.0f / (float)ncol;
         for (int base = threadIdx.x; base < n_el; base += 256 * 8) {
-            float v[8], mv[8];
+            float v[8];
             int at[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -554,30 +561,18 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
                 r -= (r * ncol > e) ? 1 : 0;
                 r += ((r + 1) * ncol <= e) ? 1 : 0;
                 const int q = e - r * ncol, yy = y0 + r, xx = x0 + q;
-                const bool in = e < n_el && yy >= 0 && yy < H && xx >= 0 && xx < W;
                 at[j] = e < n_el ? e : -1;
-                v[j] = in ? x[yy * W + xx] : 0.0f;
-                mv[j] = (mk && in) ? mk[yy * W + xx] : 1.0f;
+                v[j] = (e < n_el && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (at[j] >= 0) { const float g = mv[j] > 0.0f ? v[j] : 0.0f; s[at[j]] = g; bsum += g; }
+                if (at[j] >= 0) s[at[j]] = v[j];
         }
     }
     __syncthreads();
-    // bias gradient (MODE 1 with a.db): the windows have no halo, so the strips of a channel partition its positions: strip sums -> partials
-    // [channel][strip], which the last launch of the weight gradient (rpn_wino_dw_kernel) adds in strip order.  (A ticket + last-arriver
-    // sum inside this launch held every block's resources for the round trips of its thread 0: +30 % on the whole transform.)
-    if (MODE == 1 && a.db_part) {
-        __shared__ float red[4];
-#pragma unroll
-        for (int h = 32; h > 0; h >>= 1) bsum += __shfl_down(bsum, h, 64);   // wave sums by lane shuffles (fixed tree), then four values through LDS
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bsum;
-        __syncthreads();
-        if (threadIdx.x == 0) a.db_part[(size_t)c * st.first[FRCNN_MAX_LEVELS] + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    }
     const size_t plane = (size_t)a.C * a.Ttot, col0 = (size_t)c * a.Ttot + a.lv[l].off;
     const int n_tiles = nr * wt;
+    float bsum = 0.0f;                                                    // this thread's share of the strip's gradient sum (MODE 1 with a.db_part)
 #pragma unroll 1
     for (int u = 0; u < Wn<M>::TPB / 256; ++u) {
         const int e = u * 256 + (int)threadIdx.x;
@@ -592,6 +587,36 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
                 const float2 p = *(const float2 *)(row + q);
                 d[r][q] = p.x; d[r][q + 1] = p.y;
             }
+        }
+        if (mk) {
+            const unsigned short *wc = &wb[(rr + 1) * (wt + 2) + txl + 1];      // this tile's word; its neighbours at +-1 and +-(wt + 2)
+            if (MODE == 1) {
+                const unsigned w0 = wc[0];
+#pragma unroll
+                for (int r = 0; r < IN; ++r)
+#pragma unroll
+                    for (int q = 0; q < IN; ++q) d[r][q] = ((w0 >> (r * M + q)) & 1u) ? d[r][q] : 0.0f;
+            } else {
+                unsigned w9[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) w9[i][j] = wc[(i - 1) * (wt + 2) + (j - 1)];
+#pragma unroll
+                for (int r = 0; r < IN; ++r)
+#pragma unroll
+                    for (int q = 0; q < IN; ++q) {
+                        const int tr = r == 0 ? 0 : (r <= M ? 1 : 2), br = r == 0 ? M - 1 : (r <= M ? r - 1 : 0);      // patch row r = image row m ty - 1 + r
+                        const int tc = q == 0 ? 0 : (q <= M ? 1 : 2), bc = q == 0 ? M - 1 : (q <= M ? q - 1 : 0);
+                        d[r][q] = ((w9[tr][tc] >> (br * M + bc)) & 1u) ? d[r][q] : 0.0f;
+                    }
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int r = 0; r < IN; ++r)
+#pragma unroll
+                for (int q = 0; q < IN; ++q) bsum += d[r][q];               // the tile's share of the bias gradient (masked values, every position once)
         }
         float wv[A][IN];                                                  // columns first: wv[.][q] = T d[.][q]
 #pragma unroll
@@ -611,6 +636,17 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 #pragma unroll
             for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];
         }
+    }
+    // bias gradient (MODE 1 with a.db_part): the windows have no halo, so the strips of a channel partition its positions: strip sums -> partials
+    // [channel][strip], which the last launch of the weight gradient (rpn_wino_dw_kernel) adds in strip order.  (A ticket + last-arriver
+    // sum inside this launch held every block's resources for the round trips of its thread 0: +30 % on the whole transform.)
+    if (MODE == 1 && a.db_part) {
+        __shared__ float red[4];
+#pragma unroll
+        for (int h = 32; h > 0; h >>= 1) bsum += __shfl_down(bsum, h, 64);   // wave sums by lane shuffles (fixed tree), then four values through LDS
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bsum;
+        __syncthreads();
+        if (threadIdx.x == 0) a.db_part[(size_t)c * st.first[FRCNN_MAX_LEVELS] + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
     if (a.zero_pad && strip == 0) {                                       // this level's padding columns of channel c, all planes
         const int T = a.lv[l].T, Tp = (T + CF_NT - 1) / CF_NT * CF_NT, np = Tp - T;
@@ -646,6 +682,7 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     const float b = a.bias ? a.bias[c] : 0.0f;
     const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
     float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(M * ty) * W + M * tx;
+    unsigned word = 0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         float o[M];
@@ -655,10 +692,14 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
             for (int j = 0; j < M; ++j) {
                 float v = o[j] + b;
                 if (a.relu) v = fmaxf(v, 0.0f);
-                if (M * tx + j < W) y[(size_t)i * W + j] = v;
+                if (M * tx + j < W) {
+                    y[(size_t)i * W + j] = v;
+                    word |= (v > 0.0f) ? (1u << (i * M + j)) : 0u;
+                }
             }
         }
     }
+    if (a.bits_out) a.bits_out[at] = (unsigned short)word;
 }
 
 // dW[co][ci] = G^T dU G: (m + 2)^2 -> 3 x 3, thread = (co, ci); n = Cout * Cin
@@ -1246,17 +1287,17 @@ static bool cf_use_direct()
     return d;
 }
 
-static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels)
+static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const *out, const int *H, const int *W, int n_levels)
 {
     long long off = 0;
     for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
         if (l < n_levels) {
             const int tw = (W[l] + M - 1) / M, th = (H[l] + M - 1) / M;
-            a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, mask ? mask[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
+            a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
             off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
-        } else a->lv[l] = {nullptr, nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
+        } else a->lv[l] = {nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
-    a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr;
+    a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr; a->bits_out = nullptr; a->bits = nullptr;
     a->n_levels = n_levels; a->C = 0; a->Ttot = (int)off;
     return off;
 }
@@ -1286,7 +1327,7 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_
     size_t need = 0;
     for (int M = 2; M <= 4; M += 2) {                                // whichever tile size a call picks (the choice may be forced by the environment)
         WnArgs a;
-        const long long Ttot = wn_fill(&a, M, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
+        const long long Ttot = wn_fill(&a, M, nullptr, nullptr, H_host, W_host, n_levels);
         need = std::max(need, wn_carve(nullptr, Cin, Cout, M, Ttot).total);
     }
     return need;
@@ -1326,13 +1367,14 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
 // launches for all levels.  forward: K = Cin, M = Cout (+ bias, ReLU in the output transform);  data gradient: K = Cout, M = Cin, the
 // incoming gradient optionally masked by the forward's ReLU output
 template <int M>
-static int wn_run(const float *const *in, float *const *out, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                  const float *w, bool transposed, const float *bias, int relu, float *xt, void *workspace, hipStream_t s)
+static int wn_run(const float *const *in, float *const *out, const unsigned short *bits_in, const int *H, const int *W, int n_levels, int Cin, int Cout,
+                  const float *w, bool transposed, const float *bias, int relu, unsigned short *bits_out, float *xt, void *workspace, hipStream_t s)
 {
     constexpr int P = Wn<M>::P;
     const int K = transposed ? Cout : Cin, Mo = transposed ? Cin : Cout;
     WnArgs a;
-    const long long Ttot = wn_fill(&a, M, in, out, mask, H, W, n_levels);
+    const long long Ttot = wn_fill(&a, M, in, out, H, W, n_levels);
+    a.bits = bits_in;
     FRCNN_REQUIRE(Ttot < (1ll << 24) && (long long)P * std::max(K, Mo) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
     const int MT = Mo % CF_MT == 0 ? CF_MT : 64;                     // a 64-channel output side (conv1_2, the data gradient of conv2_1): 64-row tiles
@@ -1360,7 +1402,7 @@ static int wn_run(const float *const *in, float *const *out, const float *const 
         if (n_tiles >= 2ll * g.G && per * g.G * 100 <= n_tiles * 116) g.whole = 1;
     }
     { const int rc = wn_launch_gemm(false, MT, CF_NT, g, ws.part, ws.cnt, s); if (rc) return rc; }
-    a.C = Mo; a.bias = bias; a.relu = relu;
+    a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
     FRCNN_LAUNCH(rpn_wino_output_kernel<M>, dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
     return FRCNN_OK;
@@ -1384,15 +1426,22 @@ static int cf_check(const void *const *p0, const void *const *p1, const int *H, 
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *y_dev, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
-                                       const float *w_dev, const float *bias_dev, int relu, float *x_transformed_dev, void *workspace, size_t workspace_bytes,
-                                       void *stream)
+                                       const float *w_dev, const float *bias_dev, int relu, unsigned short *relu_bits_dev, float *x_transformed_dev, void *workspace,
+                                       size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, 64, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, x_transformed_dev, workspace, (hipStream_t)stream);
-    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, x_transformed_dev, workspace, (hipStream_t)stream);
+        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+}
+
+FRCNN_EXPORT size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || Cout <= 0) return 0;
+    WnArgs a;
+    return (size_t)Cout * (size_t)wn_fill(&a, wn_pick_m(H_host, W_host, n_levels), nullptr, nullptr, H_host, W_host, n_levels);
 }
 
 FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin)
@@ -1400,32 +1449,30 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_
     if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || Cin <= 0) return 0;
     const int M = wn_pick_m(H_host, W_host, n_levels);
     WnArgs a;
-    return (size_t)((M + 2) * (M + 2)) * (size_t)Cin * (size_t)wn_fill(&a, M, nullptr, nullptr, nullptr, H_host, W_host, n_levels);
+    return (size_t)((M + 2) * (M + 2)) * (size_t)Cin * (size_t)wn_fill(&a, M, nullptr, nullptr, H_host, W_host, n_levels);
 }
 
-FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const float *const *y_mask_dev, float *const *dx_dev, const int *H_host, const int *W_host,
+FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const unsigned short *relu_bits_dev, float *const *dx_dev, const int *H_host, const int *W_host,
                                             int n_levels, int Cin, int Cout, const float *w_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
     if (rc) return rc;
-    if (y_mask_dev)
-        for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_bwd_data: NULL mask level %d", l);
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, workspace, (hipStream_t)stream);
-    return wn_run<2>(dy_dev, dx_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, workspace, (hipStream_t)stream);
+        return wn_run<4>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream);
+    return wn_run<2>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream);
 }
 
 // weight gradient through the Winograd domain: V = B^T d B of the features and dM = A g A^T of the (masked) output gradient, both [xi][channel][t];
 // dU = sum over the tiles on the k-contiguous form of the stage's GEMM (K = Ttot); dW = G^T dU G: four launches for all levels (+ one for the
 // bias gradient)
 template <int M>
-static int wn_wgrad(const float *const *feats, const float *const *d_outs, const float *const *mask, const int *H, const int *W, int n_levels, int Cin, int Cout,
+static int wn_wgrad(const float *const *feats, const float *const *d_outs, const unsigned short *bits, const int *H, const int *W, int n_levels, int Cin, int Cout,
                     float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s)
 {
     constexpr int P = Wn<M>::P;
     WnArgs a;
-    const long long Ttot = wn_fill(&a, M, feats, nullptr, nullptr, H, W, n_levels);
+    const long long Ttot = wn_fill(&a, M, feats, nullptr, H, W, n_levels);
     FRCNN_REQUIRE(Ttot < (1ll << 24), "conv3x3_f32_wgrad: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
     const int MT = Cout % CF_MT == 0 ? CF_MT : 64, NW = Cin % CF_NT == 0 ? CF_NT : 64;
@@ -1442,7 +1489,8 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
         FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     }
     WnArgs g1 = a;                                                   // the output gradient (and its mask) as the transform's input
-    for (int l = 0; l < n_levels; ++l) { g1.lv[l].x = d_outs[l]; g1.lv[l].m = mask ? mask[l] : nullptr; }
+    for (int l = 0; l < n_levels; ++l) g1.lv[l].x = d_outs[l];
+    g1.bits = bits;
     g1.C = Cout;
     n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds);
     const int n_strips_dy = n_strips;
@@ -1460,18 +1508,16 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     return FRCNN_OK;
 }
 
-FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const float *const *y_mask_dev, const int *H_host, const int *W_host,
+FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const unsigned short *relu_bits_dev, const int *H_host, const int *W_host,
                                          int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, void *workspace,
                                          size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, 64, 64, dw_dev, workspace, workspace_bytes,
                       "conv3x3_f32_wgrad");
     if (rc) return rc;
-    if (y_mask_dev)
-        for (int l = 0; l < n_levels; ++l) FRCNN_REQUIRE(y_mask_dev[l], "conv3x3_f32_wgrad: NULL mask level %d", l);
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_wgrad<4>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
-    return wn_wgrad<2>(x_dev, dy_dev, y_mask_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+        return wn_wgrad<4>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+    return wn_wgrad<2>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
 }
 
 // ---- the RPN head's entry points: Cin = Cout = C, no bias (rpn_head.hip adds it), no mask; FRCNN_CONV_F32_DIRECT=1 routes them to the direct kernels
@@ -1479,7 +1525,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float 
                                            const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, nullptr, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_fwd");
     if (rc) return rc;

@@ -536,11 +536,11 @@ def rpn_conv_wgrad(feats, d_raws):
 CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
 
 
-def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False):
+def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False, relu_bits=False):
     if CONV_TRACE is not None:
         kind = "wgrad" if what.endswith("wgrad") else ("bwd_data" if what.endswith("bwd_data") else "fwd")
         CONV_TRACE.append({"kind": kind, "Cin": int(Cin), "Cout": int(Cout), "shapes": [(int(h), int(w)) for h, w in zip(H, W)], "mask": bool(mask),
-                           "bias": bool(bias), "cached": bool(cached)})
+                           "bias": bool(bias), "cached": bool(cached), "relu_bits": bool(relu_bits)})
 
 
 def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
@@ -625,8 +625,8 @@ def rpn_conv3x3(feats, w3):
 
 
 # ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
-def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False):
-    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached)
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False, relu_bits=False):
+    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached, relu_bits)
     Hh, Wh = _host_i32(H), _host_i32(W)
     nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
     if nb == 0:
@@ -650,9 +650,11 @@ def _conv3x3_levels(ts, Cc, name):
     return ts
 
 
-def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False):
+def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=False):
     """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd).
-    keep_transformed: also return the transformed activations (a flat fp32 tensor) for conv3x3_wgrad(..., x_transformed=)."""
+    keep_transformed: also return the transformed activations (a flat fp32 tensor) for conv3x3_wgrad(..., x_transformed=).
+    want_bits (with relu): also return the ReLU's sign pattern, one int16 word per (channel, output tile), for the gradient calls' relu_bits=.
+    Returns ys, or (ys, x_transformed | None, relu_bits | None) when either extra is asked for."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     if w.dim() != 4 or tuple(w.shape[2:]) != (3, 3):
@@ -664,34 +666,44 @@ def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False):
             raise ValueError("conv3x3: bias must be [Cout]")
     ys = [torch.empty((1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
     xp, yp = _ptr_list(xs), _ptr_list(ys)
-    xt = None
+    xt = bits = None
+    Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
     if keep_transformed:
-        Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
         xt = torch.empty((int(lib.frcnn_conv3x3_f32_xt_floats(_np_ptr(Hh), _np_ptr(Wh), len(xs), Cin)),), dtype=torch.float32, device=xs[0].device)
+    if want_bits:
+        if not relu:
+            raise ValueError("conv3x3_fwd: want_bits needs relu=True")
+        bits = torch.empty((int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(xs), Cout)),), dtype=torch.int16, device=xs[0].device)
     _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
-                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, _ptr(xt), ws, nws, st),
-                  bias=bias is not None)
-    return (ys, xt) if keep_transformed else ys
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, _ptr(bits), _ptr(xt), ws, nws, st),
+                  bias=bias is not None, relu_bits=bits is not None)
+    return (ys, xt, bits) if (keep_transformed or want_bits) else ys
 
 
-def conv3x3_bwd_data(dys, w, y_masks=None):
-    """Input gradient of conv3x3_fwd; y_masks = the forward's ReLU outputs (the gradient counts where they are > 0) or None."""
+def conv3x3_bwd_data(dys, w, relu_bits=None):
+    """Input gradient of conv3x3_fwd; relu_bits = the forward's sign words (the gradient counts where the ReLU output was > 0) or None."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     dys = _conv3x3_levels(dys, Cout, "d_out")
-    if y_masks is not None:
-        y_masks = _conv3x3_levels(y_masks, Cout, "mask")
-        if len(y_masks) != len(dys) or any(a.shape != b.shape for a, b in zip(dys, y_masks)):
-            raise ValueError("conv3x3_bwd_data: d_out and mask differ in shape")
+    relu_bits = _conv3x3_bits(relu_bits, dys, Cout)
     dxs = [torch.empty((1, Cin, d.shape[2], d.shape[3]), dtype=torch.float32, device=d.device) for d in dys]
     gp, xp = _ptr_list(dys), _ptr_list(dxs)
-    mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
     _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [d.shape[2] for d in dys], [d.shape[3] for d in dys], len(dys), Cin, Cout,
-                  dys[0].device, lambda H, W, ws, nws, st: (gp, mp, xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st), mask=y_masks is not None)
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st), mask=relu_bits is not None)
     return dxs
 
 
-def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False, x_transformed=None):
+def _conv3x3_bits(relu_bits, dys, Cout):
+    if relu_bits is None:
+        return None
+    relu_bits = _req(relu_bits, torch.int16, "relu_bits")
+    Hh, Wh = _host_i32([d.shape[2] for d in dys]), _host_i32([d.shape[3] for d in dys])
+    if relu_bits.numel() != int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(dys), Cout)):
+        raise ValueError("conv3x3: relu_bits does not belong to these shapes")
+    return relu_bits
+
+
+def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None):
     """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels.  x_transformed: what conv3x3_fwd(..., keep_transformed=True)
     returned for the same xs (the activations are then not transformed again)."""
     Cin, Cout = int(xs[0].shape[1]), int(dys[0].shape[1])
@@ -699,18 +711,14 @@ def conv3x3_wgrad(xs, dys, y_masks=None, want_bias=False, x_transformed=None):
     dys = _conv3x3_levels(dys, Cout, "d_out")
     if len(xs) != len(dys) or any(a.shape[2:] != b.shape[2:] for a, b in zip(xs, dys)):
         raise ValueError("conv3x3_wgrad: inputs and d_out differ in shape")
-    if y_masks is not None:
-        y_masks = _conv3x3_levels(y_masks, Cout, "mask")
-        if len(y_masks) != len(dys) or any(a.shape != b.shape for a, b in zip(dys, y_masks)):
-            raise ValueError("conv3x3_wgrad: d_out and mask differ in shape")
+    relu_bits = _conv3x3_bits(relu_bits, dys, Cout)
     dev = xs[0].device
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
     db = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_bias else None
     xp, gp = _ptr_list(xs), _ptr_list(dys)
-    mp = _ptr_list(y_masks) if y_masks is not None else C.c_void_p(0)
     _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
-                  lambda H, W, ws, nws, st: (xp, gp, mp, H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), ws, nws, st),
-                  mask=y_masks is not None, bias=want_bias, cached=x_transformed is not None)
+                  lambda H, W, ws, nws, st: (xp, gp, _ptr(relu_bits), H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), ws, nws, st),
+                  mask=relu_bits is not None, bias=want_bias, cached=x_transformed is not None)
     return dw, db
 
 
@@ -737,22 +745,21 @@ class _Conv3x3F32Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, relu, w, bias, x):
         # the transformed activations are kept for the weight gradient when there will be one (0.6 GB per VGG16 step; HBM is 288 GB)
-        keep = ctx.needs_input_grad[1] and int(w.shape[1]) % 64 == 0
-        if keep:
-            ys, xt = conv3x3_fwd([x], w, bias, relu, keep_transformed=True)
+        keep = bool(ctx.needs_input_grad[1]) and int(w.shape[1]) % 64 == 0
+        grads = any(ctx.needs_input_grad[1:])
+        if keep or (relu and grads):
+            ys, xt, bits = conv3x3_fwd([x], w, bias, relu, keep_transformed=keep, want_bits=bool(relu) and grads)
         else:
-            ys, xt = conv3x3_fwd([x], w, bias, relu), None
-        y = ys[0]
+            ys, xt, bits = conv3x3_fwd([x], w, bias, relu), None, None
         ctx.relu = bool(relu)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(w, x, y if relu else None, xt)
-        return y
+        ctx.save_for_backward(w, x, bits, xt)              # the ReLU's backward needs the sign words, not the activations
+        return ys[0]
 
     @staticmethod
     def backward(ctx, g):
-        w, x, y, xt = ctx.saved_tensors
+        w, x, mask, xt = ctx.saved_tensors
         g = g.contiguous()
-        mask = [y] if ctx.relu else None
         dx = conv3x3_bwd_data([g], w, mask)[0] if ctx.needs_input_grad[3] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):

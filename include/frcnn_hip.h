@@ -222,8 +222,10 @@ int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feat_levels, const float *co
  * are 2/3 of the training step's GPU time through the vendor library.  w [Cout, Cin, 3, 3] in the reference's layout.
  *   _fwd      : y[co] = act(bias[co] + sum_ci conv3x3(x[ci], w[co][ci])); bias may be NULL; act = ReLU when relu != 0 (the Conv2d + ReLU(inplace)
  *               pair of vgg16.features in one pass).  Cin a multiple of 32, Cout a multiple of 64 (64-row GEMM tiles where a side is not a multiple of 128).
- *   _bwd_data : dx[ci] = sum_co conv3x3(g[co], w[co][ci] flipped), g = dy where y_mask > 0 (y_mask_levels = the forward's ReLU outputs: autograd's
- *               threshold_backward folded into the input transform), or g = dy when y_mask_levels is NULL.  Cin a multiple of 64, Cout of 32.
+ *               relu_bits (optional, frcnn_conv3x3_f32_relu_bits_words(H, W, n_levels, Cout) uint16 words, caller-owned): the sign pattern of the
+ *               ReLU outputs, one word per (channel, output tile) -- all the backward needs of them, at 1/32 of their bytes.
+ *   _bwd_data : dx[ci] = sum_co conv3x3(g[co], w[co][ci] flipped), g = dy where the forward's relu_bits are set (autograd's threshold_backward
+ *               folded into the input transform), or g = dy when relu_bits is NULL.  Cin a multiple of 64, Cout of 32.
  *   _wgrad    : dw[co][ci][ky][kx] = sum over levels and positions of g[co](y, x) * x[ci](y + ky - 1, x + kx - 1) (fully overwritten); dbias[co] =
  *               sum of g[co] (NULL: not wanted).  Cin and Cout multiples of 64.
  * Workspace: frcnn_conv3x3_f32_workspace(H, W, n_levels, Cin, Cout) bytes, the same DEDICATED zero-before-first-use block as the RPN calls
@@ -233,11 +235,13 @@ size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_l
  * B^T d B there instead of in the scratch workspace, and a later _wgrad of the same layer given the same buffer skips transforming them
  * again -- 0.6 GB per VGG16 step on a 288 GB device for one launch less per layer.  NULL: scratch / transform again. */
 size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin);
+size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout);
 int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
-                          const float *w, const float *bias, int relu, float *x_transformed, void *workspace, size_t workspace_bytes, void *stream);
-int frcnn_conv3x3_f32_bwd_data(const float *const *dy_levels, const float *const *y_mask_levels, float *const *dx_levels, const int *H_host, const int *W_host,
+                          const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int frcnn_conv3x3_f32_bwd_data(const float *const *dy_levels, const unsigned short *relu_bits, float *const *dx_levels, const int *H_host, const int *W_host,
                                int n_levels, int Cin, int Cout, const float *w, void *workspace, size_t workspace_bytes, void *stream);
-int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy_levels, const float *const *y_mask_levels, const int *H_host, const int *W_host,
+int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy_levels, const unsigned short *relu_bits, const int *H_host, const int *W_host,
                             int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, void *workspace, size_t workspace_bytes,
                             void *stream);
 

@@ -1565,11 +1565,11 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     xd, dyd, wd = [x.to(DEV) for x in xs], [t.to(DEV) for t in dys], wt.to(DEV)
     bd = b.to(DEV) if use_bias else None
     pre = [F.conv2d(x.double(), wt.double(), b.double() if use_bias else None, padding=1) for x in xs]
-    ys = ops.conv3x3_fwd(xd, wd, bd, relu)
+    ys, _, bits = ops.conv3x3_fwd(xd, wd, bd, relu, want_bits=relu, keep_transformed=not relu)
     for y, p in zip(ys, pre):
         r = p.clamp_min(0) if relu else p
         assert y.shape == r.shape and float((y.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(p.abs().max()))
-    assert all(torch.equal(a, c) for a, c in zip(ys, ops.conv3x3_fwd(xd, wd, bd, relu)))          # bit-reproducible
+    assert all(torch.equal(a, c) for a, c in zip(ys, ops.conv3x3_fwd(xd, wd, bd, relu)))          # bit-reproducible, with or without the extras
     if not grads:
         return
     masks = [(y.cpu() > 0) for y in ys] if relu else [torch.ones_like(p, dtype=torch.bool) for p in pre]
@@ -1578,26 +1578,26 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
         assert int(flips.sum()) == 0 or float(p[flips].abs().max()) < 1e-5                          # sign disagreements only at rounding-level zeros
     gs = [t.double() * m for t, m in zip(dys, masks)]
     dx_ref = [F.conv_transpose2d(t, wt.double(), None, padding=1) for t in gs]
-    dx = ops.conv3x3_bwd_data(dyd, wd, ys if relu else None)
+    dx = ops.conv3x3_bwd_data(dyd, wd, bits)
     for o, r in zip(dx, dx_ref):
         assert o.shape == r.shape and float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
-    assert all(torch.equal(a, c) for a, c in zip(dx, ops.conv3x3_bwd_data(dyd, wd, ys if relu else None)))
+    assert all(torch.equal(a, c) for a, c in zip(dx, ops.conv3x3_bwd_data(dyd, wd, bits)))
     w_ref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64)
     b_ref = torch.zeros(Cout, dtype=torch.float64)
     for x, t in zip(xs, gs):
         w_ref += torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), t, padding=1)
         b_ref += t.sum(dim=(0, 2, 3))
-    dw, db = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True)
+    dw, db = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True)
     assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
     assert float((db.double().cpu() - b_ref).abs().max()) < 1e-4 * max(1.0, float(b_ref.abs().max()))
-    dw2, db2 = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True)
+    dw2, db2 = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
     # the forward can keep its transformed activations for the weight gradient: same outputs, same gradient, one launch less
-    ys_k, xt = ops.conv3x3_fwd(xd, wd, bd, relu, keep_transformed=True)
+    ys_k, xt, _ = ops.conv3x3_fwd(xd, wd, bd, relu, keep_transformed=True)
     assert all(torch.equal(a, c) for a, c in zip(ys, ys_k))
     from faster_rcnn_pytorch_amd import _lib
     _lib.prof_reset(); _lib.prof_enable(True)
-    dw3, db3 = ops.conv3x3_wgrad(xd, dyd, ys if relu else None, want_bias=True, x_transformed=xt)
+    dw3, db3 = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True, x_transformed=xt)
     _lib.prof_enable(False)
     assert torch.equal(dw, dw3) and torch.equal(db, db3)
     assert _lib.prof_report()["rpn_wino_input_kernel"][1] == 1                                     # only the output gradient was transformed
@@ -1654,16 +1654,16 @@ for Cin, Cout, shapes in ((128, 256, [(96, 130)]), (256, 128, [(9, 14), (30, 5),
     b = torch.randn(Cout, generator=g) * 0.2
     dys = [torch.randn(1, Cout, h, w, generator=g) for h, w in shapes]
     xd, dyd, wd, bd = [x.to(dev) for x in xs], [t.to(dev) for t in dys], wt.to(dev), b.to(dev)
-    ys = ops.conv3x3_fwd(xd, wd, bd, True)
+    ys, _, bits = ops.conv3x3_fwd(xd, wd, bd, True, want_bits=True)
     pre = [F.conv2d(x.double(), wt.double(), b.double(), padding=1) for x in xs]
     for y, p in zip(ys, pre):
         assert float((y.double().cpu() - p.clamp_min(0)).abs().max()) < tol * max(1.0, float(p.abs().max()))
     gs = [t.double() * (y.cpu() > 0) for t, y in zip(dys, ys)]
-    dx = ops.conv3x3_bwd_data(dyd, wd, ys)
+    dx = ops.conv3x3_bwd_data(dyd, wd, bits)
     for o, t in zip(dx, gs):
         r = F.conv_transpose2d(t, wt.double(), None, padding=1)
         assert float((o.double().cpu() - r).abs().max()) < tol * max(1.0, float(r.abs().max()))
-    dw, db = ops.conv3x3_wgrad(xd, dyd, ys, want_bias=True)
+    dw, db = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True)
     w_ref = sum(torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), t, padding=1) for x, t in zip(xs, gs))
     b_ref = sum(t.sum(dim=(0, 2, 3)) for t in gs)
     assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))

@@ -18,10 +18,10 @@ def main():
         w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.02
         b = torch.randn(Cout, device=dev)
         dy = torch.randn(1, Cout, H, W, device=dev)
-        y = ops.conv3x3_fwd([x], w, b, True)[0]
+        bits = ops.conv3x3_fwd([x], w, b, True, want_bits=True)[2]
         print("%d -> %d on %d x %d" % (Cin, Cout, H, W))
-        for name, fn in (("fwd", lambda: ops.conv3x3_fwd([x], w, b, True)), ("bwd_data", lambda: ops.conv3x3_bwd_data([dy], w, [y])),
-                         ("wgrad", lambda: ops.conv3x3_wgrad([x], [dy], [y], want_bias=True))):
+        for name, fn in (("fwd", lambda: ops.conv3x3_fwd([x], w, b, True)), ("bwd_data", lambda: ops.conv3x3_bwd_data([dy], w, bits)),
+                         ("wgrad", lambda: ops.conv3x3_wgrad([x], [dy], bits, want_bias=True))):
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
