@@ -155,18 +155,19 @@ def wino_work(calls):
         P = (m + 2) ** 2
         Tp = sum(-(-(((h + m - 1) // m) * ((w + m - 1) // m)) // 128) * 128 for h, w in c["shapes"])
         bits = 2 * Cout * Tp if c.get("mask") else 0                    # the ReLU's sign words: one uint16 per (channel, tile)
+        HWo = sum((h // 2) * (w // 2) for h, w in c["shapes"]) if c.get("pooled") else HW     # fused max-pool: outputs / incoming gradients at the pooled size
         conv_flops += 18 * Cin * Cout * HW
         add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
         if c["kind"] == "wgrad":
             if not c.get("cached"):
                 add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
-            add("rpn_wino_input_kernel", 4 * Cout * HW + bits + 4 * P * Cout * Tp)        # A g A^T of the (masked) output gradient
+            add("rpn_wino_input_kernel", 4 * Cout * HWo + bits + 4 * P * Cout * Tp)       # A g A^T of the (masked, possibly pooled) output gradient
             add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)                           # (the bias gradient rides in the output gradient's transform)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
             add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
-            add("rpn_wino_input_kernel", 4 * K * HW + (bits if c["kind"] == "bwd_data" else 0) + 4 * P * K * Tp)
-            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * HW + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
+            add("rpn_wino_input_kernel", 4 * K * (HWo if c["kind"] == "bwd_data" else HW) + (bits if c["kind"] == "bwd_data" else 0) + 4 * P * K * Tp)
+            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * (HWo if c["kind"] == "fwd" else HW) + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
     return tot, conv_flops
 
 

@@ -500,10 +500,16 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
 // Padding columns of a level (tiles past its last) are written as zeros only when a.zero_pad is set (weight gradient: the product sums
 // over the tiles); forward / data gradient never read the product's columns there, and a column depends on the same column of V only.
 struct WnStrips { int first[FRCNN_MAX_LEVELS + 1]; int segs[FRCNN_MAX_LEVELS]; int rows[FRCNN_MAX_LEVELS]; };   // first strip, strips per tile row, tile rows per strip
-template <int M, int MODE>
+// POOL (m = 4, gradients only): the forward fused ReLU + max_pool2d(2, 2) into its output transform (rpn_wino_output_kernel<4, true>), so the
+// incoming gradient is at the POOLED resolution and the words carry, per 2 x 2 window of the tile, the position of the maximum and whether
+// it was positive (3 bits each): the window staged is the pooled one (half the rows and columns), and a thread rebuilds its full-resolution
+// patch from it -- max_pool2d's and the ReLU's backward without the full-resolution gradient ever existing in memory.
+template <int M, int MODE, bool POOL>
 __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips st, float *__restrict__ V)
 {
+    static_assert(!POOL || M == 4, "pooled gradients: 4 x 4 tiles only");
     constexpr int A = Wn<M>::A, P = Wn<M>::P, WT = Wn<M>::WT, HALO = MODE == 0 ? 1 : 0, IN = MODE == 0 ? A : M;
+    constexpr int SM = POOL ? 2 : M, SIN = POOL ? (MODE == 0 ? 4 : 2) : IN;       // staged pixels per tile side; staged patch side
     extern __shared__ __attribute__((aligned(8))) float s[];          // the largest window of the launch's levels (wn_strips): <= Wn<M>::LDS floats
     const int c = blockIdx.y;
     int l = 0;
@@ -512,9 +518,10 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
     const int strip = blockIdx.x - st.first[l], segs = st.segs[l], R = st.rows[l];
     const int H = a.lv[l].H, W = a.lv[l].W, tw = a.lv[l].tw, th = (H + M - 1) / M;
     const int ty0 = (strip / segs) * R, tx0 = (strip % segs) * WT, wt = min(WT, tw - tx0), nr = min(R, th - ty0);
-    const float *x = a.lv[l].x + (size_t)c * H * W;
+    const int Hs = POOL ? H >> 1 : H, Ws = POOL ? W >> 1 : W;              // the staged tensor's size (pooled: floor, like max_pool2d)
+    const float *x = a.lv[l].x + (size_t)c * Hs * Ws;
     const unsigned short *mk = a.bits ? a.bits + (size_t)c * a.Ttot + a.lv[l].off : nullptr;    // this channel's sign words of the level, [ty * tw + tx]
-    const int x0 = M * tx0 - HALO, y0 = M * ty0 - HALO, ncol = M * wt + 2 * HALO, nrow = M * nr + 2 * HALO;      // the strip's input window
+    const int x0 = SM * tx0 - HALO, y0 = SM * ty0 - HALO, ncol = SM * wt + 2 * HALO, nrow = SM * nr + 2 * HALO;      // the strip's input window
     // the sign words of the strip's tiles and of the ring of tiles around it (MODE 0's halo pixels belong to those): (nr + 2) x (wt + 2) words in
     // LDS; a thread then masks its patch with nine (MODE 0) or one (MODE 1) of them at compile-time bit positions.  (Looked up per staged
     // element -- one 2-byte load each -- the mask cost as much as the 4-byte float mask it replaced: the staging is load-instruction bound.)
@@ -532,14 +539,14 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int r = wave; r < nrow; r += 4) {
             const int yy = y0 + r;
-            const bool row_in = yy >= 0 && yy < H;
-            const float *xr = x + (size_t)yy * W + x0;
+            const bool row_in = yy >= 0 && yy < Hs;
+            const float *xr = x + (size_t)yy * Ws + x0;
             for (int qb = lane; qb < ncol; qb += 64 * 8) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = qb + 64 * j, xx = x0 + q;
-                    v[j] = (row_in && q < ncol && xx >= 0 && xx < W) ? xr[q] : 0.0f;
+                    v[j] = (row_in && q < ncol && xx >= 0 && xx < Ws) ? xr[q] : 0.0f;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
                 r += ((r + 1) * ncol <= e) ? 1 : 0;
                 const int q = e - r * ncol, yy = y0 + r, xx = x0 + q;
                 at[j] = e < n_el ? e : -1;
-                v[j] = (e < n_el && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[yy * W + xx] : 0.0f;
+                v[j] = (e < n_el && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) ? x[yy * Ws + xx] : 0.0f;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j)
@@ -578,17 +585,44 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         const int e = u * 256 + (int)threadIdx.x;
         if (e >= n_tiles) break;
         const int rr = e / wt, txl = e - rr * wt;
-        float d[IN][IN];
+        float d[IN][IN], sp[SIN][SIN];
 #pragma unroll
-        for (int r = 0; r < IN; ++r) {
-            const float *row = &s[(M * rr + r) * ncol + M * txl];          // even offset: ncol and M are even
+        for (int r = 0; r < SIN; ++r) {
+            const float *row = &s[(SM * rr + r) * ncol + SM * txl];        // even offset: ncol and SM are even
 #pragma unroll
-            for (int q = 0; q < IN; q += 2) {
+            for (int q = 0; q < SIN; q += 2) {
                 const float2 p = *(const float2 *)(row + q);
-                d[r][q] = p.x; d[r][q + 1] = p.y;
+                sp[r][q] = p.x; sp[r][q + 1] = p.y;
             }
         }
-        if (mk) {
+        if (POOL) {
+            // full-resolution pixel (r, q) of the patch = in-tile pixel (iy, ix) of tile (tr, tc) of the 3 x 3 neighbourhood; it gets the pooled
+            // gradient of its window iff the window's word says "maximum here, and positive"
+            const unsigned short *wc = &wb[(rr + 1) * (wt + 2) + txl + 1];
+            unsigned w9[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) w9[i][j] = (MODE == 1 && (i != 1 || j != 1)) ? 0u : (unsigned)wc[(i - 1) * (wt + 2) + (j - 1)];
+#pragma unroll
+            for (int r = 0; r < IN; ++r)
+#pragma unroll
+                for (int q = 0; q < IN; ++q) {
+                    const int fr = MODE == 0 ? r - 1 : r, fq = MODE == 0 ? q - 1 : q;                 // row / column relative to the tile's first
+                    const int tr = fr < 0 ? 0 : (fr < 4 ? 1 : 2), iy = fr < 0 ? 3 : (fr < 4 ? fr : 0);
+                    const int tc = fq < 0 ? 0 : (fq < 4 ? 1 : 2), ix = fq < 0 ? 3 : (fq < 4 ? fq : 0);
+                    const int k = (iy >> 1) * 2 + (ix >> 1), pos = (iy & 1) * 2 + (ix & 1);
+                    const unsigned w3 = (w9[tr][tc] >> (3 * k)) & 7u;
+                    const float g = sp[MODE == 0 ? (r + 1) >> 1 : r >> 1][MODE == 0 ? (q + 1) >> 1 : q >> 1];
+                    d[r][q] = (w3 == (4u | (unsigned)pos)) ? g : 0.0f;
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < IN; ++r)
+#pragma unroll
+                for (int q = 0; q < IN; ++q) d[r][q] = sp[r][q];
+        }
+        if (!POOL && mk) {
             const unsigned short *wc = &wb[(rr + 1) * (wt + 2) + txl + 1];      // this tile's word; its neighbours at +-1 and +-(wt + 2)
             if (MODE == 1) {
                 const unsigned w0 = wc[0];
@@ -657,9 +691,12 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
     }
 }
 
-template <int M>
+// POOL (m = 4): ReLU + max_pool2d(2, 2) in the same pass -- the tile's four 2 x 2 windows -> the pooled outputs [C][H/2][W/2] (floor) and, per window,
+// 3 bits of the word: the position of the (first) maximum and whether it was positive; the full-resolution activations are never written.
+template <int M, bool POOL>
 __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ Mp)
 {
+    static_assert(!POOL || M == 4, "fused pooling: 4 x 4 tiles only");
     constexpr int A = Wn<M>::A;
     const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
     if (t >= a.Ttot) return;
@@ -681,8 +718,37 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     }
     const float b = a.bias ? a.bias[c] : 0.0f;
     const int H = a.lv[l].H, W = a.lv[l].W, ty = tl / a.lv[l].tw, tx = tl - ty * a.lv[l].tw;
-    float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(M * ty) * W + M * tx;
     unsigned word = 0;
+    if (POOL) {
+        float v[M][M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            float o[M];
+            wn_at<M>(s[i], o);
+#pragma unroll
+            for (int j = 0; j < M; ++j) v[i][j] = fmaxf(o[j] + b, 0.0f);
+        }
+        const int Hp = H >> 1, Wp = W >> 1;
+        float *yp = a.lv[l].y + (size_t)c * Hp * Wp;
+#pragma unroll
+        for (int wi = 0; wi < 2; ++wi)
+#pragma unroll
+            for (int wj = 0; wj < 2; ++wj) {
+                const int py = 2 * ty + wi, px = 2 * tx + wj;
+                if (py < Hp && px < Wp) {                                     // floor mode: a window exists only with all four of its pixels
+                    float mx = v[2 * wi][2 * wj];
+                    unsigned arg = 0;
+                    if (v[2 * wi][2 * wj + 1] > mx) { mx = v[2 * wi][2 * wj + 1]; arg = 1; }      // scan order, strict >: the first maximum, as max_pool2d
+                    if (v[2 * wi + 1][2 * wj] > mx) { mx = v[2 * wi + 1][2 * wj]; arg = 2; }
+                    if (v[2 * wi + 1][2 * wj + 1] > mx) { mx = v[2 * wi + 1][2 * wj + 1]; arg = 3; }
+                    yp[(size_t)py * Wp + px] = mx;
+                    word |= (arg | (mx > 0.0f ? 4u : 0u)) << (3 * (wi * 2 + wj));
+                }
+            }
+        if (a.bits_out) a.bits_out[at] = (unsigned short)word;
+        return;
+    }
+    float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(M * ty) * W + M * tx;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         float o[M];
@@ -1339,7 +1405,7 @@ FRCNN_EXPORT size_t frcnn_rpn_conv3x3_f32_workspace(const int *H_host, const int
 }
 
 template <int M>
-static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, long long channels, int halo, size_t *lds_bytes)
+static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, long long channels, int halo, size_t *lds_bytes, int sm = M)
 {
     int n_strips = 0;
     for (int per_block = Wn<M>::TPB; per_block >= 256; per_block /= 2) {       // the largest strips that still give the chip >= 4096 workgroups
@@ -1357,7 +1423,7 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
     size_t fl = 0;                                                   // LDS: the largest (M R + 2 halo)(M wt + 2 halo) window of the levels
     for (int l = 0; l < n_levels; ++l) {
         const int wt = std::min(a.lv[l].tw, Wn<M>::WT), th = (H[l] + M - 1) / M, nr = std::min(st->rows[l], th);
-        fl = std::max(fl, (size_t)(M * nr + 2 * halo) * (size_t)(M * wt + 2 * halo));
+        fl = std::max(fl, (size_t)(sm * nr + 2 * halo) * (size_t)(sm * wt + 2 * halo));      // sm = staged pixels per tile side (2 for pooled gradients)
     }
     *lds_bytes = fl * sizeof(float);
     return n_strips;
@@ -1368,8 +1434,10 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
 // incoming gradient optionally masked by the forward's ReLU output
 template <int M>
 static int wn_run(const float *const *in, float *const *out, const unsigned short *bits_in, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                  const float *w, bool transposed, const float *bias, int relu, unsigned short *bits_out, float *xt, void *workspace, hipStream_t s)
+                  const float *w, bool transposed, const float *bias, int relu, unsigned short *bits_out, float *xt, void *workspace, hipStream_t s,
+                  bool pooled = false)
 {
+    // relu (forward): 0 none, 1 ReLU, 2 ReLU + max_pool2d(2, 2);  pooled (data gradient): `in` is at the pooled resolution, bits_in are pool words
     constexpr int P = Wn<M>::P;
     const int K = transposed ? Cout : Cin, Mo = transposed ? Cin : Cout;
     WnArgs a;
@@ -1390,8 +1458,10 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     a.zero_pad = xt ? 1 : 0;
     WnStrips st;
     size_t lds = 0;
-    const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds);
-    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
+    const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds, pooled ? 2 : M);
+    if (pooled) {
+        if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 0, true>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
+    } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0, false>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.U, Vb, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
                 n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
@@ -1403,7 +1473,9 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     }
     { const int rc = wn_launch_gemm(false, MT, CF_NT, g, ws.part, ws.cnt, s); if (rc) return rc; }
     a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
-    FRCNN_LAUNCH(rpn_wino_output_kernel<M>, dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
+    if (relu == 2) {
+        if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_output_kernel<4, true>), dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
+    } else FRCNN_LAUNCH((rpn_wino_output_kernel<M, false>), dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_output_kernel");
     return FRCNN_OK;
 }
@@ -1432,9 +1504,18 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *
     int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, 64, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
     if (rc) return rc;
+    FRCNN_REQUIRE(relu >= 0 && relu <= 2, "conv3x3_f32_fwd: relu = %d (0 none, 1 ReLU, 2 ReLU + max_pool2d(2, 2))", relu);
+    if (relu == 2 && wn_pick_m(H_host, W_host, n_levels) != 4)
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_fwd: the fused max-pool needs the 4 x 4 tile (frcnn_conv3x3_f32_tile_size)");
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
         return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
     return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+}
+
+FRCNN_EXPORT int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_levels)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS) return 0;
+    return wn_pick_m(H_host, W_host, n_levels);
 }
 
 FRCNN_EXPORT size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout)
@@ -1453,13 +1534,17 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const unsigned short *relu_bits_dev, float *const *dx_dev, const int *H_host, const int *W_host,
-                                            int n_levels, int Cin, int Cout, const float *w_dev, void *workspace, size_t workspace_bytes, void *stream)
+                                            int n_levels, int Cin, int Cout, const float *w_dev, int pooled, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream);
+    if (pooled && (!relu_bits_dev || wn_pick_m(H_host, W_host, n_levels) != 4))
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_bwd_data: a pooled gradient needs the forward's words and the 4 x 4 tile");
+    if (wn_pick_m(H_host, W_host, n_levels) == 4)
+        return wn_run<4>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream,
+                         pooled != 0);
     return wn_run<2>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream);
 }
 
@@ -1468,7 +1553,7 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const un
 // bias gradient)
 template <int M>
 static int wn_wgrad(const float *const *feats, const float *const *d_outs, const unsigned short *bits, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                    float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s)
+                    float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s, bool pooled = false)
 {
     constexpr int P = Wn<M>::P;
     WnArgs a;
@@ -1485,19 +1570,21 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     int n_strips = 0;
     if (!xt) {                                                       // the forward did not keep B^T d B of the activations: transform them again
         n_strips = wn_strips<M>(&st, a, H, n_levels, Cin, 1, &lds);
-        FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0>), dim3((unsigned)n_strips, (unsigned)Cin), dim3(256), lds, s, a, st, ws.V);
+        FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0, false>), dim3((unsigned)n_strips, (unsigned)Cin), dim3(256), lds, s, a, st, ws.V);
         FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     }
     WnArgs g1 = a;                                                   // the output gradient (and its mask) as the transform's input
     for (int l = 0; l < n_levels; ++l) g1.lv[l].x = d_outs[l];
     g1.bits = bits;
     g1.C = Cout;
-    n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds);
+    n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds, pooled ? 2 : M);
     const int n_strips_dy = n_strips;
     FRCNN_REQUIRE(!dbias || (size_t)Cout * n_strips_dy <= (size_t)C9 * C9 * 9, "conv3x3_f32_wgrad: %d strips are too many for the bias partials", n_strips_dy);
     if (dbias) g1.db_part = ws.wt;                                   // the bias gradient's strip partials ride in this launch (in the direct form's weight
                                                                      // buffer, idle in this form) and are added up by the last launch
-    FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
+    if (pooled) {
+        if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 1, true>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
+    } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1, false>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
                 (int)std::min<long long>(cf_ranges(), units), 0};
@@ -1509,14 +1596,16 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const unsigned short *relu_bits_dev, const int *H_host, const int *W_host,
-                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, void *workspace,
+                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, int pooled, void *workspace,
                                          size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, 64, 64, dw_dev, workspace, workspace_bytes,
                       "conv3x3_f32_wgrad");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_wgrad<4>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+        return wn_wgrad<4>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream,
+                           pooled != 0);
+    if (pooled) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_wgrad: a pooled gradient needs the forward's words and the 4 x 4 tile");
     return wn_wgrad<2>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
 }
 
@@ -1536,7 +1625,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
                                                 int C, const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, 0, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace,
                       workspace_bytes, "rpn_conv3x3_f32_bwd_data");
     if (rc) return rc;
@@ -1551,7 +1640,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, cons
                                              int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, nullptr, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, dw_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_wgrad");
     if (rc) return rc;

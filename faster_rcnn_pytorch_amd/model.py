@@ -69,8 +69,11 @@ class VGGExtractor(nn.Sequential):
             if (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1) and m.dilation == (1, 1)
                     and m.groups == 1 and m.bias is not None and not torch.is_autocast_enabled() and ops.conv3x3_supported(x, m.weight)):
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                x = ops.conv3x3(x, m.weight, m.bias, relu=fuse)
-                i += 2 if fuse else 1
+                p = mods[i + 2] if fuse and i + 2 < len(mods) else None
+                pool = (isinstance(p, nn.MaxPool2d) and p.kernel_size in (2, (2, 2)) and p.stride in (2, (2, 2)) and p.padding in (0, (0, 0))
+                        and p.dilation in (1, (1, 1)) and not p.ceil_mode and not p.return_indices and ops.conv3x3_pool_supported(x))
+                x = ops.conv3x3(x, m.weight, m.bias, relu=fuse, pool=pool)      # conv + ReLU (+ the 2 x 2 max-pool behind it) in one stage call
+                i += 3 if pool else (2 if fuse else 1)
                 continue
             x = m(x)
             i += 1

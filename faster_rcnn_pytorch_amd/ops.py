@@ -536,11 +536,11 @@ def rpn_conv_wgrad(feats, d_raws):
 CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
 
 
-def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False, relu_bits=False):
+def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False, relu_bits=False, pooled=False):
     if CONV_TRACE is not None:
         kind = "wgrad" if what.endswith("wgrad") else ("bwd_data" if what.endswith("bwd_data") else "fwd")
         CONV_TRACE.append({"kind": kind, "Cin": int(Cin), "Cout": int(Cout), "shapes": [(int(h), int(w)) for h, w in zip(H, W)], "mask": bool(mask),
-                           "bias": bool(bias), "cached": bool(cached), "relu_bits": bool(relu_bits)})
+                           "bias": bool(bias), "cached": bool(cached), "relu_bits": bool(relu_bits), "pooled": bool(pooled)})
 
 
 def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
@@ -625,8 +625,8 @@ def rpn_conv3x3(feats, w3):
 
 
 # ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
-def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False, relu_bits=False):
-    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached, relu_bits)
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False, relu_bits=False, pooled=False):
+    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached, relu_bits, pooled)
     Hh, Wh = _host_i32(H), _host_i32(W)
     nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
     if nb == 0:
@@ -650,10 +650,11 @@ def _conv3x3_levels(ts, Cc, name):
     return ts
 
 
-def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=False):
+def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=False, pool=False):
     """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd).
     keep_transformed: also return the transformed activations (a flat fp32 tensor) for conv3x3_wgrad(..., x_transformed=).
     want_bits (with relu): also return the ReLU's sign pattern, one int16 word per (channel, output tile), for the gradient calls' relu_bits=.
+    pool (with relu): max_pool2d(2, 2) in the same pass -- ys are [1,Cout,h//2,w//2] and the words describe the pooling windows.
     Returns ys, or (ys, x_transformed | None, relu_bits | None) when either extra is asked for."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
@@ -664,7 +665,9 @@ def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=
         bias = _req(bias, name="bias")
         if tuple(bias.shape) != (Cout,):
             raise ValueError("conv3x3: bias must be [Cout]")
-    ys = [torch.empty((1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
+    if pool and not relu:
+        raise ValueError("conv3x3_fwd: pool needs relu=True")
+    ys = [torch.empty((1, Cout, x.shape[2] // 2, x.shape[3] // 2) if pool else (1, Cout, x.shape[2], x.shape[3]), dtype=torch.float32, device=x.device) for x in xs]
     xp, yp = _ptr_list(xs), _ptr_list(ys)
     xt = bits = None
     Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
@@ -675,50 +678,63 @@ def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=
             raise ValueError("conv3x3_fwd: want_bits needs relu=True")
         bits = torch.empty((int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(xs), Cout)),), dtype=torch.int16, device=xs[0].device)
     _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
-                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, _ptr(bits), _ptr(xt), ws, nws, st),
-                  bias=bias is not None, relu_bits=bits is not None)
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), (2 if pool else 1) if relu else 0, _ptr(bits), _ptr(xt), ws, nws, st),
+                  bias=bias is not None, relu_bits=bits is not None, pooled=bool(pool))
     return (ys, xt, bits) if (keep_transformed or want_bits) else ys
 
 
-def conv3x3_bwd_data(dys, w, relu_bits=None):
-    """Input gradient of conv3x3_fwd; relu_bits = the forward's sign words (the gradient counts where the ReLU output was > 0) or None."""
+def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None):
+    """Input gradient of conv3x3_fwd; relu_bits = the forward's words (the gradient counts where the ReLU output was > 0) or None.
+    pooled_from = [(h, w), ...]: the forward ran with pool=True on maps of that size; dys are at the pooled resolution."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     dys = _conv3x3_levels(dys, Cout, "d_out")
-    relu_bits = _conv3x3_bits(relu_bits, dys, Cout)
-    dxs = [torch.empty((1, Cin, d.shape[2], d.shape[3]), dtype=torch.float32, device=d.device) for d in dys]
+    hw = _conv3x3_full_sizes(dys, pooled_from)
+    relu_bits = _conv3x3_bits(relu_bits, hw, Cout)
+    dxs = [torch.empty((1, Cin, h, w_), dtype=torch.float32, device=d.device) for d, (h, w_) in zip(dys, hw)]
     gp, xp = _ptr_list(dys), _ptr_list(dxs)
-    _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [d.shape[2] for d in dys], [d.shape[3] for d in dys], len(dys), Cin, Cout,
-                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), ws, nws, st), mask=relu_bits is not None)
+    _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [h for h, _ in hw], [w_ for _, w_ in hw], len(dys), Cin, Cout,
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), 1 if pooled_from else 0, ws, nws, st),
+                  mask=relu_bits is not None, pooled=bool(pooled_from))
     return dxs
 
 
-def _conv3x3_bits(relu_bits, dys, Cout):
+def _conv3x3_full_sizes(dys, pooled_from):
+    """The convolution's own output sizes: those of dys, or -- for a pooled gradient -- the ones given (checked against dys)."""
+    if not pooled_from:
+        return [(int(d.shape[2]), int(d.shape[3])) for d in dys]
+    hw = [(int(h), int(w_)) for h, w_ in pooled_from]
+    if len(hw) != len(dys) or any((h // 2, w_ // 2) != (int(d.shape[2]), int(d.shape[3])) for d, (h, w_) in zip(dys, hw)):
+        raise ValueError("conv3x3: pooled gradient shapes do not match pooled_from")
+    return hw
+
+
+def _conv3x3_bits(relu_bits, hw, Cout):
     if relu_bits is None:
         return None
     relu_bits = _req(relu_bits, torch.int16, "relu_bits")
-    Hh, Wh = _host_i32([d.shape[2] for d in dys]), _host_i32([d.shape[3] for d in dys])
-    if relu_bits.numel() != int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(dys), Cout)):
+    Hh, Wh = _host_i32([h for h, _ in hw]), _host_i32([w_ for _, w_ in hw])
+    if relu_bits.numel() != int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(hw), Cout)):
         raise ValueError("conv3x3: relu_bits does not belong to these shapes")
     return relu_bits
 
 
-def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None):
+def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None, pooled=False):
     """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels.  x_transformed: what conv3x3_fwd(..., keep_transformed=True)
     returned for the same xs (the activations are then not transformed again)."""
     Cin, Cout = int(xs[0].shape[1]), int(dys[0].shape[1])
     xs = _conv3x3_levels(xs, Cin, "input")
     dys = _conv3x3_levels(dys, Cout, "d_out")
-    if len(xs) != len(dys) or any(a.shape[2:] != b.shape[2:] for a, b in zip(xs, dys)):
+    if len(xs) != len(dys) or any(((a.shape[2] // 2, a.shape[3] // 2) if pooled else tuple(a.shape[2:])) != tuple(b.shape[2:]) for a, b in zip(xs, dys)):
         raise ValueError("conv3x3_wgrad: inputs and d_out differ in shape")
-    relu_bits = _conv3x3_bits(relu_bits, dys, Cout)
+    relu_bits = _conv3x3_bits(relu_bits, [(int(x.shape[2]), int(x.shape[3])) for x in xs], Cout)
     dev = xs[0].device
     dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
     db = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_bias else None
     xp, gp = _ptr_list(xs), _ptr_list(dys)
     _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
-                  lambda H, W, ws, nws, st: (xp, gp, _ptr(relu_bits), H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), ws, nws, st),
-                  mask=relu_bits is not None, bias=want_bias, cached=x_transformed is not None)
+                  lambda H, W, ws, nws, st: (xp, gp, _ptr(relu_bits), H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), 1 if pooled else 0, ws, nws, st),
+                  mask=relu_bits is not None, bias=want_bias, cached=x_transformed is not None, pooled=pooled)
     return dw, db
 
 
@@ -740,18 +756,21 @@ def conv3x3_supported(x, weight, need_input_grad=None):
 
 
 class _Conv3x3F32Fn(torch.autograd.Function):
-    """args: (relu, w, bias | None, x) -> act(bias + conv3x3(x, w)); the ReLU's backward rides in the gradient kernels' transforms."""
+    """args: (act, w, bias | None, x) -> act(bias + conv3x3(x, w)), act = 0 none / 1 ReLU / 2 ReLU + max_pool2d(2, 2); the activation's backward
+    rides in the gradient kernels' transforms."""
 
     @staticmethod
     def forward(ctx, relu, w, bias, x):
         # the transformed activations are kept for the weight gradient when there will be one (0.6 GB per VGG16 step; HBM is 288 GB)
         keep = bool(ctx.needs_input_grad[1]) and int(w.shape[1]) % 64 == 0
         grads = any(ctx.needs_input_grad[1:])
+        pool = relu == 2
         if keep or (relu and grads):
-            ys, xt, bits = conv3x3_fwd([x], w, bias, relu, keep_transformed=keep, want_bits=bool(relu) and grads)
+            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), keep_transformed=keep, want_bits=bool(relu) and grads, pool=pool)
         else:
-            ys, xt, bits = conv3x3_fwd([x], w, bias, relu), None, None
+            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), pool=pool), None, None
         ctx.relu = bool(relu)
+        ctx.pool = pool
         ctx.has_bias = bias is not None
         ctx.save_for_backward(w, x, bits, xt)              # the ReLU's backward needs the sign words, not the activations
         return ys[0]
@@ -760,18 +779,27 @@ class _Conv3x3F32Fn(torch.autograd.Function):
     def backward(ctx, g):
         w, x, mask, xt = ctx.saved_tensors
         g = g.contiguous()
-        dx = conv3x3_bwd_data([g], w, mask)[0] if ctx.needs_input_grad[3] else None
+        dx = conv3x3_bwd_data([g], w, mask, [tuple(x.shape[2:])] if ctx.pool else None)[0] if ctx.needs_input_grad[3] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2], x_transformed=xt)
+            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2], x_transformed=xt, pooled=ctx.pool)
             if not ctx.needs_input_grad[1]:
                 dw = None
         return None, dw, db, dx
 
 
-def conv3x3(x, weight, bias=None, relu=False):
-    """nn.Conv2d(Cin, Cout, 3, padding=1) [+ nn.ReLU] on one fp32 [1,Cin,h,w] map through the hand-written Winograd stage; differentiable."""
-    return _Conv3x3F32Fn.apply(bool(relu), weight, bias, x)
+def conv3x3(x, weight, bias=None, relu=False, pool=False):
+    """nn.Conv2d(Cin, Cout, 3, padding=1) [+ nn.ReLU [+ nn.MaxPool2d(2, 2)]] on one fp32 [1,Cin,h,w] map through the hand-written Winograd stage;
+    differentiable."""
+    if pool and not relu:
+        raise ValueError("conv3x3: pool needs relu=True")
+    return _Conv3x3F32Fn.apply((2 if pool else 1) if relu else 0, weight, bias, x)
+
+
+def conv3x3_pool_supported(x):
+    """Whether conv3x3(..., pool=True) can take a map of x's size: the fused max-pool lives in the 4 x 4 tile's output transform."""
+    Hh, Wh = _host_i32([x.shape[2]]), _host_i32([x.shape[3]])
+    return int(lib.frcnn_conv3x3_f32_tile_size(_np_ptr(Hh), _np_ptr(Wh), 1)) == 4
 
 
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):

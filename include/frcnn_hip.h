@@ -236,14 +236,20 @@ size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_l
  * again -- 0.6 GB per VGG16 step on a 288 GB device for one launch less per layer.  NULL: scratch / transform again. */
 size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin);
 size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout);
+/* relu = 2 (fwd): ReLU + max_pool2d(2, 2) (floor) in the output transform -- the MaxPool2d behind conv1_2 / conv2_2 / conv3_3 / conv4_3 of vgg16.features:
+ * y_levels are then [Cout, H/2, W/2], the full-resolution activations are never written, and relu_bits holds per 2 x 2 window the position of the
+ * maximum and whether it was positive.  The gradient calls take `pooled` = 1 with those words: dy_levels are [Cout, H/2, W/2] and max_pool2d's and the
+ * ReLU's backward happen while the gradient is staged (H, W stay the convolution's own size everywhere).  Needs the 4 x 4 tile: frcnn_conv3x3_f32_tile_size
+ * (2 or 4, the tile the calls will use for these shapes). */
+int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_levels);
 int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
                           const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, void *workspace, size_t workspace_bytes,
                           void *stream);
 int frcnn_conv3x3_f32_bwd_data(const float *const *dy_levels, const unsigned short *relu_bits, float *const *dx_levels, const int *H_host, const int *W_host,
-                               int n_levels, int Cin, int Cout, const float *w, void *workspace, size_t workspace_bytes, void *stream);
+                               int n_levels, int Cin, int Cout, const float *w, int pooled, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy_levels, const unsigned short *relu_bits, const int *H_host, const int *W_host,
-                            int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, void *workspace, size_t workspace_bytes,
-                            void *stream);
+                            int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, void *workspace,
+                            size_t workspace_bytes, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

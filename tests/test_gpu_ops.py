@@ -1636,6 +1636,75 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
         ops.conv3x3_fwd([x32], torch.zeros(32, 32, 3, 3, device=DEV))                            # Cout = 32
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W", [(128, 128, 96, 132), (64, 128, 75, 125), (64, 64, 150, 250)], ids=["even", "odd_rows_cols", "narrow"])
+def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
+    """conv3x3(..., relu=True, pool=True) = Conv2d + ReLU + MaxPool2d(2, 2) of vgg16.features in one stage call: the pooled output and the
+    words of the 2 x 2 windows come out of the output transform (the full-resolution activations are never written), and the gradient
+    calls rebuild max_pool2d's + the ReLU's backward from the pooled gradient and the words while staging.  Checked (a) against float64
+    (pooled values; gradients with the window selection decoded from the DEVICE words, which must agree with float64's own choice except
+    where the two largest values of a window are within rounding) and (b) bit for bit against the unfused form of the same stage followed
+    by torch's max_pool2d, forward and all gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(H + Cin)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.2
+    Hp, Wp = H // 2, W // 2
+    dp = torch.randn(1, Cout, Hp, Wp, generator=g)
+    xd, wd, bd, dpd = x.to(DEV), wt.to(DEV), b.to(DEV), dp.to(DEV)
+    assert ops.conv3x3_pool_supported(xd)
+    (yp,), xt, bits = ops.conv3x3_fwd([xd], wd, bd, True, keep_transformed=True, want_bits=True, pool=True)
+    pre = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    act = pre.clamp_min(0)
+    ref_p = F.max_pool2d(act, 2, 2)
+    assert tuple(yp.shape) == (1, Cout, Hp, Wp)
+    assert float((yp.double().cpu() - ref_p).abs().max()) < 2e-5 * max(1.0, float(pre.abs().max()))
+    # decode the words: tile (ty, tx) of 4 x 4, window k = wi * 2 + wj: bits 3k .. 3k + 1 = position of the maximum, bit 3k + 2 = maximum > 0
+    th, tw = (H + 3) // 4, (W + 3) // 4
+    words = bits.cpu().view(Cout, -1)[:, :th * tw].to(torch.int32).bitwise_and(0xFFFF).view(Cout, th, tw)
+    sel = torch.zeros(Cout, 4 * th, 4 * tw, dtype=torch.float64)
+    for k in range(4):
+        w3 = (words >> (3 * k)) & 7
+        for pos in range(4):
+            hit = (w3 == (4 | pos)).double()
+            sel[:, (k // 2) * 2 + pos // 2::4, (k % 2) * 2 + pos % 2::4] = hit
+    sel = sel[:, :H, :W]
+    up = torch.zeros(1, Cout, H, W, dtype=torch.float64)
+    up[:, :, :2 * Hp, :2 * Wp] = dp.double().repeat_interleave(2, 2).repeat_interleave(2, 3)
+    gfull = up * sel                                                       # max_pool2d backward + ReLU backward with the device's selection
+    # the device's selection = float64's own, except where a window's two largest activations are within rounding of each other (or of zero)
+    _, idx = F.max_pool2d(act, 2, 2, return_indices=True)
+    sel64 = torch.zeros(Cout, H * W, dtype=torch.float64).scatter_(1, idx.view(Cout, -1), (ref_p > 0).double().view(Cout, -1)).view(Cout, H, W)
+    differ = (sel64 != sel)
+    if int(differ.sum()):
+        win = act[0, :, :2 * Hp, :2 * Wp].reshape(Cout, Hp, 2, Wp, 2).permute(0, 1, 3, 2, 4).reshape(Cout, Hp, Wp, 4)
+        top2 = win.topk(2, dim=-1).values
+        gap = torch.minimum(top2[..., 0] - top2[..., 1], top2[..., 0])          # distance to the runner-up, or to zero
+        bad = differ[:, :2 * Hp, :2 * Wp].reshape(Cout, Hp, 2, Wp, 2).permute(0, 1, 3, 2, 4).reshape(Cout, Hp, Wp, 4).any(-1)
+        assert float(gap[bad].max()) < 1e-5 and int(bad.sum()) < 1e-4 * bad.numel() + 4
+    dx = ops.conv3x3_bwd_data([dpd], wd, bits, pooled_from=[(H, W)])[0]
+    dx_ref = F.conv_transpose2d(gfull, wt.double(), None, padding=1)
+    assert tuple(dx.shape) == (1, Cin, H, W)
+    assert float((dx.double().cpu() - dx_ref).abs().max()) < 2e-5 * max(1.0, float(dx_ref.abs().max()))
+    dw, db = ops.conv3x3_wgrad([xd], [dpd], bits, want_bias=True, x_transformed=xt, pooled=True)
+    w_ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), gfull, padding=1)
+    assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
+    assert float((db.double().cpu() - gfull.sum(dim=(0, 2, 3))).abs().max()) < 1e-4 * max(1.0, float(gfull.sum(dim=(0, 2, 3)).abs().max()))
+    # (b) bit for bit against the unfused stage + torch's max_pool2d under autograd
+    outs = []
+    for fused in (True, False):
+        xr, wr, br = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+        y = ops.conv3x3(xr, wr, br, relu=True, pool=True) if fused else F.max_pool2d(ops.conv3x3(xr, wr, br, relu=True), 2, 2)
+        y.backward(dpd)
+        outs.append((y.detach(), xr.grad, wr.grad, br.grad))
+    for a_, c_ in zip(*outs):
+        assert torch.equal(a_, c_)
+    small = torch.zeros(1, 128, 40, 40, device=DEV)
+    assert not ops.conv3x3_pool_supported(small)                            # 100 tiles: the 2 x 2 tile, no fused pool
+    with pytest.raises(Exception):
+        ops.conv3x3_fwd([small], torch.zeros(128, 128, 3, 3, device=DEV), None, True, pool=True)
+
+
 @pytest.mark.parametrize("m", ["2", "4"])
 def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
     """The stage picks F(4x4, 3x3) from 512 tiles per call on and F(2x2, 3x3) below; FRCNN_WINO_M (read once per process) forces one.  A child process
