@@ -1,0 +1,236 @@
+// conv_c3.hip -- the first convolution of the backbone, nn.Conv2d(3, Cout, 3, padding=1) + ReLU: `vgg16.features[0]` + `[1]` behind
+// models/model.py:279-281, on the 3 x 600 x 1000 image.  With three input channels it is not a contraction for the matrix cores (K = 27) but a
+// byte mover: 7 MB in, 154 MB out, 2 GFLOP.  The vendor path ran it as a Winograd kernel + a bias pass + a ReLU pass forward (175 us) and, backward,
+// a threshold pass + an igemm weight gradient behind an NCHW -> NHWC transpose + a 146-us reduction for the bias gradient (370 us).  Here:
+//   conv3x3_c3_fwd_kernel    thread = output pixel of a 256-wide row piece: its 27 inputs from an LDS-staged 3 x 3 x 258 window into registers, then
+//                            a loop over the output channels with the weights as SCALAR operands (uniform loads) -- y = relu(b + sum w x), one
+//                            coalesced store per channel.  fp32 fmaf chain in (ci, ky, kx) order.  The signs of the outputs go out as one 64-bit word
+//                            per pixel and 64 channels (5 MB instead of the 154 MB of activations the ReLU's backward would read).
+//   conv3x3_c3_wgrad_kernel  dw[co][ci][ky][kx] = sum_p g[co][p] x[ci][p + off], db[co] = sum_p g[co][p], g = dy where the forward's sign word has the
+//                            channel's bit.  block = (4 image rows, 16 output channels); wave = 4 channels, its lanes walk a row 256 pixels at a
+//                            time with sixteen gradient loads in flight, 4 x 28 running sums per lane, one shuffle reduction per wave at the end ->
+//                            partials [block of 4 rows][co][28] (one DPP reduction per wave and four rows);  conv3x3_c3_wgrad_finalize_kernel adds them in order (bit-reproducible).
+// The input gradient is never needed (the input is the image).
+#include "frcnn_common.h"
+#include "frcnn_internal.h"
+#include "frcnn_layout.h"
+FRCNN_LAYOUT_STAMP(conv_c3);
+
+#define C3_TW 256                      // pixels per forward block
+
+__global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int Cout,
+                                                             const float *__restrict__ w, const float *__restrict__ bias, int relu,
+                                                             unsigned long long *__restrict__ bits)
+{
+    __shared__ float s[9][C3_TW + 4];                                     // [ci * 3 + ky][column x0 - 1 .. x0 + 256]
+    extern __shared__ __attribute__((aligned(16))) float sw[];            // [Cout][28]: the 27 weights of a channel + its bias (16-byte rows)
+    const int row = blockIdx.y, x0 = blockIdx.x * C3_TW, tid = threadIdx.x;
+    for (int e = tid; e < Cout * 28; e += 256) {
+        const int co = e / 28, k = e - co * 28;
+        sw[e] = k < 27 ? w[(size_t)co * 27 + k] : (bias ? bias[co] : 0.0f);
+    }
+    {
+        float v[10];                                                      // ten loads in flight per thread, then the LDS writes
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int e = tid + 256 * j, r = e / (C3_TW + 2), q = e - r * (C3_TW + 2), ci = r / 3, ky = r - 3 * ci, yy = row - 1 + ky, xx = x0 - 1 + q;
+            v[j] = (r < 9 && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)ci * H + yy) * W + xx] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int e = tid + 256 * j, r = e / (C3_TW + 2), q = e - r * (C3_TW + 2);
+            if (r < 9) s[r][q] = v[j];
+        }
+    }
+    __syncthreads();
+    const int xx = x0 + tid;
+    if (xx >= W) return;
+    float v[27];
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[r][tid + kx];
+    float *yo = y + (size_t)row * W + xx;
+    const size_t plane = (size_t)H * W;
+    unsigned long long word = 0;
+    for (int c2 = 0; c2 < Cout; c2 += 2) {                                // two independent chains per pass; the weights come as LDS broadcasts
+        const bool two = c2 + 1 < Cout;                                   // (four channels' weights as scalar operands overflowed the SGPR file)
+        const float4 *w0 = (const float4 *)&sw[c2 * 28], *w1 = (const float4 *)&sw[(two ? c2 + 1 : c2) * 28];
+        float acc0 = sw[c2 * 28 + 27], acc1 = sw[(two ? c2 + 1 : c2) * 28 + 27];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const float4 a = w0[q], c = w1[q];
+            const float aw[4] = {a.x, a.y, a.z, a.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (q * 4 + e < 27) { acc0 = fmaf(aw[e], v[q * 4 + e], acc0); acc1 = fmaf(cw[e], v[q * 4 + e], acc1); }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = c2 + j;
+            if (co < Cout) {
+                const float pre = j ? acc1 : acc0, o = relu ? fmaxf(pre, 0.0f) : pre;
+                yo[(size_t)co * plane] = o;
+                word |= o > 0.0f ? 1ull << (co & 63) : 0ull;
+                if (bits && ((co & 63) == 63 || co == Cout - 1)) { bits[(size_t)(co >> 6) * plane + (size_t)row * W + xx] = word; word = 0; }
+            }
+        }
+    }
+}
+
+// sum over the wave's 64 lanes on DPP row shifts / broadcasts (plain VALU adds, no LDS crossbar), result in lane 63; fixed order
+__device__ __forceinline__ float c3_wave_sum(float v)
+{
+#define C3_DPP_ADD(ctrl, rmask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+    C3_DPP_ADD(0x111, 0xf);    // row_shr:1
+    C3_DPP_ADD(0x112, 0xf);    // row_shr:2
+    C3_DPP_ADD(0x114, 0xf);    // row_shr:4
+    C3_DPP_ADD(0x118, 0xf);    // row_shr:8   -> lane 15 of every row holds the row's sum
+    C3_DPP_ADD(0x142, 0xa);    // row_bcast:15 into rows 1 and 3
+    C3_DPP_ADD(0x143, 0xc);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+#undef C3_DPP_ADD
+    return v;
+}
+
+#define C3_ROWS 4                      // image rows per weight-gradient block: one cross-lane reduction (112 values per lane) per four rows
+#define C3_WAVES 4                     // waves per block
+#define C3_CPW 4                       // output channels per wave: 4 x 28 running sums per lane (two channels per wave, eight waves: 233 us against 189)
+// dynamic LDS: 9 x (W + 2) floats (the three rows of the three input channels around the row being walked).  Measured and not kept: all six
+// rows of a block staged at once with eight waves and the next batch's loads issued ahead (218 registers, one block per CU: 212 us against 146).
+__global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int H, int W, int Cout,
+                                                                       const unsigned long long *__restrict__ bits, float *__restrict__ part)
+{
+    extern __shared__ float s[];                                          // [9][W + 2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ws = W + 2, NT = 64 * C3_WAVES;
+    const int co0 = (blockIdx.y * C3_WAVES + wave) * C3_CPW;              // this wave's output channels (a wave past Cout only helps staging)
+    const size_t plane = (size_t)H * W;
+    float acc[C3_CPW][28];
+#pragma unroll
+    for (int j = 0; j < C3_CPW; ++j)
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[j][k] = 0.0f;
+    for (int row = blockIdx.x * C3_ROWS; row < min(H, (int)(blockIdx.x + 1) * C3_ROWS); ++row) {
+        __syncthreads();                                                  // the previous row's reads are done
+        for (int base = tid; base < 9 * ws; base += NT * 8) {             // eight loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = base + NT * j, r = e / ws, q = e - r * ws, ci = r / 3, ky = r - 3 * ci, yy = row - 1 + ky, xx = q - 1;
+                v[j] = (e < 9 * ws && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)ci * H + yy) * W + xx] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int e = base + NT * j;
+                if (e < 9 * ws) s[e] = v[j];
+            }
+        }
+        __syncthreads();
+        if (co0 >= Cout) continue;
+        const float *g0 = dy + (size_t)co0 * plane + (size_t)row * W;
+        const unsigned long long *b0 = bits ? bits + (size_t)(co0 >> 6) * plane + (size_t)row * W : nullptr;
+        for (int xb = 0; xb < W; xb += 256) {                             // 4 pixels x 4 channels of gradient in flight per lane
+            float g[4][C3_CPW];
+            unsigned mb[4];                                               // the wave's channels' sign bits of each pixel (co0 % C3_CPW == 0: never across words)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xx = xb + 64 * i + lane;
+                mb[i] = (b0 && xx < W) ? (((const unsigned *)b0)[2 * xx + ((co0 & 63) >> 5)] >> (co0 & 31)) & ((1u << C3_CPW) - 1u) : ~0u;      // the 32-bit half that holds the four bits
+#pragma unroll
+                for (int j = 0; j < C3_CPW; ++j) g[i][j] = xx < W ? g0[(size_t)j * plane + xx] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int xx = xb + 64 * i + lane;
+                if (xb + 64 * i < W) {                                    // uniform
+                    float v[27];
+                    const int xc = xx < W ? xx : W - 1;                   // lanes past the row read a valid column (their gradient is zero)
+#pragma unroll
+                    for (int r = 0; r < 9; ++r)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[r * ws + xc + kx];
+#pragma unroll
+                    for (int j = 0; j < C3_CPW; ++j) {
+                        const float gg = ((mb[i] >> j) & 1u) ? g[i][j] : 0.0f;      // the ReLU's backward from the forward's sign word
+#pragma unroll
+                        for (int k = 0; k < 27; ++k) acc[j][k] = fmaf(gg, v[k], acc[j][k]);
+                        acc[j][27] += gg;
+                    }
+                }
+            }
+        }
+    }
+    if (co0 >= Cout) return;
+#pragma unroll
+    for (int j = 0; j < C3_CPW; ++j)
+#pragma unroll
+        for (int k = 0; k < 28; ++k) {
+            const float t = c3_wave_sum(acc[j][k]);
+            if (lane == 63) part[((size_t)blockIdx.x * Cout + co0 + j) * 28 + k] = t;
+        }
+}
+
+// thread = (co, k): the rows' partials in row order; k < 27 -> dw[co][k], k = 27 -> db[co]
+__global__ __launch_bounds__(256) void conv3x3_c3_wgrad_finalize_kernel(const float *__restrict__ part, int H, int Cout, float *__restrict__ dw,
+                                                                        float *__restrict__ db)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= Cout * 28) return;
+    const size_t stride = (size_t)Cout * 28;
+    float t = 0.0f;
+    int r = 0;
+    for (; r + 8 <= H; r += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(r + j) * stride + o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += v[j];
+    }
+    for (; r < H; ++r) t += part[(size_t)r * stride + o];
+    const int co = o / 28, k = o - co * 28;
+    if (k < 27) dw[(size_t)co * 27 + k] = t;
+    else if (db) db[co] = t;
+}
+
+static int c3_check(const void *x, const void *y, int H, int W, int Cout, const void *w, const char *what)
+{
+    FRCNN_REQUIRE(x && y && w, "%s: NULL pointer", what);
+    FRCNN_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout <= 512 && (long long)H * W * Cout < (1ll << 31), "%s: bad size %d x %d x %d", what, Cout, H, W);
+    return FRCNN_OK;
+}
+
+FRCNN_EXPORT int frcnn_conv3x3_c3_fwd(const float *x_dev, float *y_dev, int H, int W, int Cout, const float *w_dev, const float *bias_dev, int relu,
+                                      unsigned long long *relu_bits_dev, void *stream)
+{
+    int rc = c3_check(x_dev, y_dev, H, W, Cout, w_dev, "conv3x3_c3_fwd");
+    if (rc) return rc;
+    FRCNN_LAUNCH(conv3x3_c3_fwd_kernel, dim3((unsigned)((W + C3_TW - 1) / C3_TW), (unsigned)H), dim3(256), (size_t)Cout * 28 * sizeof(float), (hipStream_t)stream, x_dev, y_dev, H, W, Cout,
+                 w_dev, bias_dev, relu, relu_bits_dev);
+    FRCNN_CHECK_LAUNCH("conv3x3_c3_fwd_kernel");
+    return FRCNN_OK;
+}
+
+FRCNN_EXPORT size_t frcnn_conv3x3_c3_wgrad_workspace(int H, int Cout)
+{
+    return (H > 0 && Cout > 0) ? (size_t)((H + C3_ROWS - 1) / C3_ROWS) * Cout * 28 * sizeof(float) : 0;
+}
+
+FRCNN_EXPORT int frcnn_conv3x3_c3_wgrad(const float *x_dev, const float *dy_dev, int H, int W, int Cout, const unsigned long long *relu_bits_dev,
+                                        float *dw_dev, float *dbias_dev, void *workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = c3_check(x_dev, dy_dev, H, W, Cout, dw_dev, "conv3x3_c3_wgrad");
+    if (rc) return rc;
+    FRCNN_REQUIRE(dw_dev && workspace, "conv3x3_c3_wgrad: NULL pointer");
+    if (Cout % 4 != 0 || W > 1700)
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_c3_wgrad: Cout = %d must be a multiple of 4 and W = %d at most 1700", Cout, W);
+    if (workspace_bytes < frcnn_conv3x3_c3_wgrad_workspace(H, Cout))
+        return frcnn_set_error(FRCNN_ERR_WORKSPACE, "conv3x3_c3_wgrad: workspace %zu < %zu bytes", workspace_bytes, frcnn_conv3x3_c3_wgrad_workspace(H, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    const int nb = (H + C3_ROWS - 1) / C3_ROWS;
+    FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel, dim3((unsigned)nb, (unsigned)((Cout + C3_CPW * C3_WAVES - 1) / (C3_CPW * C3_WAVES))), dim3(64 * C3_WAVES),
+                 (size_t)9 * (W + 2) * sizeof(float), s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
+    FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_kernel");
+    FRCNN_LAUNCH(conv3x3_c3_wgrad_finalize_kernel, dim3((unsigned)((Cout * 28 + 255) / 256)), dim3(256), 0, s, part, nb, Cout, dw_dev, dbias_dev);
+    FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_finalize_kernel");
+    return FRCNN_OK;
+}

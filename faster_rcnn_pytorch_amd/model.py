@@ -58,8 +58,9 @@ class VGGExtractor(nn.Sequential):
     """`nn.Sequential(*list(vgg16.features)[:-1])` (models/model.py:279-281) with the same children, indices and state_dict keys.  Its forward walks
     the children like nn.Sequential does, except that a 3x3 convolution the fp32 Winograd stage takes (ops.conv3x3_supported: 128-multiples of
     channels, batch 1, fp32 on the device) runs there TOGETHER with the ReLU behind it -- bias and ReLU in the output transform, the ReLU's
-    backward in the gradient kernels' transforms -- instead of three vendor / elementwise launches forward and four backward.  Every other
-    child (conv1_x, conv2_1, the pools; any layer under autocast or with batch > 1) runs as it is."""
+    backward in the gradient kernels' transforms -- instead of three vendor / elementwise launches forward and four backward; a 2 x 2 max-pool
+    behind such a pair joins the same call where the stage uses its 4 x 4 tile; the first convolution (three input channels) has kernels of
+    its own.  Every other child (small maps' pools; any layer under autocast or with batch > 1) runs as it is."""
 
     def forward(self, x):
         mods = list(self)
@@ -74,6 +75,12 @@ class VGGExtractor(nn.Sequential):
                         and p.dilation in (1, (1, 1)) and not p.ceil_mode and not p.return_indices and ops.conv3x3_pool_supported(x))
                 x = ops.conv3x3(x, m.weight, m.bias, relu=fuse, pool=pool)      # conv + ReLU (+ the 2 x 2 max-pool behind it) in one stage call
                 i += 3 if pool else (2 if fuse else 1)
+                continue
+            if (isinstance(m, nn.Conv2d) and m.in_channels == 3 and m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride == (1, 1)
+                    and m.dilation == (1, 1) and m.groups == 1 and not torch.is_autocast_enabled() and ops.conv3x3_c3_supported(x, m.weight)):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = ops.conv3x3_c3(x, m.weight, m.bias, relu=fuse)              # features[0] (+ [1]): three input channels, a byte mover (csrc/conv_c3.hip)
+                i += 2 if fuse else 1
                 continue
             x = m(x)
             i += 1

@@ -802,6 +802,75 @@ def conv3x3_pool_supported(x):
     return int(lib.frcnn_conv3x3_f32_tile_size(_np_ptr(Hh), _np_ptr(Wh), 1)) == 4
 
 
+# ---- the backbone's first convolution: three input channels, a byte mover on the vector units (csrc/conv_c3.hip)
+def conv3x3_c3_fwd(x, w, bias=None, relu=False, want_bits=False):
+    """act(bias + conv3x3(x, w)), padding 1: x fp32 [1,3,h,w], w [Cout,3,3,3] -> [1,Cout,h,w] (frcnn_conv3x3_c3_fwd); want_bits: also the signs of
+    the outputs as int64 words [ceil(Cout/64), h, w] for conv3x3_c3_wgrad."""
+    x, w = _req(x, name="x"), _req(w, name="w")
+    if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3 or w.dim() != 4 or tuple(w.shape[1:]) != (3, 3, 3):
+        raise ValueError("conv3x3_c3: x must be [1,3,h,w] and w [Cout,3,3,3]")
+    Cout, H, W = int(w.shape[0]), int(x.shape[2]), int(x.shape[3])
+    if bias is not None:
+        bias = _req(bias, name="bias")
+    y = torch.empty((1, Cout, H, W), dtype=torch.float32, device=x.device)
+    bits = torch.empty(((Cout + 63) // 64, H, W), dtype=torch.int64, device=x.device) if want_bits else None
+    with torch.cuda.device(x.device):
+        check(lib.frcnn_conv3x3_c3_fwd(_ptr(x), _ptr(y), H, W, Cout, _ptr(w), _ptr(bias), 1 if relu else 0, _ptr(bits), _stream()), "conv3x3_c3_fwd")
+    return (y, bits) if want_bits else y
+
+
+def conv3x3_c3_wgrad(x, dy, relu_bits=None, want_bias=True):
+    """(dw [Cout,3,3,3], dbias [Cout] | None) of conv3x3_c3_fwd; relu_bits: the forward's sign words (dy counts where the output was > 0)."""
+    x, dy = _req(x, name="x"), _req(dy, name="dy")
+    Cout, H, W = int(dy.shape[1]), int(x.shape[2]), int(x.shape[3])
+    if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3 or tuple(dy.shape) != (1, Cout, H, W):
+        raise ValueError("conv3x3_c3_wgrad: x must be [1,3,h,w] and dy [1,Cout,h,w]")
+    if relu_bits is not None:
+        relu_bits = _req(relu_bits, torch.int64, "relu_bits")
+        if tuple(relu_bits.shape) != ((Cout + 63) // 64, H, W):
+            raise ValueError("conv3x3_c3_wgrad: relu_bits does not belong to these shapes")
+    dw = torch.empty((Cout, 3, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    ws = _workspace(x.device, int(lib.frcnn_conv3x3_c3_wgrad_workspace(H, Cout)))
+    with torch.cuda.device(x.device):
+        check(lib.frcnn_conv3x3_c3_wgrad(_ptr(x), _ptr(dy), H, W, Cout, _ptr(relu_bits), _ptr(dw), _ptr(db), _ptr(ws), ws.numel(), _stream()), "conv3x3_c3_wgrad")
+    return dw, db
+
+
+class _Conv3x3C3Fn(torch.autograd.Function):
+    """args: (relu, w, bias | None, x) with x the image (no gradient flows into it)."""
+
+    @staticmethod
+    def forward(ctx, relu, w, bias, x):
+        grads = ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2])
+        if relu and grads:
+            y, bits = conv3x3_c3_fwd(x, w, bias, True, want_bits=True)
+        else:
+            y, bits = conv3x3_c3_fwd(x, w, bias, relu), None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, bits)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bits = ctx.saved_tensors
+        if ctx.needs_input_grad[3]:
+            raise RuntimeError("conv3x3_c3: no input gradient (the input is the image)")
+        dw, db = conv3x3_c3_wgrad(x, g.contiguous(), bits, want_bias=ctx.has_bias)
+        return None, dw, db, None
+
+
+def conv3x3_c3(x, weight, bias=None, relu=False):
+    """nn.Conv2d(3, Cout, 3, padding=1) [+ nn.ReLU] on the fp32 image [1,3,h,w]; differentiable in weight and bias."""
+    return _Conv3x3C3Fn.apply(bool(relu), weight, bias, x)
+
+
+def conv3x3_c3_supported(x, weight):
+    """fp32 on a HIP device, batch 1, [Cout,3,3,3] with Cout % 4 == 0, the input itself needing no gradient, rows of at most 1700 pixels."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3
+            and tuple(weight.shape[1:]) == (3, 3, 3) and weight.shape[0] % 4 == 0 and x.shape[3] <= 1700 and not x.requires_grad)
+
+
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):
     """(pred_cls [1, sum P_l * A, 2], pred_reg [1, sum P_l * A, 4]) of the shared FPN RPN head on bf16 feature maps (models/new_model.py:37-44,
     89-114): one launch for conv3x3 + ReLU + both heads on the bf16 matrix cores; box regression outputs stay fp32."""

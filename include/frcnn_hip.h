@@ -251,6 +251,18 @@ int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy
                             int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* The backbone's FIRST convolution, nn.Conv2d(3, Cout, 3, padding=1) (+ ReLU): `vgg16.features[0]` + `[1]` behind models/model.py:279-281.  Three input
+ * channels are no contraction for the matrix cores: a byte mover on the vector units (csrc/conv_c3.hip).  x [3, H, W], y / dy [Cout, H, W], w [Cout, 3, 3, 3],
+ * fp32, batch 1.  relu_bits (optional, ceil(Cout / 64) * H * W uint64 words): the signs of the ReLU outputs, bit co % 64 of word [co / 64][pixel]; _wgrad
+ * given the same words counts dy where the bit is set (NULL: dy as it is).  dw [Cout, 3, 3, 3] and dbias [Cout] (or NULL) are fully overwritten; Cout a
+ * multiple of 4 and W <= 1700 for _wgrad; workspace >= frcnn_conv3x3_c3_wgrad_workspace(H, Cout) bytes of plain scratch.  No input gradient (the
+ * input is the image).  Bit-reproducible. */
+int frcnn_conv3x3_c3_fwd(const float *x, float *y, int H, int W, int Cout, const float *w, const float *bias, int relu, unsigned long long *relu_bits,
+                         void *stream);
+size_t frcnn_conv3x3_c3_wgrad_workspace(int H, int Cout);
+int frcnn_conv3x3_c3_wgrad(const float *x, const float *dy, int H, int W, int Cout, const unsigned long long *relu_bits, float *dw, float *dbias,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).
  * Sampling (torch.randperm on the host in the reference, model_.py:228,235):

@@ -1705,6 +1705,45 @@ def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
         ops.conv3x3_fwd([small], torch.zeros(128, 128, 3, 3, device=DEV), None, True, pool=True)
 
 
+@pytest.mark.parametrize("Cout,H,W", [(64, 75, 130), (32, 9, 700), (80, 33, 257)], ids=["vgg_like", "wide", "two_words"])
+def test_conv3x3_c3_first_convolution(ops, Cout, H, W):
+    """frcnn_conv3x3_c3_fwd / _wgrad: `vgg16.features[0]` + `[1]` (Conv2d(3, 64, 3, padding=1) + ReLU) and their backward -- weight and bias
+    gradient, the ReLU's backward from the forward's sign words -- against float64 (mask from the device output) and, through
+    ops.conv3x3_c3 under autograd, against torch's own conv2d + relu on the device; bit-reproducible."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(Cout + W)
+    x = torch.randn(1, 3, H, W, generator=g)
+    wt = torch.randn(Cout, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(Cout, generator=g) * 0.2
+    dy = torch.randn(1, Cout, H, W, generator=g)
+    xd, wd, bd, dyd = x.to(DEV), wt.to(DEV), b.to(DEV), dy.to(DEV)
+    y, bits = ops.conv3x3_c3_fwd(xd, wd, bd, True, want_bits=True)
+    pre = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    assert float((y.double().cpu() - pre.clamp_min(0)).abs().max()) < 1e-5 * max(1.0, float(pre.abs().max()))
+    assert torch.equal(y, ops.conv3x3_c3_fwd(xd, wd, bd, True))
+    lin = ops.conv3x3_c3_fwd(xd, wd, None, False)
+    assert float((lin.double().cpu() - F.conv2d(x.double(), wt.double(), None, padding=1)).abs().max()) < 1e-5 * max(1.0, float(pre.abs().max()))
+    mask = (y.cpu() > 0)
+    flips = mask != (pre > 0)
+    assert int(flips.sum()) == 0 or float(pre[flips].abs().max()) < 1e-5
+    gm = dy.double() * mask
+    dw, db = ops.conv3x3_c3_wgrad(xd, dyd, bits)
+    w_ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, 3, 3, 3), gm, padding=1)
+    assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
+    assert float((db.double().cpu() - gm.sum(dim=(0, 2, 3))).abs().max()) < 1e-4 * max(1.0, float(gm.sum(dim=(0, 2, 3)).abs().max()))
+    dw2, db2 = ops.conv3x3_c3_wgrad(xd, dyd, bits)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw0, _ = ops.conv3x3_c3_wgrad(xd, dyd, None)                                  # no ReLU: the plain weight gradient
+    w0 = torch.nn.grad.conv2d_weight(x.double(), (Cout, 3, 3, 3), dy.double(), padding=1)
+    assert float((dw0.double().cpu() - w0).abs().max()) < 1e-4 * max(1.0, float(w0.abs().max()))
+    if Cout % 16 == 0:
+        wr, br = wd.clone().requires_grad_(True), bd.clone().requires_grad_(True)
+        assert ops.conv3x3_c3_supported(xd, wr)
+        out = ops.conv3x3_c3(xd, wr, br, relu=True)
+        out.backward(dyd)
+        assert torch.equal(out.detach(), y) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
+
+
 @pytest.mark.parametrize("m", ["2", "4"])
 def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
     """The stage picks F(4x4, 3x3) from 512 tiles per call on and F(2x2, 3x3) below; FRCNN_WINO_M (read once per process) forces one.  A child process
