@@ -22,7 +22,7 @@ int frcnn_set_error(int code, const char *fmt, ...)
 }
 
 // ---- layout stamps (frcnn_layout.h): every object of the library registers the stamp it was compiled with ----
-#define FRCNN_N_OBJECTS 14             // the thirteen .hip objects + api.o (csrc/Makefile: SRCS_HIP)
+#define FRCNN_N_OBJECTS 15             // the fourteen .hip objects + api.o (csrc/Makefile: SRCS_HIP)
 struct LayoutReg { const char *object; uint64_t stamp; };
 static std::vector<LayoutReg> &layout_registry() { static std::vector<LayoutReg> r; return r; }     // function-local: static initialisers of other objects may run first
 void frcnn_layout_register(const char *object, uint64_t stamp) { layout_registry().push_back({object, stamp}); }

@@ -83,9 +83,19 @@ class Bottleneck(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
+    def _norm(self, bn, x, res=None, relu=False):
+        """bn(x) [+ res] [-> ReLU]: one fused pass on the fp32 device path (ops.affine_act: the same operations in the same order), the torch form otherwise."""
+        if ops.affine_act_supported(x):
+            scale, shift = bn.affine()
+            return ops.affine_act(x, scale, shift, res, relu)
+        out = bn(x)
+        if res is not None:
+            out = out + res
+        return self.relu(out) if relu else out
+
     def forward(self, x):
         idt = x
-        out = self.relu(self.bn1(self.conv1(x)))
+        out = self._norm(self.bn1, self.conv1(x), relu=True)
         if self.conv2.stride == (1, 1) and not torch.is_autocast_enabled() and ops.conv3x3_supported(out, self.conv2.weight):
             # conv2 + bn2 + ReLU in one stage call: the frozen norm's scale folded into the weight (s * conv(x, w) = conv(x, s w): one small
             # elementwise launch, differentiable), its shift as the bias, the ReLU in the output transform and its backward in the gradient
@@ -93,11 +103,10 @@ class Bottleneck(nn.Module):
             scale, shift = self.bn2.affine()
             out = ops.conv3x3(out, self.conv2.weight * scale.reshape(-1, 1, 1, 1), shift.reshape(-1), relu=True)
         else:
-            out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+            out = self._norm(self.bn2, self.conv2(out), relu=True)
         if self.downsample is not None:
-            idt = self.downsample(x)
-        return self.relu(out + idt)
+            idt = self._norm(self.downsample[1], self.downsample[0](x))
+        return self._norm(self.bn3, self.conv3(out), res=idt, relu=True)
 
 
 class ResNet50Body(nn.Module):
@@ -129,7 +138,12 @@ class ResNet50Body(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.conv1(x)
+        if ops.affine_act_supported(x):
+            scale, shift = self.bn1.affine()
+            x = self.maxpool(ops.affine_act(x, scale, shift, None, True))
+        else:
+            x = self.maxpool(self.relu(self.bn1(x)))
         out = OrderedDict()
         for i, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             x = layer(x)

@@ -802,6 +802,49 @@ def conv3x3_pool_supported(x):
     return int(lib.frcnn_conv3x3_f32_tile_size(_np_ptr(Hh), _np_ptr(Wh), 1)) == 4
 
 
+# ---- FrozenBatchNorm2d (+ residual) (+ ReLU) of a ResNet bottleneck in one pass each way (csrc/affine.hip)
+class _AffineActFn(torch.autograd.Function):
+    """args: (relu, scale [C], shift [C], x [1,C,h,w], res | None) -> act((x * scale + shift) [+ res]); scale / shift are frozen (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, relu, scale, shift, x, res):
+        x = _req(x, name="x")
+        Cc, HW = int(x.shape[1]), int(x.shape[2] * x.shape[3])
+        if res is not None:
+            res = _req(res, name="res")
+            if res.shape != x.shape:
+                raise ValueError("affine_act: residual and input differ in shape")
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            check(lib.frcnn_affine_act_fwd(_ptr(x), _ptr(res), _ptr(y), _ptr(scale), _ptr(shift), Cc, HW, 1 if relu else 0, _stream()), "affine_act_fwd")
+        ctx.relu, ctx.has_res = bool(relu), res is not None
+        ctx.save_for_backward(scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, y = ctx.saved_tensors
+        g = g.contiguous()
+        Cc, HW = int(g.shape[1]), int(g.shape[2] * g.shape[3])
+        need_x, need_r = ctx.needs_input_grad[3], ctx.has_res and ctx.needs_input_grad[4]
+        if not need_x and not need_r:
+            return None, None, None, None, None
+        dx = torch.empty_like(g)
+        dres = torch.empty_like(g) if (need_r and ctx.relu) else None     # without a ReLU the residual's gradient is g itself
+        with torch.cuda.device(g.device):
+            check(lib.frcnn_affine_act_bwd(_ptr(g), _ptr(y), _ptr(scale), _ptr(dx), _ptr(dres), Cc, HW, 1 if ctx.relu else 0, _stream()), "affine_act_bwd")
+        return None, None, None, (dx if need_x else None), ((dres if ctx.relu else g) if need_r else None)
+
+
+def affine_act(x, scale, shift, res=None, relu=False):
+    """FrozenBatchNorm2d(x) [+ res] [-> ReLU] for an fp32 [1,C,h,w] map: scale / shift = the norm's folded [C] (or [1,C,1,1]) statistics."""
+    return _AffineActFn.apply(bool(relu), scale.reshape(-1), shift.reshape(-1), x, res)
+
+
+def affine_act_supported(x):
+    return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1 and not torch.is_autocast_enabled()
+
+
 # ---- the backbone's first convolution: three input channels, a byte mover on the vector units (csrc/conv_c3.hip)
 def conv3x3_c3_fwd(x, w, bias=None, relu=False, want_bits=False):
     """act(bias + conv3x3(x, w)), padding 1: x fp32 [1,3,h,w], w [Cout,3,3,3] -> [1,Cout,h,w] (frcnn_conv3x3_c3_fwd); want_bits: also the signs of

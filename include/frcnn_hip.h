@@ -263,6 +263,13 @@ size_t frcnn_conv3x3_c3_wgrad_workspace(int H, int Cout);
 int frcnn_conv3x3_c3_wgrad(const float *x, const float *dy, int H, int W, int Cout, const unsigned long long *relu_bits, float *dw, float *dbias,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* FrozenBatchNorm2d (+ residual add) (+ ReLU) of torchvision's ResNet bottleneck behind models/new_model.py:372, one pass each way (csrc/affine.hip):
+ *   _fwd : y = act((x * scale[c] + shift[c]) [+ res]), the torch form's operations in its order (bit-identical); res may be NULL; act = ReLU when relu != 0.
+ *   _bwd : gm = g where y > 0 (relu != 0; y = the forward's output) or g;  dx = gm * scale[c];  dres = gm (NULL: not wanted).
+ * x, y, res, g, dx, dres: [C, HW] fp32 (NCHW, batch 1); scale, shift: [C] (the frozen statistics folded as torchvision does). */
+int frcnn_affine_act_fwd(const float *x, const float *res, float *y, const float *scale, const float *shift, int C, int HW, int relu, void *stream);
+int frcnn_affine_act_bwd(const float *g, const float *y, const float *scale, float *dx, float *dres, int C, int HW, int relu, void *stream);
+
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).
  * Sampling (torch.randperm on the host in the reference, model_.py:228,235):

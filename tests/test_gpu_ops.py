@@ -1744,6 +1744,35 @@ def test_conv3x3_c3_first_convolution(ops, Cout, H, W):
         assert torch.equal(out.detach(), y) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
 
 
+@pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False), (True, False)])
+def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
+    """frcnn_affine_act_fwd / _bwd: FrozenBatchNorm2d (+ residual) (+ ReLU) of torchvision's Bottleneck.forward in one pass each way -- the torch
+    form's operations in its order, so values and gradients are bit-identical to `relu(x * scale + shift + res)` under autograd."""
+    g = torch.Generator().manual_seed(5 + with_res * 2 + relu)
+    C_, H, W = 96, 37, 53                                                       # an odd plane size: tails of the 1024-element pieces
+    x = torch.randn(1, C_, H, W, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(1, C_, H, W, generator=g).to(DEV).requires_grad_(True) if with_res else None
+    scale = (torch.rand(C_, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(C_, generator=g).to(DEV)
+    dy = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    ref = x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    if with_res:
+        ref = ref + r
+    if relu:
+        ref = torch.relu(ref)
+    ref.backward(dy)
+    want = [x.grad.clone()] + ([r.grad.clone()] if with_res else [])
+    x.grad = None
+    if with_res:
+        r.grad = None
+    out = ops.affine_act(x, scale, shift, r, relu)
+    out.backward(dy)
+    assert torch.equal(out, ref)
+    for a_, c_ in zip([x.grad] + ([r.grad] if with_res else []), want):
+        assert torch.equal(a_, c_)
+    assert ops.affine_act_supported(x) and not ops.affine_act_supported(x.half())
+
+
 @pytest.mark.parametrize("m", ["2", "4"])
 def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
     """The stage picks F(4x4, 3x3) from 512 tiles per call on and F(2x2, 3x3) below; FRCNN_WINO_M (read once per process) forces one.  A child process
