@@ -63,7 +63,7 @@ MFMA_PEAK_F32_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32 / 16x16x4_f32: th
 
 CONFIGS = {
     "vgg": dict(H=600, W=1000, num_classes=21, label_lo=0, label_hi=20,          # labels U{0..19} (model.py:141 adds 1)
-                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62),
+                shape=dict(N=20646, K=12000, P=2000, R=128, C=512, G=8, feat_bytes=4 * 512 * 37 * 62, A=9, P_head=37 * 62, img_px=600 * 1000, C1=64),
                 metric="train images/sec (VGG16 Faster R-CNN, 600x1000, bs=1/GPU)",
                 workload="VGG16 Faster R-CNN train step, synthetic 600x1000 frames, bs=1/GPU, HIP proposal/RoI path "
                          "(N=20646 anchors, pre/post NMS 12000/2000, 128 RoIs, RoIPool 7x7 on 512x37x62)"),
@@ -85,7 +85,8 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm"}
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv3x3_c3_fwd_kernel": "hbm", "conv3x3_c3_wgrad_kernel": "hbm",
+         "affine_act_fwd_kernel": "hbm", "affine_act_bwd_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
               "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: input x 2, gemm, dw
@@ -103,7 +104,7 @@ def synth_frame(cfg, rank, step):
     return x, boxes, labels
 
 
-def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
+def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, img_px=0, C1=0):
     """Algorithmic HBM bytes per launch (SURVEY 8d / DESIGN.md 'kernels'); None where the figure would say nothing."""
     nblk = (K + 63) // 64
     pooled = R * C * 49
@@ -125,10 +126,12 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
         "roi_align_bwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "rpn_head_tail_kernel": 4 * C * P_head + 4 * 6 * A * C + 4 * 6 * A * P_head,   # conv output + weights in, cls + reg out
         "rpn_conv_f32_pack_kernel": 2 * 4 * 9 * C * C,                    # the 3x3 weights in, transposed + flipped out
+        "conv3x3_c3_fwd_kernel": (4 * 3 + 4 * C1 + 8 * ((C1 + 63) // 64)) * img_px or None,        # image in, activations + sign words out
+        "conv3x3_c3_wgrad_kernel": (4 * 3 + 4 * C1 + 8 * ((C1 + 63) // 64)) * img_px or None,      # image + gradient + sign words in
     }.get(kernel)
 
 
-def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head):
+def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, img_px=0, C1=0):
     """Algorithmic flops per launch of the MFMA-bound kernels (useful positions only: no tile padding, no halo)."""
     conv = 2 * C * 9 * C * P_head                                         # C -> C 3x3 on every RPN position (model.py:68-70, new_model.py:96-98)
     return {"rpn_conv3x3_head_kernel": conv + 2 * C * 6 * A * P_head,     # raw = conv3x3 + both 1x1 heads
