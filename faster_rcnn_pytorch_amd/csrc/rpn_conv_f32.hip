@@ -1,15 +1,17 @@
-// rpn_conv_f32.hip -- the RPN head's 3x3 convolution in the reference's own precision (fp32), hand-written for gfx950:
+// rpn_conv_f32.hip -- 3x3 convolutions (padding 1, stride 1, batch 1) in the reference's own precision (fp32), hand-written for gfx950.  Built for
 //   models/model.py:68-70, 79      self.inter_layer = nn.Conv2d(512, 512, 3, padding=1)  on the 37 x 62 VGG16 feature map
 //   models/new_model.py:96-98, 109 self.inter_layer = nn.Conv2d(256, 256, 3, padding=1)  on the five FPN levels
+// (frcnn_rpn_conv3x3_f32_*: bias-free; the bias, the ReLU and both 1x1 heads stay in rpn_head.hip), and then generalised (frcnn_conv3x3_f32_*:
+// Cin != Cout, bias / ReLU / 2 x 2 max-pool in the output transform, their backward in the gradient transforms) for the backbone's own layers
+// behind models/model.py:279-281 and models/new_model.py:372, which the vendor library ran on the vector units.
 // forward, data gradient and weight gradient on v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain,
-// no reduced precision; 64 cycles per instruction and SIMD = the fp32 vector rate, 157 TFLOP/s per chip).  Until round 4 this
-// convolution was the one MIOpen call left on the hot path (igemm_fwd_gtcx35_nhwc_fp32 at 67 % of that peak, Winograd / igemm_wrw
-// for its backward).  The bias, the ReLU and both 1x1 heads stay in rpn_head.hip, which reads the bias-free output written here.
+// no reduced precision; 64 cycles per instruction and SIMD = the fp32 vector rate, 157 TFLOP/s per chip).
 //
-// TWO forms live in this file.  The DEFAULT one for all three directions is the Winograd F(2x2, 3x3) stage (section "Winograd" below:
-// rpn_wino_weight / _input / _gemm / _output, and rpn_wino_tr_t x 2 / _gemm / _dw for the weight gradient): 2.25 x fewer MFMAs.
-// The DIRECT form (9 C deep implicit GEMM, described next) is kept behind FRCNN_CONV_F32_DIRECT=1 as the A/B partner and the
-// independent check of the stage (tests/test_gpu_ops.py runs it in a child process); the stage's GEMM reuses its stream-K skeleton.
+// TWO forms live in this file.  The DEFAULT one for all three directions is the Winograd F(4x4 | 2x2, 3x3) stage (section "Winograd" below:
+// rpn_wino_weight / _input<m,0> / _gemm<false> / _output for forward and data gradient, rpn_wino_input<m,0> + <m,1> / _gemm<true> / _dw for the
+// weight gradient): 4 x or 2.25 x fewer MFMAs.  The DIRECT form (9 C deep implicit GEMM, described next; Cin = Cout only) is kept behind
+// FRCNN_CONV_F32_DIRECT=1 for the RPN entry points as the A/B partner and the independent check of the stage (tests/test_gpu_ops.py runs it in a
+// child process); the stage's GEMM reuses its stream-K skeleton.
 //
 // rpn_conv3x3_f32_kernel (forward; data gradient = the same kernel on the weights transposed and flipped by rpn_conv_f32_pack_kernel):
 //   implicit GEMM  Y[co][p] = sum_{ci, tap} Wt[co][ci * 9 + tap] * X[ci][p + off(tap)],  M = co, N = flat positions p of one level, K = 9 C.
