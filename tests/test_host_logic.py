@@ -204,3 +204,34 @@ def test_const_tensor_is_cached_per_values_and_device():
     b = ops.const_tensor([1.0, 2.0, 3.0, 4.0], torch.device("cpu"))
     c = ops.const_tensor((1, 2, 3, 5), torch.device("cpu"))
     assert a is b and a is not c and a.tolist() == [1.0, 2.0, 3.0, 4.0] and a.dtype == torch.float32
+
+
+def test_backbone_wrappers_are_the_reference_modules_off_the_fp32_device_path():
+    """model.VGGExtractor and the FPN's Bottleneck / FeaturePyramidNetwork route layers to the library's conv stage only for fp32 tensors on a HIP
+    device; anywhere else (here: the CPU) they must BE the reference's modules: the extractor the plain nn.Sequential of its children (same
+    indices, same state-dict keys as `nn.Sequential(*list(vgg16.features)[:-1])`, models/model.py:279-281), the bottleneck torchvision's
+    conv-norm-relu chain; and the eligibility predicates must say no without touching the library."""
+    import torch
+    import torch.nn as nn
+    from faster_rcnn_pytorch_amd import ops
+    from faster_rcnn_pytorch_amd.model import VGGExtractor, vgg16_features
+    from faster_rcnn_pytorch_amd.new_model import Bottleneck, FrozenBatchNorm2d
+    torch.manual_seed(0)
+    layers = vgg16_features()[:-1]
+    ext = VGGExtractor(*layers)
+    assert len(ext) == 30 and isinstance(ext[0], nn.Conv2d) and isinstance(ext[4], nn.MaxPool2d) and isinstance(ext[29], nn.ReLU)
+    conv_idx = [i for i, m in enumerate(ext) if isinstance(m, nn.Conv2d)]
+    assert conv_idx == [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]                       # torchvision's vgg16.features indices
+    assert sorted(ext.state_dict()) == sorted("%d.%s" % (i, k) for i in conv_idx for k in ("weight", "bias"))
+    x = torch.randn(1, 3, 64, 96)
+    assert torch.equal(ext(x), nn.Sequential(*layers)(x))
+    assert not ops.conv3x3_supported(x, ext[2].weight) and not ops.conv3x3_c3_supported(x, ext[0].weight) and not ops.affine_act_supported(x)
+    blk = Bottleneck(64, 16, 1, nn.Sequential(nn.Conv2d(64, 64, 1, bias=False), FrozenBatchNorm2d(64)))
+    for bn in (blk.bn1, blk.bn2, blk.bn3, blk.downsample[1]):
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    xb = torch.randn(1, 64, 20, 24)
+    out = blk(xb)
+    ref = torch.relu(blk.bn1(blk.conv1(xb)))
+    ref = torch.relu(blk.bn2(blk.conv2(ref)))
+    ref = torch.relu(blk.bn3(blk.conv3(ref)) + blk.downsample(xb))
+    assert torch.equal(out, ref)
