@@ -1514,6 +1514,26 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *
     return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
 }
 
+// 1 when the three calls would accept these shapes (channel multiples, tile / unit counts within the control block, sizes within the 32-bit offsets the
+// kernels use), 0 otherwise: what a caller's dispatch (ops.conv3x3_supported) asks before it routes a layer here instead of to the vendor library
+FRCNN_EXPORT int frcnn_conv3x3_f32_supported(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout, int need_grads)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || !wn_dims_ok(Cin, Cout) || Cout % 64 != 0 || (need_grads && Cin % 64 != 0)) return 0;
+    const int M = wn_pick_m(H_host, W_host, n_levels), P = (M + 2) * (M + 2), Cm = std::max(Cin, Cout);
+    WnArgs a;
+    const long long Ttot = wn_fill(&a, M, nullptr, nullptr, H_host, W_host, n_levels);
+    for (int l = 0; l < n_levels; ++l)
+        if (H_host[l] <= 0 || W_host[l] <= 0 || (long long)H_host[l] * W_host[l] * Cm >= (1ll << 31)) return 0;
+    if (Ttot >= (1ll << 24) || (long long)P * Cm * Ttot >= (1ll << 31) * 4) return 0;
+    auto tiles_ok = [&](long long m_side, long long n_side, long long k_chunks) {
+        const long long mt = m_side % CF_MT == 0 ? m_side / CF_MT : m_side / 64, nt = n_side % CF_NT == 0 ? n_side / CF_NT : n_side / 64, n = P * mt * nt;
+        return n <= CF_MAX_TILES && n * k_chunks < (1ll << 31);
+    };
+    if (!tiles_ok(Cout, Ttot, Cin / WN_KC)) return 0;                                            // forward
+    if (need_grads && (!tiles_ok(Cin, Ttot, Cout / WN_KC) || !tiles_ok(Cout, Cin, Ttot / WN_KC))) return 0;      // data gradient, weight gradient
+    return 1;
+}
+
 FRCNN_EXPORT int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_levels)
 {
     if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS) return 0;

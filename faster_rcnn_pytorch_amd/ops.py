@@ -752,7 +752,8 @@ def conv3x3_supported(x, weight, need_input_grad=None):
     if tuple(weight.shape[2:]) != (3, 3) or Cout % 64 != 0 or Cin % 32 != 0 or Cin * Cout * x.shape[2] * x.shape[3] < CONV3X3_MIN_WORK:
         return False
     grads = torch.is_grad_enabled() and (weight.requires_grad or (x.requires_grad if need_input_grad is None else need_input_grad))
-    return (not grads) or Cin % 64 == 0
+    Hh, Wh = _host_i32([x.shape[2]]), _host_i32([x.shape[3]])
+    return bool(lib.frcnn_conv3x3_f32_supported(_np_ptr(Hh), _np_ptr(Wh), 1, Cin, Cout, 1 if grads else 0))       # channel multiples and the control block's limits
 
 
 class _Conv3x3F32Fn(torch.autograd.Function):

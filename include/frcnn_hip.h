@@ -242,6 +242,8 @@ size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, i
  * ReLU's backward happen while the gradient is staged (H, W stay the convolution's own size everywhere).  Needs the 4 x 4 tile: frcnn_conv3x3_f32_tile_size
  * (2 or 4, the tile the calls will use for these shapes). */
 int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_levels);
+/* 1 when _fwd (and, with need_grads, _bwd_data and _wgrad) would accept these shapes, else 0: the question a caller's dispatch asks before routing a layer here. */
+int frcnn_conv3x3_f32_supported(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout, int need_grads);
 int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
                           const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, void *workspace, size_t workspace_bytes,
                           void *stream);

@@ -1634,6 +1634,8 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
         ops.conv3x3_wgrad([x32], [torch.zeros(1, 128, 256, 256, device=DEV)])
     with pytest.raises(FrcnnError):
         ops.conv3x3_fwd([x32], torch.zeros(32, 32, 3, 3, device=DEV))                            # Cout = 32
+    big = torch.empty(1, 64, 1024, 2048, device=DEV)                                             # 36 x 1024 GEMM tiles: past the control block's ticket words
+    assert not ops.conv3x3_supported(big, torch.zeros(64, 64, 3, 3, device=DEV, requires_grad=True))      # -> the caller keeps torch's convolution
 
 
 @pytest.mark.parametrize("Cin,Cout,H,W", [(128, 128, 96, 132), (64, 128, 75, 125), (64, 64, 150, 250)], ids=["even", "odd_rows_cols", "narrow"])
