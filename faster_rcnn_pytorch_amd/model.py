@@ -125,7 +125,8 @@ class RegionProposalNetwork(nn.Module):
         normal_init(self.reg_layer, 0, 0.01)
 
     def forward(self, features):
-        if features.is_cuda and features.dtype == torch.float32 and features.size(0) == 1:
+        if (features.is_cuda and features.dtype == torch.float32 and features.size(0) == 1 and not torch.is_autocast_enabled()
+                and ops.rpn_conv3x3_supported([features], self.inter_layer.weight)):
             # the 3x3 without its bias on the fp32 matrix cores (csrc/rpn_conv_f32.hip: forward, data and weight gradient hand-written);
             # bias + ReLU + both 1x1 heads + the NHWC layout in one more MFMA kernel
             raw = ops.rpn_conv3x3([features], self.inter_layer.weight)[0]

@@ -223,7 +223,7 @@ class RPNHead(nn.Module):
                 return ops.rpn_conv_head_levels([f.to(torch.bfloat16) for f in feats], self.inter_layer.weight, self.inter_layer.bias,
                                                 self.cls_layer.weight, self.cls_layer.bias, self.reg_layer.weight, self.reg_layer.bias)
         if f0.is_cuda and f0.size(0) == 1 and f0.dtype in (torch.float32, torch.bfloat16):
-            if f0.dtype == torch.float32 and not torch.is_autocast_enabled():
+            if f0.dtype == torch.float32 and not torch.is_autocast_enabled() and ops.rpn_conv3x3_supported(feats, self.inter_layer.weight):
                 raws = ops.rpn_conv3x3(list(feats), self.inter_layer.weight)      # fp32 MFMA implicit GEMM, all levels in one launch (csrc/rpn_conv_f32.hip)
             else:
                 raws = [torch.nn.functional.conv2d(f, self.inter_layer.weight, None, padding=1) for f in feats]

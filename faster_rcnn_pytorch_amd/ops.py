@@ -619,6 +619,15 @@ class _RPNConv3x3F32Fn(torch.autograd.Function):
         return (dw, *d_feats)
 
 
+def rpn_conv3x3_supported(feats, w3):
+    """Whether rpn_conv3x3 takes these levels (C a multiple of 128, sizes within the stage's control block): else the caller keeps torch's conv2d."""
+    C_ = int(w3.shape[0])
+    if C_ % 128 != 0 or tuple(w3.shape) != (C_, C_, 3, 3) or len(feats) > 5:
+        return False
+    Hh, Wh = _host_i32([f.shape[2] for f in feats]), _host_i32([f.shape[3] for f in feats])
+    return bool(lib.frcnn_conv3x3_f32_supported(_np_ptr(Hh), _np_ptr(Wh), len(feats), C_, C_, 1))
+
+
 def rpn_conv3x3(feats, w3):
     """`inter_layer` without its bias for a list of fp32 levels [1,C,h,w]; differentiable (hand-written forward / backward kernels)."""
     return list(_RPNConv3x3F32Fn.apply(w3, *feats))
