@@ -151,6 +151,10 @@ def wino_work(calls):
     def add(k, b=0, f=0):
         tot[k]["launches"] += 1; tot[k]["bytes"] += b; tot[k]["flops"] += f
     for c in calls:
+        if c["kind"] == "gemm_nt":                                          # a 1 x 1 convolution's weight gradient on the stage's GEMM: dW = dY . X^T
+            add("rpn_wino_gemm_kernel", 0, 2 * c["M"] * c["N"] * c["K"])
+            conv_flops += 2 * c["M"] * c["N"] * c["K"]
+            continue
         Cin, Cout = c["Cin"], c["Cout"]
         HW = sum(h * w for h, w in c["shapes"])
         # the library's choice of the output tile (csrc/rpn_conv_f32.hip wn_pick_m): 4 x 4 from 512 such tiles on, else 2 x 2
@@ -462,7 +466,8 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         d["stage_kernels"] = [k for k in tot if k in per_kernel]
         d["conv_flops_per_img"] = conv_flops
         d["conv_equivalent_TFLOP_s"] = round(conv_flops / stage_us * 1e-6, 2) if matched else None
-        d["layers"] = sorted({"%dx%d %s" % (c["Cin"], c["Cout"], "+".join("%dx%d" % s for s in c["shapes"])) for c in conv_calls})
+        d["layers"] = sorted({"%dx%d %s" % (c["Cin"], c["Cout"], "+".join("%dx%d" % s for s in c["shapes"])) if c["kind"] != "gemm_nt"
+                              else "1x1 wgrad %dx%dx%d" % (c["M"], c["N"], c["K"]) for c in conv_calls})
         d["note"] = ("Winograd F(2x2,3x3), all launches of one image (the RPN convolution and the backbone layers in `layers`, forward + data gradient "
                      "+ weight gradient): the GEMM is priced on the flops it executes (32 Cin Cout per padded 2x2 tile, 2.25x fewer than the "
                      "convolutions it serves); conv_equivalent_TFLOP_s = the convolutions' own flop count over the time of ALL the stage's launches")

@@ -42,6 +42,8 @@ SIGNATURES = {
     "frcnn_rpn_conv_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_workspace": (_sz, [_vp, _vp, _i, _i]),
+    "frcnn_gemm_nt_f32_workspace": (_sz, []),
+    "frcnn_gemm_nt_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "frcnn_affine_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "frcnn_conv3x3_c3_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),

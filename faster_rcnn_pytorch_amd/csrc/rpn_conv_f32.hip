@@ -1631,6 +1631,29 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float 
     return wn_wgrad<2>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
 }
 
+// ---- the stage's k-contiguous GEMM on its own: O[m][n] = sum_k A[m][k] B[n][k] (fp32, fixed summation order).  The weight gradient of a 1 x 1 convolution
+// IS this product -- dW[co][ci] = sum_p dY[co][p] X[ci][p], both operands NCHW planes with the positions contiguous -- so the bottlenecks' and the FPN
+// laterals' 1 x 1 convolutions behind models/new_model.py:372 get theirs without the vendor path's NCHW -> NHWC transposes (igemm_wrw + batched_transpose:
+// 1.3 ms per 800 x 1344 step).  M, N multiples of 64, K a multiple of 32 (a partial last chunk would read past a row).
+// splits: the K range cut into that many equal pieces, each a product of its own into O[split][M][N] (the caller adds them in order): a product with few
+// output tiles and a very long K (dW [128][512] over 16 800 positions: four tiles) would otherwise hand every tile to ~100 workgroups and leave the
+// fixed-order sum of their 64-KB slabs to ONE of them (133 us where the vendor kernel took 67); with 35 splits a tile is shared by three or four.
+FRCNN_EXPORT int frcnn_gemm_nt_f32(const float *A_dev, const float *B_dev, float *O_dev, int M, int N, int K, int splits, void *workspace, size_t workspace_bytes,
+                                   void *stream)
+{
+    FRCNN_REQUIRE(A_dev && B_dev && O_dev && workspace, "gemm_nt_f32: NULL pointer");
+    if (M <= 0 || N <= 0 || K <= 0 || splits < 1 || M % 64 != 0 || N % 64 != 0 || K % (WN_KC * splits) != 0 || M > 4096 || N > 4096)
+        return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "gemm_nt_f32: M = %d, N = %d must be multiples of 64 (<= 4096), K = %d of %d x splits (%d)", M, N, K, WN_KC, splits);
+    const CfWs ws = cf_carve(workspace, CF_MT);
+    if (workspace_bytes < ws.total) return frcnn_set_error(FRCNN_ERR_WORKSPACE, "gemm_nt_f32: workspace %zu < %zu bytes", workspace_bytes, ws.total);
+    const int MT = M % CF_MT == 0 ? CF_MT : 64, NW = N % CF_NT == 0 ? CF_NT : 64, mt = M / MT, nt = N / NW, Ks = K / splits;
+    const long long n_tiles = (long long)splits * mt * nt, Kc = Ks / WN_KC, units = n_tiles * Kc;
+    FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "gemm_nt_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
+    WgArgs g = {A_dev, B_dev, O_dev, Ks, Ks, (long long)M * N, K, K, N, mt, nt, (int)Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
+    return wn_launch_gemm(true, MT, NW, g, ws.part, ws.cnt, (hipStream_t)stream);
+}
+FRCNN_EXPORT size_t frcnn_gemm_nt_f32_workspace(void) { return cf_carve(nullptr, CF_MT).total; }
+
 // ---- the RPN head's entry points: Cin = Cout = C, no bias (rpn_head.hip adds it), no mask; FRCNN_CONV_F32_DIRECT=1 routes them to the direct kernels
 FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float *const *outs_dev, const int *H_host, const int *W_host, int n_levels, int C,
                                            const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)

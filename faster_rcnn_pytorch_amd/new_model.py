@@ -93,9 +93,17 @@ class Bottleneck(nn.Module):
             out = out + res
         return self.relu(out) if relu else out
 
+    @staticmethod
+    def _c1(conv, x):
+        """A 1 x 1 convolution: torch's forward and input gradient; its weight gradient dW = dY . X^T on the library's k-contiguous GEMM where the
+        shapes allow (the vendor path transposes both operands to NHWC first)."""
+        if conv.stride == (1, 1) and conv.bias is None and ops.conv1x1_supported(x, conv.weight):
+            return ops.conv1x1(x, conv.weight)
+        return conv(x)
+
     def forward(self, x):
         idt = x
-        out = self._norm(self.bn1, self.conv1(x), relu=True)
+        out = self._norm(self.bn1, self._c1(self.conv1, x), relu=True)
         if self.conv2.stride == (1, 1) and not torch.is_autocast_enabled() and ops.conv3x3_supported(out, self.conv2.weight):
             # conv2 + bn2 + ReLU in one stage call: the frozen norm's scale folded into the weight (s * conv(x, w) = conv(x, s w): one small
             # elementwise launch, differentiable), its shift as the bias, the ReLU in the output transform and its backward in the gradient
@@ -106,7 +114,7 @@ class Bottleneck(nn.Module):
             out = self._norm(self.bn2, self.conv2(out), relu=True)
         if self.downsample is not None:
             idt = self._norm(self.downsample[1], self.downsample[0](x))
-        return self._norm(self.bn3, self.conv3(out), res=idt, relu=True)
+        return self._norm(self.bn3, self._c1(self.conv3, out), res=idt, relu=True)
 
 
 class ResNet50Body(nn.Module):
@@ -170,10 +178,15 @@ class FeaturePyramidNetwork(nn.Module):
             if not torch.is_autocast_enabled() and ops.conv3x3_supported(t, conv.weight):
                 return ops.conv3x3(t, conv.weight, conv.bias)            # the 256 -> 256 output convolution on the fp32 Winograd stage
             return self.layer_blocks[idx](t)
-        last = self.inner_blocks[-1](xs[-1])
+        def inner(idx, t):
+            conv = self.inner_blocks[idx][0]
+            if ops.conv1x1_supported(t, conv.weight):
+                return ops.conv1x1(t, conv.weight, conv.bias)            # the lateral 1 x 1: weight gradient on the library's GEMM
+            return self.inner_blocks[idx](t)
+        last = inner(-1, xs[-1])
         results = [layer(-1, last)]
         for idx in range(len(xs) - 2, -1, -1):
-            lat = self.inner_blocks[idx](xs[idx])
+            lat = inner(idx, xs[idx])
             last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
             results.insert(0, layer(idx, last))
         names.append("pool")

@@ -812,6 +812,77 @@ def conv3x3_pool_supported(x):
     return int(lib.frcnn_conv3x3_f32_tile_size(_np_ptr(Hh), _np_ptr(Wh), 1)) == 4
 
 
+# ---- 1 x 1 convolutions: torch's forward and input gradient, the weight gradient on the conv stage's k-contiguous GEMM (no NHWC transposes)
+def _gemm_nt_splits(M, N, K):
+    """How many equal pieces to cut K into: the largest divisor of K / 32 up to 64 that still leaves a piece of >= 8 chunks, once the product has fewer
+    than 128 output tiles (few tiles + a long K = one workgroup adding ~100 slabs per tile)."""
+    tiles = (M // (128 if M % 128 == 0 else 64)) * (N // (128 if N % 128 == 0 else 64))
+    kc = K // 32
+    if tiles >= 128:
+        return 1
+    best = 1
+    for d in range(2, 65):
+        if kc % d == 0 and kc // d >= 8 and tiles * d <= 2048:
+            best = d
+    return best
+
+
+def gemm_nt(a, b):
+    """a [M,K] . b [N,K]^T -> [M,N] in fp32 on the matrix cores (frcnn_gemm_nt_f32): M, N multiples of 64, K of 32; bit-reproducible."""
+    a, b = _req(a, name="a"), _req(b, name="b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise ValueError("gemm_nt: a [M,K] and b [N,K]")
+    M, N, K = int(a.shape[0]), int(b.shape[0]), int(a.shape[1])
+    if K % 32 != 0:
+        raise ValueError("gemm_nt: K must be a multiple of 32")
+    sp = _gemm_nt_splits(M, N, K)
+    if CONV_TRACE is not None:
+        CONV_TRACE.append({"kind": "gemm_nt", "M": M, "N": N, "K": K, "splits": sp})
+    out = torch.empty((sp, M, N), dtype=torch.float32, device=a.device)
+    ws = _ctrl_workspace(a.device, "rpn_conv_f32", int(lib.frcnn_gemm_nt_f32_workspace()))
+    with torch.cuda.device(a.device):
+        check(lib.frcnn_gemm_nt_f32(_ptr(a), _ptr(b), _ptr(out), M, N, K, sp, _ptr(ws), ws.numel(), _stream()), "gemm_nt_f32")
+    return out[0] if sp == 1 else out.sum(0)                  # the pieces in order (a deterministic reduction)
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """args: (w [Cout,Cin,1,1], bias [Cout] | None, x [1,Cin,h,w]) -> conv2d(x, w, bias), stride 1: forward, input gradient and bias gradient are
+    torch's, dW = dY . X^T runs here."""
+
+    @staticmethod
+    def forward(ctx, w, bias, x):
+        ctx.save_for_backward(w, x)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.conv2d(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        g = g.contiguous()
+        dx = db = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        if ctx.needs_input_grad[2] or want_b:
+            dx, _, db = torch.ops.aten.convolution_backward(g, x, w, [int(w.shape[0])] if ctx.has_bias else None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                            [bool(ctx.needs_input_grad[2]), False, bool(want_b)])
+        dw = None
+        if ctx.needs_input_grad[0]:
+            Cout, Cin, HW = int(w.shape[0]), int(w.shape[1]), int(x.shape[2] * x.shape[3])
+            dw = gemm_nt(g.reshape(Cout, HW), x.contiguous().reshape(Cin, HW)).reshape(Cout, Cin, 1, 1)
+        return dw, db, dx
+
+
+def conv1x1(x, weight, bias=None):
+    """nn.Conv2d(Cin, Cout, 1) on one fp32 [1,Cin,h,w] map with the weight gradient on the library's GEMM; differentiable."""
+    return _Conv1x1Fn.apply(weight, bias, x)
+
+
+def conv1x1_supported(x, weight):
+    """fp32 on a HIP device, batch 1, a trainable [Cout,Cin,1,1] weight with Cout, Cin multiples of 64 and h * w a multiple of 32 (the GEMM's K chunk)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1 and not torch.is_autocast_enabled()
+            and tuple(weight.shape[2:]) == (1, 1) and weight.shape[0] % 64 == 0 and weight.shape[1] % 64 == 0 and weight.shape[0] <= 4096
+            and weight.shape[1] <= 4096 and (x.shape[2] * x.shape[3]) % 32 == 0 and torch.is_grad_enabled() and weight.requires_grad)
+
+
 # ---- FrozenBatchNorm2d (+ residual) (+ ReLU) of a ResNet bottleneck in one pass each way (csrc/affine.hip)
 class _AffineActFn(torch.autograd.Function):
     """args: (relu, scale [C], shift [C], x [1,C,h,w], res | None) -> act((x * scale + shift) [+ res]); scale / shift are frozen (no gradient)."""

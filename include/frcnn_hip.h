@@ -253,6 +253,14 @@ int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy
                             int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, void *workspace,
                             size_t workspace_bytes, void *stream);
 
+/* O[m][n] = sum_k A[m][k] * B[n][k], fp32, both operands with k contiguous (the conv stage's weight-gradient GEMM on its own; fixed summation order).  The
+ * weight gradient of a 1 x 1 convolution is this product on the NCHW planes as they are: dW [Cout, Cin] = dY [Cout, H*W] . X [Cin, H*W]^T -- the bottlenecks'
+ * and the FPN laterals' 1 x 1 convolutions behind models/new_model.py:372.  M, N multiples of 64 (<= 4096); splits >= 1 cuts K into equal pieces with
+ * one partial product each, O [splits, M, N] (the caller adds them in order; keeps a long K from being one tile's many slabs); K a multiple of 32 * splits.  workspace: the conv
+ * stage's dedicated zero-before-first-use block (>= frcnn_gemm_nt_f32_workspace() bytes; any block sized by frcnn_conv3x3_f32_workspace is larger). */
+size_t frcnn_gemm_nt_f32_workspace(void);
+int frcnn_gemm_nt_f32(const float *A, const float *B, float *O, int M, int N, int K, int splits, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The backbone's FIRST convolution, nn.Conv2d(3, Cout, 3, padding=1) (+ ReLU): `vgg16.features[0]` + `[1]` behind models/model.py:279-281.  Three input
  * channels are no contraction for the matrix cores: a byte mover on the vector units (csrc/conv_c3.hip).  x [3, H, W], y / dy [Cout, H, W], w [Cout, 3, 3, 3],
  * fp32, batch 1.  relu_bits (optional, ceil(Cout / 64) * H * W uint64 words): the signs of the ReLU outputs, bit co % 64 of word [co / 64][pixel]; _wgrad

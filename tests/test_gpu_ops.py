@@ -1746,6 +1746,38 @@ def test_conv3x3_c3_first_convolution(ops, Cout, H, W):
         assert torch.equal(out.detach(), y) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 512, 16800), (256, 256, 67200), (64, 192, 96), (512, 128, 4224)])
+def test_gemm_nt_and_the_1x1_convolution_weight_gradient(ops, M, N, K):
+    """frcnn_gemm_nt_f32 (O = A . B^T, both operands k-contiguous, fixed summation order) against float64, bit-reproducible; and ops.conv1x1 -- torch's
+    forward / input gradient / bias gradient with dW on that GEMM -- against torch's own conv2d under autograd."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV))
+    ref = a.double() @ b.double().t()
+    assert float((out.double().cpu() - ref).abs().max()) < 1e-5 * K ** 0.5 * 4
+    assert torch.equal(out, ops.gemm_nt(a.to(DEV), b.to(DEV)))
+    if K % 168 == 0:                                                          # as a convolution: [1, N, h, 168] -> [1, M, h, 168]
+        h = K // 168
+        x = b.reshape(1, N, h, 168).to(DEV).requires_grad_(True)
+        w = (torch.randn(M, N, 1, 1, generator=g) * 0.05).to(DEV).requires_grad_(True)
+        bias = torch.randn(M, generator=g).to(DEV).requires_grad_(True)
+        dy = a.reshape(1, M, h, 168).to(DEV)
+        assert ops.conv1x1_supported(x, w)
+        y = ops.conv1x1(x, w, bias)
+        y.backward(dy)
+        got = [y.detach(), x.grad.clone(), w.grad.clone(), bias.grad.clone()]
+        for t in (x, w, bias):
+            t.grad = None
+        y2 = F.conv2d(x, w, bias)
+        y2.backward(dy)
+        assert torch.equal(got[0], y2.detach()) and torch.equal(got[1], x.grad) and torch.equal(got[3], bias.grad)
+        assert float((got[2] - w.grad).abs().max()) < 1e-4 * max(1.0, float(w.grad.abs().max()))
+    with pytest.raises(Exception):
+        ops.gemm_nt(torch.zeros(64, 40, device=DEV), torch.zeros(64, 40, device=DEV))      # K % 32 != 0
+
+
 @pytest.mark.parametrize("with_res,relu", [(False, True), (True, True), (False, False), (True, False)])
 def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
     """frcnn_affine_act_fwd / _bwd: FrozenBatchNorm2d (+ residual) (+ ReLU) of torchvision's Bottleneck.forward in one pass each way -- the torch
