@@ -1355,6 +1355,11 @@ static bool cf_use_direct()
     return d;
 }
 
+// ranges of the k-contiguous GEMM (weight gradients): ONE workgroup per CU -- two did not run the matrix pipe any busier and cost this form 8-17 % in
+// LDS / DMA contention (123 -> 113 us at 256 x 150 x 250, 60 -> 50 at 512 x 37 x 62); the K-major form keeps two (one per CU: 125 -> 137 us).  A ring of
+// three chunk buffers with transfers two chunks ahead (96 KB, one workgroup per CU) was slower in both forms (143 / 121 us).
+static int wn_ranges_nt() { return cf_ranges() / CF_WPS; }
+
 static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const *out, const int *H, const int *W, int n_levels)
 {
     long long off = 0;
@@ -1609,7 +1614,7 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1, false>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
     WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
-                (int)std::min<long long>(cf_ranges(), units), 0};
+                (int)std::min<long long>(wn_ranges_nt(), units), 0};
     { const int rc = wn_launch_gemm(true, MT, NW, g, ws.part, ws.cnt, s); if (rc) return rc; }
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
     FRCNN_LAUNCH(rpn_wino_dw_kernel<M>, dim3((n + 255u) / 256u + (dbias ? (unsigned)Cout : 0u)), dim3(256), 0, s, ws.U, dw, n, dbias, ws.wt, n_strips_dy);
@@ -1649,7 +1654,7 @@ FRCNN_EXPORT int frcnn_gemm_nt_f32(const float *A_dev, const float *B_dev, float
     const int MT = M % CF_MT == 0 ? CF_MT : 64, NW = N % CF_NT == 0 ? CF_NT : 64, mt = M / MT, nt = N / NW, Ks = K / splits;
     const long long n_tiles = (long long)splits * mt * nt, Kc = Ks / WN_KC, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "gemm_nt_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
-    WgArgs g = {A_dev, B_dev, O_dev, Ks, Ks, (long long)M * N, K, K, N, mt, nt, (int)Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
+    WgArgs g = {A_dev, B_dev, O_dev, Ks, Ks, (long long)M * N, K, K, N, mt, nt, (int)Kc, (int)units, (int)std::min<long long>(wn_ranges_nt(), units), 0};
     return wn_launch_gemm(true, MT, NW, g, ws.part, ws.cnt, (hipStream_t)stream);
 }
 FRCNN_EXPORT size_t frcnn_gemm_nt_f32_workspace(void) { return cf_carve(nullptr, CF_MT).total; }
