@@ -96,7 +96,9 @@ __device__ __forceinline__ float c3_wave_sum(float v)
 #define C3_WAVES 4                     // waves per block
 #define C3_CPW 4                       // output channels per wave: 4 x 28 running sums per lane (two channels per wave, eight waves: 233 us against 189)
 // dynamic LDS: 9 x (W + 2) floats (the three rows of the three input channels around the row being walked).  Measured and not kept: all six
-// rows of a block staged at once with eight waves and the next batch's loads issued ahead (218 registers, one block per CU: 212 us against 146).
+// rows of a block staged at once with eight waves and the next batch's loads issued ahead (218 registers, one block per CU: 212 us against 146);
+// the 28 sums split over two waves (4 x 14 per lane, four waves per SIMD, the gradient loaded by both: 228 us against 189 -- the loads, not the
+// arithmetic, are what the kernel waits for: without the sign words it takes 127).
 __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int H, int W, int Cout,
                                                                        const unsigned long long *__restrict__ bits, float *__restrict__ part)
 {
