@@ -95,14 +95,16 @@ __device__ __forceinline__ float c3_wave_sum(float v)
 #define C3_ROWS 4                      // image rows per weight-gradient block: one cross-lane reduction (112 values per lane) per four rows
 #define C3_WAVES 4                     // waves per block
 #define C3_CPW 4                       // output channels per wave: 4 x 28 running sums per lane (two channels per wave, eight waves: 233 us against 189)
-// dynamic LDS: 9 x (W + 2) floats (the three rows of the three input channels around the row being walked).  Measured and not kept: all six
+// dynamic LDS: 3 x (C3_ROWS + 2) x (W + 2) floats (the block's image rows of the three input channels with their halo, staged once).  BITS is a
+// template flag: with a run-time `bits != NULL` test in front of every sign-word load the kernel took 170 us against 118.  Measured and not kept: all six
 // rows of a block staged at once with eight waves and the next batch's loads issued ahead (218 registers, one block per CU: 212 us against 146);
 // the 28 sums split over two waves (4 x 14 per lane, four waves per SIMD, the gradient loaded by both: 228 us against 189 -- the loads, not the
 // arithmetic, are what the kernel waits for: without the sign words it takes 127).
+template <bool BITS>
 __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int H, int W, int Cout,
                                                                        const unsigned long long *__restrict__ bits, float *__restrict__ part)
 {
-    extern __shared__ float s[];                                          // [9][W + 2]
+    extern __shared__ float s[];                                          // [3][C3_ROWS + 2][W + 2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ws = W + 2, NT = 64 * C3_WAVES;
     const int co0 = (blockIdx.y * C3_WAVES + wave) * C3_CPW;              // this wave's output channels (a wave past Cout only helps staging)
     const size_t plane = (size_t)H * W;
@@ -111,32 +113,35 @@ __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const f
     for (int j = 0; j < C3_CPW; ++j)
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[j][k] = 0.0f;
-    for (int row = blockIdx.x * C3_ROWS; row < min(H, (int)(blockIdx.x + 1) * C3_ROWS); ++row) {
-        __syncthreads();                                                  // the previous row's reads are done
-        for (int base = tid; base < 9 * ws; base += NT * 8) {             // eight loads in flight per thread
-            float v[8];
+    // the block's C3_ROWS + 2 image rows of the three channels, staged ONCE: [ci][row r0 - 1 .. r0 + C3_ROWS][W + 2] (per image row the staging's
+    // five dependent load batches were a third of the kernel's time)
+    const int r0 = blockIdx.x * C3_ROWS, nrow = min(C3_ROWS, H - r0), RS = C3_ROWS + 2, n_el = 3 * RS * ws;
+    for (int base = tid; base < n_el; base += NT * 8) {                   // eight loads in flight per thread
+        float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = base + NT * j, r = e / ws, q = e - r * ws, ci = r / 3, ky = r - 3 * ci, yy = row - 1 + ky, xx = q - 1;
-                v[j] = (e < 9 * ws && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)ci * H + yy) * W + xx] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = base + NT * j;
-                if (e < 9 * ws) s[e] = v[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + NT * j, rr = e / ws, q = e - rr * ws, ci = rr / RS, ry = rr - RS * ci, yy = r0 - 1 + ry, xx = q - 1;
+            v[j] = (e < n_el && yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[((size_t)ci * H + yy) * W + xx] : 0.0f;
         }
-        __syncthreads();
-        if (co0 >= Cout) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = base + NT * j;
+            if (e < n_el) s[e] = v[j];
+        }
+    }
+    __syncthreads();
+    if (co0 >= Cout) return;
+    for (int ry = 0; ry < nrow; ++ry) {
+        const int row = r0 + ry;
         const float *g0 = dy + (size_t)co0 * plane + (size_t)row * W;
-        const unsigned long long *b0 = bits ? bits + (size_t)(co0 >> 6) * plane + (size_t)row * W : nullptr;
+        const unsigned *b0 = BITS ? (const unsigned *)(bits + (size_t)(co0 >> 6) * plane + (size_t)row * W) + ((co0 & 63) >> 5) : nullptr;      // the 32-bit half that holds this wave's four bits
         for (int xb = 0; xb < W; xb += 256) {                             // 4 pixels x 4 channels of gradient in flight per lane
             float g[4][C3_CPW];
             unsigned mb[4];                                               // the wave's channels' sign bits of each pixel (co0 % C3_CPW == 0: never across words)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int xx = xb + 64 * i + lane;
-                mb[i] = (b0 && xx < W) ? (((const unsigned *)b0)[2 * xx + ((co0 & 63) >> 5)] >> (co0 & 31)) & ((1u << C3_CPW) - 1u) : ~0u;      // the 32-bit half that holds the four bits
+                mb[i] = BITS ? (xx < W ? b0[2 * xx] : 0u) : ~0u;
 #pragma unroll
                 for (int j = 0; j < C3_CPW; ++j) g[i][j] = xx < W ? g0[(size_t)j * plane + xx] : 0.0f;
             }
@@ -149,10 +154,10 @@ __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const f
 #pragma unroll
                     for (int r = 0; r < 9; ++r)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[r * ws + xc + kx];
+                        for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[((r / 3) * RS + ry + r % 3) * ws + xc + kx];      // tap (ci = r / 3, ky = r % 3)
 #pragma unroll
                     for (int j = 0; j < C3_CPW; ++j) {
-                        const float gg = ((mb[i] >> j) & 1u) ? g[i][j] : 0.0f;      // the ReLU's backward from the forward's sign word
+                        const float gg = (!BITS || ((mb[i] >> ((co0 & 31) + j)) & 1u)) ? g[i][j] : 0.0f;      // the ReLU's backward from the forward's sign word
 #pragma unroll
                         for (int k = 0; k < 27; ++k) acc[j][k] = fmaf(gg, v[k], acc[j][k]);
                         acc[j][27] += gg;
@@ -161,7 +166,6 @@ __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const f
             }
         }
     }
-    if (co0 >= Cout) return;
 #pragma unroll
     for (int j = 0; j < C3_CPW; ++j)
 #pragma unroll
@@ -222,15 +226,17 @@ FRCNN_EXPORT int frcnn_conv3x3_c3_wgrad(const float *x_dev, const float *dy_dev,
     int rc = c3_check(x_dev, dy_dev, H, W, Cout, dw_dev, "conv3x3_c3_wgrad");
     if (rc) return rc;
     FRCNN_REQUIRE(dw_dev && workspace, "conv3x3_c3_wgrad: NULL pointer");
-    if (Cout % 4 != 0 || W > 1700)
+    if (Cout % 4 != 0 || W > 1700)      // LDS: 18 x (W + 2) floats
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_c3_wgrad: Cout = %d must be a multiple of 4 and W = %d at most 1700", Cout, W);
     if (workspace_bytes < frcnn_conv3x3_c3_wgrad_workspace(H, Cout))
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "conv3x3_c3_wgrad: workspace %zu < %zu bytes", workspace_bytes, frcnn_conv3x3_c3_wgrad_workspace(H, Cout));
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)workspace;
     const int nb = (H + C3_ROWS - 1) / C3_ROWS;
-    FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel, dim3((unsigned)nb, (unsigned)((Cout + C3_CPW * C3_WAVES - 1) / (C3_CPW * C3_WAVES))), dim3(64 * C3_WAVES),
-                 (size_t)9 * (W + 2) * sizeof(float), s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
+    const dim3 wg((unsigned)nb, (unsigned)((Cout + C3_CPW * C3_WAVES - 1) / (C3_CPW * C3_WAVES)));
+    const size_t wl = (size_t)3 * (C3_ROWS + 2) * (W + 2) * sizeof(float);
+    if (relu_bits_dev) FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<true>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
+    else FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<false>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
     FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_kernel");
     FRCNN_LAUNCH(conv3x3_c3_wgrad_finalize_kernel, dim3((unsigned)((Cout * 28 + 255) / 256)), dim3(256), 0, s, part, nb, Cout, dw_dev, dbias_dev);
     FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_finalize_kernel");
