@@ -184,3 +184,23 @@ def test_winograd_stage_accounting_in_the_roofline():
     short = dict(samples, rpn_wino_gemm_kernel=[0.09] * 25)
     r2 = bench.build_record("vgg", "none", samples=short, conv_calls=calls, **kw)["roofline"]
     assert r2["kernel"] != "rpn_wino_gemm_kernel" or r2.get("frac") is None
+
+
+def test_stage_accounting_of_pooled_calls_and_1x1_weight_gradients():
+    """wino_work() prices what ops.CONV_TRACE records: a forward that pooled writes a quarter of the pixels (+ the window words), its gradient calls read the
+    gradient at the pooled size (+ the words); a 1 x 1 convolution's weight gradient is one GEMM launch of 2 M N K flops and nothing else."""
+    import bench
+    lay = {"Cin": 64, "Cout": 64, "shapes": [(600, 1000)], "bias": True}
+    T = 150 * 250                                                            # 4 x 4 tiles: >= 512 -> m = 4, P = 36
+    Tp = -(-T // 128) * 128
+    fwd = dict(lay, kind="fwd", mask=False, cached=False, relu_bits=True, pooled=True)
+    bwd = dict(lay, kind="bwd_data", mask=True, cached=False, relu_bits=False, pooled=True)
+    wg = dict(lay, kind="wgrad", mask=True, cached=True, relu_bits=False, pooled=True)
+    tot, conv = bench.wino_work([fwd, bwd, wg, {"kind": "gemm_nt", "M": 128, "N": 512, "K": 16800, "splits": 35}])
+    assert tot["rpn_wino_gemm_kernel"]["launches"] == 4
+    assert tot["rpn_wino_gemm_kernel"]["flops"] == 3 * 2 * 36 * 64 * 64 * Tp + 2 * 128 * 512 * 16800
+    assert conv == 3 * 18 * 64 * 64 * 600 * 1000 + 2 * 128 * 512 * 16800
+    words = 2 * 64 * Tp
+    assert tot["rpn_wino_output_kernel"]["bytes"] == (4 * 36 * 64 * Tp + 4 * 64 * 300 * 500 + words) + (4 * 36 * 64 * Tp + 4 * 64 * 600 * 1000)
+    assert tot["rpn_wino_input_kernel"]["launches"] == 3                      # x (forward), pooled dy twice; the weight gradient's x transform was kept
+    assert tot["rpn_wino_input_kernel"]["bytes"] == (4 * 64 * 600 * 1000 + 4 * 36 * 64 * Tp) + 2 * (4 * 64 * 300 * 500 + words + 4 * 36 * 64 * Tp)
