@@ -172,7 +172,10 @@ def wino_work(calls):
             add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)                           # (the bias gradient rides in the output gradient's transform)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
-            add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
+            if c["kind"] == "fwd":                                          # with `urot` the forward's launch also writes the data gradient's transform,
+                add("rpn_wino_weight_kernel", 4 * ((2 * P if c.get("urot") else P) + 9) * Cin * Cout)
+            elif not c.get("urot"):                                         # and the data gradient has no weight launch of its own
+                add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
             add("rpn_wino_input_kernel", 4 * K * (HWo if c["kind"] == "bwd_data" else HW) + (bits if c["kind"] == "bwd_data" else 0) + 4 * P * K * Tp)
             add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * (HWo if c["kind"] == "fwd" else HW) + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
     return tot, conv_flops

@@ -52,10 +52,11 @@ SIGNATURES = {
     "frcnn_conv3x3_f32_workspace": (_sz, [_vp, _vp, _i, _i, _i]),
     "frcnn_conv3x3_f32_xt_floats": (_sz, [_vp, _vp, _i, _i]),
     "frcnn_conv3x3_f32_relu_bits_words": (_sz, [_vp, _vp, _i, _i]),
-    "frcnn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_conv3x3_f32_u_floats": (_sz, [_vp, _vp, _i, _i, _i]),
+    "frcnn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_conv3x3_f32_tile_size": (_i, [_vp, _vp, _i]),
     "frcnn_conv3x3_f32_supported": (_i, [_vp, _vp, _i, _i, _i, _i]),
-    "frcnn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "frcnn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "frcnn_conv3x3_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -456,13 +456,21 @@ template <> __device__ __forceinline__ void wn_gt<4>(const float *u, float *w)
 
 // 16 x 16 (m, k) blocks: the data gradient reads W[k][m] (m contiguous) and writes U[m][k] (k contiguous), so its block goes through LDS
 // (the plain one-thread-per-element form read 36-byte pieces 18 KB apart: 15 us at C = 512)
-template <int M, bool TR>
-__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int Mo, int K, int Cin)
+// both = 1: ONE launch makes the forward's U (blocks [0, n)) and the data gradient's rotated U (blocks [n, 2n), into U2) -- a forward that will be
+// followed by a backward keeps the second for it (frcnn_conv3x3_f32_fwd's u_rotated) and the backward starts one launch shorter
+template <int M>
+__global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, float *__restrict__ U2, int Cout, int Cin,
+                                                              int tr_only)
 {
     // w [Cout][Cin][9].  forward: m = co, k = ci;  data gradient (TR): m = ci, k = co
     constexpr int A = Wn<M>::A;
     __shared__ float s[16][16 * 9 + 1];
-    const unsigned nb = (unsigned)K / 16u, m0 = (blockIdx.x / nb) * 16u, k0 = (blockIdx.x % nb) * 16u, row = (unsigned)Cin * 9u;
+    const unsigned nblk = (unsigned)(Cout / 16) * (unsigned)(Cin / 16);
+    const bool TR = tr_only || blockIdx.x >= nblk;                        // uniform per block
+    const unsigned b = blockIdx.x >= nblk ? blockIdx.x - nblk : blockIdx.x;
+    const int Mo = TR ? Cin : Cout, K = TR ? Cout : Cin;
+    if (blockIdx.x >= nblk) U = U2;
+    const unsigned nb = (unsigned)K / 16u, m0 = (b / nb) * 16u, k0 = (b % nb) * 16u, row = (unsigned)Cin * 9u;
 #pragma unroll
     for (unsigned q = 0; q < 9; ++q) {
         const unsigned e = threadIdx.x + 256u * q, r = e / 144u, c = e - r * 144u;
@@ -1442,7 +1450,7 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
 template <int M>
 static int wn_run(const float *const *in, float *const *out, const unsigned short *bits_in, const int *H, const int *W, int n_levels, int Cin, int Cout,
                   const float *w, bool transposed, const float *bias, int relu, unsigned short *bits_out, float *xt, void *workspace, hipStream_t s,
-                  bool pooled = false)
+                  bool pooled = false, const float *u_rot = nullptr)
 {
     // relu (forward): 0 none, 1 ReLU, 2 ReLU + max_pool2d(2, 2);  pooled (data gradient): `in` is at the pooled resolution, bits_in are pool words
     constexpr int P = Wn<M>::P;
@@ -1457,9 +1465,12 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     const long long n_tiles = (long long)P * n_m_tiles * n_t_tiles, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     const unsigned wb = (unsigned)((Mo / 16) * (K / 16));
-    if (transposed) FRCNN_LAUNCH((rpn_wino_weight_kernel<M, true>), dim3(wb), dim3(256), 0, s, w, ws.U, Mo, K, Cin);
-    else FRCNN_LAUNCH((rpn_wino_weight_kernel<M, false>), dim3(wb), dim3(256), 0, s, w, ws.U, Mo, K, Cin);
-    FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
+    const float *Uuse = ws.U;
+    if (transposed && u_rot) Uuse = u_rot;                           // the forward already made the rotated transform
+    else {
+        FRCNN_LAUNCH(rpn_wino_weight_kernel<M>, dim3(!transposed && u_rot ? 2 * wb : wb), dim3(256), 0, s, w, ws.U, (float *)u_rot, Cout, Cin, transposed ? 1 : 0);
+        FRCNN_CHECK_LAUNCH("rpn_wino_weight_kernel");
+    }
     a.C = K;
     float *Vb = xt ? xt : ws.V;                                      // kept for the weight gradient (zero padding columns included) or scratch
     a.zero_pad = xt ? 1 : 0;
@@ -1470,7 +1481,7 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
         if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 0, true>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0, false>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.U, Vb, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
+    WgArgs g = {Uuse, Vb, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
                 n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
     {
         // several tiles per workgroup: cut the ranges at tile boundaries (no partial tiles, no slabs, no tickets) when the rounding costs less
@@ -1505,8 +1516,8 @@ static int cf_check(const void *const *p0, const void *const *p1, const int *H, 
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *y_dev, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
-                                       const float *w_dev, const float *bias_dev, int relu, unsigned short *relu_bits_dev, float *x_transformed_dev, void *workspace,
-                                       size_t workspace_bytes, void *stream)
+                                       const float *w_dev, const float *bias_dev, int relu, unsigned short *relu_bits_dev, float *x_transformed_dev, float *u_rotated_dev,
+                                       void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)y_dev, H_host, W_host, n_levels, Cin, Cout, WN_KC, 64, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_fwd");
@@ -1515,8 +1526,10 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_fwd(const float *const *x_dev, float *const *
     if (relu == 2 && wn_pick_m(H_host, W_host, n_levels) != 4)
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_fwd: the fused max-pool needs the 4 x 4 tile (frcnn_conv3x3_f32_tile_size)");
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
-        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
-    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+        return wn_run<4>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream,
+                         false, u_rotated_dev);
+    return wn_run<2>(x_dev, y_dev, nullptr, H_host, W_host, n_levels, Cin, Cout, w_dev, false, bias_dev, relu, relu_bits_dev, x_transformed_dev, workspace, (hipStream_t)stream,
+                     false, u_rotated_dev);
 }
 
 // 1 when the three calls would accept these shapes (channel multiples, tile / unit counts within the control block, sizes within the 32-bit offsets the
@@ -1552,6 +1565,13 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const i
     return (size_t)Cout * (size_t)wn_fill(&a, wn_pick_m(H_host, W_host, n_levels), nullptr, nullptr, H_host, W_host, n_levels);
 }
 
+FRCNN_EXPORT size_t frcnn_conv3x3_f32_u_floats(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout)
+{
+    if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || Cin <= 0 || Cout <= 0) return 0;
+    const int M = wn_pick_m(H_host, W_host, n_levels);
+    return (size_t)((M + 2) * (M + 2)) * (size_t)Cin * (size_t)Cout;
+}
+
 FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin)
 {
     if (!H_host || !W_host || n_levels < 1 || n_levels > FRCNN_MAX_LEVELS || Cin <= 0) return 0;
@@ -1561,7 +1581,8 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const unsigned short *relu_bits_dev, float *const *dx_dev, const int *H_host, const int *W_host,
-                                            int n_levels, int Cin, int Cout, const float *w_dev, int pooled, void *workspace, size_t workspace_bytes, void *stream)
+                                            int n_levels, int Cin, int Cout, const float *w_dev, const float *u_rotated_dev, int pooled, void *workspace,
+                                            size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
@@ -1571,8 +1592,9 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const un
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_bwd_data: a pooled gradient needs the forward's words and the 4 x 4 tile");
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
         return wn_run<4>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream,
-                         pooled != 0);
-    return wn_run<2>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream);
+                         pooled != 0, u_rotated_dev);
+    return wn_run<2>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream,
+                     false, u_rotated_dev);
 }
 
 // weight gradient through the Winograd domain: V = B^T d B of the features and dM = A g A^T of the (masked) output gradient, both [xi][channel][t];
@@ -1664,7 +1686,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_fwd(const float *const *feats_dev, float 
                                            const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, nullptr, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_fwd(feats_dev, outs_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_fwd");
     if (rc) return rc;
@@ -1675,7 +1697,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
                                                 int C, const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, 0, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace,
                       workspace_bytes, "rpn_conv3x3_f32_bwd_data");
     if (rc) return rc;

@@ -536,11 +536,11 @@ def rpn_conv_wgrad(feats, d_raws):
 CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
 
 
-def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False, relu_bits=False, pooled=False):
+def _conv_trace(what, Cin, Cout, H, W, mask=False, bias=False, cached=False, relu_bits=False, pooled=False, urot=False):
     if CONV_TRACE is not None:
         kind = "wgrad" if what.endswith("wgrad") else ("bwd_data" if what.endswith("bwd_data") else "fwd")
         CONV_TRACE.append({"kind": kind, "Cin": int(Cin), "Cout": int(Cout), "shapes": [(int(h), int(w)) for h, w in zip(H, W)], "mask": bool(mask),
-                           "bias": bool(bias), "cached": bool(cached), "relu_bits": bool(relu_bits), "pooled": bool(pooled)})
+                           "bias": bool(bias), "cached": bool(cached), "relu_bits": bool(relu_bits), "pooled": bool(pooled), "urot": bool(urot)})
 
 
 def _conv_f32_call(fn, what, ins, outs, C_, w_or_dw):
@@ -634,8 +634,8 @@ def rpn_conv3x3(feats, w3):
 
 
 # ---- the same stage for the backbone's 3x3 convolutions (Cin != Cout, bias + ReLU in the output transform, ReLU's backward in the input transforms)
-def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False, relu_bits=False, pooled=False):
-    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached, relu_bits, pooled)
+def _conv3x3_call(fn, what, H, W, n, Cin, Cout, dev, args_of, mask=False, bias=False, cached=False, relu_bits=False, pooled=False, urot=False):
+    _conv_trace(what, Cin, Cout, H, W, mask, bias, cached, relu_bits, pooled, urot)
     Hh, Wh = _host_i32(H), _host_i32(W)
     nb = int(lib.frcnn_conv3x3_f32_workspace(_np_ptr(Hh), _np_ptr(Wh), n, Cin, Cout))
     if nb == 0:
@@ -659,11 +659,12 @@ def _conv3x3_levels(ts, Cc, name):
     return ts
 
 
-def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=False, pool=False):
+def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=False, pool=False, u_rotated=None):
     """y_l = act(bias + conv3x3(x_l, w)), padding 1, for a list of fp32 levels [1,Cin,h,w] sharing w [Cout,Cin,3,3] (frcnn_conv3x3_f32_fwd).
     keep_transformed: also return the transformed activations (a flat fp32 tensor) for conv3x3_wgrad(..., x_transformed=).
     want_bits (with relu): also return the ReLU's sign pattern, one int16 word per (channel, output tile), for the gradient calls' relu_bits=.
     pool (with relu): max_pool2d(2, 2) in the same pass -- ys are [1,Cout,h//2,w//2] and the words describe the pooling windows.
+    u_rotated: a buffer from conv3x3_u_buffer() that also receives the data gradient's weight transform (for conv3x3_bwd_data(..., u_rotated=)).
     Returns ys, or (ys, x_transformed | None, relu_bits | None) when either extra is asked for."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
@@ -687,12 +688,19 @@ def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=
             raise ValueError("conv3x3_fwd: want_bits needs relu=True")
         bits = torch.empty((int(lib.frcnn_conv3x3_f32_relu_bits_words(_np_ptr(Hh), _np_ptr(Wh), len(xs), Cout)),), dtype=torch.int16, device=xs[0].device)
     _conv3x3_call(lib.frcnn_conv3x3_f32_fwd, "conv3x3_f32_fwd", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, xs[0].device,
-                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), (2 if pool else 1) if relu else 0, _ptr(bits), _ptr(xt), ws, nws, st),
-                  bias=bias is not None, relu_bits=bits is not None, pooled=bool(pool))
+                  lambda H, W, ws, nws, st: (xp, yp, H, W, len(xs), Cin, Cout, _ptr(w), _ptr(bias), (2 if pool else 1) if relu else 0, _ptr(bits), _ptr(xt), _ptr(u_rotated), ws, nws, st),
+                  bias=bias is not None, relu_bits=bits is not None, pooled=bool(pool), urot=u_rotated is not None)
     return (ys, xt, bits) if (keep_transformed or want_bits) else ys
 
 
-def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None):
+def conv3x3_u_buffer(xs, w):
+    """An uninitialised buffer for the rotated weight transform of these levels (frcnn_conv3x3_f32_u_floats)."""
+    Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
+    n = int(lib.frcnn_conv3x3_f32_u_floats(_np_ptr(Hh), _np_ptr(Wh), len(xs), int(w.shape[1]), int(w.shape[0])))
+    return torch.empty((n,), dtype=torch.float32, device=w.device)
+
+
+def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None, u_rotated=None):
     """Input gradient of conv3x3_fwd; relu_bits = the forward's words (the gradient counts where the ReLU output was > 0) or None.
     pooled_from = [(h, w), ...]: the forward ran with pool=True on maps of that size; dys are at the pooled resolution."""
     w = _req(w, name="w")
@@ -703,8 +711,8 @@ def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None):
     dxs = [torch.empty((1, Cin, h, w_), dtype=torch.float32, device=d.device) for d, (h, w_) in zip(dys, hw)]
     gp, xp = _ptr_list(dys), _ptr_list(dxs)
     _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [h for h, _ in hw], [w_ for _, w_ in hw], len(dys), Cin, Cout,
-                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), 1 if pooled_from else 0, ws, nws, st),
-                  mask=relu_bits is not None, pooled=bool(pooled_from))
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), _ptr(u_rotated), 1 if pooled_from else 0, ws, nws, st),
+                  mask=relu_bits is not None, pooled=bool(pooled_from), urot=u_rotated is not None)
     return dxs
 
 
@@ -775,21 +783,22 @@ class _Conv3x3F32Fn(torch.autograd.Function):
         keep = bool(ctx.needs_input_grad[1]) and int(w.shape[1]) % 64 == 0
         grads = any(ctx.needs_input_grad[1:])
         pool = relu == 2
+        urot = conv3x3_u_buffer([x], w) if ctx.needs_input_grad[3] else None       # the backward's weight transform rides in the forward's launch (A/B: +1.1 % images/s)
         if keep or (relu and grads):
-            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), keep_transformed=keep, want_bits=bool(relu) and grads, pool=pool)
+            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), keep_transformed=keep, want_bits=bool(relu) and grads, pool=pool, u_rotated=urot)
         else:
-            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), pool=pool), None, None
+            ys, xt, bits = conv3x3_fwd([x], w, bias, bool(relu), pool=pool, u_rotated=urot), None, None
         ctx.relu = bool(relu)
         ctx.pool = pool
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(w, x, bits, xt)              # the ReLU's backward needs the sign words, not the activations
+        ctx.save_for_backward(w, x, bits, xt, urot)        # the ReLU's backward needs the sign words, not the activations
         return ys[0]
 
     @staticmethod
     def backward(ctx, g):
-        w, x, mask, xt = ctx.saved_tensors
+        w, x, mask, xt, urot = ctx.saved_tensors
         g = g.contiguous()
-        dx = conv3x3_bwd_data([g], w, mask, [tuple(x.shape[2:])] if ctx.pool else None)[0] if ctx.needs_input_grad[3] else None
+        dx = conv3x3_bwd_data([g], w, mask, [tuple(x.shape[2:])] if ctx.pool else None, u_rotated=urot)[0] if ctx.needs_input_grad[3] else None
         dw = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2], x_transformed=xt, pooled=ctx.pool)

@@ -235,6 +235,9 @@ size_t frcnn_conv3x3_f32_workspace(const int *H_host, const int *W_host, int n_l
  * B^T d B there instead of in the scratch workspace, and a later _wgrad of the same layer given the same buffer skips transforming them
  * again -- 0.6 GB per VGG16 step on a 288 GB device for one launch less per layer.  NULL: scratch / transform again. */
 size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_levels, int Cin);
+/* u_rotated (optional, frcnn_conv3x3_f32_u_floats floats, caller-owned): _fwd also leaves the transformed ROTATED weights there (same launch), and a later
+ * _bwd_data of the same layer given the buffer starts without its weight transform.  NULL: _bwd_data transforms the weights itself. */
+size_t frcnn_conv3x3_f32_u_floats(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout);
 size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout);
 /* relu = 2 (fwd): ReLU + max_pool2d(2, 2) (floor) in the output transform -- the MaxPool2d behind conv1_2 / conv2_2 / conv3_3 / conv4_3 of vgg16.features:
  * y_levels are then [Cout, H/2, W/2], the full-resolution activations are never written, and relu_bits holds per 2 x 2 window the position of the
@@ -245,10 +248,11 @@ int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_leve
 /* 1 when _fwd (and, with need_grads, _bwd_data and _wgrad) would accept these shapes, else 0: the question a caller's dispatch asks before routing a layer here. */
 int frcnn_conv3x3_f32_supported(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout, int need_grads);
 int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
-                          const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, float *u_rotated, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int frcnn_conv3x3_f32_bwd_data(const float *const *dy_levels, const unsigned short *relu_bits, float *const *dx_levels, const int *H_host, const int *W_host,
-                               int n_levels, int Cin, int Cout, const float *w, int pooled, void *workspace, size_t workspace_bytes, void *stream);
+                               int n_levels, int Cin, int Cout, const float *w, const float *u_rotated, int pooled, void *workspace, size_t workspace_bytes,
+                               void *stream);
 int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy_levels, const unsigned short *relu_bits, const int *H_host, const int *W_host,
                             int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, void *workspace,
                             size_t workspace_bytes, void *stream);

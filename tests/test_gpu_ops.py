@@ -1582,6 +1582,10 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     for o, r in zip(dx, dx_ref):
         assert o.shape == r.shape and float((o.double().cpu() - r).abs().max()) < 2e-5 * max(1.0, float(r.abs().max()))
     assert all(torch.equal(a, c) for a, c in zip(dx, ops.conv3x3_bwd_data(dyd, wd, bits)))
+    urot = ops.conv3x3_u_buffer(xd, wd)                                                          # the rotated weight transform made by the forward's launch
+    ys_u = ops.conv3x3_fwd(xd, wd, bd, relu, u_rotated=urot)
+    assert all(torch.equal(a, c) for a, c in zip(ys, ys_u))
+    assert all(torch.equal(a, c) for a, c in zip(dx, ops.conv3x3_bwd_data(dyd, wd, bits, u_rotated=urot)))
     w_ref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64)
     b_ref = torch.zeros(Cout, dtype=torch.float64)
     for x, t in zip(xs, gs):
