@@ -168,7 +168,8 @@ def wino_work(calls):
         if c["kind"] == "wgrad":
             if not c.get("cached"):
                 add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
-            add("rpn_wino_input_kernel", 4 * Cout * HWo + bits + 4 * P * Cout * Tp)       # A g A^T of the (masked, possibly pooled) output gradient
+            if not c.get("urot"):                                           # (`urot` on a weight-gradient call: the data gradient's launch already made it)
+                add("rpn_wino_input_kernel", 4 * Cout * HWo + bits + 4 * P * Cout * Tp)   # A g A^T of the (masked, possibly pooled) output gradient
             add("rpn_wino_dw_kernel", 4 * (P + 9) * Cin * Cout)                           # (the bias gradient rides in the output gradient's transform)
         else:
             K, M = (Cin, Cout) if c["kind"] == "fwd" else (Cout, Cin)
@@ -176,7 +177,8 @@ def wino_work(calls):
                 add("rpn_wino_weight_kernel", 4 * ((2 * P if c.get("urot") else P) + 9) * Cin * Cout)
             elif not c.get("urot"):                                         # and the data gradient has no weight launch of its own
                 add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
-            add("rpn_wino_input_kernel", 4 * K * (HWo if c["kind"] == "bwd_data" else HW) + (bits if c["kind"] == "bwd_data" else 0) + 4 * P * K * Tp)
+            add("rpn_wino_input_kernel", 4 * K * (HWo if c["kind"] == "bwd_data" else HW) + (bits if c["kind"] == "bwd_data" else 0)
+                + 4 * P * K * Tp * (2 if c["kind"] == "bwd_data" and c.get("cached") else 1))       # (`cached` on a data gradient: both transforms in one pass)
             add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * (HWo if c["kind"] == "fwd" else HW) + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
     return tot, conv_flops
 

@@ -56,8 +56,8 @@ SIGNATURES = {
     "frcnn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_conv3x3_f32_tile_size": (_i, [_vp, _vp, _i]),
     "frcnn_conv3x3_f32_supported": (_i, [_vp, _vp, _i, _i, _i, _i]),
-    "frcnn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp]),
-    "frcnn_conv3x3_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "frcnn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "frcnn_conv3x3_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_bwd_data": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_rpn_conv3x3_f32_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),

@@ -370,7 +370,8 @@ struct WnArgs {
     // threshold_backward computes in a launch of its own, from 1/32 of the bytes of the activations)
     unsigned short *bits_out; const unsigned short *bits;
     int relu, zero_pad;                // zero_pad: the input transforms also write zeros into the padding columns (weight gradient: the product sums over them)
-    float *db_part;                    // MODE 1 of the input transform also leaves per-strip sums of its (masked) gradient: the bias gradient's partials (NULL: not wanted)
+    float *out2;                       // MODE 2 of the input transform: where the second (weight-gradient) transform of the staged gradient goes
+    float *db_part;                    // MODE 1 / 2 of the input transform also leaves per-strip sums of its (masked) gradient: the bias gradient's partials (NULL: not wanted)
     int n_levels, C, Ttot;             // C = channels of the side the launch touches
 };
 // the batched product of the stage, both forms:
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
 // each thread then reads its patches as 8-byte LDS reads.  The ReLU mask of a gradient is applied while staging.
 //   MODE 0: V  = B^T d B of the (m + 2)^2 patch with its one-pixel halo (activations; the masked output gradient for the data gradient)
 //   MODE 1: dM = A g A^T of the m x m tile of the (masked) output gradient (weight gradient)
+//   MODE 2: both of the gradient's transforms from one staging pass: V as MODE 0 and dM (to a.out2) as MODE 1
 // Padding columns of a level (tiles past its last) are written as zeros only when a.zero_pad is set (weight gradient: the product sums
 // over the tiles); forward / data gradient never read the product's columns there, and a column depends on the same column of V only.
 struct WnStrips { int first[FRCNN_MAX_LEVELS + 1]; int segs[FRCNN_MAX_LEVELS]; int rows[FRCNN_MAX_LEVELS]; };   // first strip, strips per tile row, tile rows per strip
@@ -518,8 +520,8 @@ template <int M, int MODE, bool POOL>
 __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips st, float *__restrict__ V)
 {
     static_assert(!POOL || M == 4, "pooled gradients: 4 x 4 tiles only");
-    constexpr int A = Wn<M>::A, P = Wn<M>::P, WT = Wn<M>::WT, HALO = MODE == 0 ? 1 : 0, IN = MODE == 0 ? A : M;
-    constexpr int SM = POOL ? 2 : M, SIN = POOL ? (MODE == 0 ? 4 : 2) : IN;       // staged pixels per tile side; staged patch side
+    constexpr int A = Wn<M>::A, P = Wn<M>::P, WT = Wn<M>::WT, HALO = MODE == 1 ? 0 : 1, IN = MODE == 1 ? M : A;
+    constexpr int SM = POOL ? 2 : M, SIN = POOL ? (MODE == 1 ? 2 : 4) : IN;       // staged pixels per tile side; staged patch side
     extern __shared__ __attribute__((aligned(8))) float s[];          // the largest window of the launch's levels (wn_strips): <= Wn<M>::LDS floats
     const int c = blockIdx.y;
     int l = 0;
@@ -618,12 +620,12 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
             for (int r = 0; r < IN; ++r)
 #pragma unroll
                 for (int q = 0; q < IN; ++q) {
-                    const int fr = MODE == 0 ? r - 1 : r, fq = MODE == 0 ? q - 1 : q;                 // row / column relative to the tile's first
+                    const int fr = MODE != 1 ? r - 1 : r, fq = MODE != 1 ? q - 1 : q;                 // row / column relative to the tile's first
                     const int tr = fr < 0 ? 0 : (fr < 4 ? 1 : 2), iy = fr < 0 ? 3 : (fr < 4 ? fr : 0);
                     const int tc = fq < 0 ? 0 : (fq < 4 ? 1 : 2), ix = fq < 0 ? 3 : (fq < 4 ? fq : 0);
                     const int k = (iy >> 1) * 2 + (ix >> 1), pos = (iy & 1) * 2 + (ix & 1);
                     const unsigned w3 = (w9[tr][tc] >> (3 * k)) & 7u;
-                    const float g = sp[MODE == 0 ? (r + 1) >> 1 : r >> 1][MODE == 0 ? (q + 1) >> 1 : q >> 1];
+                    const float g = sp[MODE != 1 ? (r + 1) >> 1 : r >> 1][MODE != 1 ? (q + 1) >> 1 : q >> 1];
                     d[r][q] = (w3 == (4u | (unsigned)pos)) ? g : 0.0f;
                 }
         } else {
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
             float col[IN], o[A];
 #pragma unroll
             for (int r = 0; r < IN; ++r) col[r] = d[r][q];
-            if (MODE == 0) wn_bt<M>(col, o); else wn_a<M>(col, o);
+            if (MODE != 1) wn_bt<M>(col, o); else wn_a<M>(col, o);
 #pragma unroll
             for (int r = 0; r < A; ++r) wv[r][q] = o[r];
         }
@@ -676,15 +678,40 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 #pragma unroll
         for (int r = 0; r < A; ++r) {
             float o[A];
-            if (MODE == 0) wn_bt<M>(wv[r], o); else wn_a<M>(wv[r], o);
+            if (MODE != 1) wn_bt<M>(wv[r], o); else wn_a<M>(wv[r], o);
 #pragma unroll
             for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];
+        }
+        if (MODE == 2) {
+            // the same staged gradient's SECOND transform: A g A^T of the tile's own m x m pixels (the patch without its halo), for the weight gradient's
+            // product -- one pass over the gradient and its words serves both of its consumers
+            float w2[A][M];
+#pragma unroll
+            for (int r = 0; r < M; ++r)
+#pragma unroll
+                for (int q = 0; q < M; ++q) bsum += d[r + 1][q + 1];        // the order of MODE 1's sum: the bias gradient does not depend on the form
+#pragma unroll
+            for (int q = 0; q < M; ++q) {
+                float col[M], o[A];
+#pragma unroll
+                for (int r = 0; r < M; ++r) col[r] = d[r + 1][q + 1];
+                wn_a<M>(col, o);
+#pragma unroll
+                for (int r = 0; r < A; ++r) w2[r][q] = o[r];
+            }
+#pragma unroll
+            for (int r = 0; r < A; ++r) {
+                float o[A];
+                wn_a<M>(w2[r], o);
+#pragma unroll
+                for (int q = 0; q < A; ++q) a.out2[(size_t)(r * A + q) * plane + at] = o[q];
+            }
         }
     }
     // bias gradient (MODE 1 with a.db_part): the windows have no halo, so the strips of a channel partition its positions: strip sums -> partials
     // [channel][strip], which the last launch of the weight gradient (rpn_wino_dw_kernel) adds in strip order.  (A ticket + last-arriver
     // sum inside this launch held every block's resources for the round trips of its thread 0: +30 % on the whole transform.)
-    if (MODE == 1 && a.db_part) {
+    if (MODE != 0 && a.db_part) {
         __shared__ float red[4];
 #pragma unroll
         for (int h = 32; h > 0; h >>= 1) bsum += __shfl_down(bsum, h, 64);   // wave sums by lane shuffles (fixed tree), then four values through LDS
@@ -696,7 +723,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         const int T = a.lv[l].T, Tp = (T + CF_NT - 1) / CF_NT * CF_NT, np = Tp - T;
         for (int e = threadIdx.x; e < P * np; e += 256) {
             const int xi = e / np, q = e - xi * np;
-            V[(size_t)xi * plane + col0 + T + q] = 0.0f;
+            (MODE == 2 ? a.out2 : V)[(size_t)xi * plane + col0 + T + q] = 0.0f;
         }
     }
 }
@@ -1378,7 +1405,7 @@ static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const 
             off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
         } else a->lv[l] = {nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
-    a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr; a->bits_out = nullptr; a->bits = nullptr;
+    a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr; a->out2 = nullptr; a->bits_out = nullptr; a->bits = nullptr;
     a->n_levels = n_levels; a->C = 0; a->Ttot = (int)off;
     return off;
 }
@@ -1450,7 +1477,7 @@ static int wn_strips(WnStrips *st, const WnArgs &a, const int *H, int n_levels, 
 template <int M>
 static int wn_run(const float *const *in, float *const *out, const unsigned short *bits_in, const int *H, const int *W, int n_levels, int Cin, int Cout,
                   const float *w, bool transposed, const float *bias, int relu, unsigned short *bits_out, float *xt, void *workspace, hipStream_t s,
-                  bool pooled = false, const float *u_rot = nullptr)
+                  bool pooled = false, const float *u_rot = nullptr, float *dm_out = nullptr, bool want_bias = false)
 {
     // relu (forward): 0 none, 1 ReLU, 2 ReLU + max_pool2d(2, 2);  pooled (data gradient): `in` is at the pooled resolution, bits_in are pool words
     constexpr int P = Wn<M>::P;
@@ -1477,7 +1504,17 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     WnStrips st;
     size_t lds = 0;
     const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds, pooled ? 2 : M);
-    if (pooled) {
+    if (dm_out) {                                                    // data gradient that also feeds the weight gradient: both transforms, one pass
+        a.out2 = dm_out; a.zero_pad = 1;
+        if (want_bias) {
+            const size_t C9 = (size_t)((std::max(Cin, Cout) + CF_MT - 1) / CF_MT) * CF_MT;
+            FRCNN_REQUIRE((size_t)K * n_strips <= C9 * C9 * 9, "conv3x3_f32_bwd_data: %d strips are too many for the bias partials", n_strips);
+            a.db_part = ws.wt;
+        }
+        if (pooled) {
+            if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 2, true>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
+        } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 2, false>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
+    } else if (pooled) {
         if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 0, true>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0, false>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
@@ -1581,8 +1618,8 @@ FRCNN_EXPORT size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const unsigned short *relu_bits_dev, float *const *dx_dev, const int *H_host, const int *W_host,
-                                            int n_levels, int Cin, int Cout, const float *w_dev, const float *u_rotated_dev, int pooled, void *workspace,
-                                            size_t workspace_bytes, void *stream)
+                                            int n_levels, int Cin, int Cout, const float *w_dev, const float *u_rotated_dev, int pooled, float *dy_transformed_dev,
+                                            int want_bias_partials, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
@@ -1592,9 +1629,9 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const un
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_bwd_data: a pooled gradient needs the forward's words and the 4 x 4 tile");
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
         return wn_run<4>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream,
-                         pooled != 0, u_rotated_dev);
+                         pooled != 0, u_rotated_dev, dy_transformed_dev, want_bias_partials != 0);
     return wn_run<2>(dy_dev, dx_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, w_dev, true, nullptr, 0, nullptr, nullptr, workspace, (hipStream_t)stream,
-                     false, u_rotated_dev);
+                     false, u_rotated_dev, dy_transformed_dev, want_bias_partials != 0);
 }
 
 // weight gradient through the Winograd domain: V = B^T d B of the features and dM = A g A^T of the (masked) output gradient, both [xi][channel][t];
@@ -1602,7 +1639,7 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const un
 // bias gradient)
 template <int M>
 static int wn_wgrad(const float *const *feats, const float *const *d_outs, const unsigned short *bits, const int *H, const int *W, int n_levels, int Cin, int Cout,
-                    float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s, bool pooled = false)
+                    float *dw, float *dbias, const float *xt, void *workspace, hipStream_t s, bool pooled = false, const float *dm_in = nullptr)
 {
     constexpr int P = Wn<M>::P;
     WnArgs a;
@@ -1626,16 +1663,18 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     for (int l = 0; l < n_levels; ++l) g1.lv[l].x = d_outs[l];
     g1.bits = bits;
     g1.C = Cout;
-    n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, 0, &lds, pooled ? 2 : M);
+    n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, dm_in ? 1 : 0, &lds, pooled ? 2 : M);      // (dm_in: the strips of the data gradient's launch that made it)
     const int n_strips_dy = n_strips;
     FRCNN_REQUIRE(!dbias || (size_t)Cout * n_strips_dy <= (size_t)C9 * C9 * 9, "conv3x3_f32_wgrad: %d strips are too many for the bias partials", n_strips_dy);
     if (dbias) g1.db_part = ws.wt;                                   // the bias gradient's strip partials ride in this launch (in the direct form's weight
                                                                      // buffer, idle in this form) and are added up by the last launch
-    if (pooled) {
+    if (dm_in) {
+        // the data gradient's call already transformed the output gradient for this product (and left the bias partials in ws.wt)
+    } else if (pooled) {
         if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 1, true>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 1, false>), dim3((unsigned)n_strips, (unsigned)Cout), dim3(256), lds, s, g1, st, ws.M);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
-    WgArgs g = {ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
+    WgArgs g = {dm_in ? dm_in : ws.M, xt ? xt : ws.V, ws.U, Ttot * Cout, Ttot * Cin, (long long)Cout * Cin, (int)Ttot, (int)Ttot, Cin, mt, nt, (int)Kc, (int)units,
                 (int)std::min<long long>(wn_ranges_nt(), units), 0};
     { const int rc = wn_launch_gemm(true, MT, NW, g, ws.part, ws.cnt, s); if (rc) return rc; }
     const unsigned n = (unsigned)Cout * (unsigned)Cin;
@@ -1645,17 +1684,18 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_f32_wgrad(const float *const *x_dev, const float *const *dy_dev, const unsigned short *relu_bits_dev, const int *H_host, const int *W_host,
-                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, int pooled, void *workspace,
-                                         size_t workspace_bytes, void *stream)
+                                         int n_levels, int Cin, int Cout, float *dw_dev, float *dbias_dev, const float *x_transformed_dev, int pooled,
+                                         const float *dy_transformed_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     int rc = cf_check((const void *const *)x_dev, (const void *const *)dy_dev, H_host, W_host, n_levels, Cin, Cout, 64, 64, dw_dev, workspace, workspace_bytes,
                       "conv3x3_f32_wgrad");
     if (rc) return rc;
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
         return wn_wgrad<4>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream,
-                           pooled != 0);
+                           pooled != 0, dy_transformed_dev);
     if (pooled) return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_wgrad: a pooled gradient needs the forward's words and the 4 x 4 tile");
-    return wn_wgrad<2>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream);
+    return wn_wgrad<2>(x_dev, dy_dev, relu_bits_dev, H_host, W_host, n_levels, Cin, Cout, dw_dev, dbias_dev, x_transformed_dev, workspace, (hipStream_t)stream, false,
+                       dy_transformed_dev);
 }
 
 // ---- the stage's k-contiguous GEMM on its own: O[m][n] = sum_k A[m][k] B[n][k] (fp32, fixed summation order).  The weight gradient of a 1 x 1 convolution
@@ -1697,7 +1737,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_bwd_data(const float *const *d_outs_dev, 
                                                 int C, const float *w3_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_bwd_data(d_outs_dev, nullptr, d_feats_dev, H_host, W_host, n_levels, C, C, w3_dev, nullptr, 0, nullptr, 0, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)d_outs_dev, (const void *const *)d_feats_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, w3_dev, workspace,
                       workspace_bytes, "rpn_conv3x3_f32_bwd_data");
     if (rc) return rc;
@@ -1712,7 +1752,7 @@ FRCNN_EXPORT int frcnn_rpn_conv3x3_f32_wgrad(const float *const *feats_dev, cons
                                              int C, float *dw_dev, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!cf_use_direct())
-        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, nullptr, 0, workspace, workspace_bytes, stream);
+        return frcnn_conv3x3_f32_wgrad(feats_dev, d_outs_dev, nullptr, H_host, W_host, n_levels, C, C, dw_dev, nullptr, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
     int rc = cf_check((const void *const *)feats_dev, (const void *const *)d_outs_dev, H_host, W_host, n_levels, C, C, CF_MT, CF_MT, dw_dev, workspace, workspace_bytes,
                       "rpn_conv3x3_f32_wgrad");
     if (rc) return rc;

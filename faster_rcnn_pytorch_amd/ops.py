@@ -693,6 +693,12 @@ def conv3x3_fwd(xs, w, bias=None, relu=False, keep_transformed=False, want_bits=
     return (ys, xt, bits) if (keep_transformed or want_bits) else ys
 
 
+def conv3x3_dy_buffer(hw, Cout, device):
+    """An uninitialised buffer for the weight-gradient transform of an output gradient over maps of sizes hw = [(h, w), ...] (the convolution's own sizes)."""
+    Hh, Wh = _host_i32([h for h, _ in hw]), _host_i32([w_ for _, w_ in hw])
+    return torch.empty((int(lib.frcnn_conv3x3_f32_xt_floats(_np_ptr(Hh), _np_ptr(Wh), len(hw), int(Cout))),), dtype=torch.float32, device=device)
+
+
 def conv3x3_u_buffer(xs, w):
     """An uninitialised buffer for the rotated weight transform of these levels (frcnn_conv3x3_f32_u_floats)."""
     Hh, Wh = _host_i32([x.shape[2] for x in xs]), _host_i32([x.shape[3] for x in xs])
@@ -700,9 +706,11 @@ def conv3x3_u_buffer(xs, w):
     return torch.empty((n,), dtype=torch.float32, device=w.device)
 
 
-def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None, u_rotated=None):
+def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None, u_rotated=None, dy_transformed=None, want_bias_partials=False):
     """Input gradient of conv3x3_fwd; relu_bits = the forward's words (the gradient counts where the ReLU output was > 0) or None.
-    pooled_from = [(h, w), ...]: the forward ran with pool=True on maps of that size; dys are at the pooled resolution."""
+    pooled_from = [(h, w), ...]: the forward ran with pool=True on maps of that size; dys are at the pooled resolution.
+    dy_transformed: a buffer from conv3x3_dy_buffer() that also receives the gradient's weight-gradient transform, for a conv3x3_wgrad(...,
+    dy_transformed=) called next (want_bias_partials: that call will also want the bias gradient)."""
     w = _req(w, name="w")
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     dys = _conv3x3_levels(dys, Cout, "d_out")
@@ -711,8 +719,9 @@ def conv3x3_bwd_data(dys, w, relu_bits=None, pooled_from=None, u_rotated=None):
     dxs = [torch.empty((1, Cin, h, w_), dtype=torch.float32, device=d.device) for d, (h, w_) in zip(dys, hw)]
     gp, xp = _ptr_list(dys), _ptr_list(dxs)
     _conv3x3_call(lib.frcnn_conv3x3_f32_bwd_data, "conv3x3_f32_bwd_data", [h for h, _ in hw], [w_ for _, w_ in hw], len(dys), Cin, Cout,
-                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), _ptr(u_rotated), 1 if pooled_from else 0, ws, nws, st),
-                  mask=relu_bits is not None, pooled=bool(pooled_from), urot=u_rotated is not None)
+                  dys[0].device, lambda H, W, ws, nws, st: (gp, _ptr(relu_bits), xp, H, W, len(dys), Cin, Cout, _ptr(w), _ptr(u_rotated), 1 if pooled_from else 0, _ptr(dy_transformed),
+                                            1 if want_bias_partials else 0, ws, nws, st),
+                  mask=relu_bits is not None, pooled=bool(pooled_from), urot=u_rotated is not None, cached=dy_transformed is not None)
     return dxs
 
 
@@ -736,7 +745,7 @@ def _conv3x3_bits(relu_bits, hw, Cout):
     return relu_bits
 
 
-def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None, pooled=False):
+def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None, pooled=False, dy_transformed=None):
     """(dw [Cout,Cin,3,3], dbias [Cout] | None) of conv3x3_fwd, summed over the levels.  x_transformed: what conv3x3_fwd(..., keep_transformed=True)
     returned for the same xs (the activations are then not transformed again)."""
     Cin, Cout = int(xs[0].shape[1]), int(dys[0].shape[1])
@@ -750,8 +759,9 @@ def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None, 
     db = torch.empty((Cout,), dtype=torch.float32, device=dev) if want_bias else None
     xp, gp = _ptr_list(xs), _ptr_list(dys)
     _conv3x3_call(lib.frcnn_conv3x3_f32_wgrad, "conv3x3_f32_wgrad", [x.shape[2] for x in xs], [x.shape[3] for x in xs], len(xs), Cin, Cout, dev,
-                  lambda H, W, ws, nws, st: (xp, gp, _ptr(relu_bits), H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), 1 if pooled else 0, ws, nws, st),
-                  mask=relu_bits is not None, bias=want_bias, cached=x_transformed is not None, pooled=pooled)
+                  lambda H, W, ws, nws, st: (xp, gp, _ptr(relu_bits), H, W, len(xs), Cin, Cout, _ptr(dw), _ptr(db), _ptr(x_transformed), 1 if pooled else 0, _ptr(dy_transformed),
+                                            ws, nws, st),
+                  mask=relu_bits is not None, bias=want_bias, cached=x_transformed is not None, pooled=pooled, urot=dy_transformed is not None)
     return dw, db
 
 
@@ -798,10 +808,16 @@ class _Conv3x3F32Fn(torch.autograd.Function):
     def backward(ctx, g):
         w, x, mask, xt, urot = ctx.saved_tensors
         g = g.contiguous()
-        dx = conv3x3_bwd_data([g], w, mask, [tuple(x.shape[2:])] if ctx.pool else None, u_rotated=urot)[0] if ctx.needs_input_grad[3] else None
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        want_b = bool(ctx.has_bias and ctx.needs_input_grad[2])
+        # both gradients: the data gradient's call stages dy once and leaves its weight-gradient transform (and the bias partials) for the call behind it
+        dyt = conv3x3_dy_buffer([tuple(x.shape[2:])], int(w.shape[0]), g.device) if (ctx.needs_input_grad[3] and want_w) else None
+        dx = None
+        if ctx.needs_input_grad[3]:
+            dx = conv3x3_bwd_data([g], w, mask, [tuple(x.shape[2:])] if ctx.pool else None, u_rotated=urot, dy_transformed=dyt, want_bias_partials=want_b)[0]
         dw = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=ctx.has_bias and ctx.needs_input_grad[2], x_transformed=xt, pooled=ctx.pool)
+        if want_w:
+            dw, db = conv3x3_wgrad([x], [g], mask, want_bias=want_b, x_transformed=xt, pooled=ctx.pool, dy_transformed=dyt)
             if not ctx.needs_input_grad[1]:
                 dw = None
         return None, dw, db, dx

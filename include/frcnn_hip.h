@@ -238,6 +238,9 @@ size_t frcnn_conv3x3_f32_xt_floats(const int *H_host, const int *W_host, int n_l
 /* u_rotated (optional, frcnn_conv3x3_f32_u_floats floats, caller-owned): _fwd also leaves the transformed ROTATED weights there (same launch), and a later
  * _bwd_data of the same layer given the buffer starts without its weight transform.  NULL: _bwd_data transforms the weights itself. */
 size_t frcnn_conv3x3_f32_u_floats(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout);
+/* dy_transformed (optional, frcnn_conv3x3_f32_xt_floats(H, W, n_levels, Cout) floats, caller-owned): _bwd_data stages the output gradient once and also writes
+ * its weight-gradient transform A g A^T there (with want_bias_partials != 0 also the bias gradient's partial sums, in the workspace); a _wgrad of the same
+ * layer called NEXT on the same workspace with that buffer skips its own pass over the gradient.  NULL: each call transforms the gradient itself. */
 size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, int n_levels, int Cout);
 /* relu = 2 (fwd): ReLU + max_pool2d(2, 2) (floor) in the output transform -- the MaxPool2d behind conv1_2 / conv2_2 / conv3_3 / conv4_3 of vgg16.features:
  * y_levels are then [Cout, H/2, W/2], the full-resolution activations are never written, and relu_bits holds per 2 x 2 window the position of the
@@ -251,11 +254,11 @@ int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, 
                           const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, float *u_rotated, void *workspace,
                           size_t workspace_bytes, void *stream);
 int frcnn_conv3x3_f32_bwd_data(const float *const *dy_levels, const unsigned short *relu_bits, float *const *dx_levels, const int *H_host, const int *W_host,
-                               int n_levels, int Cin, int Cout, const float *w, const float *u_rotated, int pooled, void *workspace, size_t workspace_bytes,
-                               void *stream);
+                               int n_levels, int Cin, int Cout, const float *w, const float *u_rotated, int pooled, float *dy_transformed,
+                               int want_bias_partials, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_conv3x3_f32_wgrad(const float *const *x_levels, const float *const *dy_levels, const unsigned short *relu_bits, const int *H_host, const int *W_host,
-                            int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, void *workspace,
-                            size_t workspace_bytes, void *stream);
+                            int n_levels, int Cin, int Cout, float *dw, float *dbias, const float *x_transformed, int pooled, const float *dy_transformed,
+                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* O[m][n] = sum_k A[m][k] * B[n][k], fp32, both operands with k contiguous (the conv stage's weight-gradient GEMM on its own; fixed summation order).  The
  * weight gradient of a 1 x 1 convolution is this product on the NCHW planes as they are: dW [Cout, Cin] = dY [Cout, H*W] . X [Cin, H*W]^T -- the bottlenecks'

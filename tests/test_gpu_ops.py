@@ -1605,6 +1605,14 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     _lib.prof_enable(False)
     assert torch.equal(dw, dw3) and torch.equal(db, db3)
     assert _lib.prof_report()["rpn_wino_input_kernel"][1] == 1                                     # only the output gradient was transformed
+    # the data gradient's call can stage the output gradient once for both consumers: its own transform and the weight gradient's (+ bias partials)
+    dyt = ops.conv3x3_dy_buffer(shapes, Cout, DEV)
+    dx_s = ops.conv3x3_bwd_data(dyd, wd, bits, dy_transformed=dyt, want_bias_partials=True)
+    _lib.prof_reset(); _lib.prof_enable(True)
+    dw4, db4 = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True, x_transformed=xt, dy_transformed=dyt)
+    _lib.prof_enable(False)
+    assert all(torch.equal(a, c) for a, c in zip(dx, dx_s)) and torch.equal(dw, dw4) and torch.equal(db, db4)
+    assert "rpn_wino_input_kernel" not in _lib.prof_report()                                       # nothing left to transform
 
 
 def test_conv3x3_f32_autograd_and_argument_checks(ops):
@@ -1693,6 +1701,10 @@ def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
     assert tuple(dx.shape) == (1, Cin, H, W)
     assert float((dx.double().cpu() - dx_ref).abs().max()) < 2e-5 * max(1.0, float(dx_ref.abs().max()))
     dw, db = ops.conv3x3_wgrad([xd], [dpd], bits, want_bias=True, x_transformed=xt, pooled=True)
+    dyt = ops.conv3x3_dy_buffer([(H, W)], Cout, DEV)                         # the same with the pooled gradient staged once for both consumers
+    dx_s = ops.conv3x3_bwd_data([dpd], wd, bits, pooled_from=[(H, W)], dy_transformed=dyt, want_bias_partials=True)[0]
+    dw_s, db_s = ops.conv3x3_wgrad([xd], [dpd], bits, want_bias=True, x_transformed=xt, pooled=True, dy_transformed=dyt)
+    assert torch.equal(dx, dx_s) and torch.equal(dw, dw_s) and torch.equal(db, db_s)
     w_ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), gfull, padding=1)
     assert float((dw.double().cpu() - w_ref).abs().max()) < 1e-4 * max(1.0, float(w_ref.abs().max()))
     assert float((db.double().cpu() - gfull.sum(dim=(0, 2, 3))).abs().max()) < 1e-4 * max(1.0, float(gfull.sum(dim=(0, 2, 3)).abs().max()))
