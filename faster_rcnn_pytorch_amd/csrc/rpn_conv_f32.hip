@@ -558,7 +558,11 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int q = qb + 64 * j, xx = x0 + q;
+#if defined(WN_TABL) && (WN_TABL & 1)
+                    v[j] = 0.5f;
+#else
                     v[j] = (row_in && q < ncol && xx >= 0 && xx < Ws) ? xr[q] : 0.0f;
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -680,7 +684,11 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
             float o[A];
             if (MODE != 1) wn_bt<M>(wv[r], o); else wn_a<M>(wv[r], o);
 #pragma unroll
+#if defined(WN_TABL) && (WN_TABL & 2)
+            for (int q = 0; q < A; ++q) if (o[q] == 1.2345e-30f) V[(size_t)(r * A + q) * plane + at] = o[q];
+#else
             for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];
+#endif
         }
         if (MODE == 2) {
             // the same staged gradient's SECOND transform: A g A^T of the tile's own m x m pixels (the patch without its halo), for the weight gradient's
@@ -748,7 +756,11 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
     for (int q = 0; q < A; ++q) {
         float col[A], o[M];
 #pragma unroll
+#if defined(WN_TABL) && (WN_TABL & 4)
+        for (int r = 0; r < A; ++r) { col[r] = (float)(r + q); asm volatile("" : "+v"(col[r])); }
+#else
         for (int r = 0; r < A; ++r) col[r] = Mp[(size_t)(r * A + q) * plane + at];
+#endif
         wn_at<M>(col, o);
 #pragma unroll
         for (int i = 0; i < M; ++i) s[i][q] = o[i];
@@ -786,19 +798,32 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
         return;
     }
     float *y = a.lv[l].y + (size_t)c * H * W + (size_t)(M * ty) * W + M * tx;
+    // a tile row as ONE store where the map's width allows (W a multiple of m: every tile is whole and every row piece m-float aligned) -- as
+    // four dword stores, each wave-instruction wrote every fourth dword of a 1-KB span and the 154 MB of a 64 x 600 x 1000 map left at 2.5 TB/s
+    const bool vec = (W % M) == 0 && ((size_t)a.lv[l].y & (4 * M - 1)) == 0, pairs = (W & 1) == 0 && ((size_t)a.lv[l].y & 7) == 0;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
         float o[M];
         wn_at<M>(s[i], o);
         if (M * ty + i < H) {
+            float v[M];
 #pragma unroll
             for (int j = 0; j < M; ++j) {
-                float v = o[j] + b;
-                if (a.relu) v = fmaxf(v, 0.0f);
-                if (M * tx + j < W) {
-                    y[(size_t)i * W + j] = v;
-                    word |= (v > 0.0f) ? (1u << (i * M + j)) : 0u;
-                }
+                v[j] = o[j] + b;
+                if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                if (M * tx + j < W) word |= (v[j] > 0.0f) ? (1u << (i * M + j)) : 0u;
+            }
+            if (vec) {
+                if (M == 4) *(float4 *)(y + (size_t)i * W) = make_float4(v[0], v[1], v[2], v[3]);
+                else *(float2 *)(y + (size_t)i * W) = make_float2(v[0], v[1]);
+            } else if (M == 4 && pairs) {                                 // an even width: pairs stay whole and 8-byte aligned
+#pragma unroll
+                for (int j = 0; j < M; j += 2)
+                    if (M * tx + j < W) *(float2 *)(y + (size_t)i * W + j) = make_float2(v[j], v[j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < M; ++j)
+                    if (M * tx + j < W) y[(size_t)i * W + j] = v[j];
             }
         }
     }
@@ -1039,7 +1064,9 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         Tl Tn = T;
         const bool more = u + 1 < u1;
         if (more && ntile != tile) Tn = tile_of(ntile);
+#if !(defined(WN_ABL) && (WN_ABL & 2))                             // developer ablation 2: nothing staged behind the first chunk
         if (more) issue_dma(Tn, nchunk, buf ^ 1);                   // every wave is past the barrier that ended the last reads of that buffer
+#endif
         if (NT) {
             // lane (i = li, half lh) takes k = 16 lh + s at step s: sixteen consecutive floats of its row = four ds_read_b128 per operand row
             // and chunk (the contraction does not care which k goes to which step as long as both operands agree)
@@ -1075,6 +1102,13 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
             const float *pb = &sB[buf][lh * NW + wn * (NW / 2) + li];
             float oa[2][MI], ob[2][NI];
             auto fetch = [&](int s, int slot) {
+#if defined(WN_ABL) && (WN_ABL & 4)                                 // developer ablation 4: no operand reads from LDS
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) { oa[slot][mi] = (float)s; asm volatile("" : "+v"(oa[slot][mi])); }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) { ob[slot][ni] = (float)s; asm volatile("" : "+v"(ob[slot][ni])); }
+                return;
+#endif
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) oa[slot][mi] = pa[2 * s * MT + 32 * mi];
 #pragma unroll
@@ -1104,7 +1138,9 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         }
         tile = ntile; chunk = nchunk;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next chunk's transfers have landed (this wave's; the barrier covers the others')
+#if !(defined(WN_ABL) && (WN_ABL & 8))                             // developer ablation 8: no barrier between chunks
         __syncthreads();
+#endif
     }
 }
 
