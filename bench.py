@@ -140,11 +140,23 @@ def algorithmic_flops(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, img_px=0,
     # (rpn_wino_gemm_kernel serves several layers per image: build_record prices it from the traced calls of one step, wino_work)
 
 
+def wino_tiling(shapes):
+    """(m, padded tile total) of a stage call over these (H, W) levels: the library's rule (csrc/rpn_conv_f32.hip wn_padded / wn_pick_m; the
+    CPU suite checks this mirror against the library's own answers).  Per level the m x m tiles are padded to the product's tile width -- 128, or 64
+    where that shortens the total by 15 % or more --, and m = 4 wherever 36 planes x its total is at least 15 % below 16 planes x the 2 x 2 total."""
+    def padded(m):
+        t = [(-(-h // m)) * (-(-w // m)) for h, w in shapes]
+        t128, t64 = sum(-(-x // 128) * 128 for x in t), sum(-(-x // 64) * 64 for x in t)
+        return t64 if t64 * 100 <= t128 * 85 else t128
+    m = 4 if 36 * padded(4) * 100 <= 16 * padded(2) * 85 else 2
+    return m, padded(m)
+
+
 def wino_work(calls):
     """Per-image algorithmic totals of the fp32 Winograd stage's kernels from the calls ONE training step makes (ops.CONV_TRACE: the RPN
     convolution and every backbone layer the stage takes, each forward / data gradient / weight gradient): kernel -> launches, bytes,
-    flops; plus the flop count of the convolutions served (18 Cin Cout per position and direction).  Tiles are padded to 128 per level
-    (that padding is executed, so the GEMM is priced on it); transforms move the activations once and the 16 planes once."""
+    flops; plus the flop count of the convolutions served (18 Cin Cout per position and direction).  Tiles are padded per level (wino_tiling:
+    that padding is executed, so the GEMM is priced on it); transforms move the activations once and the 16 planes once."""
     tot = {k: {"launches": 0, "bytes": 0, "flops": 0} for k in WINO_STAGE}
     conv_flops = 0
 
@@ -157,10 +169,8 @@ def wino_work(calls):
             continue
         Cin, Cout = c["Cin"], c["Cout"]
         HW = sum(h * w for h, w in c["shapes"])
-        # the library's choice of the output tile (csrc/rpn_conv_f32.hip wn_pick_m): 4 x 4 from 512 such tiles on, else 2 x 2
-        m = 4 if sum(((h + 3) // 4) * ((w + 3) // 4) for h, w in c["shapes"]) >= 512 else 2
+        m, Tp = wino_tiling(c["shapes"])                                # the library's choice of the output tile and its padded tile total
         P = (m + 2) ** 2
-        Tp = sum(-(-(((h + m - 1) // m) * ((w + m - 1) // m)) // 128) * 128 for h, w in c["shapes"])
         bits = 2 * Cout * Tp if c.get("mask") else 0                    # the ReLU's sign words: one uint16 per (channel, tile)
         HWo = sum((h // 2) * (w // 2) for h, w in c["shapes"]) if c.get("pooled") else HW     # fused max-pool: outputs / incoming gradients at the pooled size
         conv_flops += 18 * Cin * Cout * HW

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // the m x m output tiles (T = ceil(H/m) ceil(W/m) per level) instead of one with K = 9 Cin.  m = 2: 16 products, 2.25 x fewer MFMAs
 // (fp32: ~3e-7 of the output scale, as good as the direct sum); m = 4: 36 products over a quarter of the tiles, 4 x fewer MFMAs and 0.56 x
 // the transformed bytes (fp32: ~5e-6 of the scale -- the 1/24 .. 8 range of its transform constants -- inside the path's 1e-4; maps with fewer
-// than WN_M4_MIN_TILES 4 x 4 tiles stay with m = 2, where the 128-tile padding would eat the gain).  Four launches, all levels each:
+// the tile padding would eat the gain stay with m = 2: wn_pick_m prices both forms by planes x padded tiles).  Four launches, all levels each:
 //   rpn_wino_weight_kernel   U[xi][k][m] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
 //   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded (m + 2)^2 input patch of tile t; rows padded to a multiple of 128 tiles
 //   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][k][m] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
@@ -360,7 +360,6 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // XOR-swizzled at the source side of the LDS-DMA, fragments by ds_read_b128); no transposing pass.
 // The transformed operands travel through the workspace (P C Ttot floats each way).
 #define WN_KC 32                       // K values per chunk
-#define WN_M4_MIN_TILES 512            // 4 x 4 tiles (all levels) from which m = 4 is used
 struct WnLevel { const float *x; float *y; int H, W, tw, T, off; };
 struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
@@ -373,6 +372,7 @@ struct WnArgs {
     float *out2;                       // MODE 2 of the input transform: where the second (weight-gradient) transform of the staged gradient goes
     float *db_part;                    // MODE 1 / 2 of the input transform also leaves per-strip sums of its (masked) gradient: the bias gradient's partials (NULL: not wanted)
     int n_levels, C, Ttot;             // C = channels of the side the launch touches
+    int tg;                            // the levels' tile counts are padded to multiples of tg (128, or 64: wn_tgran) = the product's tile width on that side
 };
 // the batched product of the stage, both forms:
 //   <false>  O[xi][m][n] = sum_k A[xi][k][m] B[xi][k][n], operands K-major (rows k, 128 columns per tile): forward / data gradient,
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
         if (threadIdx.x == 0) a.db_part[(size_t)c * st.first[FRCNN_MAX_LEVELS] + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
     if (a.zero_pad && strip == 0) {                                       // this level's padding columns of channel c, all planes
-        const int T = a.lv[l].T, Tp = (T + CF_NT - 1) / CF_NT * CF_NT, np = Tp - T;
+        const int T = a.lv[l].T, Tp = (T + a.tg - 1) / a.tg * a.tg, np = Tp - T;
         for (int e = threadIdx.x; e < P * np; e += 256) {
             const int xi = e / np, q = e - xi * np;
             (MODE == 2 ? a.out2 : V)[(size_t)xi * plane + col0 + T + q] = 0.0f;
@@ -1155,6 +1155,8 @@ static int wn_launch_gemm(bool nt, int MT, int NW, const WgArgs &g, float *part,
     }
     WN_GEMM_CASE(false, 128, 128)
     WN_GEMM_CASE(false, 64, 128)
+    WN_GEMM_CASE(false, 128, 64)
+    WN_GEMM_CASE(false, 64, 64)
     WN_GEMM_CASE(true, 128, 128)
     WN_GEMM_CASE(true, 128, 64)
     WN_GEMM_CASE(true, 64, 128)
@@ -1431,14 +1433,30 @@ static bool cf_use_direct()
 // three chunk buffers with transfers two chunks ahead (96 KB, one workgroup per CU) was slower in both forms (143 / 121 us).
 static int wn_ranges_nt() { return cf_ranges() / CF_WPS; }
 
+// Padded tile total of the levels at tile size M, and the granularity it is padded to: the product's 128-wide tile, or its 64-wide one where that
+// shortens the total by 15 % or more (160 tiles of a 37 x 62 map: 192 instead of 256; the narrow tile re-stages its 128 x 32 operand twice as often)
+static long long wn_padded(int M, const int *H, const int *W, int n_levels, int *tg)
+{
+    long long t128 = 0, t64 = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const long long t = (long long)((H[l] + M - 1) / M) * ((W[l] + M - 1) / M);
+        t128 += (t + 127) / 128 * 128;
+        t64 += (t + 63) / 64 * 64;
+    }
+    const bool narrow = t64 * 100 <= t128 * 85;
+    if (tg) *tg = narrow ? 64 : 128;
+    return narrow ? t64 : t128;
+}
+
 static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const *out, const int *H, const int *W, int n_levels)
 {
     long long off = 0;
+    wn_padded(M, H, W, n_levels, &a->tg);
     for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
         if (l < n_levels) {
             const int tw = (W[l] + M - 1) / M, th = (H[l] + M - 1) / M;
             a->lv[l] = {in ? in[l] : nullptr, out ? out[l] : nullptr, H[l], W[l], tw, th * tw, (int)off};
-            off += ((long long)th * tw + CF_NT - 1) / CF_NT * CF_NT;
+            off += ((long long)th * tw + a->tg - 1) / a->tg * a->tg;
         } else a->lv[l] = {nullptr, nullptr, 1, 1, 1, 0, 1 << 30};
     }
     a->bias = nullptr; a->relu = 0; a->zero_pad = 0; a->db_part = nullptr; a->out2 = nullptr; a->bits_out = nullptr; a->bits = nullptr;
@@ -1446,15 +1464,15 @@ static long long wn_fill(WnArgs *a, int M, const float *const *in, float *const 
     return off;
 }
 
-// m = 4 from WN_M4_MIN_TILES 4 x 4 tiles on (below that the padding to 128 tiles eats what the larger tile saves); FRCNN_WINO_M=2|4 forces one
-// (development A/B and the tests' second form)
+// The tile size of a call: what the stage executes scales with planes x padded tiles (36 planes over a quarter of the tiles against 16), so m = 4
+// wherever that product is at least 15 % smaller -- every map of more than a few hundred tiles; small maps, whose 4 x 4 tiles would mostly be
+// padding, keep m = 2 and its smaller rounding error.  FRCNN_WINO_M=2|4 forces one (development A/B and the tests' second form)
 static int wn_pick_m(const int *H, const int *W, int n_levels)
 {
     static const int forced = [] { const char *e = getenv("FRCNN_WINO_M"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 4) ? v : 0; }();
     if (forced) return forced;
-    long long t4 = 0;
-    for (int l = 0; l < n_levels; ++l) t4 += (long long)((H[l] + 3) / 4) * ((W[l] + 3) / 4);
-    return t4 >= WN_M4_MIN_TILES ? 4 : 2;
+    const long long c2 = 16 * wn_padded(2, H, W, n_levels, nullptr), c4 = 36 * wn_padded(4, H, W, n_levels, nullptr);
+    return c4 * 100 <= c2 * 85 ? 4 : 2;
 }
 
 static bool wn_dims_ok(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % WN_KC == 0 && Cout % WN_KC == 0 && Cin <= 4096 && Cout <= 4096; }
@@ -1524,7 +1542,7 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     FRCNN_REQUIRE(Ttot < (1ll << 24) && (long long)P * std::max(K, Mo) * Ttot < (1ll << 31) * 4, "conv3x3_f32: %lld output tiles are too many", Ttot);
     const CfWs ws = wn_carve(workspace, Cin, Cout, M, Ttot);
     const int MT = Mo % CF_MT == 0 ? CF_MT : 64;                     // a 64-channel output side (conv1_2, the data gradient of conv2_1): 64-row tiles
-    const int n_m_tiles = Mo / MT, n_t_tiles = (int)(Ttot / CF_NT), Kc = K / WN_KC;
+    const int n_m_tiles = Mo / MT, n_t_tiles = (int)(Ttot / a.tg), Kc = K / WN_KC;
     const long long n_tiles = (long long)P * n_m_tiles * n_t_tiles, units = n_tiles * Kc;
     FRCNN_REQUIRE(n_tiles <= CF_MAX_TILES && units < (1ll << 31), "conv3x3_f32: %lld tiles above the limit %d", n_tiles, CF_MAX_TILES);
     const unsigned wb = (unsigned)((Mo / 16) * (K / 16));
@@ -1562,7 +1580,7 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
         const long long per = (n_tiles + g.G - 1) / g.G;
         if (n_tiles >= 2ll * g.G && per * g.G * 100 <= n_tiles * 116) g.whole = 1;
     }
-    { const int rc = wn_launch_gemm(false, MT, CF_NT, g, ws.part, ws.cnt, s); if (rc) return rc; }
+    { const int rc = wn_launch_gemm(false, MT, a.tg, g, ws.part, ws.cnt, s); if (rc) return rc; }
     a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
     if (relu == 2) {
         if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_output_kernel<4, true>), dim3((unsigned)((Ttot + 255) / 256), (unsigned)Mo), dim3(256), 0, s, a, ws.M);
@@ -1616,12 +1634,13 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_supported(const int *H_host, const int *W_hos
     for (int l = 0; l < n_levels; ++l)
         if (H_host[l] <= 0 || W_host[l] <= 0 || (long long)H_host[l] * W_host[l] * Cm >= (1ll << 31)) return 0;
     if (Ttot >= (1ll << 24) || (long long)P * Cm * Ttot >= (1ll << 31) * 4) return 0;
-    auto tiles_ok = [&](long long m_side, long long n_side, long long k_chunks) {
-        const long long mt = m_side % CF_MT == 0 ? m_side / CF_MT : m_side / 64, nt = n_side % CF_NT == 0 ? n_side / CF_NT : n_side / 64, n = P * mt * nt;
+    auto side = [](long long c) { return c % CF_MT == 0 ? c / CF_MT : c / 64; };                 // tiles along a channel side (128 wide, or 64)
+    auto tiles_ok = [&](long long mt, long long nt, long long k_chunks) {
+        const long long n = P * mt * nt;
         return n <= CF_MAX_TILES && n * k_chunks < (1ll << 31);
     };
-    if (!tiles_ok(Cout, Ttot, Cin / WN_KC)) return 0;                                            // forward
-    if (need_grads && (!tiles_ok(Cin, Ttot, Cout / WN_KC) || !tiles_ok(Cout, Cin, Ttot / WN_KC))) return 0;      // data gradient, weight gradient
+    if (!tiles_ok(side(Cout), Ttot / a.tg, Cin / WN_KC)) return 0;                               // forward
+    if (need_grads && (!tiles_ok(side(Cin), Ttot / a.tg, Cout / WN_KC) || !tiles_ok(side(Cout), side(Cin), Ttot / WN_KC))) return 0;      // data gradient, weight gradient
     return 1;
 }
 

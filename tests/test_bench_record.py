@@ -155,13 +155,13 @@ def test_winograd_stage_accounting_in_the_roofline():
     makes (ops.CONV_TRACE) -- over the per-image time of its launches: a fraction of the fp32 MFMA peak, never above it; the convolutions'
     own flop count over the time of ALL the stage's launches rides beside it."""
     import bench
-    rpn = {"Cin": 512, "Cout": 512, "shapes": [(37, 62)], "mask": False, "bias": False, "cached": False}          # 10 x 16 tiles of 4 x 4 < 512: m = 2
+    rpn = {"Cin": 512, "Cout": 512, "shapes": [(13, 21)], "mask": False, "bias": False, "cached": False}          # 4 x 6 tiles of 4 x 4 would be padding: m = 2, 7 x 11 = 77 -> 128
     c4 = {"Cin": 512, "Cout": 512, "shapes": [(75, 125)], "mask": True, "bias": True, "cached": True}            # 19 x 32 = 608 tiles: m = 4
     calls = [dict(rpn, kind=k) for k in ("fwd", "bwd_data", "wgrad")] + [dict(c4, kind="fwd", mask=False), dict(c4, kind="bwd_data"), dict(c4, kind="wgrad")]
     tot, conv = bench.wino_work(calls)
     assert tot["rpn_wino_gemm_kernel"]["launches"] == 6 and tot["rpn_wino_input_kernel"]["launches"] == 4 + 2 + 1     # rpn wgrad transforms x, the cached one does not
-    own = 3 * 2 * 16 * 512 * 512 * 640 + 3 * 2 * 36 * 512 * 512 * 640                                            # 589 -> 640 and 608 -> 640 padded tiles
-    assert tot["rpn_wino_gemm_kernel"]["flops"] == own and conv == 3 * 18 * 512 * 512 * (37 * 62 + 75 * 125)
+    own = 3 * 2 * 16 * 512 * 512 * 128 + 3 * 2 * 36 * 512 * 512 * 640                                            # 77 -> 128 and 608 -> 640 padded tiles
+    assert tot["rpn_wino_gemm_kernel"]["flops"] == own and conv == 3 * 18 * 512 * 512 * (13 * 21 + 75 * 125)
     us = {"rpn_wino_gemm_kernel": 0.090, "rpn_wino_input_kernel": 0.020, "rpn_wino_output_kernel": 0.012, "rpn_wino_weight_kernel": 0.008,
           "rpn_wino_dw_kernel": 0.008, "nms_kernel": 0.070}
     n = {k: tot[k]["launches"] for k in tot}
@@ -204,3 +204,23 @@ def test_stage_accounting_of_pooled_calls_and_1x1_weight_gradients():
     assert tot["rpn_wino_output_kernel"]["bytes"] == (4 * 36 * 64 * Tp + 4 * 64 * 300 * 500 + words) + (4 * 36 * 64 * Tp + 4 * 64 * 600 * 1000)
     assert tot["rpn_wino_input_kernel"]["launches"] == 3                      # x (forward), pooled dy twice; the weight gradient's x transform was kept
     assert tot["rpn_wino_input_kernel"]["bytes"] == (4 * 64 * 600 * 1000 + 4 * 36 * 64 * Tp) + 2 * (4 * 64 * 300 * 500 + words + 4 * 36 * 64 * Tp)
+
+
+def test_the_bench_mirror_of_the_stage_tiling_is_the_library_rule():
+    """bench.wino_tiling (tile size and padded tile total of a stage call: what the GEMM's flops are priced on) against the library's own answers
+    (frcnn_conv3x3_f32_tile_size; frcnn_conv3x3_f32_relu_bits_words with one channel = the padded total) over the shapes of both configurations, the
+    FPN's five-level call and a sweep of small maps -- including the 37 x 62 map whose 160 4 x 4 tiles are padded to 192 (64-wide product tiles), not 256."""
+    import numpy as np
+    import bench
+    from faster_rcnn_pytorch_amd import _lib
+    lib = _lib.lib
+    cases = [[(600, 1000)], [(300, 500)], [(150, 250)], [(75, 125)], [(37, 62)], [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)],
+             [(200, 336)], [(100, 168)], [(50, 84)], [(25, 42)], [(13, 21)]] + [[(h, w)] for h in (1, 5, 16, 23, 31, 40) for w in (3, 17, 32, 47, 64)]
+    for shapes in cases:
+        H = np.ascontiguousarray([h for h, _ in shapes], dtype=np.int32)
+        W = np.ascontiguousarray([w for _, w in shapes], dtype=np.int32)
+        m = int(lib.frcnn_conv3x3_f32_tile_size(H.ctypes.data, W.ctypes.data, len(shapes)))
+        tp = int(lib.frcnn_conv3x3_f32_relu_bits_words(H.ctypes.data, W.ctypes.data, len(shapes), 1))
+        assert (m, tp) == bench.wino_tiling(shapes), shapes
+    assert bench.wino_tiling([(37, 62)]) == (4, 192) and bench.wino_tiling([(75, 125)]) == (4, 640) and bench.wino_tiling([(13, 21)]) == (2, 128)
+

@@ -1547,6 +1547,8 @@ CONV3X3_CASES = [   # name, Cin, Cout, level shapes, bias, relu, gradients
     ("vgg_conv2_1", 64, 128, [(100, 160)], True, True, True),                 # features[5] + [6]: a 64-channel input side
     ("narrow_both", 64, 64, [(20, 30), (7, 9)], True, True, True),            # the same with F(2x2)
     ("wide_out_64", 256, 64, [(25, 33)], True, False, True),                  # 64 outputs of a wide input
+    ("rpn_37x62", 256, 128, [(37, 62)], True, True, True),                    # the RPN's / conv5's map at 600x1000: 160 4 x 4 tiles padded to 192 (64-wide product tiles)
+    ("c5_25x42", 128, 128, [(25, 42)], False, True, True),                    # 273 2 x 2 tiles padded to 320: the 64-wide product tile with F(2x2)
 ]
 
 
@@ -1717,8 +1719,8 @@ def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
         outs.append((y.detach(), xr.grad, wr.grad, br.grad))
     for a_, c_ in zip(*outs):
         assert torch.equal(a_, c_)
-    small = torch.zeros(1, 128, 40, 40, device=DEV)
-    assert not ops.conv3x3_pool_supported(small)                            # 100 tiles: the 2 x 2 tile, no fused pool
+    small = torch.zeros(1, 128, 12, 20, device=DEV)
+    assert not ops.conv3x3_pool_supported(small)                            # 15 4 x 4 tiles would be padded to 64: the 2 x 2 tile, no fused pool
     with pytest.raises(Exception):
         ops.conv3x3_fwd([small], torch.zeros(128, 128, 3, 3, device=DEV), None, True, pool=True)
 
