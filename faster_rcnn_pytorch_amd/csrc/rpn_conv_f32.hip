@@ -501,6 +501,78 @@ __global__ __launch_bounds__(256) void rpn_wino_weight_kernel(const float *__res
     }
 }
 
+// Staging loads of the input-side transforms.  The loads are inline assembly, unconditional, at clamped addresses (the window's zeros are a select
+// behind them), and ONE counted wait follows a whole batch.  Written in C++, with the bounds tests in front of them or folded into a select right
+// behind, the compiler put every load into a basic block of its own (s_and_saveexec, or a branch on the wave-uniform row test) with its
+// s_waitcnt vmcnt(0) directly behind it: one load in flight per wave and ~36 instructions per load instruction -- at 64 x 600 x 1000 the staging
+// took 82 of the transform's 123 us.
+__device__ __forceinline__ float wn_ld(const float *base, unsigned off_bytes)
+{
+    float t;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(t) : "v"(off_bytes), "s"(base) : "memory");
+    return t;
+}
+// wide windows: a wave per row, two rows x NP 64-column pieces in flight (pieces past the row's end fetch its last element again: one cached line)
+template <int NP>
+__device__ __forceinline__ void wn_stage_wide(float *s, const float *x, int x0, int y0, int nrow, int ncol, int Hs, int Ws, int lane, int wave)
+{
+    unsigned off[NP];
+    bool in[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int xx = x0 + lane + 64 * j;
+        off[j] = 4u * (unsigned)min(max(xx, 0), Ws - 1);
+        in[j] = (unsigned)xx < (unsigned)Ws;
+    }
+    for (int r0 = wave; r0 < nrow; r0 += 8) {
+        float v[2][NP];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *xr = x + (size_t)min(max(y0 + r0 + 4 * h, 0), Hs - 1) * Ws;             // wave-uniform
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v[h][j] = wn_ld(xr, off[j]);
+        }
+        if constexpr (NP == 9)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]), "+v"(v[0][5]), "+v"(v[0][6]), "+v"(v[0][7]),
+                         "+v"(v[0][8]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[1][4]), "+v"(v[1][5]), "+v"(v[1][6]), "+v"(v[1][7]), "+v"(v[1][8]) :: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]),
+                         "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]), "+v"(v[1][4]) :: "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = r0 + 4 * h;
+            const bool row_in = (unsigned)(y0 + r) < (unsigned)Hs;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                if (r < nrow && lane + 64 * j < ncol) s[r * ncol + lane + 64 * j] = (row_in && in[j]) ? v[h][j] : 0.0f;
+        }
+    }
+}
+// narrow windows flattened: any shape keeps eight loads per lane busy
+__device__ __forceinline__ void wn_stage_flat(float *s, const float *x, int x0, int y0, int nrow, int ncol, int Hs, int Ws)
+{
+    const int n_el = nrow * ncol;
+    const float inv_ncol = 1.0f / (float)ncol;
+    for (int base = threadIdx.x; base < n_el; base += 256 * 8) {
+        float v[8];
+        bool in[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = min(base + 256 * j, n_el - 1);
+            int r = (int)((float)e * inv_ncol);                               // e / ncol, fixed up below (e < 2^14: the estimate is off by one at most)
+            r -= (r * ncol > e) ? 1 : 0;
+            r += ((r + 1) * ncol <= e) ? 1 : 0;
+            const int q = e - r * ncol, yy = y0 + r, xx = x0 + q;
+            in[j] = (unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws;
+            v[j] = wn_ld(x, 4u * (unsigned)(min(max(yy, 0), Hs - 1) * Ws + min(max(xx, 0), Ws - 1)));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (base + 256 * j < n_el) s[base + 256 * j] = in[j] ? v[j] : 0.0f;
+    }
+}
+
 // The input-side transforms.  Block = (channel, strip); a strip = up to TPB tiles: tile rows x a piece of at most WT tile columns, as many
 // whole rows as fit.  The strip's input window is staged in LDS by coalesced loads -- every element is fetched once (plus the halo rows
 // that neighbouring strips share); read straight from global memory each patch cost (m + 2)^2 loads of a stride-m pattern that touched
@@ -545,52 +617,12 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
             wb[e] = (ty >= 0 && ty < th && tx >= 0 && tx < tw) ? mk[ty * tw + tx] : (unsigned short)0;
         }
     }
-    // eight loads in flight per lane before the first LDS write: written as load -> ds_write per element the loop kept ONE load in flight per
-    // wave and the staging ran at memory latency (77 MB in 57 us at 128 x 300 x 500; the stores alone take 30 us)
-    if (ncol >= 192) {                                                    // wide windows: a wave per row, eight column pieces per lane
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        for (int r = wave; r < nrow; r += 4) {
-            const int yy = y0 + r;
-            const bool row_in = yy >= 0 && yy < Hs;
-            const float *xr = x + (size_t)yy * Ws + x0;
-            for (int qb = lane; qb < ncol; qb += 64 * 8) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = qb + 64 * j, xx = x0 + q;
-#if defined(WN_TABL) && (WN_TABL & 1)
-                    v[j] = 0.5f;
-#else
-                    v[j] = (row_in && q < ncol && xx >= 0 && xx < Ws) ? xr[q] : 0.0f;
-#endif
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = qb + 64 * j;
-                    if (q < ncol) s[r * ncol + q] = v[j];
-                }
-            }
-        }
-    } else {                                                              // narrow windows flattened: any shape keeps the eight loads busy
-        const int n_el = nrow * ncol;
-        const float inv_ncol = 1.0f / (float)ncol;
-        for (int base = threadIdx.x; base < n_el; base += 256 * 8) {
-            float v[8];
-            int at[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int e = base + 256 * j;
-                int r = (int)((float)e * inv_ncol);                           // e / ncol, fixed up below (e < 2^14: the estimate is off by one at most)
-                r -= (r * ncol > e) ? 1 : 0;
-                r += ((r + 1) * ncol <= e) ? 1 : 0;
-                const int q = e - r * ncol, yy = y0 + r, xx = x0 + q;
-                at[j] = e < n_el ? e : -1;
-                v[j] = (e < n_el && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws) ? x[yy * Ws + xx] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (at[j] >= 0) s[at[j]] = v[j];
-        }
+    // Staging: every load of a batch is issued before the first one is used (wn_stage_wide / wn_stage_flat).
+    {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (ncol > 320) wn_stage_wide<9>(s, x, x0, y0, nrow, ncol, Hs, Ws, lane, wave);            // <= 514 = m WT + 2 columns
+        else if (ncol >= 192) wn_stage_wide<5>(s, x, x0, y0, nrow, ncol, Hs, Ws, lane, wave);
+        else wn_stage_flat(s, x, x0, y0, nrow, ncol, Hs, Ws);
     }
     __syncthreads();
     const size_t plane = (size_t)a.C * a.Ttot, col0 = (size_t)c * a.Ttot + a.lv[l].off;
