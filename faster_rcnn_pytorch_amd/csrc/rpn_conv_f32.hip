@@ -1007,6 +1007,20 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         int tt = ldo;
         asm volatile("" : "+s"(tt));                                 // opaque here: otherwise the 64 store offsets are hoisted out of the unit loop
                                                                      // and live in 64 registers through it (the staging registers went to scratch)
+        if constexpr (!NT) {
+            // K-major form: MFMA tile (mi, ni) of the wave holds rows MI i + mi and columns NI j + ni of its quarter (see the operand reads below), so a
+            // lane's NI values of a row are neighbours in memory: one 8-byte store per row instead of two dwords 128 bytes apart
+            float *o = T.o + (size_t)(wm * (MT / 2) + MI * 4 * lh) * tt + wn * (NW / 2) + NI * li;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *d = o + (size_t)(MI * ((r & 3) + 8 * (r >> 2)) + mi) * tt;
+                    if constexpr (NI == 2) *(float2 *)d = make_float2(acc[mi][0][r], acc[mi][1][r]);
+                    else d[0] = acc[mi][0][r];
+                }
+            return;
+        }
         float *o = T.o + (size_t)(wm * (MT / 2) + 4 * lh) * tt + wn * (NW / 2) + li;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
@@ -1130,8 +1144,10 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            const float *pa = &sA[buf][lh * MT + wm * (MT / 2) + li];
-            const float *pb = &sB[buf][lh * NW + wn * (NW / 2) + li];
+            // MFMA tile mi takes rows MI i + mi of the wave's quarter (i = the lane's row index), tile ni columns NI j + ni: a lane's MI (NI) operand
+            // values of a k row are neighbours in LDS -- one ds_read_b64 per operand and step where the wave has two tiles on that side
+            const float *pa = &sA[buf][lh * MT + wm * (MT / 2) + MI * li];
+            const float *pb = &sB[buf][lh * NW + wn * (NW / 2) + NI * li];
             float oa[2][MI], ob[2][NI];
             auto fetch = [&](int s, int slot) {
 #if defined(WN_ABL) && (WN_ABL & 4)                                 // developer ablation 4: no operand reads from LDS
@@ -1141,10 +1157,10 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
                 for (int ni = 0; ni < NI; ++ni) { ob[slot][ni] = (float)s; asm volatile("" : "+v"(ob[slot][ni])); }
                 return;
 #endif
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) oa[slot][mi] = pa[2 * s * MT + 32 * mi];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) ob[slot][ni] = pb[2 * s * NW + 32 * ni];
+                if constexpr (MI == 2) { const float2 t = *(const float2 *)(pa + 2 * s * MT); oa[slot][0] = t.x; oa[slot][1] = t.y; }
+                else oa[slot][0] = pa[2 * s * MT];
+                if constexpr (NI == 2) { const float2 t = *(const float2 *)(pb + 2 * s * NW); ob[slot][0] = t.x; ob[slot][1] = t.y; }
+                else ob[slot][0] = pb[2 * s * NW];
             };
             fetch(0, 0);
 #pragma unroll
