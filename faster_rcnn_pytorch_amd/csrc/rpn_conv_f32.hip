@@ -360,6 +360,10 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // XOR-swizzled at the source side of the LDS-DMA, fragments by ds_read_b128); no transposing pass.
 // The transformed operands travel through the workspace (P C Ttot floats each way).
 #define WN_KC 32                       // K values per chunk
+#ifndef WN_ONE_TILE_NUM
+#define WN_ONE_TILE_NUM 3               // one whole tile per workgroup from NUM / DEN of the workgroup slots on
+#define WN_ONE_TILE_DEN 4
+#endif
 struct WnLevel { const float *x; float *y; int H, W, tw, T, off; };
 struct WnArgs {
     WnLevel lv[FRCNN_MAX_LEVELS];
@@ -1627,6 +1631,9 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
         // than 16 % (128 -> 128 on 300 x 500: 5.2 tiles per workgroup, 132 -> 124 us; 256 -> 256 on 150 x 250: 2.7, 121 -> 118)
         const long long per = (n_tiles + g.G - 1) / g.G;
         if (n_tiles >= 2ll * g.G && per * g.G * 100 <= n_tiles * 116) g.whole = 1;
+        // nearly one tile per workgroup slot (432 tiles of 512 -> 512 on 37 x 62): one whole tile each on fewer workgroups, rather than 13.5 chunks each
+        // with two partial segments, their slabs and a reduction per tile
+        else if (n_tiles <= g.G && n_tiles * WN_ONE_TILE_DEN >= (long long)g.G * WN_ONE_TILE_NUM) { g.G = (int)n_tiles; g.whole = 1; }
     }
     { const int rc = wn_launch_gemm(false, MT, a.tg, g, ws.part, ws.cnt, s); if (rc) return rc; }
     a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
