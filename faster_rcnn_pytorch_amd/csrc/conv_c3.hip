@@ -9,7 +9,7 @@
 //   conv3x3_c3_wgrad_kernel  dw[co][ci][ky][kx] = sum_p g[co][p] x[ci][p + off], db[co] = sum_p g[co][p], g = dy where the forward's sign word has the
 //                            channel's bit.  block = (4 image rows, 16 output channels); wave = 4 channels, its lanes walk a row 256 pixels at a
 //                            time with sixteen gradient loads in flight, 4 x 28 running sums per lane, one shuffle reduction per wave at the end ->
-//                            partials [block of 4 rows][co][28] (one DPP reduction per wave and four rows);  conv3x3_c3_wgrad_finalize_kernel adds them in order (bit-reproducible).
+//                            partials [block of rows][co][28] (one DPP reduction per wave and block; rows per block chosen per call);  conv3x3_c3_wgrad_finalize_kernel adds them in order (bit-reproducible).
 // The input gradient is never needed (the input is the image).
 #include "frcnn_common.h"
 #include "frcnn_internal.h"
@@ -92,19 +92,20 @@ __device__ __forceinline__ float c3_wave_sum(float v)
     return v;
 }
 
-#define C3_ROWS 4                      // image rows per weight-gradient block: one cross-lane reduction (112 values per lane) per four rows
-#define C3_WAVES 4                     // waves per block
+#define C3_WAVES 8                     // waves per block: 32 output channels.  The image rows per block are chosen per call (frcnn_conv3x3_c3_wgrad) so that the launch is ONE round of
+                                       // at most one block per CU: with four waves and four rows 600 blocks met 512 slots (two rounds, the second 17 % full: 120 us);
+                                       // eight waves x five rows = 240 blocks: 80 us
 #define C3_CPW 4                       // output channels per wave: 4 x 28 running sums per lane (two channels per wave, eight waves: 233 us against 189)
-// dynamic LDS: 3 x (C3_ROWS + 2) x (W + 2) floats (the block's image rows of the three input channels with their halo, staged once).  BITS is a
+// dynamic LDS: 3 x (rows + 2) x (W + 2) floats (the block's image rows of the three input channels with their halo, staged once).  BITS is a
 // template flag: with a run-time `bits != NULL` test in front of every sign-word load the kernel took 170 us against 118.  Measured and not kept: all six
 // rows of a block staged at once with eight waves and the next batch's loads issued ahead (218 registers, one block per CU: 212 us against 146);
 // the 28 sums split over two waves (4 x 14 per lane, four waves per SIMD, the gradient loaded by both: 228 us against 189 -- the loads, not the
 // arithmetic, are what the kernel waits for: without the sign words it takes 127).
 template <bool BITS>
 __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, int H, int W, int Cout,
-                                                                       const unsigned long long *__restrict__ bits, float *__restrict__ part)
+                                                                       const unsigned long long *__restrict__ bits, float *__restrict__ part, int rows)
 {
-    extern __shared__ float s[];                                          // [3][C3_ROWS + 2][W + 2]
+    extern __shared__ float s[];                                          // [3][rows + 2][W + 2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ws = W + 2, NT = 64 * C3_WAVES;
     const int co0 = (blockIdx.y * C3_WAVES + wave) * C3_CPW;              // this wave's output channels (a wave past Cout only helps staging)
     const size_t plane = (size_t)H * W;
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const f
     for (int j = 0; j < C3_CPW; ++j)
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[j][k] = 0.0f;
-    // the block's C3_ROWS + 2 image rows of the three channels, staged ONCE: [ci][row r0 - 1 .. r0 + C3_ROWS][W + 2] (per image row the staging's
+    // the block's rows + 2 image rows of the three channels, staged ONCE: [ci][row r0 - 1 .. r0 + rows][W + 2] (per image row the staging's
     // five dependent load batches were a third of the kernel's time)
-    const int r0 = blockIdx.x * C3_ROWS, nrow = min(C3_ROWS, H - r0), RS = C3_ROWS + 2, n_el = 3 * RS * ws;
+    const int r0 = blockIdx.x * rows, nrow = min(rows, H - r0), RS = rows + 2, n_el = 3 * RS * ws;
     for (int base = tid; base < n_el; base += NT * 8) {                   // eight loads in flight per thread
         float v[8];
 #pragma unroll
@@ -217,7 +218,7 @@ FRCNN_EXPORT int frcnn_conv3x3_c3_fwd(const float *x_dev, float *y_dev, int H, i
 
 FRCNN_EXPORT size_t frcnn_conv3x3_c3_wgrad_workspace(int H, int Cout)
 {
-    return (H > 0 && Cout > 0) ? (size_t)((H + C3_ROWS - 1) / C3_ROWS) * Cout * 28 * sizeof(float) : 0;
+    return (H > 0 && Cout > 0) ? (size_t)H * Cout * 28 * sizeof(float) : 0;             // one partial per row block; a block has at least one row
 }
 
 FRCNN_EXPORT int frcnn_conv3x3_c3_wgrad(const float *x_dev, const float *dy_dev, int H, int W, int Cout, const unsigned long long *relu_bits_dev,
@@ -226,17 +227,23 @@ FRCNN_EXPORT int frcnn_conv3x3_c3_wgrad(const float *x_dev, const float *dy_dev,
     int rc = c3_check(x_dev, dy_dev, H, W, Cout, dw_dev, "conv3x3_c3_wgrad");
     if (rc) return rc;
     FRCNN_REQUIRE(dw_dev && workspace, "conv3x3_c3_wgrad: NULL pointer");
-    if (Cout % 4 != 0 || W > 1700)      // LDS: 18 x (W + 2) floats
+    if (Cout % 4 != 0 || W > 1700)      // LDS: 3 (rows + 2)(W + 2) floats
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_c3_wgrad: Cout = %d must be a multiple of 4 and W = %d at most 1700", Cout, W);
     if (workspace_bytes < frcnn_conv3x3_c3_wgrad_workspace(H, Cout))
         return frcnn_set_error(FRCNN_ERR_WORKSPACE, "conv3x3_c3_wgrad: workspace %zu < %zu bytes", workspace_bytes, frcnn_conv3x3_c3_wgrad_workspace(H, Cout));
     hipStream_t s = (hipStream_t)stream;
     float *part = (float *)workspace;
-    const int nb = (H + C3_ROWS - 1) / C3_ROWS;
-    const dim3 wg((unsigned)nb, (unsigned)((Cout + C3_CPW * C3_WAVES - 1) / (C3_CPW * C3_WAVES)));
-    const size_t wl = (size_t)3 * (C3_ROWS + 2) * (W + 2) * sizeof(float);
-    if (relu_bits_dev) FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<true>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
-    else FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<false>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part);
+    // rows per block: the fewest that keep the launch within one block per CU (one round), as far as the window fits the LDS
+    const int groups = (Cout + C3_CPW * C3_WAVES - 1) / (C3_CPW * C3_WAVES);
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int fit = (int)((150 * 1024) / (12 * (size_t)(W + 2))) - 2;
+    const int rows = std::max(1, std::min(fit, (int)(((long long)H * groups + cus - 1) / cus)));
+    const int nb = (H + rows - 1) / rows;
+    const dim3 wg((unsigned)nb, (unsigned)groups);
+    const size_t wl = (size_t)3 * (rows + 2) * (W + 2) * sizeof(float);
+    if (relu_bits_dev) FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<true>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part, rows);
+    else FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<false>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part, rows);
     FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_kernel");
     FRCNN_LAUNCH(conv3x3_c3_wgrad_finalize_kernel, dim3((unsigned)((Cout * 28 + 255) / 256)), dim3(256), 0, s, part, nb, Cout, dw_dev, dbias_dev);
     FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_finalize_kernel");
