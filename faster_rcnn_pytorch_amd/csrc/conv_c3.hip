@@ -132,40 +132,58 @@ __global__ __launch_bounds__(64 * C3_WAVES) void conv3x3_c3_wgrad_kernel(const f
     }
     __syncthreads();
     if (co0 >= Cout) return;
-    for (int ry = 0; ry < nrow; ++ry) {
-        const int row = r0 + ry;
-        const float *g0 = dy + (size_t)co0 * plane + (size_t)row * W;
-        const unsigned *b0 = BITS ? (const unsigned *)(bits + (size_t)(co0 >> 6) * plane + (size_t)row * W) + ((co0 & 63) >> 5) : nullptr;      // the 32-bit half that holds this wave's four bits
-        for (int xb = 0; xb < W; xb += 256) {                             // 4 pixels x 4 channels of gradient in flight per lane
-            float g[4][C3_CPW];
-            unsigned mb[4];                                               // the wave's channels' sign bits of each pixel (co0 % C3_CPW == 0: never across words)
+    // iteration = (row, 256-pixel piece): 4 pixels x 4 channels of gradient (+ the sign words) per lane, loaded one iteration AHEAD at clamped
+    // addresses (unconditional loads; a lane past the row's end counts zero): the next piece's round trip runs under this piece's 432 FMAs
+    const int nxb = (W + 255) / 256;
+    auto load = [&](int ry, int xb, float (&gq)[4][C3_CPW], unsigned (&mq)[4]) {
+        const float *g0 = dy + (size_t)co0 * plane + (size_t)(r0 + ry) * W;
+        const unsigned *b0 = BITS ? (const unsigned *)(bits + (size_t)(co0 >> 6) * plane + (size_t)(r0 + ry) * W) + ((co0 & 63) >> 5) : nullptr;      // the 32-bit half that holds this wave's four bits
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xx = xb + 64 * i + lane;
-                mb[i] = BITS ? (xx < W ? b0[2 * xx] : 0u) : ~0u;
+        for (int i = 0; i < 4; ++i) {
+            const int xc = min(xb + 64 * i + lane, W - 1);
+            mq[i] = BITS ? b0[2 * xc] : ~0u;
 #pragma unroll
-                for (int j = 0; j < C3_CPW; ++j) g[i][j] = xx < W ? g0[(size_t)j * plane + xx] : 0.0f;
-            }
+            for (int j = 0; j < C3_CPW; ++j) gq[i][j] = g0[(size_t)j * plane + xc];
+        }
+    };
+    float g[4][C3_CPW];
+    unsigned mb[4];                                                       // the wave's channels' sign bits of each pixel (co0 % C3_CPW == 0: never across words)
+    load(0, 0, g, mb);
+    for (int ry = 0, xbi = 0;;) {
+        const int xb = xbi * 256;
+        int ry2 = ry, xbi2 = xbi + 1;
+        if (xbi2 == nxb) { xbi2 = 0; ++ry2; }
+        const bool more = ry2 < nrow;
+        float gn[4][C3_CPW];
+        unsigned mn[4];
+        if (more) load(ry2, xbi2 * 256, gn, mn);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int xx = xb + 64 * i + lane;
-                if (xb + 64 * i < W) {                                    // uniform
-                    float v[27];
-                    const int xc = xx < W ? xx : W - 1;                   // lanes past the row read a valid column (their gradient is zero)
+        for (int i = 0; i < 4; ++i) {
+            const int xx = xb + 64 * i + lane;
+            if (xb + 64 * i < W) {                                        // uniform
+                float v[27];
+                const int xc = xx < W ? xx : W - 1;                       // lanes past the row read a valid column (their gradient counts zero)
 #pragma unroll
-                    for (int r = 0; r < 9; ++r)
+                for (int r = 0; r < 9; ++r)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[((r / 3) * RS + ry + r % 3) * ws + xc + kx];      // tap (ci = r / 3, ky = r % 3)
+                    for (int kx = 0; kx < 3; ++kx) v[r * 3 + kx] = s[((r / 3) * RS + ry + r % 3) * ws + xc + kx];      // tap (ci = r / 3, ky = r % 3)
 #pragma unroll
-                    for (int j = 0; j < C3_CPW; ++j) {
-                        const float gg = (!BITS || ((mb[i] >> ((co0 & 31) + j)) & 1u)) ? g[i][j] : 0.0f;      // the ReLU's backward from the forward's sign word
+                for (int j = 0; j < C3_CPW; ++j) {
+                    const float gg = (xx < W && (!BITS || ((mb[i] >> ((co0 & 31) + j)) & 1u))) ? g[i][j] : 0.0f;      // the ReLU's backward from the forward's sign word
 #pragma unroll
-                        for (int k = 0; k < 27; ++k) acc[j][k] = fmaf(gg, v[k], acc[j][k]);
-                        acc[j][27] += gg;
-                    }
+                    for (int k = 0; k < 27; ++k) acc[j][k] = fmaf(gg, v[k], acc[j][k]);
+                    acc[j][27] += gg;
                 }
             }
         }
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mb[i] = mn[i];
+#pragma unroll
+            for (int j = 0; j < C3_CPW; ++j) g[i][j] = gn[i][j];
+        }
+        ry = ry2; xbi = xbi2;
     }
 #pragma unroll
     for (int j = 0; j < C3_CPW; ++j)
