@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // the transformed bytes (fp32: ~5e-6 of the scale -- the 1/24 .. 8 range of its transform constants -- inside the path's 1e-4; maps with fewer
 // the tile padding would eat the gain stay with m = 2: wn_pick_m prices both forms by planes x padded tiles).  Four launches, all levels each:
 //   rpn_wino_weight_kernel   U[xi][k][m] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
-//   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded (m + 2)^2 input patch of tile t; rows padded to a multiple of 128 tiles
+//   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded (m + 2)^2 input patch of tile t; rows padded to a multiple of 128 (or 64: wn_padded) tiles
 //   rpn_wino_gemm_kernel     M[xi][m][t] = sum_k U[xi][k][m] V[xi][k][t]: stream-K over (xi, 128 x 128 tile, 32-channel chunk) units on
 //                            v_mfma_f32_32x32x2_f32, the direct kernel's skeleton without taps: both operand tiles (32 K rows x 128
 //                            floats) are staged by LDS-DMA (global_load_lds_dwordx4, no staging registers), no edge selects,
