@@ -47,6 +47,11 @@ _WS = {}
 
 def _workspace(device, nbytes):
     """Grow-only per-(device, stream) scratch buffer owned by the caller side (torch allocator)."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture the scratch is an ordinary allocation of the graph's own pool (it lives and dies with the graph).  A cached
+        # buffer keyed by the capture stream was first allocated inside the FIRST captured configuration's pool and then baked into the graphs of
+        # a later one, after that pool had been released: a memory fault on replay (bench.py, a graph run of one model followed by one of another)
+        return torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -42,7 +42,8 @@ def _canned(bench, config, amp, names, world=1, graph=False):
 def test_compact_line_stays_under_4k_with_every_optional_block():
     import bench
     full = _canned(bench, "vgg", "none", V_KERNELS)
-    also = []
+    also = [_canned(bench, "vgg", "none", V_KERNELS, graph=True)]            # the headline configuration as graph replays, then the two FPN entries
+    also[0]["eager_submission"] = {"value": full["value"], "ms_per_step": full["ms_per_step"], "step_ms": full["step_ms"]}
     for amp in ("none", "bf16"):
         rec = _canned(bench, "fpn", amp, F_KERNELS, graph=True)
         rec["eager_submission"] = {"value": 55.123, "ms_per_step": 18.141, "step_ms": rec["step_ms"]}
@@ -64,7 +65,8 @@ def test_compact_line_stays_under_4k_with_every_optional_block():
     for k in ("sum_kernel_us_per_img", "launches_per_img", "mean_proposals_per_img", "proposals_per_s", "nms_plus_roi_us_per_img",
               "proposal_stage_us_per_img"):
         assert out["hot_path"][k] is not None, k
-    assert [a["dtype"] for a in out["also"]] == ["f32", "bf16"] and all(a["roofline"]["kernel"] for a in out["also"])
+    assert [a["dtype"] for a in out["also"]] == ["f32", "f32", "bf16"] and all(a["roofline"]["kernel"] for a in out["also"])
+    assert out["also"][0]["eager_value"] == out["value"] and out["also"][0]["submission"].startswith("one HIP graph")
 
 
 def test_emit_prints_the_compact_line_last_and_writes_the_detail_file(tmp_path, capsys, monkeypatch):
