@@ -136,3 +136,35 @@ def test_hot_path_graph_replay_matches_eager_with_fresh_samples():
     f = frames[1]
     ro, _ = orc.region_proposal(f[1].numpy(), f[2].numpy(), orc.anchor_grid(H, W), 1 / 1000, 12000, 0.7, 2000)
     assert int(replayed[1][1][3].item()) == len(ro)
+
+
+def test_scratch_of_a_captured_op_does_not_outlive_its_graph():
+    """Two captures in one process, the first graph destroyed (and its pool released) before the second is made -- what `bench.py` does when it times
+    one model as graph replays and then another.  An op's scratch buffer (ops._workspace) must come from the CAPTURING graph's pool: cached per stream --
+    torch captures every graph on the same capture stream -- the buffer of the first capture stayed in the cache, its pool went away with the first
+    graph, and the second graph replayed on a dangling address (a memory fault in round 4).  Both replays are compared with the eager sort."""
+    from faster_rcnn_pytorch_amd import ops
+    g0 = torch.Generator().manual_seed(5)
+    outs = []
+    for n in (20000, 9000):                                              # two "models": different sizes, the second's scratch fits in the first's
+        scores = torch.randn(n, generator=g0).to(DEV)
+        ref_idx = ops.topk_sorted(scores, 2000)[0].clone()         # eager warm-up: every persistent buffer exists before the capture
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.topk_sorted(scores, 2000)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            idx = ops.topk_sorted(scores, 2000)[0]
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        outs.append(bool(torch.equal(idx, ref_idx)))
+        del g, idx
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                                         # the first graph's private pool is released here
+    assert outs == [True, True]
+    key = (torch.device(DEV).index, torch.cuda.graphs.graph.default_capture_stream.cuda_stream) if getattr(torch.cuda.graphs.graph, "default_capture_stream", None) else None
+    assert key is None or key not in ops._WS                             # nothing was cached under the capture stream
