@@ -770,8 +770,9 @@ def conv3x3_wgrad(xs, dys, relu_bits=None, want_bias=False, x_transformed=None, 
     return dw, db
 
 
-CONV3X3_MIN_WORK = 1 << 27         # Cin * Cout * positions: below this the stage's fixed costs (four launches per direction, partial-tile reduction) lose to
-                                   # the vendor kernel (tools/dev/conv_layers_time.py: 256 -> 256 on 25 x 42 loses, on 50 x 84 and 512 -> 512 on 25 x 42 win)
+CONV3X3_MIN_WORK = 1 << 26         # Cin * Cout * positions: below this the stage's fixed costs (four launches per direction, partial-tile reduction) lose to
+                                   # the vendor kernel (tools/dev/conv_layers_time.py: since the tile totals are padded to 64 where that pays, 256 -> 256 on 25 x 42
+                                   # wins too -- 38.7 against 41.8 us forward, 92 against 108 with the gradients; smaller maps were not measured and stay)
 
 
 def conv3x3_supported(x, weight, need_input_grad=None):
