@@ -85,11 +85,13 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
          "rpn_conv3x3_f32_kernel": "mfma", "rpn_conv3x3_f32_bwd_data_kernel": "mfma", "rpn_conv3x3_f32_wgrad_kernel": "mfma",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
-         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "conv3x3_c3_fwd_kernel": "hbm", "conv3x3_c3_wgrad_kernel": "hbm",
+         "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "rpn_wino_gemm_out64_kernel": "hbm",
+         "conv3x3_c3_fwd_kernel": "hbm", "conv3x3_c3_wgrad_kernel": "hbm",
          "affine_act_fwd_kernel": "hbm", "affine_act_bwd_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
-              "rpn_wino_dw_kernel")      # forward / data gradient: weight, input, gemm, output; weight gradient: input x 2, gemm, dw
+              "rpn_wino_dw_kernel", "rpn_wino_gemm_out64_kernel")      # forward / data gradient: weight, input, gemm, output (64 -> 64 channels: the
+                                                                        # last two as ONE launch, gemm_out64); weight gradient: input x 2, gemm, dw
 
 
 def synth_frame(cfg, rank, step):
@@ -174,7 +176,11 @@ def wino_work(calls):
         bits = 2 * Cout * Tp if c.get("mask") else 0                    # the ReLU's sign words: one uint16 per (channel, tile)
         HWo = sum((h // 2) * (w // 2) for h, w in c["shapes"]) if c.get("pooled") else HW     # fused max-pool: outputs / incoming gradients at the pooled size
         conv_flops += 18 * Cin * Cout * HW
-        add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
+        # 64 -> 64 channels on 4 x 4 tiles, forward and data gradient: the product and the output transform are one launch (csrc: rpn_wino_gemm_out64_kernel;
+        # it reads U and V and writes the outputs: the product planes do not exist)
+        fused = m == 4 and Cin == 64 and Cout == 64 and c["kind"] in ("fwd", "bwd_data")
+        if not fused:
+            add("rpn_wino_gemm_kernel", 0, 2 * P * Cin * Cout * Tp)
         if c["kind"] == "wgrad":
             if not c.get("cached"):
                 add("rpn_wino_input_kernel", 4 * Cin * HW + 4 * P * Cin * Tp)             # B^T d B of the activations, unless the forward kept it
@@ -189,7 +195,11 @@ def wino_work(calls):
                 add("rpn_wino_weight_kernel", 4 * (P + 9) * Cin * Cout)
             add("rpn_wino_input_kernel", 4 * K * (HWo if c["kind"] == "bwd_data" else HW) + (bits if c["kind"] == "bwd_data" else 0)
                 + 4 * P * K * Tp * (2 if c["kind"] == "bwd_data" and c.get("cached") else 1))       # (`cached` on a data gradient: both transforms in one pass)
-            add("rpn_wino_output_kernel", 4 * P * M * Tp + 4 * M * (HWo if c["kind"] == "fwd" else HW) + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0))
+            out_bytes = 4 * M * (HWo if c["kind"] == "fwd" else HW) + (2 * M * Tp if c["kind"] == "fwd" and c.get("relu_bits") else 0)
+            if fused:
+                add("rpn_wino_gemm_out64_kernel", 4 * P * K * M + 4 * P * K * Tp + out_bytes, 2 * P * Cin * Cout * Tp)
+            else:
+                add("rpn_wino_output_kernel", 4 * P * M * Tp + out_bytes)
     return tot, conv_flops
 
 

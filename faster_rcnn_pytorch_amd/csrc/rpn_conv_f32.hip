@@ -774,29 +774,24 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 
 // POOL (m = 4): ReLU + max_pool2d(2, 2) in the same pass -- the tile's four 2 x 2 windows -> the pooled outputs [C][H/2][W/2] (floor) and, per window,
 // 3 bits of the word: the position of the (first) maximum and whether it was positive; the full-resolution activations are never written.
+// One (channel, tile) of the output side: the tile's P products mv[(r, q)] -> A^T M A (+ bias, ReLU / ReLU + 2 x 2 max-pool), the store and the sign /
+// window word.  Shared by rpn_wino_output_kernel (products from memory) and rpn_wino_gemm_out64_kernel (products still in the accumulators).
 template <int M, bool POOL>
-__global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ Mp)
+__device__ __forceinline__ void wn_output_tile(const WnArgs &a, int c, int t, const float (&mv)[Wn<M>::P])
 {
-    static_assert(!POOL || M == 4, "fused pooling: 4 x 4 tiles only");
     constexpr int A = Wn<M>::A;
-    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
-    if (t >= a.Ttot) return;
     int l = 0;
 #pragma unroll
     for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < a.n_levels && t >= a.lv[q].off) ? 1 : 0;
     const int tl = t - a.lv[l].off;
     if (tl >= a.lv[l].T) return;
-    const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
+    const size_t at = (size_t)c * a.Ttot + t;
     float s[M][A];                                                        // rows first: s[i][q] = (A^T m[.][q])_i
 #pragma unroll
     for (int q = 0; q < A; ++q) {
         float col[A], o[M];
 #pragma unroll
-#if defined(WN_TABL) && (WN_TABL & 4)
-        for (int r = 0; r < A; ++r) { col[r] = (float)(r + q); asm volatile("" : "+v"(col[r])); }
-#else
-        for (int r = 0; r < A; ++r) col[r] = Mp[(size_t)(r * A + q) * plane + at];
-#endif
+        for (int r = 0; r < A; ++r) col[r] = mv[r * A + q];
         wn_at<M>(col, o);
 #pragma unroll
         for (int i = 0; i < M; ++i) s[i][q] = o[i];
@@ -864,6 +859,28 @@ __global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const fl
         }
     }
     if (a.bits_out) a.bits_out[at] = (unsigned short)word;
+}
+
+template <int M, bool POOL>
+__global__ __launch_bounds__(256) void rpn_wino_output_kernel(WnArgs a, const float *__restrict__ Mp)
+{
+    static_assert(!POOL || M == 4, "fused pooling: 4 x 4 tiles only");
+    constexpr int A = Wn<M>::A, P = Wn<M>::P;
+    const int t = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (t >= a.Ttot) return;
+    const size_t plane = (size_t)a.C * a.Ttot, at = (size_t)c * a.Ttot + t;
+    float mv[P];
+#pragma unroll
+    for (int q = 0; q < A; ++q)                                           // (the order of the loads the kernel always had: by column of the plane grid)
+#pragma unroll
+        for (int r = 0; r < A; ++r) {
+#if defined(WN_TABL) && (WN_TABL & 4)
+            mv[r * A + q] = (float)(r + q); asm volatile("" : "+v"(mv[r * A + q]));
+#else
+            mv[r * A + q] = Mp[(size_t)(r * A + q) * plane + at];
+#endif
+        }
+    wn_output_tile<M, POOL>(a, c, t, mv);
 }
 
 // dW[co][ci] = G^T dU G: (m + 2)^2 -> 3 x 3, thread = (co, ci); n = Cout * Cin
@@ -1194,6 +1211,90 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         __syncthreads();
 #endif
     }
+}
+
+// ---- the product with the output transform fused in, for 64 output channels and K = 64 (conv1_2 and its data gradient at 600 x 1000) ----
+// There the stage is a byte mover: 0.35 GB of product planes written by the GEMM and read back by the output transform, for 11 GFLOP.  Here a workgroup
+// owns WO_TB = 32 consecutive tiles x all 64 channels x ALL 36 planes: 36 x 8 accumulator registers per lane (v_mfma_f32_16x16x4_f32: wave w = channels
+// 16 w .. 16 w + 15, two 16-tile column blocks), so after the last plane every lane holds the 36 products of its eight (channel, tile) pairs and runs the
+// output transform (wn_output_tile: A^T M A, bias, ReLU / pool, store, sign word) on them in registers -- the product planes never exist in memory.
+// Operands per plane (U_xi [K][64], V_xi [K][32 tiles]) by LDS-DMA into a ring of WO_NB plane buffers; rows are rotated at the source (16 floats per k
+// row of a 4-row MFMA step for U, 16 per pair of rows for V) so that the four k rows a step reads fall into different banks.
+// 213 / 199 us (forward / data gradient) against 182 + 104 / 174 + 105 for the product + output transform pair.  What bounds it is the LDS-DMA path: 864 KB
+// of transfers per 32 tiles (two thirds of them U_xi, the same 16 KB for every workgroup) at the ~20 GB/s per CU that path gives = 40 of a block's 45 us,
+// of which 17 are MFMAs.  Measured on the way: one plane ahead 312 us (every plane waited for its round trip), ring of 4 / 6 buffers 213 / 225, operand
+// reads batched a plane ahead of the MFMAs 223, persistent blocks with the next block's planes issued before the output transform 223 (and 522 when the
+// 36 x 4 per-lane U addresses were hoisted out of the block loop into scratch), U_xi as plain register loads two planes ahead 208 (the compiler's own
+// counted waits for those loads drained the V transfers with them), K = 128 (conv2_1's data gradient) 129 against 94 unfused: not routed here.
+typedef float wn_f32x4 __attribute__((ext_vector_type(4)));
+#define WO_TB 32
+#define WO_NB 4
+__device__ __forceinline__ void wn_dma16(const float *g, const float *lds)
+{
+    const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
+}
+template <int K, bool POOL>
+__global__ __launch_bounds__(256, 1) void rpn_wino_gemm_out64_kernel(WnArgs a, const float *__restrict__ U, const float *__restrict__ V)
+{
+    constexpr int P = 36, MO = 64, NS = K / 4, bufF = K * (MO + WO_TB), NB = WO_NB;
+    constexpr int TPW = K / 16 + K / 32;                                  // 1-KB transfers per plane and wave
+    extern __shared__ __attribute__((aligned(16))) float wo_s[];          // [NB][K x 64 (U_xi) | K x 32 (V_xi)]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i16 = lane & 15, kk = lane >> 4;
+    const int t0 = blockIdx.x * WO_TB;
+    const size_t sU = (size_t)K * MO, sV = (size_t)K * a.Ttot;
+    auto issue = [&](int xi, int buf) {
+        float *sA = wo_s + buf * bufF, *sB = sA + K * MO;
+        const float *u = U + (size_t)xi * sU, *v = V + (size_t)xi * sV + t0;
+#pragma unroll
+        for (int q = 0; q < K / 16; ++q) {                                // U: 1-KB transfer d = k rows 4 d .. 4 d + 3; LDS float p of row r holds column (p - 16 r) mod 64
+            const int d = wave + 4 * q, r = lane >> 4, c = ((lane & 15) * 4 - 16 * r) & 63;
+            wn_dma16(u + (size_t)(4 * d + r) * MO + c, sA + d * 256);
+        }
+#pragma unroll
+        for (int q = 0; q < K / 32; ++q) {                                // V: transfer d = k rows 8 d .. 8 d + 7 of 32 tiles; row r holds column (p - 16 ((r & 3) >> 1)) mod 32
+            const int d = wave + 4 * q, r = lane >> 3, c = ((lane & 7) * 4 - 16 * ((r & 3) >> 1)) & 31;
+            wn_dma16(v + (size_t)(8 * d + r) * a.Ttot + c, sB + d * 256);
+        }
+    };
+    wn_f32x4 acc[P][2];
+#pragma unroll
+    for (int xi = 0; xi < P; ++xi) { acc[xi][0] = (wn_f32x4){0.0f, 0.0f, 0.0f, 0.0f}; acc[xi][1] = (wn_f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+    for (int xi = 0; xi < NB - 1; ++xi) issue(xi, xi);
+#pragma unroll
+    for (int xi = 0; xi < P; ++xi) {
+        // plane xi has landed: this wave's transfers by the counted wait (loads complete in order; the planes issued after xi may still fly), the other
+        // waves' by the barrier -- which also says that every wave is done reading the buffer the next issue refills
+        {
+            const int fl = (P - 1 - xi) < (NB - 2) ? (P - 1 - xi) : (NB - 2);      // planes issued after xi so far (compile-time: the loop is unrolled)
+            static_assert(NB - 2 <= 2, "counted waits below");
+            if (fl == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TPW) : "memory");
+            else if (fl == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (xi + NB - 1 < P) issue(xi + NB - 1, (xi + NB - 1) % NB);
+        const float *sA = wo_s + (xi % NB) * bufF, *sB = sA + K * MO;
+        const float *pa = sA + kk * MO + ((wave * 16 + i16 + 16 * kk) & 63);
+        const float *pb0 = sB + kk * WO_TB + ((i16 + 16 * (kk >> 1)) & 31), *pb1 = sB + kk * WO_TB + ((16 + i16 + 16 * (kk >> 1)) & 31);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {                                    // lane (i16, kk): k = 4 s + kk
+            const float av = pa[s * 4 * MO], b0 = pb0[s * 4 * WO_TB], b1 = pb1[s * 4 * WO_TB];
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[xi][1], 0, 0, 0);
+        }
+    }
+    // accumulator register r of column block tb: channel 16 wave + 4 kk + r, tile t0 + 16 tb + i16
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mv[P];
+#pragma unroll
+            for (int xi = 0; xi < P; ++xi) mv[xi] = acc[xi][tb][r];
+            wn_output_tile<4, POOL>(a, wave * 16 + 4 * kk + r, t0 + 16 * tb + i16, mv);
+        }
 }
 
 // the instantiation a product's tile widths need (host side)
@@ -1624,6 +1725,24 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
         if constexpr (M == 4) FRCNN_LAUNCH((rpn_wino_input_kernel<4, 0, true>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     } else FRCNN_LAUNCH((rpn_wino_input_kernel<M, 0, false>), dim3((unsigned)n_strips, (unsigned)K), dim3(256), lds, s, a, st, Vb);
     FRCNN_CHECK_LAUNCH("rpn_wino_input_kernel");
+    if constexpr (M == 4) {
+        static const bool no_fuse = [] { const char *e = getenv("FRCNN_WINO_NO_FUSE"); return e && atoi(e) != 0; }();
+        if (Mo == 64 && K == 64 && !no_fuse) {                           // 64 -> 64 channels: the product with the output transform fused in (no product planes)
+            a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
+            const size_t wl = (size_t)WO_NB * K * (64 + WO_TB) * sizeof(float);      // 96 KB
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+                (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+                attr_done = true;
+            }
+            const dim3 gr((unsigned)(Ttot / WO_TB));
+            if (relu == 2) FRCNN_LAUNCH((rpn_wino_gemm_out64_kernel<64, true>), gr, dim3(256), wl, s, a, Uuse, Vb);
+            else FRCNN_LAUNCH((rpn_wino_gemm_out64_kernel<64, false>), gr, dim3(256), wl, s, a, Uuse, Vb);
+            FRCNN_CHECK_LAUNCH("rpn_wino_gemm_out64_kernel");
+            return FRCNN_OK;
+        }
+    }
     WgArgs g = {Uuse, Vb, ws.M, (long long)Mo * K, (long long)K * Ttot, (long long)Mo * Ttot, Mo, (int)Ttot, (int)Ttot,
                 n_m_tiles, n_t_tiles, Kc, (int)units, (int)std::min<long long>(cf_ranges(), units), 0};
     {

@@ -199,11 +199,18 @@ def test_stage_accounting_of_pooled_calls_and_1x1_weight_gradients():
     bwd = dict(lay, kind="bwd_data", mask=True, cached=False, relu_bits=False, pooled=True)
     wg = dict(lay, kind="wgrad", mask=True, cached=True, relu_bits=False, pooled=True)
     tot, conv = bench.wino_work([fwd, bwd, wg, {"kind": "gemm_nt", "M": 128, "N": 512, "K": 16800, "splits": 35}])
-    assert tot["rpn_wino_gemm_kernel"]["launches"] == 4
-    assert tot["rpn_wino_gemm_kernel"]["flops"] == 3 * 2 * 36 * 64 * 64 * Tp + 2 * 128 * 512 * 16800
+    # 64 -> 64 channels on 4 x 4 tiles: forward and data gradient run the product and the output transform as ONE launch (rpn_wino_gemm_out64_kernel: U and V in,
+    # the outputs out, no product planes); the weight gradient and the 1 x 1 gradient stay on the GEMM
+    assert tot["rpn_wino_gemm_kernel"]["launches"] == 2 and tot["rpn_wino_output_kernel"]["launches"] == 0 and tot["rpn_wino_gemm_out64_kernel"]["launches"] == 2
+    assert tot["rpn_wino_gemm_kernel"]["flops"] == 2 * 36 * 64 * 64 * Tp + 2 * 128 * 512 * 16800
+    assert tot["rpn_wino_gemm_out64_kernel"]["flops"] == 2 * 2 * 36 * 64 * 64 * Tp
     assert conv == 3 * 18 * 64 * 64 * 600 * 1000 + 2 * 128 * 512 * 16800
     words = 2 * 64 * Tp
-    assert tot["rpn_wino_output_kernel"]["bytes"] == (4 * 36 * 64 * Tp + 4 * 64 * 300 * 500 + words) + (4 * 36 * 64 * Tp + 4 * 64 * 600 * 1000)
+    operands = 4 * 36 * 64 * 64 + 4 * 36 * 64 * Tp
+    assert tot["rpn_wino_gemm_out64_kernel"]["bytes"] == (operands + 4 * 64 * 300 * 500 + words) + (operands + 4 * 64 * 600 * 1000)
+    other = dict(lay, Cout=128)                                              # any other channel pair keeps the two launches
+    t2, _ = bench.wino_work([dict(other, kind="fwd", mask=False, cached=False, relu_bits=True, pooled=False)])
+    assert t2["rpn_wino_gemm_out64_kernel"]["launches"] == 0 and t2["rpn_wino_gemm_kernel"]["launches"] == 1 and t2["rpn_wino_output_kernel"]["launches"] == 1
     assert tot["rpn_wino_input_kernel"]["launches"] == 3                      # x (forward), pooled dy twice; the weight gradient's x transform was kept
     assert tot["rpn_wino_input_kernel"]["bytes"] == (4 * 64 * 600 * 1000 + 4 * 36 * 64 * Tp) + 2 * (4 * 64 * 300 * 500 + words + 4 * 36 * 64 * Tp)
 

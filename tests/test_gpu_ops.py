@@ -1827,7 +1827,7 @@ def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
 
 @pytest.mark.parametrize("m", ["2", "4"])
 def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
-    """The stage picks F(4x4, 3x3) from 512 tiles per call on and F(2x2, 3x3) below; FRCNN_WINO_M (read once per process) forces one.  A child process
+    """The stage picks its tile by cost (4 x 4 wherever 36 planes x its padded tile total is 15 % below 16 x the 2 x 2 total); FRCNN_WINO_M (read once per process) forces one.  A child process
     runs a large map with the small tile and small / odd maps with the large one (what the default choice never does) against float64: forward with
     bias + ReLU, masked data gradient, weight + bias gradient; 2e-5 of the scale for m = 2, 5e-5 for m = 4 (its transform constants span 1/24 .. 8)."""
     import subprocess
@@ -1969,3 +1969,47 @@ print("direct form OK")
     e = dict(os.environ, FRCNN_CONV_F32_DIRECT="1", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "direct form OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_conv3x3_f32_unfused_product_in_a_child_process(ops):
+    """64 -> 64 channels on 4 x 4 tiles run the product and the output transform as ONE launch (rpn_wino_gemm_out64_kernel: the 36 products of a (channel, tile)
+    stay in the accumulators); FRCNN_WINO_NO_FUSE=1 (read once per process) keeps the two launches.  Both forms against float64 -- forward with bias + ReLU and
+    with the fused 2 x 2 max-pool, sign / window words, the masked data gradient -- on a map whose tile count is no multiple of 32 and whose last tile row and
+    column are partial; and the two forms against each other within the rounding of their different summation orders."""
+    import subprocess, sys, tempfile, os
+    code = r"""
+import sys, torch, torch.nn.functional as F
+from faster_rcnn_pytorch_amd import ops
+dev = "cuda:0"
+g = torch.Generator().manual_seed(11)
+H, W = 118, 203
+x = torch.randn(1, 64, H, W, generator=g); wt = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5; b = torch.randn(64, generator=g) * 0.2
+dy = torch.randn(1, 64, H, W, generator=g); dyp = torch.randn(1, 64, H // 2, W // 2, generator=g)
+xd, wd, bd = x.to(dev), wt.to(dev), b.to(dev)
+pre = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+ys, _, bits = ops.conv3x3_fwd([xd], wd, bd, True, want_bits=True)
+assert float((ys[0].double().cpu() - pre.clamp_min(0)).abs().max()) < 5e-5 * float(pre.abs().max())
+assert torch.equal(ys[0], ops.conv3x3_fwd([xd], wd, bd, True)[0])
+dx = ops.conv3x3_bwd_data([dy.to(dev)], wd, bits)[0]
+r = F.conv_transpose2d(dy.double() * (ys[0].cpu() > 0), wt.double(), None, padding=1)
+assert float((dx.double().cpu() - r).abs().max()) < 5e-5 * float(r.abs().max())
+yp, _, pw = ops.conv3x3_fwd([xd], wd, bd, True, want_bits=True, pool=True)
+rp = F.max_pool2d(pre.clamp_min(0), 2, 2)
+assert float((yp[0].double().cpu() - rp).abs().max()) < 5e-5 * float(pre.abs().max())
+dxp = ops.conv3x3_bwd_data([dyp.to(dev)], wd, pw, pooled_from=[(H, W)])[0]
+torch.save({"y": ys[0].cpu(), "dx": dx.cpu(), "yp": yp[0].cpu(), "dxp": dxp.cpu()}, sys.argv[1])
+print("ok")
+"""
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("0", "1"):
+            path = os.path.join(td, "o%s.pt" % flag)
+            env = dict(os.environ, FRCNN_WINO_NO_FUSE=flag)
+            res = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300,
+                                 cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            assert res.returncode == 0 and "ok" in res.stdout, res.stderr[-2000:]
+            outs.append(torch.load(path))
+    for k in ("y", "dx", "yp", "dxp"):
+        a_, c_ = outs[0][k], outs[1][k]
+        assert a_.shape == c_.shape and float((a_ - c_).abs().max()) < 2e-5 * max(1.0, float(c_.abs().max())), k
+
