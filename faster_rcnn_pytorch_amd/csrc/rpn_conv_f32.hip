@@ -1274,13 +1274,18 @@ __global__ __launch_bounds__(256, 1) void rpn_wino_gemm_out64_kernel(WnArgs a, c
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+#if !(defined(WO_ABL) && (WO_ABL & 1))                             // developer ablation 1: no transfers behind the first planes
         if (xi + NB - 1 < P) issue(xi + NB - 1, (xi + NB - 1) % NB);
+#endif
         const float *sA = wo_s + (xi % NB) * bufF, *sB = sA + K * MO;
         const float *pa = sA + kk * MO + ((wave * 16 + i16 + 16 * kk) & 63);
         const float *pb0 = sB + kk * WO_TB + ((i16 + 16 * (kk >> 1)) & 31), *pb1 = sB + kk * WO_TB + ((16 + i16 + 16 * (kk >> 1)) & 31);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {                                    // lane (i16, kk): k = 4 s + kk
             const float av = pa[s * 4 * MO], b0 = pb0[s * 4 * WO_TB], b1 = pb1[s * 4 * WO_TB];
+#if defined(WO_ABL) && (WO_ABL & 2)                                 // developer ablation 2: one MFMA step per plane instead of K / 4
+            if (s > 0) continue;
+#endif
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[xi][0], 0, 0, 0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[xi][1], 0, 0, 0);
         }
