@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void rpn_wino_input_kernel(WnArgs a, WnStrips 
 #if defined(WN_TABL) && (WN_TABL & 2)
             for (int q = 0; q < A; ++q) if (o[q] == 1.2345e-30f) V[(size_t)(r * A + q) * plane + at] = o[q];
 #else
-            for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];
+            for (int q = 0; q < A; ++q) V[(size_t)(r * A + q) * plane + at] = o[q];      // (as non-temporal stores: 53 -> 93 us at 128 x 300 x 500)
 #endif
         }
         if (MODE == 2) {
@@ -981,7 +981,12 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
     // the same loop takes 366.)
     auto dma16 = [&](const float *g, const float *lds) {
         const unsigned l = (unsigned)(size_t)(const __attribute__((address_space(3))) float *)lds;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
+        // (non-temporal where both operands are streamed once from HBM -- the k-contiguous form on 64 x 64 tiles, conv1_2's weight gradient: 211 -> 176 us;
+        // on the other shapes the hint cost the product 3-8 %)
+        if constexpr (NT && MT == 64 && NW == 64)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
     };
     auto issue_dma = [&](const Tl &T, int chunk, int buf) {
         if (NT) {
