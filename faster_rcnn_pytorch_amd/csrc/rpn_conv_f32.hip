@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 // Forward and data gradient as Y = A^T [ sum_ci (G g G^T) . (B^T d B) ] A: P = (m + 2)^2 independent [Cout x Cin] . [Cin x T] products over
 // the m x m output tiles (T = ceil(H/m) ceil(W/m) per level) instead of one with K = 9 Cin.  m = 2: 16 products, 2.25 x fewer MFMAs
 // (fp32: ~3e-7 of the output scale, as good as the direct sum); m = 4: 36 products over a quarter of the tiles, 4 x fewer MFMAs and 0.56 x
-// the transformed bytes (fp32: ~5e-6 of the scale -- the 1/24 .. 8 range of its transform constants -- inside the path's 1e-4; maps with fewer
+// the transformed bytes (fp32: ~5e-6 of the scale -- the 1/24 .. 8 range of its transform constants -- inside the path's 1e-4; maps where
 // the tile padding would eat the gain stay with m = 2: wn_pick_m prices both forms by planes x padded tiles).  Four launches, all levels each:
 //   rpn_wino_weight_kernel   U[xi][k][m] = (G g G^T)_xi of W[m][k] (forward) or of the flipped W[k][m] (data gradient): once per call
 //   rpn_wino_input_kernel    V[xi][k][t] = (B^T d B)_xi of the zero-padded (m + 2)^2 input patch of tile t; rows padded to a multiple of 128 (or 64: wn_padded) tiles
@@ -353,7 +353,8 @@ __global__ __launch_bounds__(256) void rpn_conv_f32_pack_kernel(const float *__r
 //                            v_mfma_f32_32x32x2_f32, the direct kernel's skeleton without taps: both operand tiles (32 K rows x 128
 //                            floats) are staged by LDS-DMA (global_load_lds_dwordx4, no staging registers), no edge selects,
 //                            16 k steps per chunk
-//   rpn_wino_output_kernel   Y[m][m ty + i][m tx + j] = (A^T M A)_ij (+ bias, ReLU)
+//   rpn_wino_output_kernel   Y[m][m ty + i][m tx + j] = (A^T M A)_ij (+ bias, ReLU, ReLU + 2 x 2 max-pool; sign / window words)
+//   (64 -> 64 channels on 4 x 4 tiles: the last two as ONE launch, rpn_wino_gemm_out64_kernel -- the products stay in the accumulators)
 // Weight gradient: dU[xi][co][ci] = sum_t (A dY A^T)_xi[co][t] (B^T d B)_xi[ci][t], dW = G^T dU G: the SAME input transform (of the
 // activations) and its sibling for the output gradient write [xi][channel][t] with the tiles contiguous, and the product -- which sums over
 // the tiles -- runs on the k-contiguous form of the GEMM (rpn_wino_gemm_kernel<true>: both operand tiles 128 rows x 32 k, 16-byte pieces
