@@ -596,7 +596,12 @@ def compact_record(full, also=()):
     compact `also` list; per-kernel records, percentiles, conditions, allocator counters go to bench_detail.json (emit())."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
-    out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission"))
+    out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission", "sampling"))
+    cond = full.get("conditions") or {}
+    # what the number was measured under, in three words (the sentences are in bench_detail.json): how the vendor GEMMs were picked and whether
+    # Python's collector could interrupt the enqueue (--no-tunableop --gc-on give the other figure)
+    out["conditions"] = {"tunableop": ("off" if cond.get("tunableop_results") is None else ("cached" if cond["tunableop_results"].startswith("read") else "tuned")),
+                         "gc": "on" if cond.get("python_gc") == "on" else "frozen"}
     rk = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us")
     roof = _pick(full.get("roofline"), rk + ("frac_on_issued_instructions", "stage_us_per_call", "conv_equivalent_TFLOP_s"))
     if roof is not None and full["roofline"].get("hbm_kernel"):

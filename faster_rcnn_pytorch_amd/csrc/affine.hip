@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void affine_act_fwd_kernel(const float *__rest
         const int i = blockIdx.x * 1024 + j * 256 + threadIdx.x;
         float o = v[j] * s + b;                                           // compiled without contraction: torch's mul, then add
         if (RES) o = o + r[j];
-        if (relu) o = fmaxf(o, 0.0f);
+        if (relu) o = o < 0.0f ? 0.0f : o;                    // NaN stays NaN, as torch.relu (fmaxf would return 0)
         if (i < HW) y[base + i] = o;
     }
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_fwd_kernel(const float *__rest
         for (int j = 0; j < 2; ++j) {
             const int co = c2 + j;
             if (co < Cout) {
-                const float pre = j ? acc1 : acc0, o = relu ? fmaxf(pre, 0.0f) : pre;
+                const float pre = j ? acc1 : acc0, o = relu && pre < 0.0f ? 0.0f : pre;      // NaN stays NaN (torch.relu)
                 yo[(size_t)co * plane] = o;
                 word |= o > 0.0f ? 1ull << (co & 63) : 0ull;
                 if (bits && ((co & 63) == 63 || co == Cout - 1)) { bits[(size_t)(co >> 6) * plane + (size_t)row * W + xx] = word; word = 0; }
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_wgrad_finalize_kernel(const fl
 static int c3_check(const void *x, const void *y, int H, int W, int Cout, const void *w, const char *what)
 {
     FRCNN_REQUIRE(x && y && w, "%s: NULL pointer", what);
-    FRCNN_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout <= 512 && (long long)H * W * Cout < (1ll << 31), "%s: bad size %d x %d x %d", what, Cout, H, W);
+    FRCNN_REQUIRE(H > 0 && W > 0 && Cout > 0 && Cout <= 256 && (long long)H * W * Cout < (1ll << 31), "%s: bad size %d x %d x %d", what, Cout, H, W);
     return FRCNN_OK;
 }
 
@@ -265,6 +265,9 @@ FRCNN_EXPORT int frcnn_conv3x3_c3_wgrad(const float *x_dev, const float *dy_dev,
     const int nb = (H + rows - 1) / rows;
     const dim3 wg((unsigned)nb, (unsigned)groups);
     const size_t wl = (size_t)3 * (rows + 2) * (W + 2) * sizeof(float);
+    // the window may need more than the 64 KB a launch gets without asking (84 KB at 600 x 1000): opt in, per call (the attribute is per device)
+    if (relu_bits_dev) (void)hipFuncSetAttribute((const void *)conv3x3_c3_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+    else (void)hipFuncSetAttribute((const void *)conv3x3_c3_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
     if (relu_bits_dev) FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<true>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part, rows);
     else FRCNN_LAUNCH(conv3x3_c3_wgrad_kernel<false>, wg, dim3(64 * C3_WAVES), wl, s, x_dev, dy_dev, H, W, Cout, relu_bits_dev, part, rows);
     FRCNN_CHECK_LAUNCH("conv3x3_c3_wgrad_kernel");

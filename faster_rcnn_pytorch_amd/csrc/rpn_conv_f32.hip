@@ -807,7 +807,7 @@ __device__ __forceinline__ void wn_output_tile(const WnArgs &a, int c, int t, co
             float o[M];
             wn_at<M>(s[i], o);
 #pragma unroll
-            for (int j = 0; j < M; ++j) v[i][j] = fmaxf(o[j] + b, 0.0f);
+            for (int j = 0; j < M; ++j) { const float t = o[j] + b; v[i][j] = t < 0.0f ? 0.0f : t; }      // keeps a NaN, as torch's relu does (fmaxf drops it)
         }
         const int Hp = H >> 1, Wp = W >> 1;
         float *yp = a.lv[l].y + (size_t)c * Hp * Wp;
@@ -819,9 +819,9 @@ __device__ __forceinline__ void wn_output_tile(const WnArgs &a, int c, int t, co
                 if (py < Hp && px < Wp) {                                     // floor mode: a window exists only with all four of its pixels
                     float mx = v[2 * wi][2 * wj];
                     unsigned arg = 0;
-                    if (v[2 * wi][2 * wj + 1] > mx) { mx = v[2 * wi][2 * wj + 1]; arg = 1; }      // scan order, strict >: the first maximum, as max_pool2d
-                    if (v[2 * wi + 1][2 * wj] > mx) { mx = v[2 * wi + 1][2 * wj]; arg = 2; }
-                    if (v[2 * wi + 1][2 * wj + 1] > mx) { mx = v[2 * wi + 1][2 * wj + 1]; arg = 3; }
+                    if (v[2 * wi][2 * wj + 1] > mx || v[2 * wi][2 * wj + 1] != v[2 * wi][2 * wj + 1]) { mx = v[2 * wi][2 * wj + 1]; arg = 1; }      // scan order, strict >: the first maximum, as max_pool2d (which also lets a NaN win)
+                    if (v[2 * wi + 1][2 * wj] > mx || v[2 * wi + 1][2 * wj] != v[2 * wi + 1][2 * wj]) { mx = v[2 * wi + 1][2 * wj]; arg = 2; }
+                    if (v[2 * wi + 1][2 * wj + 1] > mx || v[2 * wi + 1][2 * wj + 1] != v[2 * wi + 1][2 * wj + 1]) { mx = v[2 * wi + 1][2 * wj + 1]; arg = 3; }
                     yp[(size_t)py * Wp + px] = mx;
                     word |= (arg | (mx > 0.0f ? 4u : 0u)) << (3 * (wi * 2 + wj));
                 }
@@ -842,7 +842,7 @@ __device__ __forceinline__ void wn_output_tile(const WnArgs &a, int c, int t, co
 #pragma unroll
             for (int j = 0; j < M; ++j) {
                 v[j] = o[j] + b;
-                if (a.relu) v[j] = fmaxf(v[j], 0.0f);
+                if (a.relu) v[j] = v[j] < 0.0f ? 0.0f : v[j];                      // NaN stays NaN (torch.relu / clamp_min)
                 if (M * tx + j < W) word |= (v[j] > 0.0f) ? (1u << (i * M + j)) : 0u;
             }
             if (vec) {
@@ -1535,11 +1535,16 @@ __global__ __launch_bounds__(256, CW_WPS) void rpn_conv3x3_f32_wgrad_kernel(CwAr
 struct CfWs { int *cnt; float *wt, *part, *U, *V, *M; size_t total; };
 static int cf_ranges()
 {
-    static const int g = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return CF_WPS * cus;                                         // CF_WPS workgroups of 51.7 KB LDS per CU
-    }();
+    static int per_dev[64];                                          // 0 = not asked yet; per device: one process may drive several
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int g = __atomic_load_n(&per_dev[dev], __ATOMIC_RELAXED);
+    if (!g) {
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        g = CF_WPS * cus;                                            // CF_WPS workgroups of 51.7 KB LDS per CU
+        __atomic_store_n(&per_dev[dev], g, __ATOMIC_RELAXED);
+    }
     return g;
 }
 static CfWs cf_carve(void *ws, int C, size_t u_floats = 0, size_t vm_floats = 0)
@@ -1721,6 +1726,7 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
     a.zero_pad = xt ? 1 : 0;
     WnStrips st;
     size_t lds = 0;
+    FRCNN_REQUIRE(!pooled || M == 4, "conv3x3_f32: a pooled gradient on the %d x %d tile", M, M);      // (the entry points refuse it first)
     const int n_strips = wn_strips<M>(&st, a, H, n_levels, K, 1, &lds, pooled ? 2 : M);
     if (dm_out) {                                                    // data gradient that also feeds the weight gradient: both transforms, one pass
         a.out2 = dm_out; a.zero_pad = 1;
@@ -1741,12 +1747,9 @@ static int wn_run(const float *const *in, float *const *out, const unsigned shor
         if (Mo == 64 && K == 64 && !no_fuse) {                           // 64 -> 64 channels: the product with the output transform fused in (no product planes)
             a.C = Mo; a.bias = bias; a.relu = relu; a.bits_out = bits_out;
             const size_t wl = (size_t)WO_NB * K * (64 + WO_TB) * sizeof(float);      // 96 KB
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-                (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
-                attr_done = true;
-            }
+            // per call: the attribute is per device, and a process may drive several (the call is a table lookup in the runtime)
+            if (relu == 2) (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+            else (void)hipFuncSetAttribute((const void *)rpn_wino_gemm_out64_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
             const dim3 gr((unsigned)(Ttot / WO_TB));
             if (relu == 2) FRCNN_LAUNCH((rpn_wino_gemm_out64_kernel<64, true>), gr, dim3(256), wl, s, a, Uuse, Vb);
             else FRCNN_LAUNCH((rpn_wino_gemm_out64_kernel<64, false>), gr, dim3(256), wl, s, a, Uuse, Vb);
@@ -1864,7 +1867,6 @@ FRCNN_EXPORT int frcnn_conv3x3_f32_bwd_data(const float *const *dy_dev, const un
     int rc = cf_check((const void *const *)dy_dev, (const void *const *)dx_dev, H_host, W_host, n_levels, Cin, Cout, 64, WN_KC, w_dev, workspace, workspace_bytes,
                       "conv3x3_f32_bwd_data");
     if (rc) return rc;
-    if (wn_pick_m(H_host, W_host, n_levels) == 4)
     if (pooled && (!relu_bits_dev || wn_pick_m(H_host, W_host, n_levels) != 4))
         return frcnn_set_error(FRCNN_ERR_UNSUPPORTED, "conv3x3_f32_bwd_data: a pooled gradient needs the forward's words and the 4 x 4 tile");
     if (wn_pick_m(H_host, W_host, n_levels) == 4)
@@ -1903,6 +1905,7 @@ static int wn_wgrad(const float *const *feats, const float *const *d_outs, const
     for (int l = 0; l < n_levels; ++l) g1.lv[l].x = d_outs[l];
     g1.bits = bits;
     g1.C = Cout;
+    FRCNN_REQUIRE(!pooled || M == 4, "conv3x3_f32_wgrad: a pooled gradient on the %d x %d tile", M, M);
     n_strips = wn_strips<M>(&st, g1, H, n_levels, Cout, dm_in ? 1 : 0, &lds, pooled ? 2 : M);      // (dm_in: the strips of the data gradient's launch that made it)
     const int n_strips_dy = n_strips;
     FRCNN_REQUIRE(!dbias || (size_t)Cout * n_strips_dy <= (size_t)C9 * C9 * 9, "conv3x3_f32_wgrad: %d strips are too many for the bias partials", n_strips_dy);

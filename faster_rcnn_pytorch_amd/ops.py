@@ -61,18 +61,30 @@ def _workspace(device, nbytes):
 
 
 _CTRL = {}
+_CTRL_IN_GRAPHS = {}          # key -> buffers whose address a captured graph holds (kept alive when the cache moves on to a larger one)
 
 
 def _ctrl_workspace(device, tag, nbytes):
     """A persistent, ZERO-INITIALISED workspace per (op, device) for the ops whose kernels keep a control word between calls (a
     last-workgroup ticket that the kernel itself resets: include/frcnn_hip.h).  Never shared with the scratch of other ops; one per
     device, not per stream (calls of one op on one device are stream-ordered in the training step), so that a HIP-graph capture on its
-    own capture stream finds the buffer the warm-up created instead of allocating -- and zero-filling -- a new one inside the graph."""
+    own capture stream finds the buffer the warm-up created instead of allocating -- and zero-filling -- a new one inside the graph.
+
+    Under capture (the conv stage keeps U / V / M here: hundreds of MB sized by the largest layer seen) a missing or too small buffer is
+    NOT cached: torch.zeros would allocate it inside the capturing graph's private pool, and the cache would hand that address to eager
+    calls and to later graphs after the pool is gone (the fault ops._workspace had in round 4).  The graph gets a zeroed buffer of its own
+    pool instead (its memset node replays with it; the kernels leave the control words zero anyway).  And a cached buffer that a capture
+    has seen stays alive when the cache later grows past it."""
     key = (tag, device.index)
     buf = _CTRL.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if buf is None or buf.numel() < nbytes:
-        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        if capturing:
+            return torch.zeros(int(nbytes), dtype=torch.uint8, device=device)     # graph-private: lives and dies with the graph's pool
+        buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)          # (a buffer a graph replays into stays referenced by _CTRL_IN_GRAPHS)
         _CTRL[key] = buf
+    if capturing and not any(b is buf for b in _CTRL_IN_GRAPHS.setdefault(key, [])):
+        _CTRL_IN_GRAPHS[key].append(buf)
     return buf
 
 
@@ -1021,9 +1033,11 @@ def conv3x3_c3(x, weight, bias=None, relu=False):
 
 
 def conv3x3_c3_supported(x, weight):
-    """fp32 on a HIP device, batch 1, [Cout,3,3,3] with Cout % 4 == 0, the input itself needing no gradient, rows of at most 1700 pixels."""
+    """fp32 on a HIP device, batch 1, [Cout,3,3,3] with Cout % 4 == 0 and Cout <= 256 (the forward keeps Cout * 28 weights in LDS), the input
+    itself needing no gradient, rows of at most 1700 pixels.  Anything else stays with torch's convolution."""
     return (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3
-            and tuple(weight.shape[1:]) == (3, 3, 3) and weight.shape[0] % 4 == 0 and x.shape[3] <= 1700 and not x.requires_grad)
+            and tuple(weight.shape[1:]) == (3, 3, 3) and weight.shape[0] % 4 == 0 and weight.shape[0] <= 256 and x.shape[3] <= 1700
+            and not x.requires_grad)
 
 
 def rpn_conv_head_levels(feats, w3, b3, w_cls, b_cls, w_reg, b_reg):

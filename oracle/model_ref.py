@@ -128,6 +128,47 @@ class RefFRCNN(nn.Module):
                (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
 
 
+def ref_forward_fixed_vgg(ref, x, sample_rois, t_cls):
+    """The reference's CPU form of models/model_.py:304-341 with the SAMPLED RoIs and head classes handed in (from another run of the same step)
+    instead of re-derived: extractor -> RPN head (:307,:315), RoIPool of the given RoIs -> classifier -> heads -> class-row gather (:335-341).
+    What the same-weights tests compare the HIP-backed model's features / predictions / parameter gradients with: every value and gradient
+    depends only on the network arithmetic, not on the sort / NMS / sampling decisions (which have their own bit-exact tests).
+    Returns (features, (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [128,C], head_reg [128,4]))."""
+    features = ref.extractor(x)
+    h = torch.relu(ref.rpn.inter_layer(features))
+    pred_cls = ref.rpn.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2)
+    pred_reg = ref.rpn.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4)
+    fh, fw = features.shape[2:]
+    scaled = sample_rois.to(torch.float32) * torch.tensor([fw, fh, fw, fh], dtype=torch.float32)      # model_.py:107-109, fp32 like the reference
+    pool = _RefRoIPool.apply(features, scaled)
+    z = ref.classifier(pool.view(pool.size(0), -1))
+    head_cls = ref.fast_rcnn_head.cls_head(z)
+    R = sample_rois.shape[0]
+    head_reg = ref.fast_rcnn_head.reg_head(z).reshape(R, -1, 4)[torch.arange(R), t_cls.clamp(min=0)]
+    return features, (pred_cls, pred_reg, head_cls, head_reg)
+
+
+def ref_forward_fixed_fpn(ref, x, sample_rois, t_cls):
+    """models/new_model.py:391-412 on the CPU with the sampled RoIs / head classes handed in (see ref_forward_fixed_vgg).
+    Returns ([five feature maps], (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [512,C], head_reg [512,4]))."""
+    features = ref.backbone(x)
+    feats = list(features.values())
+    cls, reg = [], []
+    for f in feats:
+        h = torch.relu(ref.rpn_head.inter_layer(f))
+        cls.append(ref.rpn_head.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
+        reg.append(ref.rpn_head.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
+    pred_cls, pred_reg = torch.cat(cls, dim=1), torch.cat(reg, dim=1)
+    H, W = x.shape[2:]
+    scaled = sample_rois.to(torch.float32) * torch.tensor([W, H, W, H], dtype=torch.float32)          # new_model.py:136-140
+    pool = _RefMsRoIAlign.apply(scaled, *feats[:4])
+    z = ref.classifier(pool.view(pool.size(0), -1))
+    head_cls = ref.cls_head(z)
+    R = sample_rois.shape[0]
+    head_reg = ref.reg_head(z).reshape(R, -1, 4)[torch.arange(R), t_cls.clamp(min=0)]
+    return feats, (pred_cls, pred_reg, head_cls, head_reg)
+
+
 class _RefMsRoIAlign(torch.autograd.Function):
     """MultiScaleRoIAlign (models/new_model.py:127,143) through the C oracle, with its backward (per level scatter)."""
 

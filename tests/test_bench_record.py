@@ -65,6 +65,9 @@ def test_compact_line_stays_under_4k_with_every_optional_block():
     for k in ("sum_kernel_us_per_img", "launches_per_img", "mean_proposals_per_img", "proposals_per_s", "nms_plus_roi_us_per_img",
               "proposal_stage_us_per_img"):
         assert out["hot_path"][k] is not None, k
+    # what the figure was measured under rides on the line itself (the driver keeps only the parsed line)
+    assert out["conditions"]["tunableop"] in ("tuned", "cached", "off") and out["conditions"]["gc"] in ("frozen", "on")
+    assert out["config"]["sampling"] == "device-philox"
     assert [a["dtype"] for a in out["also"]] == ["f32", "f32", "bf16"] and all(a["roofline"]["kernel"] for a in out["also"])
     assert out["also"][0]["eager_value"] == out["value"] and out["also"][0]["submission"].startswith("one HIP graph")
 

@@ -168,3 +168,46 @@ def test_scratch_of_a_captured_op_does_not_outlive_its_graph():
     assert outs == [True, True]
     key = (torch.device(DEV).index, torch.cuda.graphs.graph.default_capture_stream.cuda_stream) if getattr(torch.cuda.graphs.graph, "default_capture_stream", None) else None
     assert key is None or key not in ops._WS                             # nothing was cached under the capture stream
+
+
+def test_conv_stage_workspace_grown_under_capture_is_graph_private():
+    """the conv stage keeps ticket words + U / V / M in ONE persistent block per device (ops._ctrl_workspace, tag 'rpn_conv_f32'), sized by
+    the largest layer seen.  A capture that needs MORE than the eager warm-up left there (a layer or image size first met under capture) must not put a
+    buffer of its own private pool into that cache: after the graph is gone, eager calls and later captures would run on a released address.  Two
+    captures at growing shapes without an eager warm-up at those shapes, the first graph destroyed before the second is made; then an eager call at the
+    larger shape.  Every result equals the eager result computed up front on a small cache... and the cache never holds a capture-time allocation."""
+    from faster_rcnn_pytorch_amd import ops
+    g0 = torch.Generator().manual_seed(9)
+    w = (torch.randn(128, 128, 3, 3, generator=g0) * 0.03).to(DEV)
+    b = torch.randn(128, generator=g0).to(DEV)
+    xs = [torch.randn(1, 128, h, wd, generator=g0).to(DEV) for h, wd in ((40, 56), (96, 132), (150, 250))]
+    ops._CTRL.pop(("rpn_conv_f32", torch.device(DEV).index), None)         # as in a fresh process
+    refs = []
+    for x in xs:                                                            # eager references, each computed on a cache that is dropped again
+        refs.append(ops.conv3x3_fwd([x], w, b, True)[0].clone())
+        torch.cuda.synchronize()
+        ops._CTRL.pop(("rpn_conv_f32", torch.device(DEV).index), None)
+    ops.conv3x3_fwd([xs[0]], w, b, True)                                    # the only warm-up: the SMALLEST shape
+    torch.cuda.synchronize()
+    cached = ops._CTRL[("rpn_conv_f32", torch.device(DEV).index)]
+    n_cached = cached.numel()
+    for i in (1, 2):                                                        # growing shapes, each first met under capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = ops.conv3x3_fwd([xs[i]], w, b, True)[0]
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, refs[i])
+        assert ops._CTRL[("rpn_conv_f32", torch.device(DEV).index)] is cached and cached.numel() == n_cached      # the cache did not take the graph's buffer
+        del g, y
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()                                            # the graph's private pool is released here
+    assert torch.equal(ops.conv3x3_fwd([xs[2]], w, b, True)[0], refs[2])   # eager at the large shape: grows the cache with an ordinary allocation
+    assert ops._CTRL[("rpn_conv_f32", torch.device(DEV).index)].numel() > n_cached
+    g = torch.cuda.CUDAGraph()                                              # and a capture that FINDS a large enough cached block uses it
+    with torch.cuda.graph(g):
+        y = ops.conv3x3_fwd([xs[1]], w, b, True)[0]
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, refs[1])

@@ -186,8 +186,8 @@ def fpn_model():
     return m
 
 
-def test_fpn_forward_matches_oracle_stage_by_stage(fpn_model):
-    H, W, G, seed = 384, 512, 3, 5
+@pytest.mark.parametrize("H,W,G,seed", [(384, 512, 3, 5), (800, 1344, 5, 6)], ids=["384x512", "config_F_800x1344"])
+def test_fpn_forward_matches_oracle_stage_by_stage(fpn_model, H, W, G, seed):
     x, boxes, labels = synth(seed, H, W, G)
     labels = labels + 1                                    # raw COCO-style ids, 0 = background
     cap = {}

@@ -888,6 +888,43 @@ def test_ms_roi_align_fwd_bwd_vs_oracle(ops):
         assert np.allclose(f.grad[0].cpu().numpy(), gf_o, rtol=1e-4, atol=1e-4)  # atomics: order-nondeterministic
 
 
+@pytest.mark.parametrize("regime", ["proposal_like", "spread"])
+def test_ms_roi_align_config_f_full_size_vs_oracle(ops, regime):
+    """VERDICT r4 "next" 6: MultiScaleRoIAlign (models/new_model.py:127,143) at config F's REAL shape -- 256 channels x {200x336, 100x168, 50x84,
+    25x42}, 512 RoIs on an 800 x 1344 frame -- forward (roi_align_fwd77_kernel) bit for bit and backward (lists -> plan -> tile -> combine) within
+    1e-5 of the scale against the C oracle.  'proposal_like' = what the head's sampler hands over after NMS (many small boxes, all four levels);
+    'spread' = uniformly sized boxes up to the whole frame (large footprints, split tiles, every level mapped)."""
+    rng = np.random.RandomState(11 if regime == "spread" else 12)
+    C, R, Wimg, Himg = 256, 512, 1344, 800
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    feats = [rng.randn(C, h, w).astype(np.float32) for h, w in shapes]
+    if regime == "spread":
+        rois = rand_boxes(rng, R, 0.01, 0.98)
+    else:
+        c = rng.uniform(0.05, 0.95, (R, 2)).astype(np.float32)
+        wh = np.exp(rng.uniform(np.log(0.02), np.log(0.7), (R, 2))).astype(np.float32)
+        rois = np.clip(np.concatenate([c - wh / 2, c + wh / 2], 1), 0, 1).astype(np.float32)
+    rois = (rois * np.array([Wimg, Himg, Wimg, Himg], np.float32)).astype(np.float32)
+    rois[0] = [-30, -20, 180, 150]                        # partly outside the frame
+    rois[1] = [1300, 760, 1360, 820]
+    rois[2] = [0, 0, Wimg, Himg]                          # the whole frame: the coarsest level, the largest footprint
+    out_o, lv = orc.ms_roi_align(feats, rois)
+    assert set(lv.tolist()) == {0, 1, 2, 3}
+    fts = [T(f[None]).requires_grad_(True) for f in feats]
+    m = ops.MultiScaleRoIAlign(["0", "1", "2", "3"], 7, 2)
+    out = m({str(i): f for i, f in enumerate(fts)}, [T(rois)], [(Wimg, Himg)])
+    assert np.array_equal(ops.roi_level_map(T(rois)).cpu().numpy(), lv)
+    assert np.array_equal(out.detach().cpu().numpy(), out_o)                     # the forward follows the oracle's operation order: bit-exact
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    out.backward(T(go))
+    worst = 0.0
+    for l, f in enumerate(fts):
+        gf_o = orc.roi_align_bwd(go, feats[l].shape, rois, 0.25 / (1 << l), 2, False, lv, l)
+        d = float(np.abs(f.grad[0].cpu().numpy() - gf_o).max()) / max(1.0, float(np.abs(gf_o).max()))
+        worst = max(worst, d)
+    assert worst < 1e-5, worst                                                   # a different (fixed) summation order than the oracle's scatter
+
+
 @pytest.mark.parametrize("PH,SR", [(7, 2), (5, 3), (7, 0)])
 def test_single_level_roi_align_big_footprints_and_generic_shapes(ops, PH, SR):
     """One level of 300 x 260 at scale 1: RoIs whose footprint exceeds the forward staging buffer (fh*fw > 8192) and the
@@ -1549,6 +1586,11 @@ CONV3X3_CASES = [   # name, Cin, Cout, level shapes, bias, relu, gradients
     ("wide_out_64", 256, 64, [(25, 33)], True, False, True),                  # 64 outputs of a wide input
     ("rpn_37x62", 256, 128, [(37, 62)], True, True, True),                    # the RPN's / conv5's map at 600x1000: 160 4 x 4 tiles padded to 192 (64-wide product tiles)
     ("c5_25x42", 128, 128, [(25, 42)], False, True, True),                    # 273 2 x 2 tiles padded to 320: the 64-wide product tile with F(2x2)
+    # the sizes bench.py runs: features[2] + [3] at 600 x 1000 = rpn_wino_gemm_out64_kernel forward and data gradient and the
+    # k-contiguous 64 x 64-tile weight-gradient product with non-temporal operand transfers (commit 4d2cc32); features[5] + [6] at 300 x 500
+    ("vgg_conv1_2_full", 64, 64, [(600, 1000)], True, True, True),
+    ("vgg_conv2_1_full", 64, 128, [(300, 500)], True, True, True),
+    ("resnet_layer1_full", 64, 64, [(200, 336)], True, True, True),           # layer1's conv2 at 800 x 1344 (the fused 64 -> 64 product on a second size)
 ]
 
 
@@ -1652,7 +1694,8 @@ def test_conv3x3_f32_autograd_and_argument_checks(ops):
     assert not ops.conv3x3_supported(big, torch.zeros(64, 64, 3, 3, device=DEV, requires_grad=True))      # -> the caller keeps torch's convolution
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W", [(128, 128, 96, 132), (64, 128, 75, 125), (64, 64, 150, 250)], ids=["even", "odd_rows_cols", "narrow"])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(128, 128, 96, 132), (64, 128, 75, 125), (64, 64, 150, 250), (64, 64, 600, 1000), (128, 128, 300, 500)],
+                         ids=["even", "odd_rows_cols", "narrow", "vgg_conv1_2_full_with_pool", "vgg_conv2_2_full_with_pool"])
 def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
     """conv3x3(..., relu=True, pool=True) = Conv2d + ReLU + MaxPool2d(2, 2) of vgg16.features in one stage call: the pooled output and the
     words of the 2 x 2 windows come out of the output transform (the full-resolution activations are never written), and the gradient
@@ -1723,9 +1766,17 @@ def test_conv3x3_f32_fused_relu_maxpool(ops, Cin, Cout, H, W):
     assert not ops.conv3x3_pool_supported(small)                            # 15 4 x 4 tiles would be padded to 64: the 2 x 2 tile, no fused pool
     with pytest.raises(Exception):
         ops.conv3x3_fwd([small], torch.zeros(128, 128, 3, 3, device=DEV), None, True, pool=True)
+    # ... and so do the gradient calls (a stray `if` used to let a pooled gradient on the 2 x 2 tile through to an H x W staging of a half-size buffer)
+    from faster_rcnn_pytorch_amd._lib import FrcnnError
+    w128 = torch.zeros(128, 128, 3, 3, device=DEV)
+    _, _, bits_small = ops.conv3x3_fwd([small], w128, None, True, want_bits=True)
+    with pytest.raises(FrcnnError):
+        ops.conv3x3_bwd_data([torch.zeros(1, 128, 6, 10, device=DEV)], w128, bits_small, pooled_from=[(12, 20)])
+    with pytest.raises(FrcnnError):
+        ops.conv3x3_wgrad([small], [torch.zeros(1, 128, 6, 10, device=DEV)], bits_small, pooled=True)
 
 
-@pytest.mark.parametrize("Cout,H,W", [(64, 75, 130), (32, 9, 700), (80, 33, 257)], ids=["vgg_like", "wide", "two_words"])
+@pytest.mark.parametrize("Cout,H,W", [(64, 75, 130), (32, 9, 700), (80, 33, 257), (64, 600, 1000)], ids=["vgg_like", "wide", "two_words", "vgg_conv1_1_full"])
 def test_conv3x3_c3_first_convolution(ops, Cout, H, W):
     """frcnn_conv3x3_c3_fwd / _wgrad: `vgg16.features[0]` + `[1]` (Conv2d(3, 64, 3, padding=1) + ReLU) and their backward -- weight and bias
     gradient, the ReLU's backward from the forward's sign words -- against float64 (mask from the device output) and, through
@@ -1762,6 +1813,38 @@ def test_conv3x3_c3_first_convolution(ops, Cout, H, W):
         out = ops.conv3x3_c3(xd, wr, br, relu=True)
         out.backward(dyd)
         assert torch.equal(out.detach(), y) and torch.equal(wr.grad, dw) and torch.equal(br.grad, db)
+
+
+def test_fused_relu_keeps_a_nan_like_torch_relu(ops):
+    """the ReLUs fused into the conv stage's output transform (plain and with the 2 x 2 max-pool) and into the first convolution must
+    propagate a NaN as torch.relu / clamp_min / max_pool2d do -- fmaxf(NaN, 0) returns 0 and would hide a diverged activation.  The first
+    convolution is a direct sum: its NaN set equals torch's.  The Winograd stage transforms 6 x 6 patches, so a NaN input reaches every output
+    of the tiles whose patch holds it: a superset of torch's 3 x 3 neighbourhood, never a subset."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(3)
+    x3 = torch.randn(1, 3, 40, 70, generator=g).to(DEV)
+    x3[0, 1, 17, 33] = float("nan")
+    w3 = (torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(DEV)
+    b3 = torch.randn(64, generator=g).to(DEV)
+    y = ops.conv3x3_c3_fwd(x3, w3, b3, True)
+    ref = torch.relu(F.conv2d(x3, w3, b3, padding=1))
+    assert int(torch.isnan(ref).sum()) == 64 * 9 and torch.equal(torch.isnan(y), torch.isnan(ref))
+    x = torch.randn(1, 128, 96, 132, generator=g).to(DEV)
+    x[0, 5, 41, 77] = float("nan")
+    w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).to(DEV)
+    b = torch.randn(128, generator=g).to(DEV)
+    ref = torch.relu(F.conv2d(x, w, b, padding=1))
+    y = ops.conv3x3_fwd([x], w, b, True)[0]
+    nan_ref, nan_y = torch.isnan(ref), torch.isnan(y)
+    assert int(nan_ref.sum()) == 128 * 9 and bool((nan_y | ~nan_ref).all()) and int(nan_y.sum()) <= 128 * 64
+    yp = ops.conv3x3_fwd([x], w, b, True, pool=True)[0]
+    nan_p = torch.isnan(F.max_pool2d(ref, 2, 2))
+    assert int(nan_p.sum()) > 0 and bool((torch.isnan(yp) | ~nan_p).all())
+    small = torch.randn(1, 128, 12, 20, generator=g).to(DEV)               # the 2 x 2 tile's output transform
+    small[0, 0, 6, 9] = float("nan")
+    ys = ops.conv3x3_fwd([small], w, b, True)[0]
+    nan_s = torch.isnan(torch.relu(F.conv2d(small, w, b, padding=1)))
+    assert bool((torch.isnan(ys) | ~nan_s).all())
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 512, 16800), (256, 256, 67200), (64, 192, 96), (512, 128, 4224)])
@@ -1823,6 +1906,18 @@ def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
     for a_, c_ in zip([x.grad] + ([r.grad] if with_res else []), want):
         assert torch.equal(a_, c_)
     assert ops.affine_act_supported(x) and not ops.affine_act_supported(x.half())
+    # a NaN activation stays a NaN through the fused ReLU, as through torch.relu (fmaxf(NaN, 0) would have returned 0: ADVICE r4)
+    xn = x.detach().clone()
+    xn[0, 3, 5, 7] = float("nan")
+    xn[0, 4, 0, 0] = float("-inf")
+    out_n = ops.affine_act(xn, scale, shift, r.detach() if with_res else None, relu)
+    ref_n = xn * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    if with_res:
+        ref_n = ref_n + r.detach()
+    if relu:
+        ref_n = torch.relu(ref_n)
+    assert bool(torch.isnan(out_n[0, 3, 5, 7])) and torch.equal(torch.isnan(out_n), torch.isnan(ref_n))
+    assert torch.equal(torch.nan_to_num(out_n, nan=7.0), torch.nan_to_num(ref_n, nan=7.0))
 
 
 @pytest.mark.parametrize("m", ["2", "4"])
