@@ -128,45 +128,144 @@ class RefFRCNN(nn.Module):
                (torch.from_numpy(p["t_rpn_cls"]), torch.from_numpy(p["t_rpn_reg"]), t_cls, torch.from_numpy(p["t_reg"]))
 
 
-def ref_forward_fixed_vgg(ref, x, sample_rois, t_cls):
+class MaskPopper(nn.Module):
+    """A stand-in for nn.ReLU on the CPU side of the same-weights tests: multiplies by the next mask of a list recorded on ANOTHER run of the same
+    network (the device's), in call order, instead of deciding `x > 0` itself.  Every ReLU / max-pool / RoIPool-argmax is a DECISION: two fp32
+    evaluations that agree to 1e-6 still disagree about the sign of ~1e-5 of the pre-activations (those within rounding of zero), and one such
+    element moves a weight gradient -- a sum of random-sign terms -- by a whole dy * x: a fraction f of flipped decisions shows as ~sqrt(f) of the
+    gradient's scale (measured 1e-3 .. 7e-3 between ANY two fp32 evaluations, the reference's CPU path against float64 included).  With the
+    decisions handed over, what remains is linear arithmetic and can be compared at 1e-4.  `flips` counts how many decisions this run would have taken
+    differently, and how far from zero the largest such pre-activation was (relative to the tensor's scale)."""
+
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.k, self.flips, self.total, self.worst = masks, 0, 0, 0, 0.0
+
+    def forward(self, x):
+        m = self.masks[self.k]
+        self.k += 1
+        assert tuple(m.shape) == tuple(x.shape), "decision %d was recorded for %s, this run has %s" % (self.k - 1, tuple(m.shape), tuple(x.shape))
+        with torch.no_grad():
+            d = m != (x > 0)
+            n = int(d.sum())
+            self.flips += n
+            self.total += x.numel()
+            if n:
+                self.worst = max(self.worst, float(x[d].abs().max()) / max(float(x.abs().max()), 1e-30))
+        return x * m.to(x.dtype)
+
+
+def transplanted_roi_pool(features, argmax):
+    """RoIPool with the bins' argmax handed in (int [R,C,7,7] flat indices into a channel plane, -1 = empty bin): out[r,c,b] = feat[c, argmax[r,c,b]]."""
+    C_ = features.shape[1]
+    f = features[0].reshape(C_, -1)
+    idx = argmax.permute(1, 0, 2, 3).reshape(C_, -1)
+    vals = f.gather(1, idx.clamp(min=0).long()) * (idx >= 0).to(f.dtype)
+    R = argmax.shape[0]
+    return vals.reshape(C_, R, argmax.shape[2], argmax.shape[3]).permute(1, 0, 2, 3).contiguous()
+
+
+def vgg_extractor_with_decisions(ref, x, decisions):
+    """ref.extractor (nn.Sequential(*vgg16.features[:-1]), models/model.py:279-281) on the CPU with every ReLU sign and max-pool selection taken
+    from `decisions`, one entry per convolution in order: ("mask", bool [1,C,H,W]) for conv + ReLU, ("pool", sel [1,C,H,W]) for conv + ReLU +
+    MaxPool2d(2, 2) where sel marks the ONE pixel of each window that carries it (none: the window's maximum was not positive)."""
+    import torch.nn.functional as F
+    mods, h, i, k, flips = list(ref.extractor), x, 0, 0, []
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            y = m(h)
+            kind, dec = decisions[k]
+            k += 1
+            own = (y > 0)
+            if kind == "pool":
+                assert isinstance(mods[i + 1], nn.ReLU) and isinstance(mods[i + 2], nn.MaxPool2d)
+                Hp, Wp = y.shape[2] // 2, y.shape[3] // 2
+                with torch.no_grad():
+                    act = y.clamp_min(0)
+                    _, idx = F.max_pool2d(act, 2, 2, return_indices=True)
+                    own_sel = torch.zeros(act.shape[1], act.shape[2] * act.shape[3], dtype=torch.bool).scatter_(
+                        1, idx.view(act.shape[1], -1), (F.max_pool2d(act, 2, 2) > 0).view(act.shape[1], -1)).view_as(act)
+                    flips.append((int((own_sel != dec).sum()) // 2, y.numel()))
+                h = F.avg_pool2d(y * dec.to(y.dtype), 2) * 4                  # exactly the selected value of each window (one non-zero term, powers of two)
+                assert h.shape[2:] == (Hp, Wp)
+                i += 3
+            else:
+                assert isinstance(mods[i + 1], nn.ReLU)
+                flips.append((int((own != dec).sum()), y.numel()))
+                h = y * dec.to(y.dtype)
+                i += 2
+        else:
+            h = m(h)                                                       # a max-pool the device did not fuse: on its own values on either side
+            i += 1
+    assert k == len(decisions)
+    return h, flips
+
+
+def ref_forward_fixed_vgg(ref, x, sample_rois, t_cls, decisions=None):
     """The reference's CPU form of models/model_.py:304-341 with the SAMPLED RoIs and head classes handed in (from another run of the same step)
     instead of re-derived: extractor -> RPN head (:307,:315), RoIPool of the given RoIs -> classifier -> heads -> class-row gather (:335-341).
     What the same-weights tests compare the HIP-backed model's features / predictions / parameter gradients with: every value and gradient
     depends only on the network arithmetic, not on the sort / NMS / sampling decisions (which have their own bit-exact tests).
-    Returns (features, (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [128,C], head_reg [128,4]))."""
-    features = ref.extractor(x)
-    h = torch.relu(ref.rpn.inter_layer(features))
+    decisions (optional) = dict(extractor=[...] for vgg_extractor_with_decisions, rpn=bool mask of the RPN's ReLU, argmax=RoIPool argmax,
+    classifier=[two bool masks]): the ReLU / pooling decisions of that other run (see MaskPopper).
+    Returns (features, (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [128,C], head_reg [128,4]), flips | None)."""
+    flips = None
+    if decisions is None:
+        features = ref.extractor(x)
+        h = torch.relu(ref.rpn.inter_layer(features))
+    else:
+        features, fl = vgg_extractor_with_decisions(ref, x, decisions["extractor"])
+        pop = MaskPopper([decisions["rpn"]])
+        h = pop(ref.rpn.inter_layer(features))
+        flips = {"extractor": fl, "rpn": (pop.flips, pop.total)}
     pred_cls = ref.rpn.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2)
     pred_reg = ref.rpn.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4)
     fh, fw = features.shape[2:]
     scaled = sample_rois.to(torch.float32) * torch.tensor([fw, fh, fw, fh], dtype=torch.float32)      # model_.py:107-109, fp32 like the reference
-    pool = _RefRoIPool.apply(features, scaled)
-    z = ref.classifier(pool.view(pool.size(0), -1))
+    if decisions is None:
+        pool = _RefRoIPool.apply(features, scaled)
+        z = ref.classifier(pool.view(pool.size(0), -1))
+    else:
+        pool = transplanted_roi_pool(features, decisions["argmax"])
+        pop = MaskPopper(decisions["classifier"])
+        z = pool.view(pool.size(0), -1)
+        for m in ref.classifier:
+            z = pop(z) if isinstance(m, nn.ReLU) else m(z)
+        flips["classifier"] = (pop.flips, pop.total)
     head_cls = ref.fast_rcnn_head.cls_head(z)
     R = sample_rois.shape[0]
     head_reg = ref.fast_rcnn_head.reg_head(z).reshape(R, -1, 4)[torch.arange(R), t_cls.clamp(min=0)]
-    return features, (pred_cls, pred_reg, head_cls, head_reg)
+    return features, (pred_cls, pred_reg, head_cls, head_reg), flips
 
 
-def ref_forward_fixed_fpn(ref, x, sample_rois, t_cls):
-    """models/new_model.py:391-412 on the CPU with the sampled RoIs / head classes handed in (see ref_forward_fixed_vgg).
-    Returns ([five feature maps], (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [512,C], head_reg [512,4]))."""
+def ref_forward_fixed_fpn(ref, x, sample_rois, t_cls, decisions=None):
+    """models/new_model.py:391-412 on the CPU with the sampled RoIs / head classes handed in (see ref_forward_fixed_vgg).  decisions (optional) =
+    dict(backbone=[bool masks of the body's ReLUs in call order], rpn=[one mask per level], classifier=[two masks]): the caller has already put
+    a MaskPopper over the first list in place of the body's nn.ReLU modules; the other two are applied here.
+    Returns ([five feature maps], (rpn_cls [1,N,2], rpn_reg [1,N,4], head_cls [512,C], head_reg [512,4]), flips | None)."""
     features = ref.backbone(x)
     feats = list(features.values())
     cls, reg = [], []
+    pop_r = MaskPopper(decisions["rpn"]) if decisions else None
     for f in feats:
-        h = torch.relu(ref.rpn_head.inter_layer(f))
+        raw = ref.rpn_head.inter_layer(f)
+        h = pop_r(raw) if decisions else torch.relu(raw)
         cls.append(ref.rpn_head.cls_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 2))
         reg.append(ref.rpn_head.reg_layer(h).permute(0, 2, 3, 1).contiguous().view(1, -1, 4))
     pred_cls, pred_reg = torch.cat(cls, dim=1), torch.cat(reg, dim=1)
     H, W = x.shape[2:]
     scaled = sample_rois.to(torch.float32) * torch.tensor([W, H, W, H], dtype=torch.float32)          # new_model.py:136-140
     pool = _RefMsRoIAlign.apply(scaled, *feats[:4])
-    z = ref.classifier(pool.view(pool.size(0), -1))
+    z = pool.view(pool.size(0), -1)
+    pop_c = MaskPopper(decisions["classifier"]) if decisions else None
+    for m in ref.classifier:
+        z = pop_c(z) if (decisions and isinstance(m, nn.ReLU)) else m(z)
     head_cls = ref.cls_head(z)
     R = sample_rois.shape[0]
     head_reg = ref.reg_head(z).reshape(R, -1, 4)[torch.arange(R), t_cls.clamp(min=0)]
-    return feats, (pred_cls, pred_reg, head_cls, head_reg)
+    flips = {"rpn": (pop_r.flips, pop_r.total), "classifier": (pop_c.flips, pop_c.total)} if decisions else None
+    return feats, (pred_cls, pred_reg, head_cls, head_reg), flips
 
 
 class _RefMsRoIAlign(torch.autograd.Function):

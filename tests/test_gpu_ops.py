@@ -1619,7 +1619,7 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     masks = [(y.cpu() > 0) for y in ys] if relu else [torch.ones_like(p, dtype=torch.bool) for p in pre]
     for m, p in zip(masks if relu else [], pre):
         flips = m != (p > 0)
-        assert int(flips.sum()) == 0 or float(p[flips].abs().max()) < 1e-5                          # sign disagreements only at rounding-level zeros
+        assert int(flips.sum()) == 0 or float(p[flips].abs().max()) < 1e-5 * max(1.0, float(p.abs().max()))    # sign disagreements only at rounding-level zeros (of the output's scale, like the value bound above)
     gs = [t.double() * m for t, m in zip(dys, masks)]
     dx_ref = [F.conv_transpose2d(t, wt.double(), None, padding=1) for t in gs]
     dx = ops.conv3x3_bwd_data(dyd, wd, bits)
