@@ -188,6 +188,20 @@ def fpn_model():
 
 @pytest.mark.parametrize("H,W,G,seed", [(384, 512, 3, 5), (800, 1344, 5, 6)], ids=["384x512", "config_F_800x1344"])
 def test_fpn_forward_matches_oracle_stage_by_stage(fpn_model, H, W, G, seed):
+    full = (H, W) == (800, 1344)
+    if full:            # the fixture doubles the box deltas; at config F's size that leaves ~300 proposals after NMS and the sampler needs 512 (new_model.py:183)
+        with torch.no_grad():
+            fpn_model.rpn.rpn_head.reg_layer.weight.mul_(0.5)
+    try:
+        _fpn_forward_vs_oracle(fpn_model, H, W, G, seed)
+    finally:
+        fpn_model.zero_grad(set_to_none=True)
+        if full:
+            with torch.no_grad():
+                fpn_model.rpn.rpn_head.reg_layer.weight.mul_(2.0)
+
+
+def _fpn_forward_vs_oracle(fpn_model, H, W, G, seed):
     x, boxes, labels = synth(seed, H, W, G)
     labels = labels + 1                                    # raw COCO-style ids, 0 = background
     cap = {}
@@ -195,19 +209,12 @@ def test_fpn_forward_matches_oracle_stage_by_stage(fpn_model, H, W, G, seed):
     h2 = fpn_model.frcnn_head.roi_pool.register_forward_hook(lambda m, i, o: cap.__setitem__("pool", o.detach()))
     fpn_model.train()
     fpn_model.zero_grad(set_to_none=True)
-    full = (H, W) == (800, 1344)
-    if full:            # the fixture doubles the box deltas; at config F's size that leaves ~300 proposals after NMS and the sampler needs 512 (new_model.py:183)
-        with torch.no_grad():
-            fpn_model.rpn.rpn_head.reg_layer.weight.mul_(0.5)
     torch.manual_seed(200 + seed)
     try:
         pred, target = fpn_model(x.to(DEV), boxes.to(DEV), labels.to(DEV))
     finally:
         h1.remove()
         h2.remove()
-        if full:
-            with torch.no_grad():
-                fpn_model.rpn.rpn_head.reg_layer.weight.mul_(2.0)
     feats = [f[0].cpu().numpy() for f in cap["feats"]]
     shapes5 = [f.shape[1:] for f in feats]
     assert len(feats) == 5 and shapes5[0] == (H // 4, W // 4) and shapes5[4] == ((H // 32 + 1) // 2, (W // 32 + 1) // 2)
