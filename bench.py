@@ -285,7 +285,8 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     if args.channels_last:
         bb = "extractor" if config == "vgg" else "backbone"
         setattr(model, bb, getattr(model, bb).to(memory_format=torch.channels_last))
-    net = parallel.wrap_ddp(model, device)
+    # (--graph at N > 1: parallel.GraphStep owns the gradient exchange; DDP's reducer hooks are not captured, so the model stays bare)
+    net = model if (graph and world > 1) else parallel.wrap_ddp(model, device)
     crit = FRCNNLoss(None)
     opt = torch.optim.SGD([p for p in net.parameters() if p.requires_grad], lr=args.lr, momentum=0.9, weight_decay=1e-4,   # main.py:55-60
                           fused=not args.no_fused_sgd)   # same update rule, one multi-tensor kernel
@@ -330,13 +331,39 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     conv_calls, ops.CONV_TRACE = ops.CONV_TRACE, None
     torch.cuda.synchronize()
     step = eager_step
-    graphs = None
-    if graph:
+    graphs = gstep = None
+    if graph and world > 1:
+        # N > 1: the step as HIP graphs with the gradient all-reduce issued between the replays (parallel.GraphStep): graph A = forward + loss +
+        # the FC head's backward, its all-reduce under graph B = the trunk's backward, second all-reduce, the optimizer's graph.  `net` is the
+        # bare model here (GraphStep broadcasts rank 0's weights and owns the gradient buffers; DDP's hooks are not captured).
+        log("capturing the data-parallel step graphs (%d frames)" % len(frames))
+        keep_loss = torch.zeros((len(frames),), dtype=torch.float32, device=device)
+        keep_cnt = torch.zeros((len(frames),), dtype=torch.int32, device=device)
+
+        def forward_loss(fi):
+            x, b, l = frames[fi]
+            if amp == "bf16":
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    pred, target = model(x, [b], [l])
+                pred = tuple(p.float() for p in pred)
+            else:
+                pred, target = model(x, [b], [l])
+            return crit(pred, target), pred
+
+        def record(fi, losses):
+            keep_loss[fi:fi + 1].copy_(losses[0].detach().reshape(1))
+            keep_cnt[fi:fi + 1].copy_(model.last_proposal_count)
+        gstep = parallel.GraphStep(model, opt, forward_loss, len(frames), device, record=record, **model.graph_stages()).capture()
+        graphs = [(None, keep_loss[fi], keep_cnt[fi:fi + 1]) for fi in range(len(frames))]
+
+        def graph_step(i):
+            gstep.step(i)
+            return graphs[i % len(graphs)][1]
+        step = graph_step
+    elif graph:
         # One HIP graph per resident frame (the number of ground-truth boxes, a launch argument, differs per frame), all in one
         # memory pool: forward + loss + backward + SGD captured once, replayed as a single submission.  Nothing on the path syncs
         # the host; the sampling RNG stream lives in device memory (ops.philox_state), so every replay draws fresh samples.
-        if world > 1:
-            raise SystemExit("--graph is a single-process mode (DDP's bucket hooks are not captured)")
         log("capturing %d step graphs" % len(frames))
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -410,7 +437,7 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     n_props = [int(c.item()) for c in counts if c is not None]       # device counts, read after the timed region
     backend = torch.distributed.get_backend() if world > 1 else None
     world_seen = torch.distributed.get_world_size() if world > 1 else 1
-    ddp = parallel.ddp_report(net)
+    ddp = gstep.report() if gstep is not None else parallel.ddp_report(net)
 
     if rank != 0:
         return None
@@ -551,7 +578,8 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if amp == "none" else "bf16(torch layers, RPN head MFMA)+f32(box path)", "data": "synthetic",
         "config": {"workload": cfg["workload"], "global_batch": world, "parallelism": "dp%d" % world, "sampling": "device-philox",
-                   "submission": "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)"},
+                   "submission": ("HIP graphs per resident frame (forward + head backward | all-reduce | trunk backward | all-reduce | optimizer), replayed" if (graph and world > 1)
+                                  else "one HIP graph per resident frame, replayed" if graph else "eager (one launch per kernel)")},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "conv_calls": conv_calls,           # every call of the fp32 conv stage in one step (ops.CONV_TRACE): what wino_work() prices
@@ -613,7 +641,8 @@ def compact_record(full, also=()):
     if full["n_gpus"] > 1:
         dd = full["distributed"]
         out["distributed"] = {"backend": dd["backend"], "per_rank_ms_per_step": dd["per_rank_ms_per_step"],
-                              "ddp": _pick(dd.get("ddp"), ("num_parameter_tensors", "total_parameter_size_bytes", "bucket_cap_bytes"))}
+                              "ddp": _pick(dd.get("ddp"), ("num_parameter_tensors", "total_parameter_size_bytes", "bucket_cap_bytes",
+                                                                   "parameter_tensors", "head_gradient_bytes", "trunk_gradient_bytes", "graphs"))}
     if also:
         out["also"] = []
         for rec in also:

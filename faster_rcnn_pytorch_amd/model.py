@@ -16,7 +16,12 @@ What changed underneath (each step cites the reference lines it replaces):
     7-9 host syncs, CPU randperm).  sampling='host' reproduces the reference's RNG stream exactly
     (torch.randperm on the CPU generator, RPN maker first: SURVEY Q4) at the price of the same syncs.
   * RoIPool: HIP forward/backward (torchvision.ops.RoIPool, model.py:97,113)
-The backbone, the RPN convolutions and the FC head stay on PyTorch-ROCm (MIOpen / hipBLASLt).
+  * RPN head: the 3x3 convolution on the fp32 matrix cores (Winograd stage, csrc/rpn_conv_f32.hip), bias + ReLU + both 1x1 heads + the
+    NHWC layout in one more MFMA kernel (csrc/rpn_head.hip) (model.py:68-83: three MIOpen calls + two transposing copies)
+  * extractor: its thirteen stride-1 3x3 convolutions run on the same fp32 stage, each with the ReLU (and, where the 4 x 4 tile is used,
+    the 2 x 2 max-pool) behind it in the same call (VGGExtractor below; csrc/conv_c3.hip for the three-channel first layer).  Layers the
+    stage does not take (autocast, batch > 1) run as the torch modules they are.
+The FC head (classifier / cls_head / reg_head), the optimizer and the loss's reductions over torch tensors stay on PyTorch-ROCm (hipBLASLt).
 """
 import numpy as np
 import torch
@@ -271,6 +276,11 @@ class FRCNN(nn.Module):
         logging / checkpoint interval.  The same failures turn the step's loss into NaN, so a caller that prints loss.item()
         sees them even without this call."""
         self.sampler.status.check()
+
+    def graph_stages(self):
+        """Where parallel.GraphStep cuts the backward: everything behind the RoI pooling (the FC head: 120 M of the 137 M parameters) has its
+        gradient first, and its all-reduce runs under the backward of the rest."""
+        return {"cut_module": self.fast_rcnn_head.roi_pool, "late_modules": (self.classifier, self.fast_rcnn_head.cls_head, self.fast_rcnn_head.reg_head)}
 
     def forward(self, x, bbox, label):
         hw = x.size()[2:]

@@ -395,6 +395,10 @@ class FRCNN(nn.Module):
         samples -- the reference asserts there, new_model.py:182) was recorded since the last call; one host sync."""
         self.sampler.status.check()
 
+    def graph_stages(self):
+        """Where parallel.GraphStep cuts the backward (see models.model.FRCNN.graph_stages): behind the multi-scale RoIAlign."""
+        return {"cut_module": self.frcnn_head.roi_pool, "late_modules": (self.classifier, self.frcnn_head.cls_head, self.frcnn_head.reg_head)}
+
     def forward(self, x, boxes, labels):
         features = self.backbone(x)                                                # new_model.py:394
         pred_rpn_cls, pred_rpn_reg, rois, n_rois, anchors = self.rpn.propose(x, features, "train")

@@ -235,3 +235,87 @@ def test_backbone_wrappers_are_the_reference_modules_off_the_fp32_device_path():
     ref = torch.relu(blk.bn2(blk.conv2(ref)))
     ref = torch.relu(blk.bn3(blk.conv3(ref)) + blk.downsample(xb))
     assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------------------------ parallel.GraphStep (N > 1, graph-submitted step)
+class _TinyDet(torch.nn.Module):
+    """A stand-in with the detection models' shape: a trunk, an `rpn` branch off the trunk, a pooling module (the cut) and a head behind it."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16))
+        self.rpn = torch.nn.Linear(16, 6)
+        self.pool = torch.nn.Tanh()
+        self.head = torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.ReLU(), torch.nn.Linear(32, 4))
+
+    def forward(self, x):
+        f = self.trunk(x)
+        r = self.rpn(f)
+        return (r[:, :2], r[:, 2:], self.head(self.pool(f)))
+
+
+def _graphstep_worker(r, world, port, q):
+    os.environ.update(RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from faster_rcnn_pytorch_amd import parallel
+    _, _, w, dev = parallel.init_for_distributed(backend="gloo")
+    xs = torch.arange(6 * 8, dtype=torch.float32).reshape(6, 8).sin()
+    frames = [xs[i:i + 1] for i in parallel.shard_indices(6, r, w)]         # rank r: frames r, r + W, ...
+
+    def losses_of(pred):
+        a, b, c = pred
+        return (a.pow(2).mean() + b.abs().mean() + c.pow(2).mean(),)
+
+    def run(kind):
+        torch.manual_seed(0 if kind != "graphstep" else 100 + r)            # GraphStep must broadcast rank 0's weights itself
+        model = _TinyDet()
+        opt_of = lambda m: torch.optim.SGD([p for p in m.parameters() if p.requires_grad], lr=0.05, momentum=0.9, weight_decay=1e-4)   # noqa: E731
+        if kind == "ddp":
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net, opt = DDP(model, find_unused_parameters=False), opt_of(model)
+            for i in range(3):
+                loss = losses_of(net(frames[i % len(frames)]))[0]
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+        else:
+            opt = opt_of(model)
+            if kind == "graphstep":
+                torch.manual_seed(0)
+                ref = _TinyDet()                                            # rank 0 starts from the seed-0 values DDP's run started from;
+                if r == 0:                                                  # rank 1 from other values, which the broadcast must replace
+                    model.load_state_dict(ref.state_dict())
+
+            def forward_loss(f):
+                pred = model(frames[f])
+                return losses_of(pred), pred
+            gs = parallel.GraphStep(model, opt, forward_loss, len(frames), dev, cut_module=model.pool, late_modules=(model.head,), graphs=False)
+            assert gs.comm_bytes[0] == 4 * sum(p.numel() for p in model.head.parameters())
+            for i in range(3):
+                gs.step(i)
+        return [p.detach().clone().numpy() for p in model.parameters()]
+    a, b = run("ddp"), run("graphstep")
+    q.put((r, a, b))
+    parallel.shutdown()
+
+
+def test_graph_step_pieces_equal_ddp_bit_for_bit_over_gloo_world2():
+    """The N > 1 form of the graph-submitted step (parallel.GraphStep) with its pieces run eagerly on the CPU: broadcast of rank 0's weights,
+    backward cut at the pooling module and at the RPN outputs, head / trunk gradients in two flat buffers, pre-scaled sum over the ranks,
+    optimizer on the flat views -- three steps, every parameter equal to DistributedDataParallel's BIT FOR BIT on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 13) % 2000
+    procs = [ctx.Process(target=_graphstep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r, a, b in res:
+        assert len(a) == len(b) == 10
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    for x, y in zip(res[0][2], res[1][2]):
+        assert np.array_equal(x, y)                                         # replicas identical
