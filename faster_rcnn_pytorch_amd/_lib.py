@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
 OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV, OP_RPN_CONV_WGRAD, OP_RPN_CONV_F32 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
@@ -67,7 +67,7 @@ SIGNATURES = {
     "frcnn_roi_pool_fwd": (_i, [_vp, _i, _i, _i, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "frcnn_roi_pool_bwd": (_i, [_vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _vp]),
     "frcnn_roi_pool_fwd_a16": (_i, [_vp, _i, _i, _i, _vp, _i64, _f, _vp, _vp, _vp]),
-    "frcnn_roi_pool_bwd_a16": (_i, [_vp, _vp, _i64, _i, _i, _i, _vp, _vp]),
+    "frcnn_roi_pool_bwd_a16": (_i, [_vp, _vp, _vp, _f, _i64, _i, _i, _i, _vp, _vp]),
     "frcnn_roi_level_map": (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp]),
     "frcnn_ms_roi_align_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i64, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "frcnn_roi_scale_order": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),

@@ -1237,19 +1237,20 @@ class _RoIPoolFn(torch.autograd.Function):
             else:
                 check(lib.frcnn_roi_pool_fwd(_ptr(feat), Cc, H, W, _ptr(rois), R, PH, PW, float(scale), _ptr(out), _ptr(arg), _stream()),
                       "roi_pool_fwd")
-        ctx.save_for_backward(arg)
-        ctx.shape = (Cc, H, W, PH, PW, R)
+        ctx.save_for_backward(arg, rois)
+        ctx.shape = (Cc, H, W, PH, PW, R, float(scale))
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        (arg,) = ctx.saved_tensors
-        Cc, H, W, PH, PW, R = ctx.shape
+        arg, rois = ctx.saved_tensors
+        Cc, H, W, PH, PW, R, scale = ctx.shape
         grad_out = _req(grad_out, name="grad_out")
         gf = torch.empty((1, Cc, H, W), dtype=torch.float32, device=grad_out.device)
         with torch.cuda.device(grad_out.device):
             if arg.dtype == torch.uint16:
-                check(lib.frcnn_roi_pool_bwd_a16(_ptr(grad_out), _ptr(arg), R, Cc, H, W, _ptr(gf), _stream()), "roi_pool_bwd_a16")
+                # (the boxes let the backward add without LDS atomics wherever a RoI spans at least 7 x 7 cells)
+                check(lib.frcnn_roi_pool_bwd_a16(_ptr(grad_out), _ptr(arg), _ptr(rois), scale, R, Cc, H, W, _ptr(gf), _stream()), "roi_pool_bwd_a16")
             else:
                 check(lib.frcnn_roi_pool_bwd(_ptr(grad_out), _ptr(arg), R, Cc, H, W, PH, PW, _ptr(gf), _stream()), "roi_pool_bwd")
         return gf, None, None, None, None      # no gradient through box coordinates

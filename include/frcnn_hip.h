@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 5
+#define FRCNN_ABI_VERSION 6
 
 typedef enum {
     FRCNN_OK = 0,
@@ -341,8 +341,10 @@ int frcnn_roi_pool_bwd(const float *grad_out, const int32_t *argmax, int64_t R, 
  * the argmax).  Same `out` / `grad_feat` as the int32 entry points; 2 bytes less per pooled element to write and to read back. */
 int frcnn_roi_pool_fwd_a16(const float *feat, int C, int H, int W, const float *rois, int64_t R, float spatial_scale,
                            float *out /*[R,C,7,7]*/, uint16_t *argmax16 /*[R,C,7,7]*/, void *stream);
-int frcnn_roi_pool_bwd_a16(const float *grad_out, const uint16_t *argmax16, int64_t R, int C, int H, int W,
-                           float *grad_feat, void *stream);
+/* `rois` / `spatial_scale`: the boxes the forward pooled (may be NULL).  With them the backward adds without LDS atomics for every RoI of at
+ * least 7 x 7 feature cells; without them, and for smaller RoIs, with ds_add_f32.  Either way the result is bit-reproducible run to run. */
+int frcnn_roi_pool_bwd_a16(const float *grad_out, const uint16_t *argmax16, const float *rois /*[R,4] or NULL*/, float spatial_scale,
+                           int64_t R, int C, int H, int W, float *grad_feat, void *stream);
 
 /* torchvision.ops.MultiScaleRoIAlign(names, PH, sampling_ratio) (models/new_model.py:127,143): level mapper
  * k = floor(k0 + log2(sqrt(area)/s0) + 1e-6) clamped to [k_min, k_min+n_levels-1]; per level roi_align

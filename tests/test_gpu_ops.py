@@ -827,6 +827,53 @@ def test_roi_pool_fwd_bwd_vs_oracle(ops, C, H, W, R):
     assert np.allclose(ft.grad[0].cpu().numpy(), gf_o, rtol=1e-5, atol=1e-5)      # fp32 sum order differs: 1e-5
 
 
+def test_roi_pool_backward_duplicate_maxima_and_bit_reproducible(ops):
+    """The round-5 backward (csrc/roi_pool.hip: wave-private planes, plain read-modify-write adds ranked among a bin's four lower
+    neighbours; ds_add_f32 only for RoIs under 7 x 7 cells) at the training shape, on inputs that maximise what it must get right:
+    a PIECEWISE-CONSTANT feature map (every bin of a flat patch takes the first pixel of its window, so neighbouring bins -- whose windows
+    overlap by a row / column -- share their maximum all over the place, in 2 x 2 groups too), RoIs of every size (tiny ones: many bins on
+    one pixel; sides of exactly 7 and 8 cells: bin sides 1 and 8/7), empty bins.  Gradient vs the oracle (1e-5: another fp32 order),
+    bit-identical over repeated launches, and equal to the int32-ABI backward (which is given no boxes and adds with ds_add_f32)."""
+    rng = np.random.RandomState(5)
+    C, H, W, R = 512, 37, 62, 128
+    f = np.repeat(np.repeat(rng.randn(C, 10, 16).astype(np.float32), 4, axis=1), 4, axis=2)[:, :H, :W].copy()      # 4 x 4 flat patches
+    f[::3] += (rng.randn(C // 3 + 1, H, W) * 0.01).astype(np.float32)[:len(f[::3])]                               # a third of the channels: near-ties instead
+    wh = rng.rand(R, 2) * np.array([0.9, 0.9]) + 0.02
+    c = rng.rand(R, 2)
+    rois = (np.concatenate([c - wh / 2, c + wh / 2], 1).clip(0, 1) * np.array([W, H, W, H])).astype(np.float32)
+    rois[0] = [3, 2, 9, 8]            # 7 x 7 cells: bin sides exactly 1
+    rois[1] = [3, 2, 10, 9]           # 8 x 8 cells: bin sides 8/7
+    rois[2] = [5, 5, 6, 6]            # 2 x 2 cells: most bins share a pixel
+    rois[3] = [20, 10, 26, 30]        # 7 wide, 21 tall
+    rois[4] = [W + 2, H + 2, W + 5, H + 5]   # outside: empty bins
+    rois[5] = [0, 0, W, H]
+    out_o, arg_o = orc.roi_pool_fwd(f, rois, 7, 7, 1.0)
+    go = rng.randn(*out_o.shape).astype(np.float32)
+    ref = orc.roi_pool_bwd(go, arg_o, C, H, W)
+    grads = []
+    for _ in range(4):
+        ft = T(f[None]).requires_grad_(True)
+        out = ops.roi_pool(ft, T(rois), (7, 7), 1.0)
+        assert np.array_equal(out.detach().cpu().numpy(), out_o)
+        out.backward(T(go))
+        grads.append(ft.grad[0].cpu().numpy())
+    # how much of the input is the hard case: elements that share their pixel with another bin of the same (RoI, channel)
+    a = arg_o.reshape(R, C, 49)
+    dup = sum(int((np.sort(a[r], axis=1)[:, 1:] == np.sort(a[r], axis=1)[:, :-1])[np.sort(a[r], axis=1)[:, 1:] >= 0].sum()) for r in range(R))
+    assert dup > 0.1 * a.size
+    assert np.allclose(grads[0], ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+    for g in grads[1:]:
+        assert np.array_equal(g, grads[0])                                          # one summation order: bit-reproducible
+    # the torchvision-shaped pair on the same inputs (int32 argmax, no boxes in backward)
+    from faster_rcnn_pytorch_amd import _lib
+    out32, arg32 = ops.roi_pool_with_argmax(T(f[None]), T(rois), (7, 7), 1.0)
+    gf = torch.empty((1, C, H, W), dtype=torch.float32, device=DEV)
+    got = T(go)
+    _lib.check(_lib.lib.frcnn_roi_pool_bwd(got.data_ptr(), arg32.data_ptr(), R, C, H, W, 7, 7, gf.data_ptr(), torch.cuda.current_stream().cuda_stream), "roi_pool_bwd")
+    torch.cuda.synchronize()
+    assert np.allclose(gf[0].cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * np.abs(ref).max())
+
+
 def test_roi_pool_backward_large_bin_grid(ops):
     """17 x 17 bins: one channel-pair run (2 * 289 elements) is longer than the LDS backward kernel's 512-thread pass; the generic int32
     entry point must route such shapes to the one-channel kernel instead of writing an all-zero gradient."""
