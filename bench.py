@@ -713,7 +713,9 @@ def main():
     rank, local_rank, world, device = parallel.init_for_distributed()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
-    torch.backends.cudnn.benchmark = False
+    # MIOpen: False = immediate mode (the perf database's pick, a GEMM fallback where it has none), True = time every applicable solver per shape
+    # in the initialisation pass.  FRCNN_BENCH_MIOPEN_FIND=1 switches the search on (an experiment switch; the record's `conditions` say which ran)
+    torch.backends.cudnn.benchmark = os.environ.get("FRCNN_BENCH_MIOPEN_FIND", "0") == "1"
 
     def release():                                    # the finished configuration's model / optimizer / graphs, before the next one is built
         gc.unfreeze()
