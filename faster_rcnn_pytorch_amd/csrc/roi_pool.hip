@@ -383,6 +383,13 @@ __global__ __launch_bounds__(64 * NW) void roi_pool_bwd_priv_kernel(const float 
             g[u] = *(const float2 *)(grad_out + idx);
 #endif
         }
+        RP_T(1, 1);
+        if (!zeroed) {                                                       // under the loads in flight
+            float4 *z = (float4 *)mine;
+            for (int i = lane; i < stride / 4; i += 64) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            zeroed = true;
+        }
+        RP_T(1, 2);
         unsigned bigbits = 0;                                                // RoI u of this batch spans at least PH x PW cells (wave-uniform)
         if (rois != nullptr) {
 #pragma unroll
@@ -393,13 +400,6 @@ __global__ __launch_bounds__(64 * NW) void roi_pool_bwd_priv_kernel(const float 
                 bigbits |= (unsigned)(rw >= PW && rh >= PH) << u;
             }
         }
-        RP_T(1, 1);
-        if (!zeroed) {                                                       // under the loads in flight
-            float4 *z = (float4 *)mine;
-            for (int i = lane; i < stride / 4; i += 64) z[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            zeroed = true;
-        }
-        RP_T(1, 2);
 #if !(RP_ABL & 1)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
