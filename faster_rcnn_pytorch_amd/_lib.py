@@ -46,6 +46,8 @@ SIGNATURES = {
     "frcnn_gemm_nt_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "frcnn_affine_act_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "frcnn_affine_act_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_affine_act_fwd_mixed": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "frcnn_affine_act_bwd_mixed": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp]),
     "frcnn_conv3x3_c3_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "frcnn_conv3x3_c3_wgrad_workspace": (_sz, [_i, _i]),
     "frcnn_conv3x3_c3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -101,7 +101,31 @@ class Bottleneck(nn.Module):
             return ops.conv1x1(x, conv.weight)
         return conv(x)
 
+    def _forward_mixed(self, x):
+        """bf16 autocast (BASELINE configs[4]): the three frozen norms with their ReLUs / the residual sum as ONE pass each (ops.affine_act_mixed, csrc/affine.hip):
+        the inner norms read and write bf16, the norm in front of the residual sum reads the convolution's bf16 output and the fp32 stream and writes the fp32
+        stream AND its bf16 twin, which the next block's convolutions read (`_frcnn_bf16` on the tensor) instead of casting the stream again.  Same values as the
+        torch form under autocast (fp32 arithmetic, one rounding per tensor); ~20 elementwise / dtype-copy launches per block and direction less."""
+        xb = getattr(x, "_frcnn_bf16", None)
+        if xb is None:
+            xb = x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+        s1, b1 = self.bn1.affine()
+        s2, b2 = self.bn2.affine()
+        s3, b3 = self.bn3.affine()
+        out = ops.affine_act_mixed(self.conv1(xb), s1, b1, relu=True, out_bf16=True)
+        out = ops.affine_act_mixed(self.conv2(out), s2, b2, relu=True, out_bf16=True)
+        if self.downsample is not None:
+            sd, bd = self.downsample[1].affine()
+            idt = ops.affine_act_mixed(self.downsample[0](xb), sd, bd)
+        else:
+            idt = x if x.dtype == torch.float32 else x.float()
+        y, yb = ops.affine_act_mixed(self.conv3(out), s3, b3, res=idt, relu=True, twin=True)
+        y._frcnn_bf16 = yb
+        return y
+
     def forward(self, x):
+        if ops.affine_act_mixed_supported(x):
+            return self._forward_mixed(x)
         idt = x
         out = self._norm(self.bn1, self._c1(self.conv1, x), relu=True)
         if self.conv2.stride == (1, 1) and not torch.is_autocast_enabled() and ops.conv3x3_supported(out, self.conv2.weight):
@@ -147,7 +171,10 @@ class ResNet50Body(nn.Module):
 
     def forward(self, x):
         x = self.conv1(x)
-        if ops.affine_act_supported(x):
+        if ops.affine_act_mixed_supported(x):
+            scale, shift = self.bn1.affine()
+            x = self.maxpool(ops.affine_act_mixed(x, scale, shift, relu=True))     # bf16 autocast: the stem's norm + ReLU in one pass, fp32 out
+        elif ops.affine_act_supported(x):
             scale, shift = self.bn1.affine()
             x = self.maxpool(ops.affine_act(x, scale, shift, None, True))
         else:
@@ -180,6 +207,8 @@ class FeaturePyramidNetwork(nn.Module):
             return self.layer_blocks[idx](t)
         def inner(idx, t):
             conv = self.inner_blocks[idx][0]
+            if torch.is_autocast_enabled() and getattr(t, "_frcnn_bf16", None) is not None:
+                return self.inner_blocks[idx](t._frcnn_bf16)         # the stream's bf16 twin, written by the last bottleneck's fused norm (no cast pass)
             if ops.conv1x1_supported(t, conv.weight):
                 return ops.conv1x1(t, conv.weight, conv.bias)            # the lateral 1 x 1: weight gradient on the library's GEMM
             return self.inner_blocks[idx](t)

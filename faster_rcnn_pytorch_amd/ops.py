@@ -969,6 +969,66 @@ def affine_act_supported(x):
     return x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[0] == 1 and not torch.is_autocast_enabled()
 
 
+class _AffineActMixedFn(torch.autograd.Function):
+    """args: (relu, out_bf16, want_twin, scale [C], shift [C], x [1,C,h,w] bf16 | fp32, res fp32 | None) -> y (bf16 when out_bf16, else fp32) or (y, twin):
+    the mixed-precision form of _AffineActFn (csrc/affine.hip, frcnn_affine_act_*_mixed): fp32 arithmetic, bf16 on either side, and optionally the fp32
+    output's bf16 twin written in the same pass; backward adds the twin's gradient to the output's before the mask."""
+
+    @staticmethod
+    def forward(ctx, relu, out_bf16, want_twin, scale, shift, x, res):
+        if x.dtype not in (torch.bfloat16, torch.float32) or not x.is_cuda:
+            raise ValueError("affine_act_mixed: x must be a bf16 or fp32 HIP tensor")
+        x = x.contiguous()
+        Cc, HW = int(x.shape[1]), int(x.shape[2] * x.shape[3])
+        if res is not None:
+            res = _req(res, name="res")
+            if res.shape != x.shape:
+                raise ValueError("affine_act_mixed: residual and input differ in shape")
+        ctx.set_materialize_grads(False)                      # an output nobody used sends None, not a tensor of zeros to read
+        y = torch.empty_like(x, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        twin = torch.empty_like(x, dtype=torch.bfloat16) if want_twin else None
+        with torch.cuda.device(x.device):
+            check(lib.frcnn_affine_act_fwd_mixed(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _ptr(res), _ptr(y), 1 if out_bf16 else 0, _ptr(twin),
+                                                 _ptr(scale), _ptr(shift), Cc, HW, 1 if relu else 0, _stream()), "affine_act_fwd_mixed")
+        ctx.relu, ctx.has_res, ctx.x_bf16, ctx.twin = bool(relu), res is not None, x.dtype == torch.bfloat16, bool(want_twin)
+        ctx.save_for_backward(scale, y if relu else None)
+        if want_twin:
+            return y, twin
+        return y
+
+    @staticmethod
+    def backward(ctx, g, g2=None):
+        scale, y = ctx.saved_tensors
+        need_x, need_r = ctx.needs_input_grad[5], ctx.has_res and ctx.needs_input_grad[6]
+        if not need_x and not need_r:
+            return None, None, None, None, None, None, None
+        if g is None and g2 is None:
+            return None, None, None, None, None, None, None
+        if g is None:                                         # only the twin was used downstream
+            g = torch.zeros_like(g2, dtype=torch.float32)
+        g = g.contiguous()
+        if g2 is not None:
+            g2 = g2.contiguous()
+        Cc, HW = int(g.shape[1]), int(g.shape[2] * g.shape[3])
+        dx = torch.empty_like(g, dtype=torch.bfloat16 if ctx.x_bf16 else torch.float32)
+        dres = torch.empty_like(g, dtype=torch.float32) if (need_r and (ctx.relu or g2 is not None or g.dtype != torch.float32)) else None
+        with torch.cuda.device(g.device):
+            check(lib.frcnn_affine_act_bwd_mixed(_ptr(g), 1 if g.dtype == torch.bfloat16 else 0, _ptr(g2), _ptr(y), _ptr(scale), _ptr(dx),
+                                                 1 if ctx.x_bf16 else 0, _ptr(dres), Cc, HW, 1 if ctx.relu else 0, _stream()), "affine_act_bwd_mixed")
+        return None, None, None, None, None, (dx if need_x else None), ((dres if dres is not None else g) if need_r else None)
+
+
+def affine_act_mixed(x, scale, shift, res=None, relu=False, out_bf16=False, twin=False):
+    """FrozenBatchNorm2d(x) [+ res] [-> ReLU] with bf16 on either side (bf16 autocast): x bf16 | fp32 [1,C,h,w], res fp32; out_bf16: y in bf16 (an inner
+    norm); twin: also return y's bf16 copy, written in the same pass -> (y, y_bf16)."""
+    return _AffineActMixedFn.apply(bool(relu), bool(out_bf16), bool(twin), scale.reshape(-1), shift.reshape(-1), x, res)
+
+
+def affine_act_mixed_supported(x):
+    return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and x.dim() == 4 and x.shape[0] == 1 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 # ---- the backbone's first convolution: three input channels, a byte mover on the vector units (csrc/conv_c3.hip)
 def conv3x3_c3_fwd(x, w, bias=None, relu=False, want_bits=False):
     """act(bias + conv3x3(x, w)), padding 1: x fp32 [1,3,h,w], w [Cout,3,3,3] -> [1,Cout,h,w] (frcnn_conv3x3_c3_fwd); want_bits: also the signs of

@@ -286,6 +286,15 @@ int frcnn_conv3x3_c3_wgrad(const float *x, const float *dy, int H, int W, int Co
  * x, y, res, g, dx, dres: [C, HW] fp32 (NCHW, batch 1); scale, shift: [C] (the frozen statistics folded as torchvision does). */
 int frcnn_affine_act_fwd(const float *x, const float *res, float *y, const float *scale, const float *shift, int C, int HW, int relu, void *stream);
 int frcnn_affine_act_bwd(const float *g, const float *y, const float *scale, float *dx, float *dres, int C, int HW, int relu, void *stream);
+/* The same passes with bf16 on either side of the fp32 arithmetic (BASELINE configs[4]: bf16 autocast of the backbone; the reference has no mixed-precision
+ * mode, torch.autocast over models/new_model.py:372 is what this replaces).  dtype codes: 0 = fp32, 1 = bf16.
+ *   _fwd_mixed : x (x_dtype) -> y (y_dtype) = act((x * scale + shift) [+ res fp32]), one rounding on the way out; twin_bf16 (or NULL) receives the same values
+ *                rounded to bf16 in the same pass (the next convolutions' input).  Forms: bf16 -> bf16 (no res, no twin); bf16 | fp32 -> fp32 (any).
+ *   _bwd_mixed : g, y in y's dtype; g2_bf16 = the gradient that arrived at the twin (or NULL), added to g first; dx in x's dtype; dres fp32 or NULL. */
+int frcnn_affine_act_fwd_mixed(const void *x, int x_dtype, const float *res, void *y, int y_dtype, void *twin_bf16, const float *scale, const float *shift,
+                               int C, int HW, int relu, void *stream);
+int frcnn_affine_act_bwd_mixed(const void *g, int g_dtype, const void *g2_bf16, const void *y, const float *scale, void *dx, int dx_dtype, float *dres,
+                               int C, int HW, int relu, void *stream);
 
 /* ---- target makers ------------------------------------------------------------------------------ */
 /* RPNTargetMaker.forward: variant 0 = VGG (models/model_.py:186-266), 1 = FPN (models/new_model.py:299-349).

@@ -1967,6 +1967,52 @@ def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
     assert torch.equal(torch.nan_to_num(out_n, nan=7.0), torch.nan_to_num(ref_n, nan=7.0))
 
 
+@pytest.mark.parametrize("form", ["inner", "stream", "stream_res_twin", "f32_res_twin"])
+def test_affine_act_mixed_is_the_autocast_torch_form(ops, form):
+    """frcnn_affine_act_fwd_mixed / _bwd_mixed (BASELINE configs[4], bf16 autocast; csrc/affine.hip): the frozen norm (+ residual) (+ ReLU) with bf16 on either
+    side of the fp32 arithmetic.  Against the torch expressions the model ran under autocast before: an INNER norm = relu(addcmul(shift_bf16, x_bf16, scale_bf16))
+    up to the rounding of scale / shift to bf16 it no longer does (compared with the fp32-parameter form rounded once: equal bit for bit); the STREAM form =
+    relu(x_bf16 * scale + shift [+ res]) in fp32: bit for bit, and its bf16 twin = that value's .bfloat16(); gradients: dx = (mask * (g + g_twin)) * scale rounded
+    to x's dtype, dres = mask * (g + g_twin): bit for bit with autograd on the torch form."""
+    g = torch.Generator().manual_seed(11)
+    C_, H, W = 64, 29, 45
+    xb = (form != "f32_res_twin")
+    x = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    x = (x.bfloat16() if xb else x).requires_grad_(True)
+    with_res, twin, inner = form.endswith("res_twin"), form.endswith("twin"), form == "inner"
+    r = torch.randn(1, C_, H, W, generator=g).to(DEV).requires_grad_(True) if with_res else None
+    scale = (torch.rand(C_, generator=g) + 0.5).to(DEV)
+    shift = torch.randn(C_, generator=g).to(DEV)
+    ref32 = x.float() * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+    if with_res:
+        ref32 = ref32 + r
+    ref32 = torch.relu(ref32)
+    ref = ref32.bfloat16() if inner else ref32
+    ref_twin = ref32.bfloat16() if twin else None
+    dy = torch.randn(1, C_, H, W, generator=g).to(DEV)
+    dy = dy.bfloat16() if inner else dy
+    dt = torch.randn(1, C_, H, W, generator=g).to(DEV).bfloat16() if twin else None
+    torch.autograd.backward([ref] + ([ref_twin] if twin else []), [dy] + ([dt] if twin else []))
+    want = [x.grad.clone()] + ([r.grad.clone()] if with_res else [])
+    x.grad = None
+    if with_res:
+        r.grad = None
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ops.affine_act_mixed_supported(x)
+        out = ops.affine_act_mixed(x, scale, shift, r, relu=True, out_bf16=inner, twin=twin)
+    y, yt = out if twin else (out, None)
+    assert y.dtype == (torch.bfloat16 if inner else torch.float32) and torch.equal(y, ref)
+    if twin:
+        assert yt.dtype == torch.bfloat16 and torch.equal(yt, ref_twin)
+    torch.autograd.backward([y] + ([yt] if twin else []), [dy] + ([dt] if twin else []))
+    assert x.grad.dtype == x.dtype
+    # the torch form rounds the twin's gradient path separately (bf16 -> fp32 is exact; the SUM g + g_twin is formed in fp32 in both): bit for bit,
+    # except that autograd's own accumulation order (g_twin + g vs g + g_twin) is commutative anyway
+    for a_, c_ in zip([x.grad] + ([r.grad] if with_res else []), want):
+        assert torch.equal(a_, c_)
+    assert not ops.affine_act_mixed_supported(x.detach())                        # outside autocast the fp32 op (or torch) serves
+
+
 @pytest.mark.parametrize("m", ["2", "4"])
 def test_conv3x3_f32_forced_tile_size_in_a_child_process(m):
     """The stage picks its tile by cost (4 x 4 wherever 36 planes x its padded tile total is 15 % below 16 x the 2 x 2 total); FRCNN_WINO_M (read once per process) forces one.  A child process
