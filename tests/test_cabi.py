@@ -78,7 +78,7 @@ def test_layout_stamp_of_every_object_agrees(L):
 
 
 def test_a_stale_object_makes_the_library_refuse_to_load(tmp_path):
-    """The class of fault behind round 3's 14:49 abort: one object compiled against another version of a shared
+    """The class of fault behind round 3's 14:49 abort (docs/HISTORY.md): one object compiled against another version of a shared
     header.  Here topk.hip is compiled with a skewed stamp and linked with the other, current objects: frcnn_abi_version() must return
     FRCNN_ERR_UNSUPPORTED and name the object, and the Python binding must refuse the library (ImportError), before any kernel runs."""
     csrc = os.path.join(ROOT, "faster_rcnn_pytorch_amd", "csrc")
