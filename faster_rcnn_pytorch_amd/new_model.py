@@ -204,6 +204,8 @@ class FeaturePyramidNetwork(nn.Module):
             conv = self.layer_blocks[idx][0]
             if not torch.is_autocast_enabled() and ops.conv3x3_supported(t, conv.weight):
                 return ops.conv3x3(t, conv.weight, conv.bias)            # the 256 -> 256 output convolution on the fp32 Winograd stage
+            if ops.conv3x3_bf16_c256_supported(t, conv.weight):
+                return ops.conv3x3_bf16_c256(t, conv.weight, conv.bias)  # bf16 autocast, the two largest levels: the RPN head's bf16 MFMA kernels
             return self.layer_blocks[idx](t)
         def inner(idx, t):
             conv = self.inner_blocks[idx][0]
@@ -216,7 +218,13 @@ class FeaturePyramidNetwork(nn.Module):
         results = [layer(-1, last)]
         for idx in range(len(xs) - 2, -1, -1):
             lat = inner(idx, xs[idx])
-            last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            if lat.dtype == torch.bfloat16 and last.dtype == torch.bfloat16:
+                # bf16 autocast: interpolate is on autocast's fp32 list, which turned the whole top-down pathway (and, behind it, a cast pass in front of
+                # every output convolution) into fp32; nearest-neighbour upsampling copies values, so it runs outside autocast and the sum stays bf16
+                with torch.autocast("cuda", enabled=False):
+                    last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
+            else:
+                last = lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest")
             results.insert(0, layer(idx, last))
         names.append("pool")
         results.append(F.max_pool2d(results[-1], 1, 2, 0))           # LastLevelMaxPool

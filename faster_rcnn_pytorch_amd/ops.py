@@ -547,6 +547,49 @@ def rpn_conv_wgrad(feats, d_raws):
     return dw
 
 
+class _Conv3x3Bf16C256Fn(torch.autograd.Function):
+    """A plain 256 -> 256 3x3 convolution (stride 1, padding 1, no bias) on bf16 [1,256,h,w] maps with an fp32 [256,256,3,3] weight, from the RPN head's own
+    bf16 MFMA kernels (csrc/rpn_conv.hip): the forward IS frcnn_rpn_conv_bwd_data on the transposed, flipped weight (that kernel is the head's implicit-GEMM
+    main loop without the head: out[b] = sum_a,t W'[a][b][t] in[a](shifted by the flipped tap) -- with W'[a][b][ky][kx] = W[b][a][2-ky][2-kx] that is conv(x, W));
+    backward = frcnn_rpn_conv_bwd_data on W itself and frcnn_rpn_conv_wgrad.  fp32 accumulate, bf16 outputs, fp32 weight gradient.  Used for the FPN's output
+    convolutions on its two largest levels under bf16 autocast, where MIOpen took 0.2 ms forward and 0.6 ms backward for the stride-4 level alone."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _req(x, torch.bfloat16, "x")
+        weight = _req(weight, name="weight")
+        if x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 256 or tuple(weight.shape) != (256, 256, 3, 3):
+            raise ValueError("conv3x3_bf16_c256: x must be bf16 [1,256,h,w] and weight fp32 [256,256,3,3]")
+        w_fwd = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+        y = rpn_conv_bwd_data([x], w_fwd)[0]
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = rpn_conv_bwd_data([g], weight.detach())[0] if ctx.needs_input_grad[0] else None
+        dw = rpn_conv_wgrad([x], [g]) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def conv3x3_bf16_c256(x, weight, bias=None):
+    """nn.Conv2d(256, 256, 3, padding=1) on one bf16 [1,256,h,w] map through the library's bf16 MFMA kernels (see _Conv3x3Bf16C256Fn); bias added in bf16."""
+    y = _Conv3x3Bf16C256Fn.apply(x, weight)
+    if bias is not None:
+        y = y + bias.to(torch.bfloat16).reshape(1, -1, 1, 1)
+    return y
+
+
+def conv3x3_bf16_c256_supported(x, weight):
+    """bf16 autocast, one bf16 [1,256,h,w] HIP map of at least 100 x 168 positions (below that the kernel's 256-channel x 8 x 32-position tiles do not fill the
+    chip and the vendor convolution is as fast), an fp32 [256,256,3,3] weight."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 256 and tuple(weight.shape) == (256, 256, 3, 3)
+            and weight.dtype == torch.float32 and x.shape[2] * x.shape[3] >= 100 * 168 and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 # --------------------------------------------------------------------------------------------
 # the RPN head's 3x3 convolution in fp32 (models/model.py:68-70,79; models/new_model.py:96-98,109) on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------

@@ -1967,6 +1967,34 @@ def test_affine_act_is_the_torch_form_bit_for_bit(ops, with_res, relu):
     assert torch.equal(torch.nan_to_num(out_n, nan=7.0), torch.nan_to_num(ref_n, nan=7.0))
 
 
+def test_conv3x3_bf16_c256_vs_torch(ops):
+    """ops.conv3x3_bf16_c256 (BASELINE configs[4]: the FPN's 256 -> 256 output convolutions under bf16 autocast, from the RPN head's bf16 MFMA kernels --
+    the forward is the data-gradient kernel on the transposed, flipped weight): forward, input gradient and weight gradient against a float64 convolution
+    of the same bf16-rounded operands (fp32 accumulate, one bf16 rounding of the outputs: 1e-2 of the scale; the weight gradient stays fp32: 2e-3)."""
+    g = torch.Generator().manual_seed(3)
+    H, W = 100, 168
+    x = (torch.randn(1, 256, H, W, generator=g) * 0.5).to(DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(DEV).requires_grad_(True)
+    b = torch.randn(256, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(1, 256, H, W, generator=g).to(DEV).bfloat16()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert ops.conv3x3_bf16_c256_supported(x, w)
+        y = ops.conv3x3_bf16_c256(x, w, b)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = w.detach().bfloat16().double().requires_grad_(True)             # the kernels round the weight to bf16 when they pack it
+    b64 = b.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, b64.bfloat16().double() if False else b64, padding=1)
+    y64.backward(dy.double())
+    rel = lambda a, c: float((a.double() - c).abs().max() / c.abs().max())      # noqa: E731
+    assert rel(y, y64) < 1e-2, rel(y, y64)
+    assert rel(x.grad, x64.grad) < 1e-2, rel(x.grad, x64.grad)
+    assert w.grad.dtype == torch.float32 and rel(w.grad, w64.grad) < 2e-3, rel(w.grad, w64.grad)
+    assert rel(b.grad, b64.grad) < 1e-2
+    assert not ops.conv3x3_bf16_c256_supported(x.detach()[:, :, :50, :84], w)   # small maps stay with the vendor convolution
+
+
 @pytest.mark.parametrize("form", ["inner", "stream", "stream_res_twin", "f32_res_twin"])
 def test_affine_act_mixed_is_the_autocast_torch_form(ops, form):
     """frcnn_affine_act_fwd_mixed / _bwd_mixed (BASELINE configs[4], bf16 autocast; csrc/affine.hip): the frozen norm (+ residual) (+ ReLU) with bf16 on either
