@@ -989,19 +989,17 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(__builtin_amdgcn_readfirstlane(l)), "v"(g) : "memory");
     };
-    auto issue_dma = [&](const Tl &T, int chunk, int buf) {
+    // one wave transfer of a chunk's staging: piece q < (TA + TB) / 4 of this wave (the first TA / 4 belong to the A tile)
+    auto issue_piece = [&](const Tl &T, int chunk, int buf, int q) {
         if (NT) {
             const float *ub = T.u + (size_t)chunk * WN_KC, *vb = T.v + (size_t)chunk * WN_KC;
             const unsigned rl = (unsigned)(lane >> 3), sl = (unsigned)lane & 7u;     // transfer d = rows 8d .. 8d + 7, 128 bytes each
-#pragma unroll
-            for (int q = 0; q < TA / 4; ++q) {
+            if (q < TA / 4) {
                 const int d = wave * (TA / 4) + q;
                 const unsigned r = (unsigned)(8 * d) + rl, p = sl ^ ((r >> 1) & 7u);
                 dma16(ub + (size_t)r * lda + 4u * p, &sA[buf][d * 256]);
-            }
-#pragma unroll
-            for (int q = 0; q < TB / 4; ++q) {
-                const int d = wave * (TB / 4) + q;
+            } else {
+                const int d = wave * (TB / 4) + (q - TA / 4);
                 const unsigned r = (unsigned)(8 * d) + rl, p = sl ^ ((r >> 1) & 7u);
                 dma16(vb + (size_t)r * ldb + 4u * p, &sB[buf][d * 256]);
             }
@@ -1009,16 +1007,18 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         }
         const float *ub = T.u + (size_t)chunk * WN_KC * lda, *vb = T.v + (size_t)chunk * WN_KC * ldb;
         constexpr int RA = 256 / MT, RB = 256 / NW;                  // k rows per transfer: 2 (128-wide tile) or 4 (64-wide)
-#pragma unroll
-        for (int q = 0; q < TA / 4; ++q) {
+        if (q < TA / 4) {
             const int d = wave * (TA / 4) + q;
             dma16(ub + (size_t)(RA * d + lane / (MT / 4)) * lda + (unsigned)(lane % (MT / 4)) * 4u, &sA[buf][d * 256]);
-        }
-#pragma unroll
-        for (int q = 0; q < TB / 4; ++q) {
-            const int d = wave * (TB / 4) + q;
+        } else {
+            const int d = wave * (TB / 4) + (q - TA / 4);
             dma16(vb + (size_t)(RB * d + lane / (NW / 4)) * ldb + (unsigned)(lane % (NW / 4)) * 4u, &sB[buf][d * 256]);
         }
+    };
+    constexpr int NPIECE = (TA + TB) / 4;                            // 8 on 128 x 128 tiles, 6 / 4 with a 64-wide side
+    auto issue_dma = [&](const Tl &T, int chunk, int buf) {
+#pragma unroll
+        for (int q = 0; q < NPIECE; ++q) issue_piece(T, chunk, buf, q);
     };
     f32x16 acc[MI][NI];
     auto zero_acc = [&]() {
@@ -1137,8 +1137,16 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
         Tl Tn = T;
         const bool more = u + 1 < u1;
         if (more && ntile != tile) Tn = tile_of(ntile);
+        // The next chunk's transfers (every wave is past the barrier that ended the last reads of that buffer).  K-major form: issued BETWEEN this chunk's k
+        // steps, one piece behind each of the first NPIECE steps' MFMAs, instead of in front of the loop with the matrix pipe idle behind the barrier: worth 1-2 %
+        // (128 -> 128 on 300 x 500: 129.4 -> 127.9 us; 512 -> 512 on 37 x 62: 42.4 -> 40.3) -- the other workgroup of the CU already filled most of that gap.
+        // The k-contiguous form keeps them in front (between its steps: 76.8 -> 81.7 us at 64 -> 128 on 300 x 500).
+        constexpr bool between = !NT;
 #if !(defined(WN_ABL) && (WN_ABL & 2))                             // developer ablation 2: nothing staged behind the first chunk
-        if (more) issue_dma(Tn, nchunk, buf ^ 1);                   // every wave is past the barrier that ended the last reads of that buffer
+        if (more && !between) issue_dma(Tn, nchunk, buf ^ 1);
+#define WN_PIECE(step) do { if (between && more && (step) < NPIECE) issue_piece(Tn, nchunk, buf ^ 1, (step)); } while (0)
+#else
+#define WN_PIECE(step) do { } while (0)
 #endif
         if (NT) {
             // lane (i = li, half lh) takes k = 16 lh + s at step s: sixteen consecutive floats of its row = four ds_read_b128 per operand row
@@ -1167,6 +1175,8 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot][mi][e], fb[slot][ni][e], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    WN_PIECE(4 * j + e);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1201,8 +1211,10 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(oa[slot][mi], ob[slot][ni], acc[mi][ni], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                WN_PIECE(s);
             }
         }
+#undef WN_PIECE
         if (!more || ntile != tile) {
             if (!more) WN_STAMP_AT(2);
             finish_segment(T, seg_first, chunk + 1 - seg_first);

@@ -14,8 +14,9 @@ crit = FRCNNLoss(None)
 opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=2e-3, momentum=0.9, weight_decay=1e-4, fused=True)
 x, b, l = bench.synth_frame(cfg, 0, 0)
 x, b, l = x.to(dev), b.to(dev), l.to(dev)
+AMP = os.environ.get("AMP", "bf16") == "bf16"
 def step():
-    with torch.autocast("cuda", dtype=torch.bfloat16):
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=AMP):
         pred, target = model(x, [b], [l])
     pred = tuple(p.float() for p in pred)
     loss = crit(pred, target)[0]
