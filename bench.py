@@ -79,7 +79,7 @@ CONFIGS = {
 
 # What bounds each hand-written kernel; keys are the kernels' own names.  Anything not listed: "latency".
 BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
-         "roi_pool_fwd_lds_kernel": "hbm", "roi_pool_bwd_lds_kernel": "hbm", "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm",
+         "roi_pool_fwd_lds_kernel": "hbm", "roi_pool_bwd_lds_kernel": "hbm", "roi_pool_bwd_priv_kernel": "hbm", "roi_pool_fwd_kernel": "hbm", "roi_pool_bwd_kernel": "hbm",
          "roi_align_fwd77_kernel": "hbm", "roi_align_fwd_nhwc_kernel": "hbm", "roi_align_bwd_tile_kernel": "hbm", "roi_align_bwd_nhwc_kernel": "hbm",
          "roi_align_bwd_combine_kernel": "hbm", "rpn_conv3x3_head_kernel": "mfma", "rpn_conv3x3_bwd_data_kernel": "mfma",
          "rpn_conv3x3_wgrad_kernel": "mfma", "rpn_conv_pack_kernel": "hbm",
@@ -87,7 +87,7 @@ BOUND = {"nms_kernel": "valu", "nms_filter_kernel": "valu",
          "rpn_conv_f32_pack_kernel": "hbm", "rpn_wino_gemm_kernel": "mfma", "rpn_wino_input_kernel": "hbm", "rpn_wino_output_kernel": "hbm",
          "rpn_wino_weight_kernel": "hbm", "rpn_wino_dw_kernel": "hbm", "rpn_wino_gemm_out64_kernel": "hbm",
          "conv3x3_c3_fwd_kernel": "hbm", "conv3x3_c3_wgrad_kernel": "hbm",
-         "affine_act_fwd_kernel": "hbm", "affine_act_bwd_kernel": "hbm"}
+         "affine_act_fwd_kernel": "hbm", "affine_act_bwd_kernel": "hbm", "affine_act_fwd_mixed_kernel": "hbm", "affine_act_bwd_mixed_kernel": "hbm"}
 F32_MFMA_KERNELS = ("rpn_conv3x3_f32_kernel", "rpn_conv3x3_f32_bwd_data_kernel", "rpn_conv3x3_f32_wgrad_kernel", "rpn_wino_gemm_kernel")
 WINO_STAGE = ("rpn_wino_weight_kernel", "rpn_wino_input_kernel", "rpn_wino_gemm_kernel", "rpn_wino_output_kernel",
               "rpn_wino_dw_kernel", "rpn_wino_gemm_out64_kernel")      # forward / data gradient: weight, input, gemm, output (64 -> 64 channels: the
@@ -122,6 +122,7 @@ def algorithmic_bytes(kernel, N, K, P, R, C, G, feat_bytes, A, P_head, img_px=0,
         "head_targets_kernel": 16 * (P + G) + 44 * R,
         "roi_pool_fwd_lds_kernel": feat_bytes + 16 * R + 6 * pooled,      # features + rois in, out (fp32) + argmax (16-bit, the autograd pair) out
         "roi_pool_bwd_lds_kernel": 6 * pooled + feat_bytes,               # grad_out + 16-bit argmax in, grad_feat out
+        "roi_pool_bwd_priv_kernel": 6 * pooled + feat_bytes,              # (the same bytes: the round-5 kernel on wave-private planes)
         "roi_align_fwd77_kernel": 4 * pooled + feat_bytes,                # out + (at most) the four pooled levels in
         "roi_align_fwd_nhwc_kernel": 4 * pooled + feat_bytes,
         "roi_align_bwd_tile_kernel": 4 * pooled + feat_bytes,             # grad_out in + every gradient pixel written once
