@@ -12,8 +12,10 @@
 //   backward: tile-owner GATHER: bilinear scatter is separable, dF = Wy^T (fh x 7) . dOut (7x7) . Wx (7 x fw), so a workgroup that
 //             owns a 16 x 8 pixel tile of one level walks the RoIs whose footprint meets the tile IN INDEX ORDER and accumulates
 //             the tile in registers; every gradient pixel is written exactly once: no atomics, no memset, bit-reproducible.
-//             The per-tile RoI lists are built once (roi_align_bwd_lists_kernel); long lists are cut into segments whose partial
-//             tiles are added in segment order (roi_align_bwd_combine_kernel).
+//             TWO launches: roi_align_bwd_lists_kernel builds the per-tile RoI lists and the (RoI, tile) weight records, and its workgroup
+//             that finishes last turns the list lengths into work items (long lists cut into segments, longest first);
+//             roi_align_bwd_tile_kernel works the items, and of a cut list's segments the workgroup that finishes last adds the
+//             partial tiles in segment order (until round 5 the planning and the adding were launches of their own).
 // Any other bin/sampling shape takes the generic one-lane-per-output kernels below (memset + fp32 atomics in backward;
 // order-nondeterministic, tolerance 1e-4).
 #include "frcnn_common.h"
@@ -306,13 +308,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 }
 
 // ---- backward as a tile-owner gather: no atomics, no memset -------------------------------------------------------
-// Four launches:
+// Two launches (four until round 5: the plan and the combine had launches of their own):
 //  roi_align_bwd_lists_kernel   one workgroup per 16 x 8 pixel tile of any level: scans the RoIs (level + footprint recomputed
 //      from the box, ~150 instructions per RoI), keeps the ones whose footprint meets the tile IN INDEX ORDER (ballot
 //      compaction) as a list in the workspace.  (Round 1 had every (tile, channel group) workgroup of the main kernel repeat
 //      this scan: 8x the work, and four barriers before the first useful load.)  One more workgroup per RoI builds the weight-table
 //      RECORDS of its (RoI, tile) pairs (RA_MAXT below).
-//  roi_align_bwd_plan_kernel    one workgroup: lists -> work items, longest first.  A list longer than RS_SPLIT entries is cut into segments.
+//      The lists workgroup that finishes LAST (a ticket; list lengths written through) then plans (ra_plan_block): lists -> work items, longest first.
+//      A list longer than RS_SPLIT entries is cut into segments.
 //  roi_align_bwd_tile_kernel    item workgroup = (tile, segment, 32 channels), one RoI per step.  dOut[r][32 ch][7][7] and the pair's record
 //      arrive by LDS-DMA one RoI ahead; then
 //        B1: lane (column, channel pair, half of the bin rows): T[bin row] = sum over the bins that reach the column of dOut * Wx -> LDS,
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RA_FWD_WAVE
 //      where 2 x 7 + 3 x 8 packed ones do now -- same sums bit for bit, because the skipped terms are exact zeros.
 //      An unsplit tile is written exactly once, straight to the gradient plane; a segment writes its partial tile to the workspace.
 //      Fill workgroups in the same launch zero the pixels of tiles whose list is empty (whole rows: 256-byte stores).
-//  roi_align_bwd_combine_kernel adds the partial tiles of a split tile in SEGMENT ORDER and writes the plane.
+//      The segment that takes the last ticket of a split tile adds its partial tiles in SEGMENT ORDER and writes the plane (the combine step).
 // The fp32 sum order is a function of the RoI list alone: bit-reproducible gradients, no atomics, nothing cleared beforehand.
 // Why segments: a workgroup advances one RoI per ~1.2 us (a chain of LDS round trips and two barriers -- not issue- or bandwidth-
 // bound: halving the instructions per step or fetching two RoIs ahead did not shorten it, more resident workgroups did), so the
@@ -438,13 +441,19 @@ template <> __device__ __forceinline__ void store_grad<float>(float *p, float v)
 
 __device__ __forceinline__ int ra_nseg(int n, int split) { return n <= split ? 1 : min(RS_NSEG, (n + split - 1) / split); }
 
+__device__ void ra_plan_block(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase, int32_t *__restrict__ tnseg,
+                              int4 *__restrict__ items, int32_t *__restrict__ slot);
+
 // cnt[tile] = list length; ent[tile * cap + i] = the i-th RoI (index order) whose footprint meets the tile.  Blocks >= tiles (when pool
 // is not NULL): block tiles + r builds the records of RoI r, one footprint tile per wave and round -- see RA_MAXT above.
 __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, TileLevels TL, const float4 *__restrict__ rois, int R, int aligned,
                                                                   int k_min, float s0, int k0, int cap, int tiles, int32_t *__restrict__ cnt,
-                                                                  RoiEnt *__restrict__ ent, float *__restrict__ pool)
+                                                                  RoiEnt *__restrict__ ent, float *__restrict__ pool, int n_cg, int32_t *__restrict__ tix,
+                                                                  int *__restrict__ ticket, int cap_items, int32_t *__restrict__ tbase,
+                                                                  int32_t *__restrict__ tnseg, int4 *__restrict__ items, int32_t *__restrict__ slot)
 {
     __shared__ int s_woff[5];
+    __shared__ int s_last;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if ((int)blockIdx.x >= tiles) {                        // block tiles + r: the records of RoI r, wave w those of footprint tiles w, w + 4, ...
         const int r = (int)blockIdx.x - tiles;
@@ -496,10 +505,20 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
         if (hit) mine[base + s_woff[wave] + __builtin_popcountll(bm & ((1ull << lane) - 1ull))] = e;
         base += s_woff[4];
     }
-    if (t == 0) cnt[tile] = base;
+    if (t < n_cg) tix[tile * n_cg + t] = 0;                // the tile kernel's last-segment tickets of this tile (consumed by the NEXT launch)
+    if (t == 0) {
+        __hip_atomic_store(&cnt[tile], base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // written through: the planning workgroup reads it in THIS launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         // ... and acknowledged before the ticket announces it
+        s_last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the last lists workgroup: every list length is in memory; leave the ticket zero for the next launch and plan
+    if (t == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ra_plan_block(tiles, cap_items, cnt, tbase, tnseg, items, slot);
 }
 
-// One workgroup: turns the list lengths into work items.  A non-empty tile q gets nseg(q) consecutive item NUMBERS from tbase[q] (an
+// The plan (ra_plan_block below): turns the list lengths into work items.  A non-empty tile q gets nseg(q) consecutive item NUMBERS from tbase[q] (an
 // exclusive prefix sum in tile order, so the cut of a list into segments -- and with it the summation order -- is a function of the
 // lists alone); an empty tile gets none (its pixels are zero-filled by the fill workgroups of the main launch).  If the items do not
 // fit the table the split threshold is doubled until they do (cap >= tiles).  The item RECORDS (tile, first entry, end entry,
@@ -509,59 +528,83 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lists_kernel(MsLevels L, Ti
 // fresh RPN whose long lists sit on the fine level, at the END of the tile order).  slot[item number] = record position, which
 // is also where a segment's partial tile goes (the combine kernel looks it up); unused records carry tile = -1.
 __device__ __forceinline__ int ra_items(int n, int split) { return n == 0 ? 0 : ra_nseg(n, split); }
-__global__ __launch_bounds__(1024) void roi_align_bwd_plan_kernel(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase,
-                                                                  int32_t *__restrict__ tnseg, int4 *__restrict__ items, int32_t *__restrict__ slot)
+__device__ __forceinline__ int ra_cnt(const int32_t *cnt, int q) { return __hip_atomic_load(&cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // written by other workgroups of this launch
+// (Round 5: no launch of its own any more -- the lists workgroup that finishes LAST runs it, 256 threads, reading the list lengths the others wrote
+// through with agent-scope loads.)
+__device__ void ra_plan_block(int tiles, int cap_items, const int32_t *__restrict__ cnt, int32_t *__restrict__ tbase, int32_t *__restrict__ tnseg,
+                              int4 *__restrict__ items, int32_t *__restrict__ slot)
 {
-    // block-wide exclusive scan of the per-thread item counts: wave scans by shuffles, 16 wave totals through LDS (two barriers;
-    // the first version used a 256-thread Hillis-Steele scan with 16 barriers and took 8-10 us)
-    __shared__ int s_wsum[16];
+    // block-wide exclusive scan of the per-thread item counts: wave scans by shuffles, the wave totals through LDS (two barriers)
+    __shared__ int s_wsum[4];
     __shared__ int s_total;
     __shared__ int s_hist[64];                             // bucket b = 63 - min(length, 63)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (tiles + 1023) / 1024, q0 = t * per, q1 = min(q0 + per, tiles);
+    const int per = (tiles + 255) / 256, q0 = t * per, q1 = min(q0 + per, tiles);
     int split = RS_SPLIT;
     int mine = 0, incl = 0;
+    // my tiles' list lengths, fetched ONCE and together (each is a trip to the L2 -- the lengths were written through by other workgroups of this launch --
+    // and the three passes below used to make it again per tile, one after the other: 13 us for the planning tail where the launch of its own took 6)
+    constexpr int PC = 4;
+    int cn[PC];
+#pragma unroll
+    for (int k = 0; k < PC; ++k) cn[k] = q0 + k < q1 ? ra_cnt(cnt, q0 + k) : 0;
+    auto each_tile = [&](auto &&f) {
+#pragma unroll
+        for (int k = 0; k < PC; ++k)
+            if (q0 + k < q1) f(q0 + k, cn[k]);
+        for (int q = q0 + PC; q < q1; ++q) f(q, ra_cnt(cnt, q));
+    };
+    // segment sgm of ns over a list of n: entries [n sgm / ns, n (sgm + 1) / ns)  (n <= R < 2^27 -- the launcher checks -- and sgm + 1 <= ns <= RS_NSEG = 32: the products fit 32 bits)
+    auto cut = [](int n, int sgm, int ns) { return (int)((unsigned)n * (unsigned)sgm / (unsigned)ns); };
     if (t < 64) s_hist[t] = 0;
     for (;;) {
         mine = 0;
-        for (int q = q0; q < q1; ++q) mine += ra_items(cnt[q], split);
+        each_tile([&](int, int n) { mine += ra_items(n, split); });
         incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
         __syncthreads();                                   // the previous round's readers of s_wsum / s_total are done
         if (lane == 63) s_wsum[wave] = incl;
         __syncthreads();
-        if (t == 0) { int a = 0; for (int w = 0; w < 16; ++w) { const int v = s_wsum[w]; s_wsum[w] = a; a += v; } s_total = a; }
+        if (t == 0) { int a = 0; for (int w = 0; w < 4; ++w) { const int v = s_wsum[w]; s_wsum[w] = a; a += v; } s_total = a; }
         __syncthreads();
         if (s_total <= cap_items) break;
         split *= 2;                                        // (terminates: at split >= max(cnt) every tile has at most one item and tiles <= cap)
     }
     const int base0 = s_wsum[wave] + incl - mine;          // exclusive prefix of my chunk
     const int total = s_total;
-    for (int q = q0; q < q1; ++q) {
-        const int n = cnt[q], ns = ra_items(n, split);
-        for (int sgm = 0; sgm < ns; ++sgm) {
-            const int len = (int)((long long)n * (sgm + 1) / ns) - (int)((long long)n * sgm / ns);
-            atomicAdd(&s_hist[63 - min(len, 63)], 1);
-        }
+    each_tile([&](int, int n) {
+        const int ns = ra_items(n, split);
+        for (int sgm = 0; sgm < ns; ++sgm) atomicAdd(&s_hist[63 - min(cut(n, sgm + 1, ns) - cut(n, sgm, ns), 63)], 1);
+    });
+    __syncthreads();
+    if (wave == 0) {                                       // exclusive scan of the 64 buckets by one wave
+        const int v = s_hist[lane];
+        int in = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(in, o); if (lane >= o) in += u; }
+        s_hist[lane] = in - v;
     }
     __syncthreads();
-    if (t == 0) { int a = 0; for (int b = 0; b < 64; ++b) { const int v = s_hist[b]; s_hist[b] = a; a += v; } }
-    __syncthreads();
     int base = base0;
-    for (int q = q0; q < q1; ++q) {
-        const int n = cnt[q], ns = ra_items(n, split);
+    each_tile([&](int q, int n) {
+        const int ns = ra_items(n, split);
         tbase[q] = base; tnseg[q] = ns;
         for (int sgm = 0; sgm < ns; ++sgm) {
-            const int lo = (int)((long long)n * sgm / ns), hi = (int)((long long)n * (sgm + 1) / ns);
+            const int lo = cut(n, sgm, ns), hi = cut(n, sgm + 1, ns);
             const int k = atomicAdd(&s_hist[63 - min(hi - lo, 63)], 1);
             items[k] = make_int4(q, lo, hi, sgm | (ns << 8));
             slot[base + sgm] = k;
         }
         base += ns;
-    }
-    for (int i = total + t; i < cap_items; i += 1024) items[i] = make_int4(-1, 0, 0, 0);
+    });
+    for (int i = total + t; i < cap_items; i += 256) items[i] = make_int4(-1, 0, 0, 0);
 }
+
+// The ticket by which the last lists workgroup is found: a word of the LIBRARY (zero when the code object is loaded, left zero by every launch), picked by
+// the workspace's address -- the workspace itself stays plain scratch whose contents on entry do not matter (frcnn_hip.h).  Two calls that run
+// CONCURRENTLY on workspaces 64 slots apart would share a word; the path's contract is one call at a time per device (the training thread's stream).
+__device__ int g_ra_plan_ticket[64];
 
 #define RF_CH 4                          // channels per fill workgroup
 struct FillLevels { int fill0[FRCNN_MAX_LEVELS + 1]; };   // first fill workgroup of level l: (row blocks of l) x (C / RF_CH) each
@@ -594,7 +637,8 @@ template <typename TOUT, bool DMA>
 __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevels L, TileLevels TL, FillLevels FL, int C, int aligned,
                                                                          const float *__restrict__ grad_out, int n_cg, int cap, int n_item_blocks, int n_first, int n_fill,
                                                                          const int32_t *__restrict__ cnt, const RoiEnt *__restrict__ ent,
-                                                                         const int4 *__restrict__ items, const float *__restrict__ pool, float *__restrict__ part)
+                                                                         const int4 *__restrict__ items, const float *__restrict__ pool, float *__restrict__ part,
+                                                                         const int32_t *__restrict__ tbase, const int32_t *__restrict__ slot, int32_t *__restrict__ tix)
 {
     __shared__ __attribute__((aligned(16))) float s_g[RT_RING][RT_CB * RT_GS];   // ring of three: dOut of the current RoI and of the next two (in flight)
     __shared__ __attribute__((aligned(16))) float s_T[(RT_CB / 2) * RT_TS];   // column-reduced dOut of the current RoI: [channel pair][bin row][column][2]
@@ -783,17 +827,50 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
             buf = buf == RT_RING - 1 ? 0 : buf + 1;
         }
     }
-    if (nseg > 1) {                                        // my partial tile: [channel][row][column], 16 KB
-        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + ((2 * cq) * RT_TH + rg * 4) * RT_TW + px;
+    if (nseg > 1) {
+        // A segment of a split tile (round 5: no combine launch).  My partial tile goes to the workspace LANE-LINEARLY -- 16 floats per lane as four
+        // 16-byte write-through stores, [q][lane][4] -- and is acknowledged before the workgroup takes the tile's ticket; the workgroup that takes the LAST
+        // ticket of (tile, channel group) then adds the nseg partial tiles IN SEGMENT ORDER, its own included (read back like the others: the sum must not
+        // depend on who came last), and writes the plane.  Same values in the same order as the combine kernel added them: bit-identical gradients.
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
+        __shared__ int s_last_seg;
+        float *dst = part + ((size_t)item * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + t * 4;
+        {   // all four stores and the wait in ONE statement, from four DISTINCT register tuples: the compiler does not see that inline asm is a store of
+            // more than 64 bits, so it neither keeps the data registers alone for the wait state such a store needs nor knows they are read late -- rebuilt
+            // in the same registers for the next piece, the last lanes of every 16 of a piece left with the next piece's values
+            const f32x4s v0 = {acc[0].x, acc[0].y, acc[1].x, acc[1].y}, v1 = {acc[2].x, acc[2].y, acc[3].x, acc[3].y};
+            const f32x4s v2 = {acc[4].x, acc[4].y, acc[5].x, acc[5].y}, v3 = {acc[6].x, acc[6].y, acc[7].x, acc[7].y};
+            asm volatile("global_store_dwordx4 %0, %4, off sc1\n\t"
+                         "global_store_dwordx4 %1, %5, off sc1\n\t"
+                         "global_store_dwordx4 %2, %6, off sc1\n\t"
+                         "global_store_dwordx4 %3, %7, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         :: "v"(dst), "v"(dst + 1024), "v"(dst + 2048), "v"(dst + 3072), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory");
+        }
+        __syncthreads();
+        if (t == 0) s_last_seg = (__hip_atomic_fetch_add(&tix[tile * n_cg + cg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nseg - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_last_seg) { RT_T(2); return; }
+        const int32_t *sl = slot + tbase[tile];                // record position of segment s = where its partial tile lies
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const float *src = part + ((size_t)sl[sgm] * n_cg + cg) * (RT_CB * RT_TH * RT_TW) + t * 4;
+            f32x4s v[4];
+            // the four loads AND their wait in one statement: data returned to a register from inline asm lands behind the compiler's back, and a copy it
+            // places between a load and a separate wait statement reads whatever has arrived by then (seen here: lanes 12-15 of every 16 stale)
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                         "global_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\t"
+                         "global_load_dwordx4 %3, %7, off sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                         : "v"(src), "v"(src + 1024), "v"(src + 2048), "v"(src + 3072)
+                         : "memory");
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                dst[((16 * p) * RT_TH + r) * RT_TW] = acc[2 * r + p].x;
-                dst[((16 * p + 1) * RT_TH + r) * RT_TW] = acc[2 * r + p].y;
+            for (int q = 0; q < 4; ++q) {
+                if (sgm == 0) { acc[2 * q] = f32x2{v[q][0], v[q][1]}; acc[2 * q + 1] = f32x2{v[q][2], v[q][3]}; }
+                else { acc[2 * q] += f32x2{v[q][0], v[q][1]}; acc[2 * q + 1] += f32x2{v[q][2], v[q][3]}; }
             }
-        RT_T(2);
-        return;
+        }
     }
     // ---- the tile is complete: a wave stores eight 32-byte row pieces per instruction
     if (tx0 + px < W) {
@@ -807,47 +884,6 @@ __global__ __launch_bounds__(256) RT_ATTR void roi_align_bwd_tile_kernel(MsLevel
             }
     }
     RT_T(2);
-}
-
-// split tiles only: partial tiles added in segment order, plane written once
-template <typename TOUT>
-__global__ __launch_bounds__(256) void roi_align_bwd_combine_kernel(MsLevels L, TileLevels TL, int C, int n_cg, const int32_t *__restrict__ tbase,
-                                                                    const int32_t *__restrict__ tnseg, const int32_t *__restrict__ slot,
-                                                                    const float *__restrict__ part)
-{
-    const int t = threadIdx.x;
-    const int cg = blockIdx.x % n_cg, tile = blockIdx.x / n_cg;
-    const int nseg = tnseg[tile];
-    if (nseg <= 1) return;
-    int l = 0;
-#pragma unroll
-    for (int q = 1; q < FRCNN_MAX_LEVELS; ++q) l += (q < L.n_levels && tile >= TL.tile0[q]) ? 1 : 0;
-    const int tl = tile - TL.tile0[l];
-    const int ty0 = (tl / TL.tiles_x[l]) * RT_TH, tx0 = (tl % TL.tiles_x[l]) * RT_TW;
-    const int H = L.H[l], W = L.W[l];
-    const int cx = t % RT_TW, cc = t / RT_TW;
-    const int c0 = cg * RT_CB;
-    const int nc = min(RT_CB, C - c0);
-    const int32_t *sl = slot + tbase[tile];                          // record position of segment s = where its partial tile lies
-    const size_t mine = (size_t)cg * (RT_CB * RT_TH * RT_TW) + (cc * RT_TH) * RT_TW + cx;
-    const size_t stride = (size_t)n_cg * (RT_CB * RT_TH * RT_TW);   // from one record's partial tiles to the next
-    float acc[RT_TH];
-    {
-        const float *p = part + (size_t)sl[0] * stride + mine;
-#pragma unroll
-        for (int y = 0; y < RT_TH; ++y) acc[y] = p[y * RT_TW];
-    }
-    for (int sgm = 1; sgm < nseg; ++sgm) {
-        const float *p = part + (size_t)sl[sgm] * stride + mine;
-#pragma unroll
-        for (int y = 0; y < RT_TH; ++y) acc[y] += p[y * RT_TW];
-    }
-    if (tx0 + cx < W && cc < nc) {
-        TOUT *out = (TOUT *)L.grad[l] + ((size_t)(c0 + cc) * H + ty0) * W + tx0 + cx;
-#pragma unroll
-        for (int y = 0; y < RT_TH; ++y)
-            if (ty0 + y < H) store_grad<TOUT>(out + (size_t)y * W, acc[y]);
-    }
 }
 
 FRCNN_EXPORT int frcnn_roi_level_map(const float *rois, int64_t R, int k_min, int k_max, float s0, int k0, float eps, int32_t *out_level,
@@ -971,7 +1007,7 @@ FRCNN_EXPORT int frcnn_ms_roi_align_fwd(const float *const *feats, const int *H,
 }
 
 // workspace of the 7 x 7 tile gather: list lengths, lists (capacity R per tile), the plan, partial tiles of split tiles
-struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *slot; int4 *items; RoiEnt *ent; float *pool, *part; int cap_items; size_t total; };
+struct RaBwdWs { int32_t *cnt, *tbase, *tnseg, *slot, *tix; int4 *items; RoiEnt *ent; float *pool, *part; int cap_items; size_t total; };
 static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
 {
     RaBwdWs w; char *p = (char *)ws; size_t o = 0;
@@ -982,6 +1018,7 @@ static RaBwdWs carve_ra_bwd(void *ws, int64_t tiles, int64_t R, int n_cg)
     w.cnt = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.tbase = (int32_t *)take((size_t)(tiles + 1) * 4);
     w.tnseg = (int32_t *)take((size_t)(tiles + 1) * 4);
+    w.tix = (int32_t *)take((size_t)(tiles + 1) * n_cg * 4);           // last-segment tickets, one per (tile, channel group): zeroed by the lists launch
     w.items = (int4 *)take((size_t)(cap_items + RS_NSEG) * sizeof(int4));
     w.slot = (int32_t *)take((size_t)(cap_items + RS_NSEG) * 4);
     w.ent = (RoiEnt *)take((size_t)tiles * (size_t)(R > 0 ? R : 1) * sizeof(RoiEnt));
@@ -1032,11 +1069,20 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         static const bool use_records = [] { const char *e = getenv("FRCNN_RA_RECORDS"); return !e || atoi(e) != 0; }();
         const int64_t table_blocks = use_records ? R : 0;
         FRCNN_REQUIRE(tiles + table_blocks < ((int64_t)1 << 31) && R * RA_MAXT < ((int64_t)1 << 31), "ms_roi_align_bwd: grid too large");
+        static int *ticket_of_dev[64];                         // device address of g_ra_plan_ticket, per device
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        int *tickets = __atomic_load_n(&ticket_of_dev[dev], __ATOMIC_RELAXED);
+        if (!tickets) {
+            if (hipGetSymbolAddress((void **)&tickets, HIP_SYMBOL(g_ra_plan_ticket)) != hipSuccess || !tickets)
+                return frcnn_set_error(FRCNN_ERR_LAUNCH, "ms_roi_align_bwd: no address for the plan ticket");
+            __atomic_store_n(&ticket_of_dev[dev], tickets, __ATOMIC_RELAXED);
+        }
+        int *ticket = tickets + (((size_t)workspace >> 12) & 63);
         FRCNN_LAUNCH(roi_align_bwd_lists_kernel, dim3((unsigned)(tiles + table_blocks)), dim3(256), 0, s, L, T, (const float4 *)rois, (int)R,
-                     aligned, k_min, s0, k0, cap, tiles, w.cnt, w.ent, use_records ? w.pool : nullptr);
+                     aligned, k_min, s0, k0, cap, tiles, w.cnt, w.ent, use_records ? w.pool : nullptr, n_cg, w.tix, ticket, w.cap_items, w.tbase,
+                     w.tnseg, w.items, w.slot);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_lists_kernel");
-        FRCNN_LAUNCH(roi_align_bwd_plan_kernel, dim3(1), dim3(1024), 0, s, tiles, w.cap_items, w.cnt, w.tbase, w.tnseg, w.items, w.slot);
-        FRCNN_CHECK_LAUNCH("roi_align_bwd_plan_kernel");
         FillLevels FLv;
         int64_t fills = 0;
         for (int l = 0; l < FRCNN_MAX_LEVELS; ++l) {
@@ -1056,14 +1102,11 @@ FRCNN_EXPORT int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *gra
         const int n_first = (int)std::min<int64_t>(n_item_blocks, (int64_t)resident / n_cg * n_cg);
         if (C % RT_CB == 0 && ((size_t)grad_out & 15) == 0)
             FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float, true>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
-                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part);
+                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part, w.tbase, w.slot, w.tix);
         else
             FRCNN_LAUNCH((roi_align_bwd_tile_kernel<float, false>), dim3((unsigned)(n_item_blocks + fills)), dim3(256), 0, s, L, T, FLv, C, aligned,
-                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part);
+                         grad_out, n_cg, cap, (int)n_item_blocks, n_first, (int)fills, w.cnt, w.ent, w.items, w.pool, w.part, w.tbase, w.slot, w.tix);
         FRCNN_CHECK_LAUNCH("roi_align_bwd_tile_kernel");
-        FRCNN_LAUNCH((roi_align_bwd_combine_kernel<float>), dim3((unsigned)(tiles * n_cg)), dim3(256), 0, s, L, T, C, n_cg, w.tbase,
-                     w.tnseg, w.slot, w.part);
-        FRCNN_CHECK_LAUNCH("roi_align_bwd_combine_kernel");
         return FRCNN_OK;
     }
     for (int l = 0; l < n_levels; ++l)                  // the scatter kernels accumulate: clear the planes first

@@ -375,8 +375,9 @@ int frcnn_roi_scale_order(const float *rois, int64_t R, const float *mul4_host, 
                           uint32_t *out_cost /*[R] or NULL*/, void *stream);
 /* grad_feats[l] [C,H_l,W_l] are OVERWRITTEN with the gradient of every level (zero where no RoI reaches); the caller does
  * not clear them.  7x7 / sampling_ratio 2: tile-owner gather (per-tile RoI lists, long lists summed by segments in a fixed
- * order), no atomics, bit-reproducible; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists, weight-table records of
- * the (RoI, tile) pairs, partial tiles; its contents on entry do not matter).  Other
+ * order), no atomics, bit-reproducible, two launches; workspace >= frcnn_ms_roi_align_bwd_workspace(...) (lists, weight-table
+ * records of the (RoI, tile) pairs, partial tiles, tickets; its contents on entry do not matter).  One call at a time per
+ * device (the last-workgroup ticket of the lists launch is a word of the library picked by the workspace address).  Other
  * shapes: memset + fp32 atomics inside the library (sum order not fixed, tolerance 1e-4; no workspace needed).             */
 size_t frcnn_ms_roi_align_bwd_workspace(const int *H_host, const int *W_host, int n_levels, int C, int64_t R);
 int frcnn_ms_roi_align_bwd(const float *grad_out, float *const *grad_feats_host, const int *H_host, const int *W_host,

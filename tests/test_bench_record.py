@@ -18,7 +18,7 @@ V_KERNELS = ["nms_kernel", "rpn_match_kernel", "roi_pool_bwd_lds_kernel", "rpn_h
 F_KERNELS = ["rpn_conv3x3_wgrad_kernel", "rpn_conv3x3_head_kernel", "rpn_conv3x3_bwd_data_kernel", "roi_align_fwd77_kernel",
              "rpn_head_tail_bwd_kernel", "roi_align_bwd_tile_kernel", "nms_kernel", "rpn_match_kernel", "topk_partition_kernel",
              "head_targets_kernel", "proposal_prologue_kernel", "det_loss_kernel", "rpn_apply_kernel", "rpn_conv_wgrad_finalize_kernel",
-             "roi_align_bwd_lists_kernel", "roi_align_bwd_combine_kernel", "roi_align_bwd_plan_kernel", "rpn_conv_pack_bwd_kernel",
+             "roi_align_bwd_lists_kernel", "rpn_conv_pack_bwd_kernel",
              "rpn_head_tail_bwd_finalize_kernel", "rpn_conv_pack_kernel"]
 
 

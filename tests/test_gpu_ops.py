@@ -997,8 +997,8 @@ def test_single_level_roi_align_big_footprints_and_generic_shapes(ops, PH, SR):
 
 def test_ms_roi_align_bwd_plan_coarsens_when_the_item_table_is_too_small(ops):
     """One level, 512 RoIs that each cover most of a 50 x 84 map: every one of the 44 tiles meets hundreds of RoIs, which asks for
-    far more list segments than the work-item table holds (tiles + 15 R / 32 + 1).  roi_align_bwd_plan_kernel must double the
-    split threshold until the plan fits -- and the gradient must still be the oracle's, bit-reproducibly."""
+    far more list segments than the work-item table holds (tiles + 15 R / 32 + 1).  The planning step (the last workgroup of
+    roi_align_bwd_lists_kernel) must double the split threshold until the plan fits -- and the gradient must still be the oracle's, bit-reproducibly."""
     from faster_rcnn_pytorch_amd import _lib
     import ctypes as C
     rng = np.random.RandomState(9)

@@ -1,5 +1,5 @@
 """Developer tool: RoIAlign backward alone at the bench's FPN RoIs (captured after STEPS SGD steps): bin-size statistics and the time
-of the four launches.  FRCNN_HIP_LIB=build_dbg/<variant>/libfrcnn_hip.so selects a variant build."""
+of its launches (two since round 5; four before).  FRCNN_HIP_LIB=build_dbg/<variant>/libfrcnn_hip.so selects a variant build."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -92,7 +92,7 @@ for key in os.environ.get("KEYS", "rois0,rois15,rois29").split(","):
         tf.append(e0.elapsed_time(e1) * 1e3 / 20)
     print("   forward: median %.1f us  min %.1f us   sha1 %s" % (float(np.median(tf)), min(tf), hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]))
     h = hashlib.sha1(b"".join(x.cpu().numpy().tobytes() for x in grads)).hexdigest()[:12]
-    print("   backward (4 launches back to back): median %.1f us  min %.1f us   sha1 %s" % (float(np.median(ts)), min(ts), h))
+    print("   backward (launches back to back): median %.1f us  min %.1f us   sha1 %s" % (float(np.median(ts)), min(ts), h))
 # the ordering kernel itself (round 4)
 for _ in range(3): ops.roi_scale_order(rois, (1.0, 1.0, 1.0, 1.0), [s[-2:] for s in shapes], scales)
 torch.cuda.synchronize(); e0.record()
