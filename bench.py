@@ -328,8 +328,10 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
         eager_step(i)
     torch.cuda.synchronize()
     ops.CONV_TRACE = []                              # which calls the fp32 conv stage gets in one step (shapes only; for the roofline's flop / byte totals)
+    ops.AFFINE_TRACE = {}                            # likewise the norm / residual / ReLU passes: launches and the bytes each must move
     eager_step(3)
     conv_calls, ops.CONV_TRACE = ops.CONV_TRACE, None
+    affine_calls, ops.AFFINE_TRACE = ops.AFFINE_TRACE, None
     torch.cuda.synchronize()
     step = eager_step
     graphs = gstep = None
@@ -446,11 +448,12 @@ def run_config(args, config, amp, steps, warmup, graph, rank, world, device, wit
     cpu = cpu_baseline(config, cfg, args.cpu_steps, args.lr) if with_cpu else None
     return build_record(config, amp, world=world, steps=steps, warmup=warmup, dt=dt, per_rank_ms=per_rank_ms, step_ms=step_ms,
                         samples=samples, n_sampled=n_sampled, n_props=n_props, graph=graph, pmc=pmc, pmc_src=pmc_src, cpu=cpu,
-                        allocator=allocator, ddp=ddp, backend=backend, world_seen=world_seen, final_loss=final_loss, gc_on=args.gc_on, conv_calls=conv_calls)
+                        allocator=allocator, ddp=ddp, backend=backend, world_seen=world_seen, final_loss=final_loss, gc_on=args.gc_on, conv_calls=conv_calls,
+                        affine_calls=affine_calls)
 
 
 def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms, samples, n_sampled, n_props, graph, pmc, pmc_src, cpu,
-                 allocator, ddp, backend, world_seen, final_loss, gc_on=False, conv_calls=None):
+                 allocator, ddp, backend, world_seen, final_loss, gc_on=False, conv_calls=None, affine_calls=None):
     """The FULL bench record (written to bench_detail.json) from plain measured values: no GPU, no torch.  `samples` = kernel name ->
     list of launch times in ms (frcnn_prof_samples), `dt` = max-over-ranks seconds of the timed region, `n_props` = device-side
     proposal counts of the timed steps.  compact_record() cuts it down to the line the driver parses."""
@@ -524,6 +527,14 @@ def build_record(config, amp, *, world, steps, warmup, dt, per_rank_ms, step_ms,
         d["note"] = ("Winograd F(2x2,3x3), all launches of one image (the RPN convolution and the backbone layers in `layers`, forward + data gradient "
                      "+ weight gradient): the GEMM is priced on the flops it executes (32 Cin Cout per padded 2x2 tile, 2.25x fewer than the "
                      "convolutions it serves); conv_equivalent_TFLOP_s = the convolutions' own flop count over the time of ALL the stage's launches")
+    # the norm / residual / ReLU passes (FPN configs) run on maps of many sizes: per-image byte totals from the traced step over the per-image time
+    for k, (launches, nbytes) in (affine_calls or {}).items():
+        if k in per_kernel and launches and abs(per_kernel[k]["launches_per_img"] - launches) < 0.01:
+            d = per_kernel[k]
+            d["algorithmic_bytes"] = round(nbytes / launches)
+            d["algorithmic_bytes_per_img"] = nbytes
+            d["GB_s"] = round(nbytes / d["us_per_img"] * 1e-3, 2)
+            d["hbm_frac"] = round(nbytes / d["us_per_img"] * 1e-3 / HBM_PEAK_GBS, 5)
     # the NMS stage is several launches of nms_kernel (+ filter / emit): its VALU figure is priced on the stage's time per image
     nms_us = sum(v["us_per_img"] for k, v in per_kernel.items() if k.startswith("nms_"))
     if "nms_kernel" in per_kernel and nms_us > 0:

@@ -970,6 +970,16 @@ def conv1x1_supported(x, weight):
 
 
 # ---- FrozenBatchNorm2d (+ residual) (+ ReLU) of a ResNet bottleneck in one pass each way (csrc/affine.hip)
+AFFINE_TRACE = None      # a dict while a caller (bench.py) records one step: kernel name -> [launches, bytes the launch must move (every tensor it reads or writes, once)]
+
+
+def _affine_trace(kernel, *tensors):
+    if AFFINE_TRACE is not None:
+        e = AFFINE_TRACE.setdefault(kernel, [0, 0])
+        e[0] += 1
+        e[1] += sum(int(t.numel()) * t.element_size() for t in tensors if t is not None)
+
+
 class _AffineActFn(torch.autograd.Function):
     """args: (relu, scale [C], shift [C], x [1,C,h,w], res | None) -> act((x * scale + shift) [+ res]); scale / shift are frozen (no gradient)."""
 
@@ -984,6 +994,7 @@ class _AffineActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         with torch.cuda.device(x.device):
             check(lib.frcnn_affine_act_fwd(_ptr(x), _ptr(res), _ptr(y), _ptr(scale), _ptr(shift), Cc, HW, 1 if relu else 0, _stream()), "affine_act_fwd")
+        _affine_trace("affine_act_fwd_kernel", x, res, y, scale, shift)
         ctx.relu, ctx.has_res = bool(relu), res is not None
         ctx.save_for_backward(scale, y if relu else None)
         return y
@@ -1000,6 +1011,7 @@ class _AffineActFn(torch.autograd.Function):
         dres = torch.empty_like(g) if (need_r and ctx.relu) else None     # without a ReLU the residual's gradient is g itself
         with torch.cuda.device(g.device):
             check(lib.frcnn_affine_act_bwd(_ptr(g), _ptr(y), _ptr(scale), _ptr(dx), _ptr(dres), Cc, HW, 1 if ctx.relu else 0, _stream()), "affine_act_bwd")
+        _affine_trace("affine_act_bwd_kernel", g, y, dx, dres, scale)
         return None, None, None, (dx if need_x else None), ((dres if ctx.relu else g) if need_r else None)
 
 
@@ -1033,6 +1045,7 @@ class _AffineActMixedFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             check(lib.frcnn_affine_act_fwd_mixed(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, _ptr(res), _ptr(y), 1 if out_bf16 else 0, _ptr(twin),
                                                  _ptr(scale), _ptr(shift), Cc, HW, 1 if relu else 0, _stream()), "affine_act_fwd_mixed")
+        _affine_trace("affine_act_fwd_mixed_kernel", x, res, y, twin, scale, shift)
         ctx.relu, ctx.has_res, ctx.x_bf16, ctx.twin = bool(relu), res is not None, x.dtype == torch.bfloat16, bool(want_twin)
         ctx.save_for_backward(scale, y if relu else None)
         if want_twin:
@@ -1058,6 +1071,7 @@ class _AffineActMixedFn(torch.autograd.Function):
         with torch.cuda.device(g.device):
             check(lib.frcnn_affine_act_bwd_mixed(_ptr(g), 1 if g.dtype == torch.bfloat16 else 0, _ptr(g2), _ptr(y), _ptr(scale), _ptr(dx),
                                                  1 if ctx.x_bf16 else 0, _ptr(dres), Cc, HW, 1 if ctx.relu else 0, _stream()), "affine_act_bwd_mixed")
+        _affine_trace("affine_act_bwd_mixed_kernel", g, g2, y, dx, dres, scale)
         return None, None, None, None, None, (dx if need_x else None), ((dres if dres is not None else g) if need_r else None)
 
 

@@ -191,6 +191,21 @@ def test_winograd_stage_accounting_in_the_roofline():
     assert r2["kernel"] != "rpn_wino_gemm_kernel" or r2.get("frac") is None
 
 
+def test_norm_passes_are_priced_on_the_bytes_the_traced_step_moved():
+    """The fused norm / residual / ReLU passes run on maps of many sizes: their HBM figure is the traced step's byte total (ops.AFFINE_TRACE) over the
+    per-image time of the launches -- and absent when the sampled steps made a different number of launches."""
+    import bench
+    samples = {"affine_act_fwd_mixed_kernel": [0.010] * (53 * 5), "nms_kernel": [0.040] * 5}
+    kw = dict(world=1, steps=20, warmup=4, dt=0.2, per_rank_ms=[10.0], step_ms=[10.0] * 20, n_sampled=5, n_props=[780], graph=False, pmc={},
+              pmc_src=None, cpu=None, allocator={}, ddp=None, backend=None, world_seen=1, final_loss=1.0)
+    nbytes = 53 * 20_000_000
+    r = bench.build_record("fpn", "bf16", samples=samples, affine_calls={"affine_act_fwd_mixed_kernel": [53, nbytes]}, **kw)["roofline"]
+    assert r["kernel"] == "affine_act_fwd_mixed_kernel" and r["bound"] == "hbm"
+    assert abs(r["achieved"] - nbytes / (53 * 10.0) * 1e-3) < 0.5 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4 and r["algorithmic_bytes"] == 20_000_000
+    r2 = bench.build_record("fpn", "bf16", samples=samples, affine_calls={"affine_act_fwd_mixed_kernel": [50, nbytes]}, **kw)["roofline"]
+    assert r2["achieved"] is None
+
+
 def test_stage_accounting_of_pooled_calls_and_1x1_weight_gradients():
     """wino_work() prices what ops.CONV_TRACE records: a forward that pooled writes a quarter of the pixels (+ the window words), its gradient calls read the
     gradient at the pooled size (+ the words); a 1 x 1 convolution's weight gradient is one GEMM launch of 2 M N K flops and nothing else."""
