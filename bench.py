@@ -636,7 +636,7 @@ def compact_record(full, also=()):
     compact `also` list; per-kernel records, percentiles, conditions, allocator counters go to bench_detail.json (emit())."""
     out = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data"))
-    out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission", "sampling"))
+    out["config"] = _pick(full["config"], ("workload", "global_batch", "parallelism", "submission", "sampling", "products"))
     cond = full.get("conditions") or {}
     # what the number was measured under, in three words (the sentences are in bench_detail.json): how the vendor GEMMs were picked and whether
     # Python's collector could interrupt the enqueue (--no-tunableop --gc-on give the other figure)
@@ -663,6 +663,8 @@ def compact_record(full, also=()):
                  "nms_plus_roi_us_per_img": (rec.get("hot_path") or {}).get("nms_plus_roi_us_per_img")}
             if rec.get("eager_submission"):
                 e["eager_value"] = rec["eager_submission"]["value"]
+            if rec["config"].get("products"):
+                e["products"] = "split: 6 bf16 MFMAs per product on exactly cut fp32 operands"
             out["also"].append(e)
     out["detail"] = "bench_detail.json"
     return out
@@ -715,6 +717,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="capture the whole step (one HIP graph per resident frame) and time replays")
     ap.add_argument("--no-also", action="store_true", help="headline run only: skip the short FPN fp32 / bf16 runs of the `also` block")
     ap.add_argument("--also-steps", type=int, default=20)
+    ap.add_argument("--products", default="native", choices=["native", "split"],
+                    help="how the fp32 conv stage takes its products (ops.conv3x3_f32_products): native = the fp32 matrix instruction (default); split = the same "
+                         "fp32 operands cut exactly into three bf16 pieces, six bf16 matrix instructions per 16 k rows, fp32 accumulation (as close to float64)")
     ap.add_argument("--amp", default="none", choices=["none", "bf16"],
                     help="autocast the torch layers (backbone / RPN convs / FC head); NOT the default: the reference trains in fp32")
     args = ap.parse_args()
@@ -733,8 +738,16 @@ def main():
         gc.unfreeze()
         gc.collect()
         torch.cuda.empty_cache()
-    out = run_config(args, args.config, args.amp, args.steps, args.warmup, args.graph, rank, world, device,
-                     with_cpu=(not args.no_cpu_baseline and world == 1))
+    from faster_rcnn_pytorch_amd import ops as _ops
+    _ops.conv3x3_f32_products(args.products)
+
+    def tag_products(rec):
+        if rec is not None and _ops.conv3x3_f32_products() == "split":
+            rec["config"]["products"] = ("fp32 conv stage: every product as six bf16 matrix instructions on operands cut exactly into three bf16 pieces, fp32 accumulation "
+                                         "(tests: as close to float64 as the fp32 matrix instruction)")
+        return rec
+    out = tag_products(run_config(args, args.config, args.amp, args.steps, args.warmup, args.graph, rank, world, device,
+                                  with_cpu=(not args.no_cpu_baseline and world == 1)))
     release()
     also = []
     if rank == 0 and world == 1 and not args.no_also and args.config == "vgg" and args.amp == "none" and not args.graph:
@@ -748,6 +761,16 @@ def main():
         rec["eager_submission"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "step_ms": out["step_ms"]}
         also.append(rec)
         release()
+        if args.products == "native":
+            # the same again with the conv stage's products on the bf16 matrix cores (opt-in, --products split): not the headline, shown beside it
+            _ops.conv3x3_f32_products("split")
+            try:
+                rec = tag_products(run_config(args, "vgg", "none", args.also_steps, 5, True, rank, world, device, with_cpu=False))
+            finally:
+                _ops.conv3x3_f32_products("native")
+            rec["config"]["note"] = "the headline configuration as graph replays with --products split: short run inside the headline command, %d timed steps, 5 warm-up" % args.also_steps
+            also.append(rec)
+            release()
         for amp in ("none", "bf16"):
             rec = run_config(args, "fpn", amp, args.also_steps, 5, True, rank, world, device, with_cpu=False)
             rec["config"]["note"] = "short run inside the headline command: %d timed steps, 5 warm-up" % args.also_steps

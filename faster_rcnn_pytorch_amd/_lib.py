@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "lib", "libfrcnn_hip.so")     # override: kernel tuning builds only
 
 OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 HT_ERR_PERM_LENGTH, HT_ERR_PERM_RANGE, HT_ERR_UPSTREAM_ABORT, HT_ERR_SHORT = 1, 2, 4, 8
 OP_TOPK, OP_NMS, OP_REGION_PROPOSAL, OP_RPN_TARGETS, OP_HEAD_TARGETS, OP_PREPROCESS, OP_HEAD_BWD, OP_RPN_CONV, OP_RPN_CONV_WGRAD, OP_RPN_CONV_F32 = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "frcnn_conv3x3_f32_xt_floats": (_sz, [_vp, _vp, _i, _i]),
     "frcnn_conv3x3_f32_relu_bits_words": (_sz, [_vp, _vp, _i, _i]),
     "frcnn_conv3x3_f32_u_floats": (_sz, [_vp, _vp, _i, _i, _i]),
+    "frcnn_conv3x3_f32_products": (_i, [_i]),
     "frcnn_conv3x3_f32_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_conv3x3_f32_tile_size": (_i, [_vp, _vp, _i]),
     "frcnn_conv3x3_f32_supported": (_i, [_vp, _vp, _i, _i, _i, _i]),

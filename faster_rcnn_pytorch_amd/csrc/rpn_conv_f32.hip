@@ -40,7 +40,9 @@
 #include "frcnn_internal.h"
 #include "frcnn_layout.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 FRCNN_LAYOUT_STAMP(rpn_conv_f32);
 
@@ -940,7 +942,27 @@ extern "C" __attribute__((visibility("default"))) int frcnn_debug_wn_stamps(unsi
 #endif
 // MT x NW = the workgroup's output tile (128 or 64 each way: the 64-channel layers of a backbone have a 64-wide side); its four waves sit
 // 2 x 2, a wave owns (MT / 2) x (NW / 2) = MI x NI MFMA tiles of 32 x 32.
-template <bool NT, int MT, int NW>
+// SPLIT (round 5; opt-in, frcnn_conv3x3_f32_products): the SAME fp32 operands from the SAME LDS image, but the product on the bf16 matrix cores -- every
+// value is cut into three bf16 pieces in registers (v = h + m + l EXACTLY: h = v's upper 16 bits, the residuals are exact fp32 differences), and a tile's
+// 16 k rows are six v_mfma_f32_32x32x16_bf16 (l h, h l, m m, m h, h m, h h; the three dropped products are each <= 2^-24 of the term) = 192 matrix-pipe
+// cycles where the fp32 instruction needs 8 x 64.  Against float64 the result is as close as the fp32 instruction's (tools/dev/micro/split_product_check.hip,
+// profiles/r05_split_product_check.txt: rms error / sum |a b| 1.9e-8 vs 2.4e-8 at K = 256 ... 4096 on mixed-sign data).
+typedef short wn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wn_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wn_cut8(const float *v, wn_u32x4 &h, wn_u32x4 &m, wn_u32x4 &l)
+{
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned x0 = __builtin_bit_cast(unsigned, v[2 * p]), x1 = __builtin_bit_cast(unsigned, v[2 * p + 1]);
+        h[p] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);                // bf16 element 2 p = upper half of x0, 2 p + 1 = upper half of x1
+        const float ra = v[2 * p] - __builtin_bit_cast(float, x0 & 0xFFFF0000u), rb = v[2 * p + 1] - __builtin_bit_cast(float, x1 & 0xFFFF0000u);
+        const unsigned r0 = __builtin_bit_cast(unsigned, ra), r1 = __builtin_bit_cast(unsigned, rb);
+        m[p] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+        const float qa = ra - __builtin_bit_cast(float, r0 & 0xFFFF0000u), qb = rb - __builtin_bit_cast(float, r1 & 0xFFFF0000u);
+        l[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, qb), __builtin_bit_cast(unsigned, qa), 0x07060302u);
+    }
+}
+template <bool NT, int MT, int NW, bool SPLIT>
 __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, float *__restrict__ part, int *__restrict__ cnt)
 {
     WN_STAMP_AT(0);
@@ -1148,7 +1170,50 @@ __global__ __launch_bounds__(256, CF_WPS) void rpn_wino_gemm_kernel(WgArgs a, fl
 #else
 #define WN_PIECE(step) do { } while (0)
 #endif
-        if (NT) {
+        if constexpr (SPLIT) {
+            // lane (i, h) supplies k = 16 kb + 8 h + j (K-major: eight rows of its column) or 16 h + 8 kb + j (k-contiguous: two 16-byte pieces of its row),
+            // j = 0 .. 7, to the MFMAs of block kb -- the bf16 instruction's operand map; both operands take the same k, which is all a contraction asks
+            float va[MI][8], vb[NI][8];
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int kb = 0; kb < WN_KC / 16; ++kb) {
+                if constexpr (NT) {
+                    const float *ra = &sA[buf][(wm * (MT / 2) + li) * WN_KC], *rb = &sB[buf][(wn * (NW / 2) + li) * WN_KC];
+                    const int fsw = (li >> 1) & 7;
+#pragma unroll
+                    for (int hj = 0; hj < 2; ++hj) {
+                        const int o = (((4 * lh + 2 * kb + hj) ^ fsw) << 2);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) { const f32x4 t = *(const f32x4 *)(ra + mi * 32 * WN_KC + o); va[mi][4 * hj] = t[0]; va[mi][4 * hj + 1] = t[1]; va[mi][4 * hj + 2] = t[2]; va[mi][4 * hj + 3] = t[3]; }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) { const f32x4 t = *(const f32x4 *)(rb + ni * 32 * WN_KC + o); vb[ni][4 * hj] = t[0]; vb[ni][4 * hj + 1] = t[1]; vb[ni][4 * hj + 2] = t[2]; vb[ni][4 * hj + 3] = t[3]; }
+                    }
+                } else {
+                    const float *qa = &sA[buf][(16 * kb + 8 * lh) * MT + wm * (MT / 2) + MI * li];
+                    const float *qb = &sB[buf][(16 * kb + 8 * lh) * NW + wn * (NW / 2) + NI * li];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (MI == 2) { const float2 t = *(const float2 *)(qa + j * MT); va[0][j] = t.x; va[1][j] = t.y; }
+                        else va[0][j] = qa[j * MT];
+                        if constexpr (NI == 2) { const float2 t = *(const float2 *)(qb + j * NW); vb[0][j] = t.x; vb[1][j] = t.y; }
+                        else vb[0][j] = qb[j * NW];
+                    }
+                }
+                wn_u32x4 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) wn_cut8(va[mi], ah[mi], am[mi], al[mi]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) wn_cut8(vb[ni], bh[ni], bm[ni], bl[ni]);
+#define WN_MM(x, y) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wn_bf16x8, x[mi]), __builtin_bit_cast(wn_bf16x8, y[ni]), acc[mi][ni], 0, 0, 0)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) { WN_MM(al, bh); WN_MM(ah, bl); WN_MM(am, bm); WN_MM(am, bh); WN_MM(ah, bm); WN_MM(ah, bh); }   // small products first
+#undef WN_MM
+#pragma unroll
+                for (int q = kb * (NPIECE / 2); q < (kb + 1) * (NPIECE / 2); ++q) WN_PIECE(q);
+            }
+        } else if (NT) {
             // lane (i = li, half lh) takes k = 16 lh + s at step s: sixteen consecutive floats of its row = four ds_read_b128 per operand row
             // and chunk (the contraction does not care which k goes to which step as long as both operands agree)
             typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1320,12 +1385,23 @@ __global__ __launch_bounds__(256, 1) void rpn_wino_gemm_out64_kernel(WnArgs a, c
         }
 }
 
+// How the stage's products are taken: 0 = v_mfma_f32_32x32x2_f32 (the default), 1 = split bf16 products (rpn_wino_gemm_kernel<.., SPLIT>).  Process-wide;
+// FRCNN_CONV_F32_PRODUCTS=split sets the initial value, frcnn_conv3x3_f32_products() changes it between calls (returns the previous value; < 0 only asks).
+static std::atomic<int> g_wn_products{[] { const char *e = getenv("FRCNN_CONV_F32_PRODUCTS"); return (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : 0; }()};
+FRCNN_EXPORT int frcnn_conv3x3_f32_products(int mode)
+{
+    if (mode < 0) return g_wn_products.load();
+    return g_wn_products.exchange(mode ? 1 : 0);
+}
+
 // the instantiation a product's tile widths need (host side)
 static int wn_launch_gemm(bool nt, int MT, int NW, const WgArgs &g, float *part, int *cnt, hipStream_t s)
 {
+    const bool split = g_wn_products.load() != 0;
 #define WN_GEMM_CASE(NTv, MTv, NWv)                                                                                          \
     if (nt == NTv && MT == MTv && NW == NWv) {                                                                               \
-        FRCNN_LAUNCH((rpn_wino_gemm_kernel<NTv, MTv, NWv>), dim3((unsigned)g.G), dim3(256), 0, s, g, part, cnt);             \
+        if (split) FRCNN_LAUNCH((rpn_wino_gemm_kernel<NTv, MTv, NWv, true>), dim3((unsigned)g.G), dim3(256), 0, s, g, part, cnt);   \
+        else FRCNN_LAUNCH((rpn_wino_gemm_kernel<NTv, MTv, NWv, false>), dim3((unsigned)g.G), dim3(256), 0, s, g, part, cnt); \
         FRCNN_CHECK_LAUNCH("rpn_wino_gemm_kernel");                                                                          \
         return FRCNN_OK;                                                                                                     \
     }

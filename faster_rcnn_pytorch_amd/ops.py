@@ -593,6 +593,18 @@ def conv3x3_bf16_c256_supported(x, weight):
 # --------------------------------------------------------------------------------------------
 # the RPN head's 3x3 convolution in fp32 (models/model.py:68-70,79; models/new_model.py:96-98,109) on the fp32 matrix cores
 # --------------------------------------------------------------------------------------------
+def conv3x3_f32_products(mode=None):
+    """How the fp32 conv stage takes its products (process-wide; csrc/rpn_conv_f32.hip, frcnn_conv3x3_f32_products): "native" = the fp32 matrix instruction (default),
+    "split" = the same fp32 operands cut exactly into three bf16 pieces each and six bf16 matrix instructions per 16 k rows with fp32 accumulation -- as
+    close to float64 as "native", 1.4-1.5 x the rate.  Returns the previous mode; None only asks."""
+    names = ("native", "split")
+    if mode is None:
+        return names[lib.frcnn_conv3x3_f32_products(-1)]
+    if mode not in names:
+        raise ValueError("conv3x3_f32_products: mode must be one of %s" % (names,))
+    return names[lib.frcnn_conv3x3_f32_products(names.index(mode))]
+
+
 CONV_TRACE = None        # a list while a caller (bench.py) records which calls the fp32 conv stage gets in one step: dicts kind / Cin / Cout / shapes / mask / bias
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FRCNN_ABI_VERSION 6
+#define FRCNN_ABI_VERSION 7
 
 typedef enum {
     FRCNN_OK = 0,
@@ -250,6 +250,13 @@ size_t frcnn_conv3x3_f32_relu_bits_words(const int *H_host, const int *W_host, i
 int frcnn_conv3x3_f32_tile_size(const int *H_host, const int *W_host, int n_levels);
 /* 1 when _fwd (and, with need_grads, _bwd_data and _wgrad) would accept these shapes, else 0: the question a caller's dispatch asks before routing a layer here. */
 int frcnn_conv3x3_f32_supported(const int *H_host, const int *W_host, int n_levels, int Cin, int Cout, int need_grads);
+/* How the stage's products (M = U . V per Winograd plane; the weight gradient's dU = dM . V^T) are taken -- a process-wide switch, 0 by default:
+ *   0  v_mfma_f32_32x32x2_f32 on the fp32 operands;
+ *   1  the same fp32 operands cut into three bf16 pieces each in registers (exactly) and six v_mfma_f32_32x32x16_bf16 per 16 k rows, fp32 accumulation:
+ *      against float64 as close as mode 0 (tests/test_gpu_ops.py: test_conv3x3_f32_split_products_*), 1.4-1.5 x the rate.  Inputs, outputs, workspaces and
+ *      every other kernel of the stage are the same.  Environment: FRCNN_CONV_F32_PRODUCTS=split sets the initial value.
+ * Returns the previous mode; mode < 0 only asks. */
+int frcnn_conv3x3_f32_products(int mode);
 int frcnn_conv3x3_f32_fwd(const float *const *x_levels, float *const *y_levels, const int *H_host, const int *W_host, int n_levels, int Cin, int Cout,
                           const float *w, const float *bias, int relu, unsigned short *relu_bits, float *x_transformed, float *u_rotated, void *workspace,
                           size_t workspace_bytes, void *stream);

@@ -39,7 +39,7 @@ def test_header_symbols_all_exported_and_bound(L):
 
 
 def test_abi_version_and_error_reporting(L):
-    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 6
+    assert L.lib.frcnn_abi_version() == L.ABI_VERSION == 7
     rc = L.lib.frcnn_nms(None, None, 10, 0.5, 10, None, None, None, None, 0, None)      # NULL out_count
     assert rc == -1 and b"nms" in L.lib.frcnn_last_error()
     with pytest.raises(L.FrcnnError):

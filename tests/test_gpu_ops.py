@@ -1706,6 +1706,54 @@ def test_conv3x3_f32_stage_vs_float64(ops, name, Cin, Cout, shapes, use_bias, re
     assert "rpn_wino_input_kernel" not in _lib.prof_report()                                       # nothing left to transform
 
 
+SPLIT_CASES = [c for c in CONV3X3_CASES if c[0] in ("vgg_conv3_1", "vgg_conv4_1", "wide_in", "levels", "vgg_conv2_1", "narrow_both", "wide_out_64", "rpn_37x62")]
+
+
+@pytest.mark.parametrize("name,Cin,Cout,shapes,use_bias,relu,grads", SPLIT_CASES, ids=[c[0] for c in SPLIT_CASES])
+def test_conv3x3_f32_split_products_are_as_close_to_float64_as_the_native_ones(ops, name, Cin, Cout, shapes, use_bias, relu, grads):
+    """ops.conv3x3_f32_products("split"): the stage's products as six bf16 matrix instructions on exactly cut fp32 operands (csrc/rpn_conv_f32.hip, SPLIT).
+    Forward, data gradient and weight gradient against float64 next to the native products' distance: within the native test's bounds, and never more than
+    1.5 x the native distance (+ a rounding-level floor); bit-reproducible; the switch comes back as it was."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(len(name) * 7 + Cin)
+    xs = [torch.randn(1, Cin, h, w, generator=g) for h, w in shapes]
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.2 if use_bias else None
+    dys = [torch.randn(1, Cout, h, w, generator=g) for h, w in shapes]
+    xd, dyd, wd = [x.to(DEV) for x in xs], [t.to(DEV) for t in dys], wt.to(DEV)
+    bd = b.to(DEV) if use_bias else None
+    pre = [F.conv2d(x.double(), wt.double(), b.double() if use_bias else None, padding=1) for x in xs]
+    assert ops.conv3x3_f32_products() == "native"
+
+    def run():
+        ys, _, bits = ops.conv3x3_fwd(xd, wd, bd, relu, want_bits=relu, keep_transformed=not relu)
+        dx = ops.conv3x3_bwd_data(dyd, wd, bits)
+        dw, db = ops.conv3x3_wgrad(xd, dyd, bits, want_bias=True)
+        return ys, bits, dx, dw, db
+    nat = run()
+    assert ops.conv3x3_f32_products("split") == "native"
+    try:
+        spl = run()
+        again = run()
+        assert ops.conv3x3_f32_products() == "split"
+    finally:
+        ops.conv3x3_f32_products("native")
+    for a, c in zip(spl[0] + spl[2] + [spl[3], spl[4]], again[0] + again[2] + [again[3], again[4]]):
+        assert torch.equal(a, c)                                                                  # bit-reproducible
+    out = {}
+    for tag, (ys, bits, dx, dw, db) in (("native", nat), ("split", spl)):
+        e_y = max(float((y.double().cpu() - (p.clamp_min(0) if relu else p)).abs().max()) / max(1.0, float(p.abs().max())) for y, p in zip(ys, pre))
+        masks = [(y.cpu() > 0) for y in ys] if relu else [torch.ones_like(p, dtype=torch.bool) for p in pre]       # each run against float64 under ITS OWN ReLU decisions
+        gs = [t.double() * m for t, m in zip(dys, masks)]
+        e_dx = max(float((o.double().cpu() - r).abs().max()) / max(1.0, float(r.abs().max()))
+                   for o, r in zip(dx, [F.conv_transpose2d(t, wt.double(), None, padding=1) for t in gs]))
+        w_ref = sum(torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, 3, 3), t, padding=1) for x, t in zip(xs, gs))
+        e_dw = float((dw.double().cpu() - w_ref).abs().max()) / max(1.0, float(w_ref.abs().max()))
+        out[tag] = (e_y, e_dx, e_dw)
+    for en, es, bound in zip(out["native"], out["split"], (2e-5, 2e-5, 1e-4)):
+        assert es < bound and es <= 1.5 * en + 2e-7, (name, out)
+
+
 def test_conv3x3_f32_autograd_and_argument_checks(ops):
     """ops.conv3x3 (what VGGExtractor calls) under autograd against torch's conv2d + relu on the device, with the reference's own mask
     tolerance handled by a bias that keeps pre-activations away from zero; and the entry points refuse what the stage is not built for."""

@@ -8,6 +8,9 @@
 //          behind the next tile's first sixteen steps' MFMAs
 //          256 wave w issues its transfer behind the (w + 1)-th MFMA of the step instead of all four waves behind the fourth (64 cycles apart at the texture unit)
 //          with 64: 512 the accumulators are not zeroed   1024 not stored   2048 stored as sixteen 16-byte stores (same bytes, the layout of no use) instead of 32 of 8 bytes
+//          4096 SPLIT PRODUCTS: the same fp32 operands from the same LDS image, every value cut into three bf16 pieces in registers (exactly: v = h + m + l) and the
+//          product taken as six v_mfma_f32_32x32x16_bf16 per accumulator tile and 16 k rows (h h, h m, m h, m m, h l, l h): 6 x 32 matrix-pipe cycles where the
+//          fp32 instruction needs 8 x 64
 //          32 LDS-DMA with the scalar-base address form (global_load_lds_dwordx4 voffset, s[base]: no 64-bit vector add per piece)
 //   hipcc --offload-arch=gfx950 -O3 -o gemm_loop_rate tools/dev/micro/gemm_loop_rate.hip && ./gemm_loop_rate
 #include <hip/hip_runtime.h>
@@ -32,7 +35,7 @@ template <int FLAGS, int KC, int NBUF, int WPE = 2>
 __global__ __launch_bounds__(256, WPE) void loop_kernel(const float *__restrict__ A, const float *__restrict__ B, int lda, int ldb, int chunks, size_t wrapA, size_t wrapB, float *out, float *tiles_out)
 {
     constexpr int MT = 128, NW = 128, MI = 2, NI = 2;
-    constexpr bool DMA = FLAGS & 1, LDSR = FLAGS & 2, BAR = FLAGS & 4, FRONT = FLAGS & 8, SBASE = FLAGS & 32, TILES = FLAGS & 64, TILES2 = FLAGS & 128, STAG = FLAGS & 256, NOZERO = FLAGS & 512, NOSTORE = FLAGS & 1024, ST16 = FLAGS & 2048;
+    constexpr bool DMA = FLAGS & 1, LDSR = FLAGS & 2, BAR = FLAGS & 4, FRONT = FLAGS & 8, SBASE = FLAGS & 32, TILES = FLAGS & 64, TILES2 = FLAGS & 128, STAG = FLAGS & 256, NOZERO = FLAGS & 512, NOSTORE = FLAGS & 1024, ST16 = FLAGS & 2048, SPLIT = FLAGS & 4096, NOMM = FLAGS & 8192, NOCUT = FLAGS & 16384;
     constexpr int PPW = (KC * (MT + NW) * 4 / 1024) / 4;             // 1-KB transfers per wave and chunk: 8 at KC = 32
     constexpr int STEPS = KC / 2;
     __shared__ __attribute__((aligned(16))) float sA[NBUF][KC * MT];
@@ -84,6 +87,58 @@ __global__ __launch_bounds__(256, WPE) void loop_kernel(const float *__restrict_
         }
         const float *pa = &sA[buf][lh * MT + wm * (MT / 2) + MI * li];
         const float *pb = &sB[buf][lh * NW + wn * (NW / 2) + NI * li];
+        if constexpr (SPLIT) {
+            typedef short bf16x8 __attribute__((ext_vector_type(8)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float *qa = &sA[buf][(8 * lh) * MT + wm * (MT / 2) + MI * li];      // lane (i, h) takes k = 16 kb + 8 h + j, j = 0 .. 7
+            const float *qb = &sB[buf][(8 * lh) * NW + wn * (NW / 2) + NI * li];
+            auto cut = [](const float *v, u32x4 &h, u32x4 &m, u32x4 &l) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const unsigned x0 = __builtin_bit_cast(unsigned, v[2 * p]), x1 = __builtin_bit_cast(unsigned, v[2 * p + 1]);
+                    h[p] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+                    const f32x2 r = f32x2{v[2 * p], v[2 * p + 1]} - f32x2{__builtin_bit_cast(float, x0 & 0xFFFF0000u), __builtin_bit_cast(float, x1 & 0xFFFF0000u)};
+                    const unsigned r0 = __builtin_bit_cast(unsigned, r.x), r1 = __builtin_bit_cast(unsigned, r.y);
+                    m[p] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
+                    const f32x2 r2 = r - f32x2{__builtin_bit_cast(float, r0 & 0xFFFF0000u), __builtin_bit_cast(float, r1 & 0xFFFF0000u)};
+                    l[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2.y), __builtin_bit_cast(unsigned, r2.x), 0x07060302u);
+                }
+            };
+#pragma unroll
+            for (int kb = 0; kb < KC / 16; ++kb) {
+                float va[MI][8], vb[NI][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float2 t = *(const float2 *)(qa + (16 * kb + j) * MT); va[0][j] = t.x; va[1][j] = t.y;
+                    const float2 w = *(const float2 *)(qb + (16 * kb + j) * NW); vb[0][j] = w.x; vb[1][j] = w.y;
+                }
+                u32x4 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (NOCUT) { ah[mi] = u32x4{__builtin_bit_cast(unsigned, va[mi][0]), __builtin_bit_cast(unsigned, va[mi][1]), __builtin_bit_cast(unsigned, va[mi][2]), __builtin_bit_cast(unsigned, va[mi][3])}; am[mi] = ah[mi]; al[mi] = u32x4{__builtin_bit_cast(unsigned, va[mi][4]), __builtin_bit_cast(unsigned, va[mi][5]), __builtin_bit_cast(unsigned, va[mi][6]), __builtin_bit_cast(unsigned, va[mi][7])}; }
+                    else cut(va[mi], ah[mi], am[mi], al[mi]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (NOCUT) { bh[ni] = u32x4{__builtin_bit_cast(unsigned, vb[ni][0]), __builtin_bit_cast(unsigned, vb[ni][1]), __builtin_bit_cast(unsigned, vb[ni][2]), __builtin_bit_cast(unsigned, vb[ni][3])}; bm[ni] = bh[ni]; bl[ni] = u32x4{__builtin_bit_cast(unsigned, vb[ni][4]), __builtin_bit_cast(unsigned, vb[ni][5]), __builtin_bit_cast(unsigned, vb[ni][6]), __builtin_bit_cast(unsigned, vb[ni][7])}; }
+                    else cut(vb[ni], bh[ni], bm[ni], bl[ni]);
+                }
+#define MM(x, y) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x[mi]), __builtin_bit_cast(bf16x8, y[ni]), acc[mi][ni], 0, 0, 0)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (NOMM) { acc[mi][ni][0] += __builtin_bit_cast(float, al[mi][0] ^ bh[ni][1] ^ am[mi][2] ^ bm[ni][3] ^ ah[mi][1] ^ bl[ni][2]); acc[mi][ni][1] += __builtin_bit_cast(float, al[mi][1] ^ bh[ni][0] ^ am[mi][3] ^ bm[ni][2] ^ ah[mi][0] ^ bl[ni][3] ^ al[mi][2] ^ al[mi][3] ^ am[mi][0] ^ am[mi][1] ^ ah[mi][2] ^ ah[mi][3] ^ bh[ni][2] ^ bh[ni][3] ^ bm[ni][0] ^ bm[ni][1] ^ bl[ni][0] ^ bl[ni][1]); }
+                        else { MM(al, bh); MM(ah, bl); MM(am, bm); MM(am, bh); MM(ah, bm); MM(ah, bh); }
+                    }
+#undef MM
+                if (DMA && !FRONT) {
+#pragma unroll
+                    for (int q = kb * (PPW / (KC / 16)); q < (kb + 1) * (PPW / (KC / 16)); ++q) issue_piece(u + NBUF - 1, nb, q);
+                }
+            }
+        } else {
         float oa[2][MI], ob[2][NI];
         auto fetch = [&](int s, int slot) {
             if (!LDSR) {
@@ -122,6 +177,7 @@ __global__ __launch_bounds__(256, WPE) void loop_kernel(const float *__restrict_
                     if (row < 32) *(float2 *)(obase + (size_t)(MI * ((r & 3) + 8 * (r >> 2)) + mi) * NW) = make_float2(old[mi][0][r], old[mi][1][r]);
                 }
             }
+        }
         }
         if (TILES2 && pending) pending = 0;
         if ((TILES || TILES2) && (u & (256 / KC - 1)) == 256 / KC - 1) {
@@ -217,6 +273,11 @@ int main()
     run<7 + 128, 32, 2>("the kernel + tiles stored behind the next tile's steps", A, B, out, cus, nA, nB);
     run<7 + 256, 32, 2>("the kernel, waves' transfers staggered inside the step", A, B, out, cus, nA, nB);
     run<7 + 256 + 64, 32, 2>("staggered + a tile stored and zeroed every 8 chunks", A, B, out, cus, nA, nB);
+    run<7 + 4096, 32, 2>("SPLIT PRODUCTS (6 bf16 MFMAs per tile and 16 k): the kernel's loop", A, B, out, cus, nA, nB);
+    run<6 + 4096, 32, 2>("SPLIT PRODUCTS without the LDS-DMA", A, B, out, cus, nA, nB);
+    run<6 + 4096 + 8192, 32, 2>("  ... the cutting alone (no MFMAs)", A, B, out, cus, nA, nB);
+    run<6 + 4096 + 16384, 32, 2>("  ... the MFMAs alone (no cutting)", A, B, out, cus, nA, nB);
+    run<7 + 4096 + 64, 32, 2>("SPLIT PRODUCTS + a tile stored and zeroed every 8 chunks", A, B, out, cus, nA, nB);
     run<15, 32, 2>("all, DMA in front of the steps", A, B, out, cus, nA, nB);
     run<7 + 32, 32, 2>("all, LDS-DMA addressed scalar base + lane offset", A, B, out, cus, nA, nB);
     run<7, 16, 2>("all, behind the steps", A, B, out, cus, nA, nB);
