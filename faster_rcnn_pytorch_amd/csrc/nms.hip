@@ -611,7 +611,9 @@ __global__ __launch_bounds__(256) void nms_kernel(const float4 *__restrict__ box
 // look[b] = (count << 1) | 1.  Logical blocks are handed out by an atomic ticket, so block b only waits for blocks that have
 // already started (the look-back of rocPRIM's single-pass scan); the spin is bounded anyway (abort flag -> count -1).
 // ------------------------------------------------------------------------------------------------
+#ifndef NMS_T_MAX
 #define NMS_T_MAX 2048
+#endif
 #define NMS_FILTER_WAVES 8
 #define NMS_LOOK_SPINS (1 << 22)
 template <bool CLS>
@@ -790,7 +792,9 @@ __global__ __launch_bounds__(256) void nms_emit_kernel(const float4 *__restrict_
 }
 
 // ---- workspace: two levels (level 1 only with the cascade) + the cascade's compacted survivors ----
+#ifndef NMS_CASCADE_MIN
 #define NMS_CASCADE_MIN 16384          // K above this: cascade with T = NMS_T_MAX
+#endif
 struct NmsLevelWs { u64 *sup, *nz, *kept, *rem; int32_t *done; int nblk, nzw; };
 struct NmsWs {
     NmsLevelWs L[2];
