@@ -708,7 +708,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=None)
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket library kernels with HIP events")
-    ap.add_argument("--event-every", type=int, default=4, help="bracket the library kernels of every n-th timed step (live roofline samples)")
+    ap.add_argument("--event-every", type=int, default=10, help="bracket the library kernels of every n-th timed step (live roofline samples)")
     ap.add_argument("--lr", type=float, default=2e-3)          # config.py:24
     ap.add_argument("--channels-last", action="store_true", help="run the backbone in NHWC memory format")
     ap.add_argument("--no-fused-sgd", action="store_true")
