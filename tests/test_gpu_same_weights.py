@@ -82,7 +82,17 @@ def _loss_list(t):
     return [float(v.detach()) for v in t]
 
 
-def test_vgg16_600x1000_same_weights_features_rpn_outputs_and_gradients_vs_the_cpu_form(monkeypatch):
+@pytest.fixture(params=["native", "split"])
+def products(request):
+    """Both forms of the fp32 conv stage's products (ops.conv3x3_f32_products): the fp32 matrix instruction (the default) and the opt-in split form --
+    the same end-to-end bounds hold for either; the split form's maxima go to gpurun_out/same_weights_<config>_split_products.json."""
+    from faster_rcnn_pytorch_amd import ops
+    prev = ops.conv3x3_f32_products(request.param)
+    yield request.param
+    ops.conv3x3_f32_products(prev)
+
+
+def test_vgg16_600x1000_same_weights_features_rpn_outputs_and_gradients_vs_the_cpu_form(monkeypatch, products):
     from faster_rcnn_pytorch_amd import ops
     from faster_rcnn_pytorch_amd.loss import FRCNNLoss
     from faster_rcnn_pytorch_amd.model import FRCNN
@@ -185,7 +195,7 @@ def test_vgg16_600x1000_same_weights_features_rpn_outputs_and_gradients_vs_the_c
     }
     for k in ("grad_rel_own_decisions_dev_vs_cpu", "grad_rel_own_decisions_cpu_vs_f64", "grad_rel_own_decisions_dev_vs_f64", "grad_rel_device_decisions_dev_vs_cpu"):
         rec[k + "_max"] = max(rec[k].values())
-    _report("vgg", rec)
+    _report("vgg" if products == "native" else "vgg_split_products", rec)
     assert set(g_dev) == set(g_cpu) == set(g_tr) and len(g_cpu) == 13 * 2 + 3 * 2 + 2 * 2 + 4      # extractor, RPN, heads, classifier (ONE module under two names: listed once)
     assert rec["features_rel_dev_vs_cpu"] < TOL
     assert rec["rpn_score_abs_dev_vs_cpu"] < TOL and rec["rpn_reg_rel_dev_vs_cpu"] < TOL
@@ -246,7 +256,7 @@ def _roi_pool_f64(features, scaled):
     return torch.stack(out, 0)
 
 
-def test_resnet50_fpn_800x1344_same_weights_features_rpn_outputs_and_gradients_vs_the_cpu_form(monkeypatch):
+def test_resnet50_fpn_800x1344_same_weights_features_rpn_outputs_and_gradients_vs_the_cpu_form(monkeypatch, products):
     from faster_rcnn_pytorch_amd import ops
     from faster_rcnn_pytorch_amd.loss import FRCNNLoss
     from faster_rcnn_pytorch_amd.new_model import BackboneWithFPN, Bottleneck, FRCNN
@@ -358,7 +368,7 @@ def test_resnet50_fpn_800x1344_same_weights_features_rpn_outputs_and_gradients_v
     }
     for k in ("grad_rel_own_decisions_dev_vs_cpu", "grad_rel_device_decisions_dev_vs_cpu"):
         rec[k + "_max"] = max(rec[k].values())
-    _report("fpn", rec)
+    _report("fpn" if products == "native" else "fpn_split_products", rec)
     assert set(g_dev) == set(g_cpu) == set(g_tr) and len(g_cpu) == 72
     assert rec["features_rel_dev_vs_cpu"] < TOL
     assert rec["rpn_score_abs_dev_vs_cpu"] < TOL and rec["rpn_reg_rel_dev_vs_cpu"] < TOL
