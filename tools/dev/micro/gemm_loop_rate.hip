@@ -93,16 +93,18 @@ __global__ __launch_bounds__(256, WPE) void loop_kernel(const float *__restrict_
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const float *qa = &sA[buf][(8 * lh) * MT + wm * (MT / 2) + MI * li];      // lane (i, h) takes k = 16 kb + 8 h + j, j = 0 .. 7
             const float *qb = &sB[buf][(8 * lh) * NW + wn * (NW / 2) + NI * li];
-            auto cut = [](const float *v, u32x4 &h, u32x4 &m, u32x4 &l) {
+            unsigned mask = 0xFFFF0000u;
+            if (FLAGS & 32768) asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(mask));       // the mask as a scalar register operand instead of a 32-bit literal in every v_and
+            auto cut = [mask](const float *v, u32x4 &h, u32x4 &m, u32x4 &l) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const unsigned x0 = __builtin_bit_cast(unsigned, v[2 * p]), x1 = __builtin_bit_cast(unsigned, v[2 * p + 1]);
                     h[p] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-                    const f32x2 r = f32x2{v[2 * p], v[2 * p + 1]} - f32x2{__builtin_bit_cast(float, x0 & 0xFFFF0000u), __builtin_bit_cast(float, x1 & 0xFFFF0000u)};
-                    const unsigned r0 = __builtin_bit_cast(unsigned, r.x), r1 = __builtin_bit_cast(unsigned, r.y);
+                    const float ra = v[2 * p] - __builtin_bit_cast(float, x0 & mask), rb = v[2 * p + 1] - __builtin_bit_cast(float, x1 & mask);
+                    const unsigned r0 = __builtin_bit_cast(unsigned, ra), r1 = __builtin_bit_cast(unsigned, rb);
                     m[p] = __builtin_amdgcn_perm(r1, r0, 0x07060302u);
-                    const f32x2 r2 = r - f32x2{__builtin_bit_cast(float, r0 & 0xFFFF0000u), __builtin_bit_cast(float, r1 & 0xFFFF0000u)};
-                    l[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2.y), __builtin_bit_cast(unsigned, r2.x), 0x07060302u);
+                    const float qa = ra - __builtin_bit_cast(float, r0 & mask), qb = rb - __builtin_bit_cast(float, r1 & mask);
+                    l[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, qb), __builtin_bit_cast(unsigned, qa), 0x07060302u);
                 }
             };
 #pragma unroll
@@ -277,6 +279,8 @@ int main()
     run<6 + 4096, 32, 2>("SPLIT PRODUCTS without the LDS-DMA", A, B, out, cus, nA, nB);
     run<6 + 4096 + 8192, 32, 2>("  ... the cutting alone (no MFMAs)", A, B, out, cus, nA, nB);
     run<6 + 4096 + 16384, 32, 2>("  ... the MFMAs alone (no cutting)", A, B, out, cus, nA, nB);
+    run<6 + 4096 + 8192 + 32768, 32, 2>("  ... the cutting alone, mask in a scalar register", A, B, out, cus, nA, nB);
+    run<7 + 4096 + 32768, 32, 2>("SPLIT PRODUCTS, mask in a scalar register", A, B, out, cus, nA, nB);
     run<7 + 4096 + 64, 32, 2>("SPLIT PRODUCTS + a tile stored and zeroed every 8 chunks", A, B, out, cus, nA, nB);
     run<15, 32, 2>("all, DMA in front of the steps", A, B, out, cus, nA, nB);
     run<7 + 32, 32, 2>("all, LDS-DMA addressed scalar base + lane offset", A, B, out, cus, nA, nB);
